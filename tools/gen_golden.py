@@ -1,0 +1,499 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+Imports the read-only reference checkout (default /root/reference) and records, for a set of
+scenarios, the exact inputs and outputs of the per-agent hot path
+(neighbour selection -> cone / half-space construction -> velocity selection) plus the env update,
+as small ``.npz`` fixtures under ``tests/golden/``.  Only *data* is written (inputs / expected
+outputs); no reference source travels.
+
+Reference entry points that are wrapped (module-level monkeypatching, the reference is not edited):
+  mamp/envs/mampenv.py:22 MACAEnv.step                -> per-step pre/post state
+  mamp/policies/*:find_next_action                    -> action[7] (via all_actions rows)
+  mamp/policies/*:compute_v_pref                      -> v_pref input of the solver
+  mamp/policies/*:computeNeighbors                    -> neighbour list (ids, kinds, distSq, order)
+  mamp/policies/*:intersect / compute_newV_is_suit    -> suitable count, fallback flag
+  orca3dPolicyOfficial.linearProgram3 / 4             -> planeFail, LP4-ran flag
+
+Usage:  python tools/gen_golden.py [--only NAME ...] [--ref /root/reference]
+"""
+import argparse
+import contextlib
+import io
+import math
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+POL_SCA, POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP, POL_RVO_DUBINS = 0, 1, 2, 3, 4, 5
+K = 16
+
+
+def _import_reference(ref):
+    sys.path.insert(0, ref)
+    sys.path.insert(0, os.path.join(ref, 'run_example'))
+    import matplotlib
+    matplotlib.use('Agg')
+    import mamp.agents.agent as agent_mod
+    # logging-only shim: Agent.to_vector appends a pandas row per agent per step (agent.py:126-147),
+    # DataFrame.append no longer exists in pandas 2 -> make the logger a no-op (off the hot path).
+    agent_mod.Agent.to_vector = lambda self: None
+    import mamp.envs.mampenv as env_mod
+    from mamp.policies.sca import scaPolicy, rvo3dDubinsPolicy
+    from mamp.policies import rvo3dPolicy, srvo3dPolicy, orca3dPolicy, orca3dPolicyOfficial
+    mods = {POL_SCA: scaPolicy, POL_RVO: rvo3dPolicy, POL_SRVO: srvo3dPolicy, POL_ORCA: orca3dPolicy,
+            POL_ORCA_LP: orca3dPolicyOfficial, POL_RVO_DUBINS: rvo3dDubinsPolicy}
+    classes = {POL_SCA: scaPolicy.SCAPolicy, POL_RVO: rvo3dPolicy.RVO3DPolicy, POL_SRVO: srvo3dPolicy.SRVO3DPolicy,
+               POL_ORCA: orca3dPolicy.ORCA3DPolicy, POL_ORCA_LP: orca3dPolicyOfficial.ORCA3DPolicy,
+               POL_RVO_DUBINS: rvo3dDubinsPolicy.RVO3dDubinsPolicy}
+    return agent_mod, env_mod, mods, classes
+
+
+class Recorder:
+    """Per-step scratch filled by the wrappers."""
+
+    def __init__(self, n):
+        self.n = n
+        self.reset()
+
+    def reset(self):
+        n = self.n
+        self.vpref = np.full((n, 3), np.nan)
+        self.called = np.zeros(n, np.uint8)
+        self.nbr_valid = np.zeros(n, np.uint8)
+        self.nbr_n = np.zeros(n, np.int32)
+        self.nbr_id = np.full((n, K), -1, np.int32)
+        self.nbr_kind = np.zeros((n, K), np.uint8)
+        self.nbr_dsq = np.zeros((n, K))
+        self.n_suit = np.full(n, -1, np.int32)
+        self.fallback = np.zeros(n, np.uint8)
+        self.plane_fail = np.full(n, -1, np.int32)
+        self.lp4 = np.zeros(n, np.uint8)
+        self.vpost = np.full((n, 3), np.nan)
+
+
+REC = None
+_SUIT_COUNT = [0]
+
+
+def _install_wrappers(mods):
+    for pid, mod in mods.items():
+        # compute_v_pref: signature (agent) for the Dubins policies, (goal, agent) otherwise.
+        orig_vp = mod.compute_v_pref
+
+        def vp(*args, _o=orig_vp):
+            out = _o(*args)
+            ag = args[-1]
+            REC.vpref[ag.id] = out
+            REC.called[ag.id] = 1
+            return out
+        mod.compute_v_pref = vp
+
+        orig_cn = mod.computeNeighbors
+
+        def cn(agent, kdTree, _o=orig_cn):
+            _o(agent, kdTree)
+            i = agent.id
+            REC.nbr_valid[i] = 1
+            REC.nbr_n[i] = len(agent.neighbors)
+            for k, (obj, dsq) in enumerate(agent.neighbors):
+                REC.nbr_id[i, k] = obj.id
+                REC.nbr_kind[i, k] = 1 if obj.is_obstacle else 0
+                REC.nbr_dsq[i, k] = dsq
+        mod.computeNeighbors = cn
+
+        if hasattr(mod, 'intersect'):
+            orig_suit = mod.compute_newV_is_suit
+
+            def suit(*args, _o=orig_suit):
+                r = _o(*args)
+                if r:
+                    _SUIT_COUNT[0] += 1
+                return r
+            mod.compute_newV_is_suit = suit
+            orig_int = mod.intersect
+            if pid == POL_ORCA:
+                def inter(agent, v_pref, planes, _o=orig_int):
+                    _SUIT_COUNT[0] = 0
+                    out = _o(agent, v_pref, planes)
+                    REC.n_suit[agent.id] = _SUIT_COUNT[0]
+                    REC.fallback[agent.id] = 1 if _SUIT_COUNT[0] == 0 else 0
+                    REC.vpost[agent.id] = out
+                    return out
+            else:
+                def inter(v_pref, rvo, agent, _o=orig_int):
+                    _SUIT_COUNT[0] = 0
+                    out = _o(v_pref, rvo, agent)
+                    REC.n_suit[agent.id] = _SUIT_COUNT[0]
+                    REC.fallback[agent.id] = 1 if _SUIT_COUNT[0] == 0 else 0
+                    REC.vpost[agent.id] = out
+                    return out
+            mod.intersect = inter
+    # LP bookkeeping for the "Official" ORCA policy
+    cls = mods[POL_ORCA_LP].ORCA3DPolicy
+    orig_fna = cls.find_next_action
+    orig_lp3 = cls.linearProgram3
+    orig_lp4 = cls.linearProgram4
+    cur = [None]
+
+    def fna(self, dict_comm, agent, kdTree):
+        cur[0] = agent.id
+        self._top = True
+        return orig_fna(self, dict_comm, agent, kdTree)
+
+    def lp3(self, planes, maxSpeed, vel_pref, dir_opt=False):
+        r = orig_lp3(self, planes, maxSpeed, vel_pref, dir_opt)
+        if not dir_opt:
+            REC.plane_fail[cur[0]] = r
+        return r
+
+    def lp4(self, planes, beginPlane, radius):
+        REC.lp4[cur[0]] = 1
+        return orig_lp4(self, planes, beginPlane, radius)
+    cls.find_next_action = fna
+    cls.linearProgram3 = lp3
+    cls.linearProgram4 = lp4
+
+
+def _flags(a):
+    return (1 if a.is_at_goal else 0) | (2 if a.is_collision else 0) | (4 if a.is_out_of_max_time else 0)
+
+
+def _snapshot(agents):
+    n = len(agents)
+    pos = np.array([a.pos_global_frame for a in agents], dtype=np.float64).reshape(n, 3)
+    vel = np.array([np.asarray(a.vel_global_frame, dtype=np.float32) for a in agents], dtype=np.float32).reshape(n, 3)
+    head = np.array([np.asarray(a.heading_global_frame, dtype=np.float64) for a in agents]).reshape(n, 3)
+    fl = np.array([_flags(a) for a in agents], np.uint8)
+    td = np.array([a.total_dist for a in agents], np.float64)
+    goal = np.array([a.goal_global_frame for a in agents], dtype=np.float64).reshape(n, 3)
+    return pos, vel, head, fl, td, goal
+
+
+def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, obstacles_spec, max_steps,
+                    record_every=1, record_first=0, radius=0.5, pref_speed=1.0, outdir='tests/golden'):
+    """Runs MACAEnv.step (mampenv.py:22) and records every `record_every`-th step (and the first
+    `record_first` steps) completely."""
+    global REC
+    from mamp.agents.obstacle import Obstacle
+    n = len(pos)
+    agents = [agent_mod.Agent(start_pos=list(pos[i]), goal_pos=list(goal[i]), vel=[0.0, 0.0, 0.0], radius=radius,
+                              pref_speed=pref_speed, policy=classes[int(policy_ids[i])], id=i, dt=0.1)
+              for i in range(n)]
+    obstacles = [Obstacle(pos=list(p), shape_dict={'shape': 'sphere', 'feature': r}, id=i)
+                 for i, (p, r) in enumerate(obstacles_spec)]
+    env = env_mod.MACAEnv()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env.set_agents(agents, obstacles=obstacles)
+    REC = Recorder(n)
+    rec = {k: [] for k in ('step', 'pos', 'vel', 'heading', 'flags', 'total_dist', 'goal', 'perm', 'vpref', 'called',
+                           'nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq', 'n_suit', 'fallback', 'plane_fail',
+                           'lp4', 'vpost', 'action', 'coll_after_policy', 'pos_after', 'vel_after', 'heading_after',
+                           'flags_after', 'total_dist_after', 'perm_after')}
+    # capture all_actions rows: wrap update_velocitie (mampenv.py:83)
+    actions = np.zeros((n, 7), np.float32)
+    coll_after = np.zeros(n, np.uint8)
+    orig_upd = env_mod.update_velocitie
+    first_upd = [True]
+
+    def upd(agent, action):
+        if first_upd[0]:
+            # the policy loop (mampenv.py:34-40) has finished for every agent at this point
+            first_upd[0] = False
+            for a in agents:
+                coll_after[a.id] = 1 if a.is_collision else 0
+        actions[agent.id] = action
+        return orig_upd(agent, action)
+    env_mod.update_velocitie = upd
+    t0 = time.time()
+    done_step = -1
+    for step in range(max_steps):
+        want = (step < record_first) or (step % record_every == 0)
+        REC.reset()
+        first_upd[0] = True
+        pre = _snapshot(agents)
+        perm = np.array(env.kdTree.agentIDs, np.int32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            done = env.step({})
+        post = _snapshot(agents)
+        if want:
+            rec['step'].append(step)
+            for k, v in zip(('pos', 'vel', 'heading', 'flags', 'total_dist', 'goal'), pre):
+                rec[k].append(v)
+            rec['perm'].append(perm)
+            for k in ('vpref', 'called', 'nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq', 'n_suit', 'fallback',
+                      'plane_fail', 'lp4', 'vpost'):
+                rec[k].append(getattr(REC, k).copy())
+            rec['action'].append(actions.copy())
+            rec['coll_after_policy'].append(coll_after.copy())
+            rec['pos_after'].append(post[0])
+            rec['vel_after'].append(post[1])
+            rec['heading_after'].append(post[2])
+            rec['flags_after'].append(post[3])
+            rec['total_dist_after'].append(post[4])
+            rec['perm_after'].append(np.array(env.kdTree.agentIDs, np.int32))
+        if done:
+            done_step = step
+            break
+    env_mod.update_velocitie = orig_upd
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(dict(
+        name=name, n_steps_run=step + 1, done_step=done_step,
+        start=np.array([np.asarray(p, dtype=np.float64) for p in pos]), goal6=np.array([np.asarray(g, dtype=np.float64) for g in goal]),
+        radius=np.full(n, radius), pref_speed=np.full(n, pref_speed), policy=np.array(policy_ids, np.uint8),
+        max_run_dist=np.array([a.max_run_dist for a in agents]),
+        obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
+        obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64),
+        numpy_version=np.__version__, ))
+    path = os.path.join(outdir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: {step + 1} steps ({len(rec["step"])} recorded), done_step={done_step}, '
+          f'{os.path.getsize(path) / 1e3:.0f} kB, {time.time() - t0:.1f} s', flush=True)
+    return agents
+
+
+def single_step_cluster(agent_mod, env_mod, classes, name, n, box, policy_id, seed, n_obs=0, min_sep=0.0,
+                        outdir='tests/golden'):
+    """Hand-built dense state (F5): random positions in a cube, random float32 velocities (so the
+    'first step' branch is not taken), one env.step.  Exercises >16 in range (agent.py:87-99 quirk),
+    collisions (agent.py:82-85) and the no-suitable-candidate fallback (scaPolicy.py:224-238)."""
+    global REC
+    from mamp.agents.obstacle import Obstacle
+    rng = np.random.default_rng(seed)
+    pts = []
+    while len(pts) < n:
+        p = rng.uniform(-box / 2, box / 2, 3) + np.array([0.0, 0.0, 20.0])
+        if min_sep > 0 and any(np.linalg.norm(p - q) < min_sep for q in pts):
+            continue
+        pts.append(p)
+    pos = [list(p) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for p in pts]
+    goal = [list(-np.array(p[:3]) + np.array([0, 0, 40.0])) + [0.0, 0.0, 0.0] for p in pos]
+    agents = [agent_mod.Agent(start_pos=pos[i], goal_pos=goal[i], vel=[0.0, 0.0, 0.0], radius=0.5, pref_speed=1.0,
+                              policy=classes[policy_id], id=i, dt=0.1) for i in range(n)]
+    for a in agents:
+        v = rng.normal(size=3)
+        v = v / np.linalg.norm(v) * rng.uniform(0.4, 1.0)
+        a.vel_global_frame = v.astype(np.float32)
+        if policy_id in (POL_SCA, POL_RVO_DUBINS):
+            # keep the Dubins tracker out of this fixture: pre-mark as planned with an empty path so
+            # compute_v_pref (scaPolicy.py:290-319) falls back to goal - pos when off-track
+            pass
+    obstacles_spec = [(list(rng.uniform(-box / 2, box / 2, 3) + np.array([0, 0, 20.0])), 1.0) for _ in range(n_obs)]
+    obstacles = [Obstacle(pos=list(p), shape_dict={'shape': 'sphere', 'feature': r}, id=i)
+                 for i, (p, r) in enumerate(obstacles_spec)]
+    env = env_mod.MACAEnv()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env.set_agents(agents, obstacles=obstacles)
+    REC = Recorder(n)
+    actions = np.zeros((n, 7), np.float32)
+    coll_after = np.zeros(n, np.uint8)
+    orig_upd = env_mod.update_velocitie
+    first_upd = [True]
+
+    def upd(agent, action):
+        if first_upd[0]:
+            first_upd[0] = False
+            for a in agents:
+                coll_after[a.id] = 1 if a.is_collision else 0
+        actions[agent.id] = action
+        return orig_upd(agent, action)
+    env_mod.update_velocitie = upd
+    pre = _snapshot(agents)
+    perm = np.array(env.kdTree.agentIDs, np.int32)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env.step({})
+    env_mod.update_velocitie = orig_upd
+    post = _snapshot(agents)
+    out = dict(name=name, step=np.array([0]), n_steps_run=1, done_step=-1)
+    for k, v in zip(('pos', 'vel', 'heading', 'flags', 'total_dist', 'goal'), pre):
+        out[k] = v[None]
+    out['perm'] = perm[None]
+    for k in ('vpref', 'called', 'nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq', 'n_suit', 'fallback',
+              'plane_fail', 'lp4', 'vpost'):
+        out[k] = getattr(REC, k).copy()[None]
+    out['action'] = actions[None]
+    out['coll_after_policy'] = coll_after[None]
+    for k, v in zip(('pos_after', 'vel_after', 'heading_after', 'flags_after', 'total_dist_after'), post[:5]):
+        out[k] = v[None]
+    out['perm_after'] = np.array(env.kdTree.agentIDs, np.int32)[None]
+    out.update(dict(start=np.array(pos, dtype=np.float64), goal6=np.array(goal, dtype=np.float64), radius=np.full(n, 0.5),
+                    pref_speed=np.full(n, 1.0), policy=np.full(n, policy_id, np.uint8),
+                    max_run_dist=np.array([a.max_run_dist for a in agents]),
+                    obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
+                    obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64), numpy_version=np.__version__))
+    path = os.path.join(outdir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: n={n} nbr_n max={REC.nbr_n.max()} fallback={int(REC.fallback.sum())} '
+          f'collisions={int(coll_after.sum())} lp4={int(REC.lp4.sum())} {time.time() - t0:.1f} s', flush=True)
+
+
+def kat_tables(outdir='tests/golden'):
+    """F8: per-function known-answer tables for the scalar helpers of mamp/util.py."""
+    import mamp.util as u
+    from mamp.policies import orca3dPolicyOfficial as off
+    rng = np.random.default_rng(1234)
+    n = 4000
+    a = rng.uniform(-30, 30, (n, 3))
+    b = rng.uniform(-30, 30, (n, 3))
+    # edge: tiny separations, exact decimal grids
+    a[:200] = np.round(a[:200], 2)
+    b[:200] = np.round(b[:200], 2)
+    b[200:300] = a[200:300] + rng.uniform(-1e-3, 1e-3, (100, 3))
+    l3 = np.array([u.l3norm(a[i], b[i]) for i in range(n)])
+    l3sq = np.array([float(u.l3normsq(a[i], b[i])) for i in range(n)])
+    dist = np.array([u.distance(a[i], b[i]) for i in range(n)])
+    v = rng.uniform(-1, 1, (n, 3))
+    v[:50, 1] = 0.0
+    v[50:100, 0] = 0.0
+    phi = np.array([u.get_phi(v[i]) for i in range(n)])
+    ang = rng.uniform(-20, 20, n)
+    p2p = np.array([u.pi_2_pi(np.float64(x)) for x in ang])
+    m2p = np.array([u.mod2pi(x) for x in ang])
+    # l3norm with a float32 second operand (scaPolicy.py:128: l3norm(v, vA), vA float32)
+    vf = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    l3_mixed = np.array([u.l3norm(v[i], vf[i]) for i in range(n)])
+    l3_f32zero = np.array([u.l3norm(vf[i], [0, 0, 0]) for i in range(n)])
+    # is_intersect (util.py:30-41)
+    pA = rng.uniform(-5, 5, (n, 3))
+    pB = pA + rng.uniform(-6, 6, (n, 3))
+    R = rng.uniform(0.6, 2.5, n)
+    vd = rng.uniform(-1.5, 1.5, (n, 3))
+    isx = np.zeros(n, np.uint8)
+    for i in range(n):
+        try:
+            isx[i] = 1 if u.is_intersect(pA[i], pB[i], R[i], vd[i]) else 0
+        except ValueError:
+            isx[i] = 2
+    # satisfied_constraint (util.py:6-20)
+
+    class A:
+        pass
+    sat = np.zeros(n, np.uint8)
+    posz = rng.uniform(-0.05, 0.3, n)
+    for i in range(n):
+        ag = A()
+        ag.vel_global_frame = vf[i]
+        ag.pos_global_frame = np.array([0.0, 0.0, posz[i]])
+        ag.timeStep = 0.1
+        ag.max_heading_change = math.pi / 4
+        sat[i] = 1 if u.satisfied_constraint(ag, v[i]) else 0
+    # cartesian2spherical (util.py:44-55) and the ORCA-official private copy (orca3dPolicyOfficial.py:331)
+    head = rng.uniform(-3.2, 3.2, (n, 3))
+    vv = v.copy()
+    vv[:20] *= 1e-4
+    c2s = np.zeros((n, 7))
+    c2s_off = np.zeros((n, 7))
+    for i in range(n):
+        ag = A()
+        ag.heading_global_frame = head[i]
+        c2s[i] = u.cartesian2spherical(ag, vv[i])
+        c2s_off[i] = off.cartesian2spherical(ag, vv[i])
+    # truncation int(x*1e5)/1e5 (scaPolicy.py:239)
+    tr_in = np.concatenate([rng.uniform(-1.2, 1.2, n - 6), [0.3, 0.29999999999999993, -0.3, 1.0, -1.0, 0.0]])
+    tr = np.array([int(x * 1e5) / 1e5 for x in tr_in])
+    np.savez_compressed(os.path.join(outdir, 'F8_kat.npz'), a=a, b=b, l3=l3, l3sq=l3sq, dist=dist, v=v, phi=phi, ang=ang,
+                        p2p=p2p, m2p=m2p, vf=vf, l3_mixed=l3_mixed, l3_f32zero=l3_f32zero, pA=pA, pB=pB, R=R, vd=vd,
+                        isx=isx, sat=sat, posz=posz, head=head, vv=vv, c2s=c2s, c2s_off=c2s_off, tr_in=tr_in, tr=tr,
+                        numpy_version=np.__version__)
+    print('F8_kat written', flush=True)
+
+
+def candidate_table(outdir='tests/golden'):
+    """The 2x256 (+2x128) Fibonacci-sphere candidate table exactly as scaPolicy.py:195-200 builds it."""
+    from math import sqrt, cos, sin, pi
+    out = {}
+    for num_N in (256, 128):
+        rows = []
+        for rad in np.arange(0.5, 1.0 + 0.03, 1.0 - 0.5):
+            for nn in range(1, num_N + 1):
+                z_n = (2 * nn - 1) / num_N - 1
+                x_n = sqrt(1 - z_n ** 2) * cos(2 * pi * nn * ((sqrt(5.0) - 1.0) / 2.0))
+                y_n = sqrt(1 - z_n ** 2) * sin(2 * pi * nn * ((sqrt(5.0) - 1.0) / 2.0))
+                rows.append([rad * x_n, rad * y_n, rad * z_n])
+        out[f'cand{num_N}'] = np.array(rows)
+    np.savez_compressed(os.path.join(outdir, 'F0_candidates.npz'), **out)
+    print('F0_candidates written', flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden'))
+    ap.add_argument('--only', nargs='*', default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    agent_mod, env_mod, mods, classes = _import_reference(args.ref)
+    _install_wrappers(mods)
+    import run_sca as rs
+    import run_orca as ro
+
+    def want(nm):
+        return args.only is None or any(nm.startswith(o) for o in args.only)
+
+    od = args.out
+    if want('F0'):
+        candidate_table(od)
+    if want('F8'):
+        kat_tables(od)
+    # F1: BASELINE config 1 -- N=8 circle rad 10, SCA, whole episode (run_sca.py:17-30)
+    if want('F1'):
+        pos, goal = rs.set_circle_pos((0, 0), 10.0, 8)
+        run_env_episode(agent_mod, env_mod, classes, 'F1_sca_circle8', pos, goal, [POL_SCA] * 8, [], 400, outdir=od)
+    # F2: N=100 circle rad 18 (run_orca.py:16-34), 40 steps, every policy
+    names = {POL_SCA: 'sca', POL_RVO: 'rvo', POL_SRVO: 'srvo', POL_ORCA: 'orca', POL_ORCA_LP: 'orcalp',
+             POL_RVO_DUBINS: 'rvodubins'}
+    for pid in (POL_ORCA_LP, POL_RVO, POL_SRVO, POL_ORCA, POL_SCA, POL_RVO_DUBINS):
+        nm = f'F2_{names[pid]}_circle100'
+        if want(nm):
+            pos, goal, _ = ro.set_circle_pos(100)
+            steps = 40 if pid not in (POL_RVO_DUBINS,) else 12
+            run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, [pid] * 100, [], steps, outdir=od)
+    # F3: N=100 random cube / Fibonacci ball (run_orca.py:36-71), seeded
+    for pid in (POL_ORCA_LP, POL_RVO, POL_SRVO, POL_ORCA):
+        nm = f'F3_{names[pid]}_random100'
+        if want(nm):
+            random.seed(7)
+            pos, goal, _ = ro.set_random_pos(100)
+            run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, [pid] * 100, [], 25, outdir=od)
+    for pid in (POL_ORCA_LP, POL_SRVO):
+        nm = f'F3_{names[pid]}_sphere100'
+        if want(nm):
+            pos, goal, _ = ro.set_sphere(100)
+            run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, [pid] * 100, [], 25, outdir=od)
+    # F4: N=16 take-off/landing + 8 sphere obstacles (run_sca.py:53-81,139-150), SCA and mixed SCA/S-RVO3D
+    obs = []
+    for j in range(8):
+        obs.append(([round(4.0 * np.cos(2 * j * np.pi / 8), 2), round(4.0 * np.sin(2 * j * np.pi / 8), 2), 5.0], 1.0))
+    if want('F4_sca_takeoff16'):
+        pos, goal = rs.set_takeoff_landing_pos(16)
+        run_env_episode(agent_mod, env_mod, classes, 'F4_sca_takeoff16', pos, goal, [POL_SCA] * 16, obs, 400, outdir=od)
+    if want('F4_mixed_takeoff16'):
+        pos, goal = rs.set_takeoff_landing_pos(16)
+        pol = [POL_SCA if i % 2 == 0 else POL_SRVO for i in range(16)]
+        run_env_episode(agent_mod, env_mod, classes, 'F4_mixed_takeoff16', pos, goal, pol, obs, 400, outdir=od)
+    if want('F4_sca_circle16_obs'):
+        pos, goal = rs.set_circle_pos((0, 0), 10.0, 16)
+        run_env_episode(agent_mod, env_mod, classes, 'F4_sca_circle16_obs', pos, goal, [POL_SCA] * 16, obs, 400,
+                        record_every=3, record_first=5, outdir=od)
+    # F5: dense clusters, one step, every solver
+    for pid in (POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP):
+        nm = f'F5_{names[pid]}_dense80'
+        if want(nm):
+            single_step_cluster(agent_mod, env_mod, classes, nm, 80, 12.0, pid, seed=11 + pid, n_obs=6, outdir=od)
+        nm = f'F5_{names[pid]}_packed60'
+        if want(nm):
+            single_step_cluster(agent_mod, env_mod, classes, nm, 60, 9.0, pid, seed=31 + pid, n_obs=14, min_sep=1.05,
+                                outdir=od)
+    # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
+    if want('F6_orcalp_circle100_long'):
+        pos, goal, _ = ro.set_circle_pos(100)
+        run_env_episode(agent_mod, env_mod, classes, 'F6_orcalp_circle100_long', pos, goal, [POL_ORCA_LP] * 100, [],
+                        600, record_every=10, record_first=0, outdir=od)
+
+
+if __name__ == '__main__':
+    main()
