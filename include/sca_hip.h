@@ -1,0 +1,135 @@
+/*
+ * sca_hip.h -- C-ABI of libsca_hip.so: the MI355X-native batched velocity solver that replaces the
+ * per-agent hot path of wuuya1/SCA (mamp/policies + neighbour search + the per-step loop in mamp/envs).
+ *
+ * Plain pointers and sizes only; caller-owned host buffers unless a function says "device".
+ * Every function returns 0 on success or a negative sca_error; sca_last_error() gives the text.
+ * One context per device; calls on one context are not thread-safe.
+ *
+ * What each entry point replaces in the reference (paths relative to wuuya1/SCA):
+ *   sca_create / sca_set_agents   Agent.__init__ solver attributes            mamp/agents/agent.py:9-77
+ *   sca_set_obstacles             Obstacle list + KDTree.buildObstacleTree    mamp/agents/obstacle.py:5-28, mamp/policies/kdTree.py:158-227
+ *   sca_set_state / sca_get_state agent.pos/vel/heading/flags attribute reads  mamp/envs/mampenv.py:34-46
+ *   sca_set_vpref                 SCA's Dubins-tracker output fed to intersect mamp/policies/sca/scaPolicy.py:32,264-338
+ *   sca_policy_pass               first loop of MACAEnv._take_action:          mamp/envs/mampenv.py:28-40
+ *                                 KDTree.buildAgentTree                        mamp/policies/kdTree.py:56-122
+ *                                 computeNeighbors / insert*Neighbor           mamp/policies/sca/scaPolicy.py:107-116, mamp/agents/agent.py:79-124
+ *                                 <Policy>.find_next_action + intersect        scaPolicy.py:26-240, rvo3dPolicy.py:23-179, srvo3dPolicy.py:23-231,
+ *                                                                              orca3dPolicy.py:38-120,400-439, orca3dPolicyOfficial.py:37-300
+ *   sca_env_update                second loop of _take_action + is_done        mamp/envs/mampenv.py:42-59,61-105
+ *   sca_run_steps                 `while ...: env.step(actions)`               run_example/run_sca.py:174-178
+ */
+#ifndef SCA_HIP_H
+#define SCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCA_MAX_NEIGHBORS 16          /* agent.py:32 */
+#define SCA_ACTION_DIM 7              /* mampenv.py:30: vx, vy, vz, speed, d_yaw, d_pitch, d_roll */
+#define SCA_DIAG_DIM 5                /* n_suitable, fallback, chosen candidate, planeFail, lp4_ran (-1 = n/a) */
+
+typedef struct sca_ctx sca_ctx;
+
+/* agent.py:27-36 + config.py; sca_default_params() fills the reference's values */
+typedef struct sca_params {
+    double neighbor_dist;        /* agent.py:33  10.0 */
+    double time_step;            /* agent.py:34  DT = 0.1 */
+    double time_horizon;         /* agent.py:35  10.0 */
+    double max_speed;            /* agent.py:36  1.0 */
+    double max_heading_change;   /* agent.py:29  pi/4 */
+    double near_goal_threshold;  /* config.py:3  0.5 */
+    int32_t max_neighbors;       /* agent.py:32  16 (<= SCA_MAX_NEIGHBORS) */
+    int32_t reserved;
+} sca_params;
+
+enum sca_policy {                 /* which find_next_action the agent runs */
+    SCA_POLICY_SCA = 0,           /* mamp/policies/sca/scaPolicy.py        (v_pref supplied: sca_set_vpref) */
+    SCA_POLICY_RVO3D = 1,         /* mamp/policies/rvo3dPolicy.py */
+    SCA_POLICY_SRVO3D = 2,        /* mamp/policies/srvo3dPolicy.py */
+    SCA_POLICY_ORCA3D = 3,        /* mamp/policies/orca3dPolicy.py         (sampled, as run_orca.py runs it) */
+    SCA_POLICY_ORCA3D_LP = 4,     /* mamp/policies/orca3dPolicyOfficial.py (linearProgram1-4) */
+    SCA_POLICY_RVO3D_DUBINS = 5   /* mamp/policies/sca/rvo3dDubinsPolicy.py (RVO3D selection, v_pref supplied) */
+};
+
+enum sca_flag { SCA_FLAG_AT_GOAL = 1, SCA_FLAG_COLLISION = 2, SCA_FLAG_TIMEOUT = 4 };   /* agent.py:70-72 */
+
+enum sca_neighbor_mode {
+    SCA_NBR_KDTREE = 0,           /* replica of the reference kd-tree visit order (exact neighbour lists) */
+    SCA_NBR_GRID = 1              /* uniform grid; identical lists whenever <= max_neighbors objects are in range */
+};
+
+enum sca_status_bit {             /* per-agent status word of the last policy pass */
+    SCA_ST_SQRT_DOMAIN = 2,       /* reference would raise ValueError (scaPolicy.py:159); clamped here */
+    SCA_ST_BAD_PREF_SPEED = 4,    /* np.arange(0.5, ps+0.03, ps-0.5) does not have 2 elements (scaPolicy.py:195) */
+    SCA_ST_KD_STACK = 16,         /* kd traversal stack overflow (tree deeper than 48) */
+    SCA_ST_NBR_OVERFLOW = 32      /* grid mode: > max_neighbors in range, reference list is visit-order dependent */
+};
+
+enum sca_error {
+    SCA_OK = 0, SCA_ERR_ARG = -1, SCA_ERR_HIP = -2, SCA_ERR_STATE = -3, SCA_ERR_NOMEM = -4, SCA_ERR_UNSUPPORTED = -5
+};
+
+void sca_default_params(sca_params *p);
+int sca_version(void);
+
+int sca_create(const sca_params *p, int device, int max_agents, int max_obstacles, sca_ctx **out);
+void sca_destroy(sca_ctx *ctx);
+const char *sca_last_error(const sca_ctx *ctx);
+
+/* static scene ---------------------------------------------------------------------------------- */
+int sca_set_obstacles(sca_ctx *ctx, int m, const double *pos /*m*3*/, const double *radius /*m*/);
+int sca_set_agents(sca_ctx *ctx, int n, const double *radius /*n*/, const double *pref_speed /*n*/,
+                   const double *goal /*n*3*/, const uint8_t *policy /*n*/, const uint8_t *zaxis /*n*/,
+                   const double *max_run_dist /*n*/);
+
+/* dynamic state (host <-> device) ---------------------------------------------------------------- */
+int sca_set_state(sca_ctx *ctx, const double *pos /*n*3*/, const float *vel /*n*3*/, const double *heading /*n*3*/,
+                  const uint8_t *flags /*n*/, const double *total_dist /*n, nullable*/,
+                  const int32_t *step_num /*n, nullable*/);
+int sca_get_state(sca_ctx *ctx, double *pos, float *vel, double *heading, uint8_t *flags, double *total_dist,
+                  int32_t *step_num); /* any pointer may be NULL */
+/* kdTree.agentIDs: the permutation the reference carries from step to step (kdTree.py:43-45,101-111) */
+int sca_set_kd_perm(sca_ctx *ctx, const int32_t *perm /*n*/);
+int sca_get_kd_perm(sca_ctx *ctx, int32_t *perm /*n*/);
+/* externally computed preferred velocity (SCA / RVO3D+Dubins); mode[i]=1 uses vpref[i], 0 = straight line */
+int sca_set_vpref(sca_ctx *ctx, const double *vpref /*n*3*/, const uint8_t *mode /*n*/);
+
+/* the hot path ----------------------------------------------------------------------------------- */
+int sca_policy_pass(sca_ctx *ctx, int neighbor_mode);
+int sca_get_actions(sca_ctx *ctx, float *action /*n*7*/);
+int sca_get_neighbors(sca_ctx *ctx, int32_t *nbr_n /*n*/, int32_t *nbr_id /*n*16*/, uint8_t *nbr_kind /*n*16*/,
+                      double *nbr_dsq /*n*16*/, uint8_t *nbr_valid /*n*/);
+int sca_get_diag(sca_ctx *ctx, int32_t *diag /*n*5*/, int32_t *status /*n*/, double *vpref_used /*n*3*/);
+int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/);
+/* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising */
+int sca_run_steps(sca_ctx *ctx, int steps, int neighbor_mode);
+int sca_synchronize(sca_ctx *ctx);
+
+/* multi-GPU / interop ------------------------------------------------------------------------------ */
+/* This rank solves agents [begin, begin+count); all agents' public records must be present. */
+int sca_set_shard(sca_ctx *ctx, int begin, int count);
+/* Device address and byte size of the public-record array (48 B per agent: pos f64x3, vel f32x3, flags u32,
+ * radius f64) so that an RCCL all-gather (torch.distributed) can exchange shards in place. */
+int sca_public_records(sca_ctx *ctx, void **device_ptr, int64_t *bytes_per_agent);
+/* Use caller-owned device memory (e.g. a torch tensor) for the public records; NULL restores the internal one. */
+int sca_bind_public_records(sca_ctx *ctx, void *device_ptr);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the internal stream. */
+int sca_set_stream(sca_ctx *ctx, void *hip_stream);
+/* average device time of the kernels of the last sca_policy_pass / sca_run_steps, measured with HIP events */
+int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float *update_ms);
+
+/* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
+/* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */
+int sca_candidate_table(int num_N, double *unit /*3*num_N*/, double *phi_num /*num_N*/);
+/* replica of KDTree.buildAgentTreeRecursive: permutes perm in place, writes (2n-1) nodes of 10 doubles
+ * [begin,end,left,right,min3,max3] when tree_out != NULL */
+int sca_kd_build_host(int n, const double *pos /*n*3*/, int32_t *perm /*n*/, double *tree_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

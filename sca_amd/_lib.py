@@ -1,0 +1,81 @@
+"""ctypes binding of libsca_hip.so (include/sca_hip.h).  No fallback: if the library is missing the import of
+anything that needs it raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+K = 16
+ACTION_DIM = 7
+DIAG_DIM = 5
+
+dp = C.POINTER(C.c_double)
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+bp = C.POINTER(C.c_uint8)
+
+
+class Params(C.Structure):
+    _fields_ = [('neighbor_dist', C.c_double), ('time_step', C.c_double), ('time_horizon', C.c_double),
+                ('max_speed', C.c_double), ('max_heading_change', C.c_double), ('near_goal_threshold', C.c_double),
+                ('max_neighbors', C.c_int32), ('reserved', C.c_int32)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/sca_hip.h
+SIGNATURES = {
+    'sca_default_params': (None, [C.POINTER(Params)]),
+    'sca_version': (C.c_int, []),
+    'sca_create': (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'sca_destroy': (None, [C.c_void_p]),
+    'sca_last_error': (C.c_char_p, [C.c_void_p]),
+    'sca_set_obstacles': (C.c_int, [C.c_void_p, C.c_int, dp, dp]),
+    'sca_set_agents': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp, bp, bp, dp]),
+    'sca_set_state': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, ip]),
+    'sca_get_state': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, ip]),
+    'sca_set_kd_perm': (C.c_int, [C.c_void_p, ip]),
+    'sca_get_kd_perm': (C.c_int, [C.c_void_p, ip]),
+    'sca_set_vpref': (C.c_int, [C.c_void_p, dp, bp]),
+    'sca_policy_pass': (C.c_int, [C.c_void_p, C.c_int]),
+    'sca_get_actions': (C.c_int, [C.c_void_p, fp]),
+    'sca_get_neighbors': (C.c_int, [C.c_void_p, ip, ip, bp, dp, bp]),
+    'sca_get_diag': (C.c_int, [C.c_void_p, ip, ip, dp]),
+    'sca_env_update': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    'sca_run_steps': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    'sca_synchronize': (C.c_int, [C.c_void_p]),
+    'sca_set_shard': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    'sca_public_records': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'sca_bind_public_records': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'sca_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
+    'sca_candidate_table': (C.c_int, [C.c_int, dp, dp]),
+    'sca_kd_build_host': (C.c_int, [C.c_int, dp, ip, dp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Loads sca_amd/lib/libsca_hip.so.  Raises if it has not been built (python -m sca_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_build.LIB):
+            raise RuntimeError(f'{_build.LIB} is missing: build it with `python -m sca_amd.build` '
+                               '(there is no CPU fallback)')
+        L = C.CDLL(_build.LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def as_d(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)

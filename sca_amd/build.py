@@ -1,0 +1,46 @@
+"""Builds sca_amd/lib/libsca_hip.so (hand-written HIP kernels + C-ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so then travels with the
+repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIBDIR = os.path.join(_HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libsca_hip.so')
+SOURCES = ['sca_hip.hip']
+DEPS = ['sca_hip.hip', 'sca_kernels.hip.h', 'sca_core.h', os.path.join('..', '..', 'include', 'sca_hip.h')]
+# -ffp-contract=off: decisions must follow the reference's unfused arithmetic; fma() is explicit where numpy fuses.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-builtin-pow']
+
+
+def hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: cannot build libsca_hip.so')
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,497 @@
+// sca_hip.hip -- host side of libsca_hip.so: context, HBM layout, launches, C-ABI (include/sca_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sca_hip.h"
+#include "sca_kernels.hip.h"
+
+using namespace sca;
+
+namespace {
+
+// libm calls that must not be folded by the compiler (the candidate table follows the reference's
+// Python expression literally: z ** 2 is pow(z, 2), not z * z)
+double (*volatile p_pow)(double, double) = std::pow;
+double (*volatile p_acos)(double) = std::acos;
+
+struct HostKdNode { int begin, end, left, right; double mn[3], mx[3]; };
+
+// Replica of KDTree.buildAgentTreeRecursive / buildObstacleTreeRecursive (kdTree.py:60-122,162-227),
+// iterative with an explicit work list.  Children live at node+1 and node+2*leftSize.
+void kd_build_host(int n, const double *pos, int32_t *ids, std::vector<KdNode> &tree) {
+    tree.assign(n > 0 ? (size_t)(2 * n) : 1, KdNode{});
+    if (n <= 0) return;
+    struct Job { int begin, end, node; };
+    std::vector<Job> work;
+    work.push_back({0, n, 0});
+    while (!work.empty()) {
+        const Job jb = work.back();
+        work.pop_back();
+        KdNode &nd = tree[jb.node];
+        nd.begin = jb.begin; nd.end = jb.end; nd.left = 0; nd.right = 0;
+        for (int k = 0; k < 3; k++) nd.mn[k] = nd.mx[k] = pos[3 * ids[jb.begin] + k];
+        for (int i = jb.begin + 1; i < jb.end; i++)
+            for (int k = 0; k < 3; k++) {
+                const double v = pos[3 * ids[i] + k];
+                if (v > nd.mx[k]) nd.mx[k] = v;
+                if (v < nd.mn[k]) nd.mn[k] = v;
+            }
+        if (jb.end - jb.begin > MAX_LEAF) {
+            const double d0 = nd.mx[0] - nd.mn[0], d1 = nd.mx[1] - nd.mn[1], d2 = nd.mx[2] - nd.mn[2];
+            const int c = (d0 > d1 && d0 > d2) ? 0 : (d1 > d2 ? 1 : 2);
+            const double split = 0.5 * (nd.mx[c] + nd.mn[c]);
+            int lo = jb.begin, hi = jb.end;
+            while (lo < hi) {
+                while (lo < hi && pos[3 * ids[lo] + c] < split) lo++;
+                while (hi > lo && pos[3 * ids[hi - 1] + c] >= split) hi--;
+                if (lo < hi) { std::swap(ids[lo], ids[hi - 1]); lo++; hi--; }
+            }
+            int leftSize = lo - jb.begin;
+            if (leftSize == 0) { leftSize = 1; lo++; }
+            nd.left = jb.node + 1;
+            nd.right = jb.node + 2 * leftSize;
+            // order of construction does not matter: the two sub-ranges are disjoint
+            work.push_back({lo, jb.end, nd.right});
+            work.push_back({jb.begin, lo, nd.left});
+        }
+    }
+}
+
+void candidate_table_host(int num_N, double *unit, double *phi) {
+    const double param_phi = (std::sqrt(5.0) - 1.0) / 2.0;                         // scaPolicy.py:191
+    for (int n = 1; n <= num_N; n++) {
+        const double z_n = (double)(2 * n - 1) / num_N - 1;                        // :197
+        const double c = std::sqrt(1 - p_pow(z_n, 2.0));
+        const double ang = 2 * M_PI * n * param_phi;
+        const double x_n = c * std::cos(ang), y_n = c * std::sin(ang);             // :198-199
+        unit[n - 1] = x_n; unit[num_N + n - 1] = y_n; unit[2 * num_N + n - 1] = z_n;
+        // get_phi (util.py:145) of the direction; rad in {0.5, 1.0} scales both atan2 arguments exactly
+        double ph = (y_n >= 0) ? std::atan2(y_n, x_n) : 2 * M_PI + std::atan2(y_n, x_n);
+        double t = std::trunc(ph * EPS5);
+        if (t == 0.0) t = 0.0;
+        phi[n - 1] = t;
+    }
+}
+
+// smallest double c with acos(c) <= mhc under the host libm: `theta <= max_heading_change` (util.py:16-17)
+// becomes `costheta >= thr` exactly (acos is monotone).
+double cos_threshold(double mhc) {
+    if (p_acos(-1.0) <= mhc) return -1.0;
+    if (!(p_acos(1.0) <= mhc)) return 2.0;      // nothing satisfies
+    double lo = -1.0, hi = 1.0;                 // acos(lo) > mhc, acos(hi) <= mhc
+    while (std::nextafter(lo, 2.0) < hi) {
+        const double mid = lo + (hi - lo) * 0.5;
+        if (mid <= lo || mid >= hi) break;
+        if (p_acos(mid) <= mhc) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+
+}  // namespace
+
+struct sca_ctx {
+    int device = 0;
+    int max_n = 0, max_m = 0, n = 0, m = 0;
+    Params P{};
+    DeviceView d{};
+    PubRec *rec_own = nullptr;
+    hipStream_t stream_own = nullptr, stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms_nbr = 0, ms_solve = 0, ms_update = 0;
+    std::vector<double> h_pos;          // host mirror of positions for the kd build
+    bool h_pos_valid = false;
+    std::vector<int32_t> h_perm;
+    std::vector<KdNode> h_tree;
+    std::vector<PubRec> h_rec;
+    bool agents_set = false, state_set = false;
+    std::string err;
+    double *tab = nullptr;
+};
+
+#define CHK(ctx, call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return SCA_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+#define ARG(ctx, cond)                                                                         \
+    do {                                                                                       \
+        if (!(cond)) { (ctx)->err = std::string("bad argument: ") + #cond; return SCA_ERR_ARG; } \
+    } while (0)
+
+template <class T>
+static int dalloc(sca_ctx *c, T **p, size_t count) {
+    CHK(c, hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    CHK(c, hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), c->stream));
+    return 0;
+}
+
+extern "C" {
+
+void sca_default_params(sca_params *p) {
+    p->neighbor_dist = 10.0; p->time_step = 0.1; p->time_horizon = 10.0; p->max_speed = 1.0;
+    p->max_heading_change = M_PI / 4; p->near_goal_threshold = 0.5; p->max_neighbors = 16; p->reserved = 0;
+}
+int sca_version(void) { return 100; }
+
+const char *sca_last_error(const sca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sca_candidate_table(int num_N, double *unit, double *phi_num) {
+    if (num_N <= 0 || !unit || !phi_num) return SCA_ERR_ARG;
+    candidate_table_host(num_N, unit, phi_num);
+    return 0;
+}
+
+int sca_kd_build_host(int n, const double *pos, int32_t *perm, double *tree_out) {
+    if (n < 0 || (n > 0 && (!pos || !perm))) return SCA_ERR_ARG;
+    std::vector<KdNode> tree;
+    kd_build_host(n, pos, perm, tree);
+    if (tree_out)
+        for (int i = 0; i < 2 * n - 1; i++) {
+            double *t = tree_out + 10 * (size_t)i;
+            t[0] = tree[i].begin; t[1] = tree[i].end; t[2] = tree[i].left; t[3] = tree[i].right;
+            for (int k = 0; k < 3; k++) { t[4 + k] = tree[i].mn[k]; t[7 + k] = tree[i].mx[k]; }
+        }
+    return 0;
+}
+
+int sca_create(const sca_params *p, int device, int max_agents, int max_obstacles, sca_ctx **out) {
+    if (!out || max_agents <= 0 || max_obstacles < 0) return SCA_ERR_ARG;
+    sca_ctx *c = new sca_ctx();
+    *out = c;
+    sca_params def;
+    sca_default_params(&def);
+    if (!p) p = &def;
+    if (p->max_neighbors < 1 || p->max_neighbors > SCA_MAX_NEIGHBORS) { c->err = "max_neighbors out of range"; return SCA_ERR_ARG; }
+    c->device = device; c->max_n = max_agents; c->max_m = max_obstacles;
+    c->P.neighbor_dist = p->neighbor_dist; c->P.time_step = p->time_step; c->P.time_horizon = p->time_horizon;
+    c->P.max_speed = p->max_speed; c->P.max_heading_change = p->max_heading_change;
+    c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0;
+    c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
+    int ndev = 0;
+    CHK(c, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { c->err = "no HIP device: libsca_hip has no CPU path"; return SCA_ERR_HIP; }
+    CHK(c, hipSetDevice(device));
+    CHK(c, hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
+    c->stream = c->stream_own;
+    for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
+    const size_t N = (size_t)max_agents, M = (size_t)max_obstacles;
+    DeviceView &d = c->d;
+    int r = 0;
+    r |= dalloc(c, &c->rec_own, N); d.rec = c->rec_own;
+    r |= dalloc(c, &d.rec_new, N);
+    r |= dalloc(c, &d.heading, 3 * N); r |= dalloc(c, &d.goal, 3 * N); r |= dalloc(c, &d.pref_speed, N);
+    r |= dalloc(c, &d.vpref_ext, 3 * N); r |= dalloc(c, &d.total_dist, N); r |= dalloc(c, &d.max_run_dist, N);
+    r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.policy, N);
+    r |= dalloc(c, &d.zaxis, N);
+    r |= dalloc(c, &d.obs, M); r |= dalloc(c, &d.atree, 2 * N); r |= dalloc(c, &d.aperm, N);
+    r |= dalloc(c, &d.otree, 2 * M); r |= dalloc(c, &d.operm, M);
+    r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
+    r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
+    r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
+    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 1);
+    if (r) return SCA_ERR_HIP;
+    // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
+    std::vector<double> tab(768 + 384 + 256 + 128);
+    candidate_table_host(256, tab.data(), tab.data() + 768 + 384);
+    candidate_table_host(128, tab.data() + 768, tab.data() + 768 + 384 + 256);
+    if (dalloc(c, &c->tab, tab.size())) return SCA_ERR_HIP;
+    CHK(c, hipMemcpyAsync(c->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    d.unit256 = c->tab; d.unit128 = c->tab + 768; d.phi256 = c->tab + 768 + 384; d.phi128 = c->tab + 768 + 384 + 256;
+    d.n = 0; d.m = 0; d.shard_begin = 0; d.shard_count = 0;
+    return 0;
+}
+
+void sca_destroy(sca_ctx *c) {
+    if (!c) return;
+    DeviceView &d = c->d;
+    if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
+    void *ptrs[] = {c->rec_own, d.rec_new, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
+                    d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
+                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.action, d.vpref_used, d.diag, d.status,
+                    d.done_count, c->tab};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
+    delete c;
+}
+
+int sca_set_obstacles(sca_ctx *c, int m, const double *pos, const double *radius) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, m >= 0 && m <= c->max_m);
+    ARG(c, m == 0 || (pos && radius));
+    c->m = m; c->d.m = m;
+    if (m == 0) return 0;
+    std::vector<ObsRec> h(m);
+    for (int i = 0; i < m; i++) { h[i].px = pos[3 * i]; h[i].py = pos[3 * i + 1]; h[i].pz = pos[3 * i + 2]; h[i].radius = radius[i]; }
+    std::vector<int32_t> perm(m);
+    for (int i = 0; i < m; i++) perm[i] = i;                           // kdTree.py:51-52
+    std::vector<KdNode> tree;
+    kd_build_host(m, pos, perm.data(), tree);                          // mampenv.py:20, built once
+    CHK(c, hipMemcpyAsync(c->d.obs, h.data(), sizeof(ObsRec) * m, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.operm, perm.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.otree, tree.data(), sizeof(KdNode) * (2 * m - 1), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_speed, const double *goal,
+                   const uint8_t *policy, const uint8_t *zaxis, const double *max_run_dist) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, n > 0 && n <= c->max_n);
+    ARG(c, radius && pref_speed && goal && policy && max_run_dist);
+    c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
+    c->h_rec.assign(n, PubRec{});
+    for (int i = 0; i < n; i++) c->h_rec[i].radius = radius[i];
+    c->h_perm.resize(n);
+    for (int i = 0; i < n; i++) c->h_perm[i] = i;                     // kdTree.py:43-45
+    std::vector<uint8_t> z(n, 0), mode(n, 0);
+    if (zaxis) z.assign(zaxis, zaxis + n);
+    for (int i = 0; i < n; i++) ARG(c, policy[i] <= SCA_POLICY_RVO3D_DUBINS);
+    CHK(c, hipMemcpyAsync(c->d.pref_speed, pref_speed, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.goal, goal, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.policy, policy, n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.zaxis, z.data(), n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode.data(), n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.max_run_dist, max_run_dist, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemsetAsync(c->d.total_dist, 0, sizeof(double) * n, c->stream));
+    CHK(c, hipMemsetAsync(c->d.step_num, 0, sizeof(int32_t) * n, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    c->agents_set = true; c->state_set = false; c->h_pos_valid = false;
+    return 0;
+}
+
+int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double *heading, const uint8_t *flags,
+                  const double *total_dist, const int32_t *step_num) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    ARG(c, pos && vel && heading && flags);
+    const int n = c->n;
+    for (int i = 0; i < n; i++) {
+        PubRec &r = c->h_rec[i];
+        r.px = pos[3 * i]; r.py = pos[3 * i + 1]; r.pz = pos[3 * i + 2];
+        r.vx = vel[3 * i]; r.vy = vel[3 * i + 1]; r.vz = vel[3 * i + 2];
+        r.flags = flags[i];
+    }
+    c->h_pos.assign(pos, pos + 3 * (size_t)n);
+    c->h_pos_valid = true;
+    CHK(c, hipMemcpyAsync(c->d.rec, c->h_rec.data(), sizeof(PubRec) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.heading, heading, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    if (total_dist) CHK(c, hipMemcpyAsync(c->d.total_dist, total_dist, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    if (step_num) CHK(c, hipMemcpyAsync(c->d.step_num, step_num, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    c->state_set = true;
+    return 0;
+}
+
+static int fetch_records(sca_ctx *c) {
+    CHK(c, hipMemcpyAsync(c->h_rec.data(), c->d.rec, sizeof(PubRec) * c->n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sca_get_state(sca_ctx *c, double *pos, float *vel, double *heading, uint8_t *flags, double *total_dist,
+                  int32_t *step_num) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->state_set) { c->err = "no state"; return SCA_ERR_STATE; }
+    const int n = c->n;
+    if (int r = fetch_records(c)) return r;
+    for (int i = 0; i < n; i++) {
+        const PubRec &r = c->h_rec[i];
+        if (pos) { pos[3 * i] = r.px; pos[3 * i + 1] = r.py; pos[3 * i + 2] = r.pz; }
+        if (vel) { vel[3 * i] = r.vx; vel[3 * i + 1] = r.vy; vel[3 * i + 2] = r.vz; }
+        if (flags) flags[i] = (uint8_t)r.flags;
+    }
+    if (heading) CHK(c, hipMemcpyAsync(heading, c->d.heading, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    if (total_dist) CHK(c, hipMemcpyAsync(total_dist, c->d.total_dist, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    if (step_num) CHK(c, hipMemcpyAsync(step_num, c->d.step_num, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sca_set_kd_perm(sca_ctx *c, const int32_t *perm) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, perm && c->agents_set);
+    c->h_perm.assign(perm, perm + c->n);
+    return 0;
+}
+int sca_get_kd_perm(sca_ctx *c, int32_t *perm) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, perm && c->agents_set);
+    std::memcpy(perm, c->h_perm.data(), sizeof(int32_t) * c->n);
+    return 0;
+}
+
+int sca_set_vpref(sca_ctx *c, const double *vpref, const uint8_t *mode) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, vpref && mode && c->agents_set);
+    CHK(c, hipMemcpyAsync(c->d.vpref_ext, vpref, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode, c->n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// KDTree.buildAgentTree (mampenv.py:28).  Round 1: built on the host from the position mirror and uploaded.
+static int build_agent_tree(sca_ctx *c) {
+    const int n = c->n;
+    if (!c->h_pos_valid) {
+        if (int r = fetch_records(c)) return r;
+        c->h_pos.resize(3 * (size_t)n);
+        for (int i = 0; i < n; i++) { c->h_pos[3 * i] = c->h_rec[i].px; c->h_pos[3 * i + 1] = c->h_rec[i].py; c->h_pos[3 * i + 2] = c->h_rec[i].pz; }
+        c->h_pos_valid = true;
+    }
+    kd_build_host(n, c->h_pos.data(), c->h_perm.data(), c->h_tree);
+    CHK(c, hipMemcpyAsync(c->d.atree, c->h_tree.data(), sizeof(KdNode) * (2 * n - 1), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int launch_policy(sca_ctx *c, int mode, bool timed) {
+    const DeviceView &d = c->d;
+    if (mode != SCA_NBR_KDTREE) { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
+    if (int r = build_agent_tree(c)) return r;
+    CHK(c, hipMemsetAsync(d.status, 0, sizeof(int32_t) * c->n, c->stream));
+    const int cnt = d.shard_count;
+    if (timed) CHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_THREADS - 1) / K1_THREADS), dim3(K1_THREADS), 0, c->stream, d, c->P);
+    if (timed) CHK(c, hipEventRecord(c->ev[1], c->stream));
+    hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (timed) CHK(c, hipEventRecord(c->ev[2], c->stream));
+    CHK(c, hipGetLastError());
+    return 0;
+}
+
+static int launch_update(sca_ctx *c, bool timed) {
+    const DeviceView &d = c->d;
+    const int cnt = d.shard_count;
+    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(k_integrate, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    hipLaunchKernelGGL(k_collide, dim3((cnt + 3) / 4), dim3(256), 0, c->stream, d, c->P);
+    hipLaunchKernelGGL(k_finish, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
+    CHK(c, hipGetLastError());
+    c->h_pos_valid = false;
+    return 0;
+}
+
+int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    if (int r = launch_policy(c, neighbor_mode, true)) return r;
+    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipEventElapsedTime(&c->ms_nbr, c->ev[0], c->ev[1]));
+    CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[1], c->ev[2]));
+    return 0;
+}
+
+int sca_env_update(sca_ctx *c, int *all_done) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    CHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (int r = launch_update(c, true)) return r;
+    if (all_done) {
+        int32_t active = 0;
+        CHK(c, hipMemcpyAsync(&active, c->d.done_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+        CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[2], c->ev[3]));
+        *all_done = (active == 0);
+    }
+    return 0;
+}
+
+int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    for (int s = 0; s < steps; s++) {
+        if (int r = launch_policy(c, neighbor_mode, false)) return r;
+        if (int r = launch_update(c, false)) return r;
+    }
+    return 0;
+}
+
+int sca_synchronize(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sca_get_actions(sca_ctx *c, float *action) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, action);
+    std::vector<float> tmp((size_t)c->n * 8);
+    CHK(c, hipMemcpyAsync(tmp.data(), c->d.action, sizeof(float) * 8 * c->n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n; i++) std::memcpy(action + 7 * (size_t)i, tmp.data() + 8 * (size_t)i, 7 * sizeof(float));
+    return 0;
+}
+
+int sca_get_neighbors(sca_ctx *c, int32_t *nbr_n, int32_t *nbr_id, uint8_t *nbr_kind, double *nbr_dsq, uint8_t *nbr_valid) {
+    if (!c) return SCA_ERR_ARG;
+    const int n = c->n;
+    std::vector<int32_t> ids((size_t)n * K_MAX);
+    CHK(c, hipMemcpyAsync(ids.data(), c->d.nbr_id, sizeof(int32_t) * K_MAX * n, hipMemcpyDeviceToHost, c->stream));
+    if (nbr_n) CHK(c, hipMemcpyAsync(nbr_n, c->d.nbr_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    if (nbr_dsq) CHK(c, hipMemcpyAsync(nbr_dsq, c->d.nbr_dsq, sizeof(double) * K_MAX * n, hipMemcpyDeviceToHost, c->stream));
+    if (nbr_valid) CHK(c, hipMemcpyAsync(nbr_valid, c->d.nbr_valid, n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < ids.size(); i++) {
+        const int32_t v = ids[i];
+        const bool ob = v >= 0 && (v & NBR_OBSTACLE_BIT);
+        if (nbr_id) nbr_id[i] = v < 0 ? -1 : (v & ~NBR_OBSTACLE_BIT);
+        if (nbr_kind) nbr_kind[i] = ob ? 1 : 0;
+    }
+    return 0;
+}
+
+int sca_get_diag(sca_ctx *c, int32_t *diag, int32_t *status, double *vpref_used) {
+    if (!c) return SCA_ERR_ARG;
+    const int n = c->n;
+    std::vector<int32_t> tmp((size_t)n * 8);
+    CHK(c, hipMemcpyAsync(tmp.data(), c->d.diag, sizeof(int32_t) * 8 * n, hipMemcpyDeviceToHost, c->stream));
+    if (status) CHK(c, hipMemcpyAsync(status, c->d.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    if (vpref_used) CHK(c, hipMemcpyAsync(vpref_used, c->d.vpref_used, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (diag) for (int i = 0; i < n; i++) std::memcpy(diag + 5 * (size_t)i, tmp.data() + 8 * (size_t)i, 5 * sizeof(int32_t));
+    return 0;
+}
+
+int sca_set_shard(sca_ctx *c, int begin, int count) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, begin >= 0 && count >= 0 && begin + count <= c->n);
+    c->d.shard_begin = begin; c->d.shard_count = count;
+    return 0;
+}
+int sca_public_records(sca_ctx *c, void **device_ptr, int64_t *bytes_per_agent) {
+    if (!c) return SCA_ERR_ARG;
+    if (device_ptr) *device_ptr = c->d.rec;
+    if (bytes_per_agent) *bytes_per_agent = (int64_t)sizeof(PubRec);
+    return 0;
+}
+int sca_bind_public_records(sca_ctx *c, void *device_ptr) {
+    if (!c) return SCA_ERR_ARG;
+    c->d.rec = device_ptr ? (PubRec *)device_ptr : c->rec_own;
+    return 0;
+}
+int sca_set_stream(sca_ctx *c, void *hip_stream) {
+    if (!c) return SCA_ERR_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->stream_own;
+    return 0;
+}
+int sca_last_kernel_ms(sca_ctx *c, float *neighbors_ms, float *solve_ms, float *update_ms) {
+    if (!c) return SCA_ERR_ARG;
+    if (neighbors_ms) *neighbors_ms = c->ms_nbr;
+    if (solve_ms) *solve_ms = c->ms_solve;
+    if (update_ms) *update_ms = c->ms_update;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,586 @@
+// sca_kernels.hip.h -- gfx950 kernels of the batched SCA / RVO3D / S-RVO3D / ORCA3D velocity solver.
+//
+//   k_neighbors_kd : replica of KDTree.query*TreeRecursive + Agent.insert*Neighbor  (kdTree.py:127-262,
+//                    agent.py:79-124), one lane per agent, explicit stack + bounded sorted list in LDS.
+//   k_solve        : cone / half-space construction + 513-candidate sweep + selection (or LP1-4),
+//                    ONE WAVEFRONT (64 lanes) PER AGENT, neighbour constants staged in LDS and read as
+//                    wave-uniform broadcasts, selection by wave-level tuple reductions / ballots.
+//   k_integrate / k_collide / k_finish : MACAEnv second loop (mampenv.py:42-59).
+//
+// HBM layout: one 48-byte PubRec per agent (pos f64x3, vel f32x3, flags, radius) -- the only thing other
+// agents / other GPUs read; private per-agent arrays are SoA.  No MFMA: there is no contraction here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "sca_core.h"
+
+namespace sca {
+
+struct KdNode { int begin, end, left, right; double mn[3], mx[3]; };   // 64 B, kdTree.py:14-21
+struct ObsRec { double px, py, pz, radius; };                          // obstacle.py:5-28 (sphere)
+
+struct DeviceView {
+    // public state
+    PubRec *rec;             // [n]
+    PubRec *rec_new;         // [n] scratch for the integrate/collide split
+    // private per-agent state (SoA)
+    double *heading;         // [n*3]
+    double *goal;            // [n*3]
+    double *pref_speed;      // [n]
+    double *vpref_ext;       // [n*3]
+    double *total_dist;      // [n]
+    double *max_run_dist;    // [n]
+    int32_t *step_num;       // [n]
+    uint8_t *vpref_mode;     // [n]
+    uint8_t *policy;         // [n]
+    uint8_t *zaxis;          // [n]
+    // obstacles + trees
+    ObsRec *obs;             // [m]
+    KdNode *atree;           // [2n]
+    int32_t *aperm;          // [n]
+    KdNode *otree;           // [2m]
+    int32_t *operm;          // [m]
+    // neighbour lists
+    int32_t *nbr_n;          // [n]
+    int32_t *nbr_id;         // [n*16]  (obstacles carry NBR_OBSTACLE_BIT)
+    double *nbr_dsq;         // [n*16]
+    uint32_t *coll_new;      // [n] collision detected by insert*Neighbor in this pass
+    uint8_t *nbr_valid;      // [n]
+    // outputs
+    float *action;           // [n*8] (7 used)
+    double *vpref_used;      // [n*3]
+    int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
+    int32_t *status;         // [n]
+    // candidate tables (SoA [3][N]) and phi numerators
+    const double *unit256, *unit128, *phi256, *phi128;
+    int32_t *done_count;     // [1] number of agents not yet done (k_finish)
+    int n, m, shard_begin, shard_count;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+struct Key3 { double a, b; int idx; };
+__device__ __forceinline__ bool key_less(const Key3 &x, const Key3 &y) {
+    if (x.a < y.a) return true;
+    if (x.a > y.a) return false;
+    if (x.b < y.b) return true;
+    if (x.b > y.b) return false;
+    return x.idx < y.idx;
+}
+__device__ __forceinline__ Key3 key_invalid() { Key3 k; k.a = INFINITY; k.b = INFINITY; k.idx = INT_MAX; return k; }
+__device__ __forceinline__ Key3 wave_argmin(Key3 k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Key3 o;
+        o.a = __shfl_xor(k.a, off);
+        o.b = __shfl_xor(k.b, off);
+        o.idx = __shfl_xor(k.idx, off);
+        if (key_less(o, k)) k = o;
+    }
+    return k;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off); if (o < v) v = o; }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: kd-tree neighbour query, one lane per agent.
+constexpr int KD_STACK = 48;
+constexpr int K1_THREADS = 64;
+
+struct NbrListLds {                      // [slot][lane] layout: consecutive lanes hit consecutive banks
+    double dsq[K_MAX][K1_THREADS];
+    int id[K_MAX][K1_THREADS];
+    int stack[KD_STACK][K1_THREADS];
+};
+
+// the `neighbors.pop(); append; sort(key=distSq)` sequence of agent.py:87-90: stable, new element after equals
+__device__ __forceinline__ void nbr_insert(NbrListLds &L, int lane, int &cnt, int maxn, int id, double dsq) {
+    if (cnt == maxn) cnt--;
+    int j = cnt;
+    while (j > 0 && L.dsq[j - 1][lane] > dsq) {
+        L.dsq[j][lane] = L.dsq[j - 1][lane];
+        L.id[j][lane] = L.id[j - 1][lane];
+        j--;
+    }
+    L.dsq[j][lane] = dsq;
+    L.id[j][lane] = id;
+    cnt++;
+}
+
+__device__ __forceinline__ double box_dist_sq(const KdNode &c, V3 p) {     // kdTree.py:132-145
+    double t, s;
+    t = fmax(0.0, c.mn[0] - p.x); s = t * t;
+    t = fmax(0.0, p.x - c.mx[0]); s = s + t * t;
+    t = fmax(0.0, c.mn[1] - p.y); s = s + t * t;
+    t = fmax(0.0, p.y - c.mx[1]); s = s + t * t;
+    t = fmax(0.0, c.mn[2] - p.z); s = s + t * t;
+    t = fmax(0.0, p.z - c.mx[2]); s = s + t * t;
+    return s;
+}
+
+__global__ __launch_bounds__(K1_THREADS) void k_neighbors_kd(DeviceView d, Params P) {
+    __shared__ NbrListLds L;
+    const int lane = threadIdx.x;
+    const int agent = d.shard_begin + blockIdx.x * K1_THREADS + lane;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    const PubRec me = d.rec[agent];
+    d.coll_new[agent] = 0;
+    d.nbr_valid[agent] = 0;
+    d.nbr_n[agent] = 0;
+    int st = 0;
+    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) return;          // mampenv.py:35
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    // SCA / RVO / S-RVO skip computeNeighbors on the bootstrap step (scaPolicy.py:34); ORCA does not (orca3dPolicy.py:51)
+    if (!orca && l3norm_f32zero(vA, false) <= 1e-5) return;
+    const V3 pA = v3(me.px, me.py, me.pz);
+    const double rangeSq = P.neighbor_dist * P.neighbor_dist;                      // scaPolicy.py:112
+    const int maxn = P.max_neighbors;
+    int cnt = 0;
+    bool coll = false;
+    for (int phase = 0; phase < 2; phase++) {                                      // obstacles first (scaPolicy.py:114-116)
+        const bool ob = (phase == 0);
+        const int total = ob ? d.m : d.n;
+        if (total <= 0) continue;
+        const KdNode *tree = ob ? d.otree : d.atree;
+        const int32_t *perm = ob ? d.operm : d.aperm;
+        int sp = 0;
+        L.stack[sp++][lane] = 0;
+        while (sp > 0) {
+            const int node = L.stack[--sp][lane];
+            const KdNode nd = tree[node];
+            if (nd.end - nd.begin <= MAX_LEAF) {
+                for (int i = nd.begin; i < nd.end; i++) {
+                    const int o = perm[i];
+                    if (ob) {                                                      // agent.py:101-124
+                        const ObsRec r = d.obs[o];
+                        const V3 pO = v3(r.px, r.py, r.pz);
+                        const double distSq1 = l3normsq(pA, pO);
+                        const double t = l3norm(pA, pO) - r.radius;
+                        const double distSq = t * t;
+                        const double rs = me.radius + r.radius;
+                        if (distSq1 < rs * rs && distSq < rangeSq) {
+                            if (!coll) { coll = true; cnt = 0; }
+                            nbr_insert(L, lane, cnt, maxn, o | NBR_OBSTACLE_BIT, distSq);
+                        } else if (!coll && distSq < rangeSq) {
+                            nbr_insert(L, lane, cnt, maxn, o | NBR_OBSTACLE_BIT, distSq);
+                        }
+                    } else if (o != agent) {                                       // agent.py:79-99
+                        const PubRec r = d.rec[o];
+                        const double distSq = l3normsq(pA, v3(r.px, r.py, r.pz));
+                        const double rs = me.radius + r.radius;
+                        if (distSq < rs * rs && distSq < rangeSq) {
+                            if (!coll) { coll = true; cnt = 0; }
+                            nbr_insert(L, lane, cnt, maxn, o, distSq);
+                        } else if (!coll && distSq < rangeSq) {
+                            nbr_insert(L, lane, cnt, maxn, o, distSq);
+                        }
+                    }
+                }
+            } else {                                                               // kdTree.py:147-156
+                const double dl = box_dist_sq(tree[nd.left], pA);
+                const double dr = box_dist_sq(tree[nd.right], pA);
+                int first, second;
+                double dfirst, dsecond;
+                if (dl < dr) { first = nd.left; second = nd.right; dfirst = dl; dsecond = dr; }
+                else { first = nd.right; second = nd.left; dfirst = dr; dsecond = dl; }
+                if (dfirst < rangeSq) {
+                    if (sp + 2 > KD_STACK) { st |= ST_KD_STACK; }
+                    else {
+                        if (dsecond < rangeSq) L.stack[sp++][lane] = second;
+                        L.stack[sp++][lane] = first;
+                    }
+                }
+            }
+        }
+    }
+    d.nbr_n[agent] = cnt;
+    d.nbr_valid[agent] = 1;
+    d.coll_new[agent] = coll ? 1u : 0u;
+    for (int k = 0; k < K_MAX; k++) {
+        d.nbr_id[agent * K_MAX + k] = (k < cnt) ? L.id[k][lane] : -1;
+        d.nbr_dsq[agent * K_MAX + k] = (k < cnt) ? L.dsq[k][lane] : 0.0;
+    }
+    if (st) atomicOr(&d.status[agent], st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2/K3: one wavefront per agent.
+constexpr int SOLVE_WAVES = 4;
+constexpr int SLOT = 16;                  // doubles per neighbour slot in LDS
+constexpr int NR = 8;                     // candidate rounds: 8 * 64 = 512 table candidates
+
+struct SolveLds {
+    double slot[SOLVE_WAVES][K_MAX][SLOT];
+    Plane planes[SOLVE_WAVES][K_MAX];
+    Plane proj[SOLVE_WAVES][K_MAX];
+};
+
+struct CandTab {
+    const double *unit;     // SoA [3][num_N]
+    const double *phi;      // [num_N] phi numerators of the unit directions
+    int num_N;
+    double rad1;
+    int vp_idx;             // generation index of the v_pref candidate (= 2 * num_N)
+};
+__device__ __forceinline__ V3 cand_from_idx(const CandTab &T, int idx, V3 vpref) {
+    if (idx >= T.vp_idx) return vpref;
+    const int n0 = (idx >= T.num_N) ? idx - T.num_N : idx;
+    const double rad = (idx >= T.num_N) ? T.rad1 : 0.5;
+    return v3(rad * T.unit[n0], rad * T.unit[T.num_N + n0], rad * T.unit[2 * T.num_N + n0]);
+}
+__device__ __forceinline__ double phi_from_idx(const CandTab &T, int idx, V3 vpref) {
+    if (idx >= T.vp_idx) return get_phi_num(vpref.x, vpref.y);
+    const int n0 = (idx >= T.num_N) ? idx - T.num_N : idx;
+    return T.phi[n0];
+}
+
+// generalized pass-on-the-right (scaPolicy.py:119-145) on a list given as per-lane slots.
+// inlist/key/idx: NR table slots per lane + one extra slot (v_pref) that only lane 0 owns.
+// Order of the reference's sorted list == lexicographic (key, idx).
+__device__ int select_from_list(bool shunted, double thr, int count, const bool inl[NR + 1], const double key[NR + 1],
+                                const int idx[NR + 1], const V3 cand[NR + 1], const CandTab &T, V3 vpref, V3 vA64) {
+    Key3 best = key_invalid();
+#pragma unroll
+    for (int r = 0; r <= NR; r++)
+        if (inl[r]) { Key3 k; k.a = key[r]; k.b = 0.0; k.idx = idx[r]; if (key_less(k, best)) best = k; }
+    best = wave_argmin(best);
+    if (!shunted || count <= 1) return best.idx;
+    const V3 c0 = cand_from_idx(T, best.idx, vpref);
+    const double s0 = l3norm(c0, vA64);
+    // first element (in sorted order) that breaks the prefix
+    bool pass[NR + 1];
+    Key3 fail = key_invalid();
+#pragma unroll
+    for (int r = 0; r <= NR; r++) {
+        pass[r] = false;
+        if (inl[r]) {
+            const double s = l3norm(cand[r], vA64);
+            pass[r] = fabs(s0 - s) < thr;
+            if (!pass[r]) { Key3 k; k.a = key[r]; k.b = 0.0; k.idx = idx[r]; if (key_less(k, fail)) fail = k; }
+        }
+    }
+    fail = wave_argmin(fail);
+    // vA_phi_min / vA_phi_max: first extremal phi in sorted order
+    Key3 kmin = key_invalid(), kmax = key_invalid();
+#pragma unroll
+    for (int r = 0; r <= NR; r++) {
+        if (inl[r]) {
+            Key3 me; me.a = key[r]; me.b = 0.0; me.idx = idx[r];
+            if (key_less(me, fail)) {
+                const double ph = phi_from_idx(T, idx[r], vpref);
+                Key3 a; a.a = ph; a.b = key[r]; a.idx = idx[r];
+                Key3 b; b.a = -ph; b.b = key[r]; b.idx = idx[r];
+                if (key_less(a, kmin)) kmin = a;
+                if (key_less(b, kmax)) kmax = b;
+            }
+        }
+    }
+    kmin = wave_argmin(kmin);
+    kmax = wave_argmin(kmax);
+    const double phi_min = kmin.a / EPS5, phi_max = (-kmax.a) / EPS5;
+    if (fabs(phi_max - phi_min) <= PI) return kmin.idx;
+    return kmax.idx;
+}
+
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
+    __shared__ SolveLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
+    if (agent >= d.shard_begin + d.shard_count) return;                             // wave-uniform
+    const PubRec me = d.rec[agent];
+    float *act_out = d.action + (size_t)agent * 8;
+    int32_t *diag = d.diag + (size_t)agent * 8;
+    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35: row stays zero
+        if (lane < 8) { act_out[lane] = 0.0f; diag[lane] = -1; }
+        if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
+        return;
+    }
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    const V3 pA = v3(me.px, me.py, me.pz);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const V3 vA64 = to_v3(vA);
+    const double rA = me.radius;
+    const double ps = d.pref_speed[agent];
+    const double yaw = d.heading[agent * 3 + 0], pitch = d.heading[agent * 3 + 1];
+    int st = 0;
+    V3 vpref;
+    if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
+    const bool first_step = l3norm_f32zero(vA, orca) <= 1e-5;                        // scaPolicy.py:34 / orca3dPolicy.py:53
+    int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
+    V3 vpost;
+    const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    if (first_step) {
+        vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
+    } else {
+        // ---- per-neighbour constants: lane j builds neighbour j, stages it in LDS -------------------
+        double (*slot)[SLOT] = S.slot[wid];
+        if (lane < K) {
+            const int nid = d.nbr_id[agent * K_MAX + lane];
+            V3 pB; F3 vB; double rB; bool stat; bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
+            if (isob) {
+                const ObsRec o = d.obs[nid & ~NBR_OBSTACLE_BIT];
+                pB = v3(o.px, o.py, o.pz); vB.x = vB.y = vB.z = 0.0f; rB = o.radius; stat = true;   // obstacle.py:22
+            } else {
+                const PubRec o = d.rec[nid];
+                pB = v3(o.px, o.py, o.pz); vB.x = o.vx; vB.y = o.vy; vB.z = o.vz; rB = o.radius;
+                stat = (o.flags & FLAG_AT_GOAL) != 0;
+            }
+            double *s = slot[lane];
+            if (!orca) {
+                const Cone c = make_cone(pA, vA, rA, pB, vB, rB, stat);
+                s[0] = c.apex.x; s[1] = c.apex.y; s[2] = c.apex.z; s[3] = c.pAB.x; s[4] = c.pAB.y; s[5] = c.pAB.z;
+                s[6] = c.g; s[7] = c.R; s[8] = c.absSq;
+            } else {
+                const OrcaOb o = make_orca(P, pA, vA, rA, pB, vB, rB, isob);
+                s[0] = o.pl.p.x; s[1] = o.pl.p.y; s[2] = o.pl.p.z; s[3] = o.pl.n.x; s[4] = o.pl.n.y; s[5] = o.pl.n.z;
+                s[6] = o.g; s[7] = o.R; s[8] = o.absSq; s[9] = o.relPos.x; s[10] = o.relPos.y; s[11] = o.relPos.z;
+                const bool moving = o.vB_f32 ? (normf(o.vB) > (float)1e-5) : false;
+                F3 h; h.x = 0.5f * (vA.x + vB.x); h.y = 0.5f * (vA.y + vB.y); h.z = 0.5f * (vA.z + vB.z);
+                s[12] = moving ? (double)h.x : 0.0; s[13] = moving ? (double)h.y : 0.0; s[14] = moving ? (double)h.z : 0.0;
+                Plane pl; pl.p = o.pl.p; pl.n = o.pl.n;
+                S.planes[wid][lane] = pl;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): LDS writes of this wave are visible to it
+        if (pol == POL_ORCA_LP) {
+            // ---- K3: LP3 (+LP4) -- orca3dPolicyOfficial.py:108-113.  Scalar chain, lane 0 drives.
+            V3 nv = v3(0, 0, 0);
+            int pf = 0, l4 = 0;
+            if (lane == 0) {
+                pf = lp3(S.planes[wid], K, P.max_speed, vpref, false, nv);
+                if (pf < K) { lp4(S.planes[wid], K, pf, P.max_speed, nv, S.proj[wid]); l4 = 1; }
+            }
+            vpost = v3(__shfl(nv.x, 0), __shfl(nv.y, 0), __shfl(nv.z, 0));
+            dg_pfail = __shfl(pf, 0);
+            dg_lp4 = __shfl(l4, 0);
+        } else {
+            // ---- K2: candidate sweep ---------------------------------------------------------------
+            CandTab T;
+            T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;                 // scaPolicy.py:188-190
+            T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
+            T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
+            T.vp_idx = 2 * T.num_N;
+            if (!candidate_speeds(ps, T.rad1)) { st |= ST_BAD_PREF_SPEED; T.rad1 = ps; }
+            const int nround = T.vp_idx >> 6;                                          // 8 or 4
+            const double nvA = (double)normf(vA);
+            V3 cand[NR + 1];
+            V3 sh[NR];                                  // cand + pA, hoisted (same value as in the reference expression)
+            int idx[NR + 1];
+            unsigned okp = 0;                           // posture bits (util.py:6-20)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                idx[r] = r * 64 + lane;
+                if (r < nround) {
+                    cand[r] = cand_from_idx(T, idx[r], vpref);
+                    sh[r] = cand[r] + pA;
+                    if (posture_ok(P, vA, nvA, pA.z, cand[r])) okp |= 1u << r;
+                } else { cand[r] = v3(0, 0, 0); sh[r] = v3(0, 0, 0); }
+            }
+            cand[NR] = vpref;
+            idx[NR] = T.vp_idx;
+            const bool vp_post = posture_ok(P, vA, nvA, pA.z, vpref);
+            unsigned alive = okp;
+            // table candidates: neighbours outer (constants broadcast from LDS), candidates in registers
+            for (int j = 0; j < K; j++) {
+                const double *s = slot[j];
+                if (!orca) {
+                    Cone c;
+                    c.apex = v3(s[0], s[1], s[2]); c.pAB = v3(s[3], s[4], s[5]); c.g = s[6];
+#pragma unroll
+                    for (int r = 0; r < NR; r++)
+                        if (r < nround && cone_hit(c, sh[r])) alive &= ~(1u << r);
+                } else {
+                    Plane pl; pl.p = v3(s[0], s[1], s[2]); pl.n = v3(s[3], s[4], s[5]);
+#pragma unroll
+                    for (int r = 0; r < NR; r++)
+                        if (r < nround && !in_orca(pl, cand[r])) alive &= ~(1u << r);
+                }
+                if (__ballot(alive != 0) == 0) break;
+            }
+            // v_pref candidate: lane j tests neighbour j
+            bool vp_hit = false;
+            if (lane < K) {
+                const double *s = slot[lane];
+                if (!orca) {
+                    Cone c; c.apex = v3(s[0], s[1], s[2]); c.pAB = v3(s[3], s[4], s[5]); c.g = s[6];
+                    vp_hit = cone_hit(c, vpref + pA);
+                } else {
+                    Plane pl; pl.p = v3(s[0], s[1], s[2]); pl.n = v3(s[3], s[4], s[5]);
+                    vp_hit = !in_orca(pl, vpref);
+                }
+            }
+            const bool vp_ok = vp_post && (__ballot(vp_hit) == 0);
+            int n_suit = vp_ok ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) n_suit += __popcll(__ballot((alive >> r) & 1u));
+            dg_nsuit = n_suit;
+            const bool shunted = (pol == POL_SCA || pol == POL_SRVO);
+            bool inl[NR + 1];
+            double key[NR + 1];
+            int chosen;
+            if (n_suit > 0) {
+                dg_fallback = 0;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    inl[r] = (alive >> r) & 1u;
+                    key[r] = inl[r] ? l3norm(cand[r], vpref) : 0.0;                    // scaPolicy.py:219
+                }
+                inl[NR] = vp_ok && lane == 0;
+                key[NR] = l3norm(vpref, vpref);
+                chosen = select_from_list(shunted, pol == POL_SCA ? 3e-2 : 1e-1, n_suit, inl, key, idx, cand, T, vpref, vA64);
+            } else {
+                // ---- no suitable candidate: compute_without_suitV (scaPolicy.py:148-165,224-238) -----------
+                dg_fallback = 1;
+                double tcm[NR];
+                bool have[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) { tcm[r] = 0.0; have[r] = false; }
+                for (int j = 0; j < K; j++) {
+                    const double *s = slot[j];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        if (r < nround && ((okp >> r) & 1u)) {
+                            V3 pAB, vd; double g, R, absSq;
+                            if (!orca) {
+                                pAB = v3(s[3], s[4], s[5]); g = s[6]; R = s[7]; absSq = s[8];
+                                vd = sh[r] - v3(s[0], s[1], s[2]);
+                            } else {
+                                pAB = v3(s[9], s[10], s[11]); g = s[6]; R = s[7]; absSq = s[8];
+                                vd = cand[r] - v3(s[12], s[13], s[14]);                 // h == 0 when vB is static: v - 0 == v
+                            }
+                            if (cone_hit_vdif(pAB, g, vd)) {
+                                const double tc = cone_tc(pAB, absSq, R, vd, &st);
+                                if (!have[r] || tc < tcm[r]) { tcm[r] = tc; have[r] = true; }
+                            }
+                        }
+                    }
+                }
+                // v_pref candidate, lanes over neighbours
+                double tcv = INFINITY;
+                if (lane < K && vp_post) {
+                    const double *s = slot[lane];
+                    V3 pAB, vd; double g, R, absSq;
+                    if (!orca) { pAB = v3(s[3], s[4], s[5]); g = s[6]; R = s[7]; absSq = s[8]; vd = (vpref + pA) - v3(s[0], s[1], s[2]); }
+                    else { pAB = v3(s[9], s[10], s[11]); g = s[6]; R = s[7]; absSq = s[8]; vd = vpref - v3(s[12], s[13], s[14]); }
+                    if (cone_hit_vdif(pAB, g, vd)) tcv = cone_tc(pAB, absSq, R, vd, &st);
+                }
+                tcv = wave_min(tcv);
+                if (tcv == INFINITY) tcv = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    inl[r] = r < nround;
+                    key[r] = inl[r] ? (0.2 / (tcm[r] + 1e-5)) + l3norm(cand[r], vpref) : 0.0;   // scaPolicy.py:231-234
+                }
+                inl[NR] = lane == 0;
+                key[NR] = (0.2 / (tcv + 1e-5)) + l3norm(vpref, vpref);
+                chosen = select_from_list(shunted, pol == POL_SCA ? 5e-2 : 1e-1, T.vp_idx + 1, inl, key, idx, cand, T, vpref, vA64);
+            }
+            dg_chosen = chosen;
+            vpost = trunc5(cand_from_idx(T, chosen, vpref));                          // scaPolicy.py:239
+        }
+    }
+    double act[7];
+    cartesian2spherical(yaw, pitch, vpost, pol == POL_ORCA_LP, act);
+    if (lane < 7) {
+        double a = act[0];
+#pragma unroll
+        for (int k = 1; k < 7; k++) if (lane == k) a = act[k];
+        act_out[lane] = (float)a;                                                     // mampenv.py:31,40 float32 row
+    }
+    if (lane == 7) act_out[7] = 0.0f;
+    if (lane == 0) {
+        diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
+        d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
+        const int stw = __builtin_amdgcn_readfirstlane(st);
+        if (stw) atomicOr(&d.status[agent], stw);
+        if (d.coll_new[agent]) d.rec[agent].flags = me.flags | FLAG_COLLISION;        // agent.py:84 is_collision = True
+    }
+    // status bits raised by other lanes (fallback sqrt domain)
+    if (lane != 0 && st) atomicOr(&d.status[agent], st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: MACAEnv second loop.  update_velocitie (mampenv.py:83-105) writes the moved record to rec_new;
+// check_agent_state (mampenv.py:61-80) then needs, for a pair i<j, new_i vs OLD_j (j not yet moved when i is
+// checked) and new_j vs new_i -- so collide reads both buffers.
+__global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    PubRec r = d.rec[agent];
+    const float *act = d.action + (size_t)agent * 8;
+    const double speed = (double)act[3];
+    const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
+    const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
+    const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
+    const double dx = speed * cos(b) * cos(a) * P.time_step;
+    const double dy = speed * cos(b) * sin(a) * P.time_step;
+    const double dz = speed * sin(b) * P.time_step;
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    d.total_dist[agent] += len;
+    r.px += dx; r.py += dy; r.pz += dz;
+    r.vx = act[0]; r.vy = act[1]; r.vz = act[2];
+    d.heading[agent * 3 + 0] = a; d.heading[agent * 3 + 1] = b; d.heading[agent * 3 + 2] = g;
+    if (!(r.flags & FLAG_AT_GOAL)) d.step_num[agent] += 1;
+    d.rec_new[agent] = r;
+}
+
+// brute-force pair scan, one wave per agent (used while n is small; the grid variant replaces it for large n)
+__global__ __launch_bounds__(256) void k_collide(DeviceView d, Params P) {
+    const int lane = threadIdx.x & 63;
+    const int agent = d.shard_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (agent >= d.shard_begin + d.shard_count) return;
+    const PubRec me = d.rec_new[agent];
+    const V3 p = v3(me.px, me.py, me.pz);
+    const V3 p_old = v3(d.rec[agent].px, d.rec[agent].py, d.rec[agent].pz);
+    const bool me_goal = (me.flags & FLAG_AT_GOAL) != 0;
+    bool hit = false;
+    for (int o = lane; o < d.m; o += 64) {
+        const ObsRec r = d.obs[o];
+        if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;       // mampenv.py:63-66
+    }
+    for (int j = lane; j < d.n; j += 64) {
+        if (j == agent) continue;
+        const PubRec rn = d.rec_new[j];
+        const PubRec ro = d.rec[j];
+        const double rs = me.radius + rn.radius;
+        const bool j_goal = (rn.flags & FLAG_AT_GOAL) != 0;
+        // new-new is seen by whichever of the two is checked second; mixed pairs by the first one
+        bool c = l3norm(p, v3(rn.px, rn.py, rn.pz)) <= rs;
+        if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);          // agent moved, j not yet
+        else c = c || (l3norm(v3(rn.px, rn.py, rn.pz), p_old) <= rs);                 // j moved, agent not yet
+        if (c && !me_goal) hit = true;                                                // mampenv.py:72-75
+        (void)j_goal;
+    }
+    const bool any = __ballot(hit) != 0;
+    if (lane == 0) {
+        uint32_t f = me.flags;
+        if (any) f |= FLAG_COLLISION;
+        if (d.total_dist[agent] > d.max_run_dist[agent]) f |= FLAG_TIMEOUT;           // mampenv.py:77-79
+        d.coll_new[agent] = f;                                                        // staged; k_finish commits
+    }
+}
+
+// commit flags, is_done (mampenv.py:51-59), publish rec <- rec_new
+__global__ __launch_bounds__(256) void k_finish(DeviceView d, Params P) {
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    PubRec r = d.rec_new[agent];
+    uint32_t f = d.coll_new[agent];
+    const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
+    if (l3norm(v3(r.px, r.py, r.pz), g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;
+    r.flags = f;
+    d.rec[agent] = r;
+    if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(d.done_count, 1);
+}
+
+}  // namespace sca
