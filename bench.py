@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/sec of the batched velocity-solver hot path on MI355X.
+
+A "step" = one pass of the hot path over the whole swarm: kd-tree neighbour selection -> RVO-cone / ORCA
+half-space construction -> 513-candidate sweep + selection (or LP) -> env update (integrate + collision / goal
+flags), with the state resident in HBM when the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workloads (BASELINE.json configs): c2 = circle N=1024 SCA (default at 1 GPU), c3 = random N=4096 ORCA3D,
+c4 = circle N=100000 SCA, c5 = take-off/landing N=16384 mixed SCA + S-RVO3D.
+SCA's preferred velocity comes from the reference's host-side Dubins tracker (scaPolicy.py:264-338), which is
+outside the kernel boundary; the bench feeds the straight-line rule (rvo3dPolicy.py:182-196)
+computed on the device instead, and says so in `config`.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# algorithmic bytes per agent-step, fp64-position records: 48 B own record + 32 B private inputs
+# + 16 neighbours x 48 B + 32 B action row
+BYTES_PER_AGENT_STEP = 48 + 32 + 16 * 48 + 32
+
+WORKLOADS = {
+    'c2': dict(kind='circle', n=1024, policy='sca', desc='c2: circle N=1024, SCA policy'),
+    'c3': dict(kind='random', n=4096, policy='orca', desc='c3: random N=4096, ORCA3D policy (sampled, as run_orca.py)'),
+    'c3lp': dict(kind='random', n=4096, policy='orcalp', desc='c3: random N=4096, ORCA3D Official (LP1-4)'),
+    'c4': dict(kind='circle', n=100000, policy='sca', desc='c4: circle N=100000, SCA policy'),
+    'c5': dict(kind='takeoff', n=16384, policy='mixed', desc='c5: take-off/landing N=16384, SCA even ids / S-RVO3D odd ids'),
+}
+POL = {'sca': 0, 'rvo': 1, 'srvo': 2, 'orca': 3, 'orcalp': 4}
+
+
+def build_scene(w, n):
+    from sca_amd import scenarios, solver as S
+    if w['kind'] == 'circle':
+        sc = scenarios.circle(n)
+    elif w['kind'] == 'random':
+        sc = scenarios.random_cube(n, seed=0)
+    else:
+        sc = scenarios.takeoff_landing(n)
+    n = len(sc['start'])
+    if w['policy'] == 'mixed':
+        policy = np.where(np.arange(n) % 2 == 0, 0, 2).astype(np.uint8)
+    else:
+        policy = np.full(n, POL[w['policy']], np.uint8)
+    return dict(n=n, sc=sc, policy=policy, radius=np.full(n, 0.5), pref_speed=np.full(n, 1.0),
+                zaxis=S.zaxis_flags(sc['start'], sc['goal']), max_run_dist=scenarios.max_run_dist(sc['start'], sc['goal']))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
+    ap.add_argument('--agents', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: libsca_hip has no CPU path')
+
+    from sca_amd import solver as S
+    from sca_amd.distributed import ShardedStepper
+
+    wname = args.workload or 'c2'
+    w = WORKLOADS[wname]
+    n_req = args.agents or w['n']
+    if world > 1:
+        n_req = ((n_req + world - 1) // world) * world
+    scene = build_scene(w, n_req)
+    n = scene['n']
+    sc = scene['sc']
+
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])), device=local_rank)
+    sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
+    sol.set_agents(scene['radius'], scene['pref_speed'], sc['goal'][:, :3], scene['policy'], scene['zaxis'],
+                   scene['max_run_dist'])
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist)
+
+    # warm-up (untimed): includes the bootstrap step (velocity 0 -> 0.3 v_pref) so the real branch runs afterwards
+    stepper.run(args.warmup)
+    stepper.sync()
+    sol.agent_steps(reset=True)
+    sol.set_profiling(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    stepper.run(args.steps)
+    stepper.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    sol.set_profiling(False)
+    my_steps = sol.agent_steps(reset=True)
+    kms = sol.kernel_ms()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([my_steps], dtype=torch.int64, device='cuda')
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_steps = int(c.item())
+    else:
+        total_steps = my_steps
+
+    if rank == 0:
+        value = total_steps / dt
+        per_launch_agents = my_steps / max(args.steps, 1)
+        solve_s = kms['solve'] * 1e-3
+        achieved = (BYTES_PER_AGENT_STEP * per_launch_agents / solve_s / 1e9) if solve_s > 0 else 0.0
+        out = {
+            'metric': 'agent_steps_per_sec', 'value': value, 'unit': 'agent-steps/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': w['desc'], 'agents': n, 'neighbor_search': 'kd-tree replica (host build, device query)',
+                       'v_pref': 'straight-line rule on device (Dubins tracker is outside the kernel boundary)',
+                       'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'
+                       if world > 1 else 'single GPU', 'agent_steps_timed': total_steps},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_solve',
+                         'kernel_ms': kms['solve'], 'neighbors_kernel_ms': kms['neighbors'],
+                         'bytes_per_agent_step': BYTES_PER_AGENT_STEP,
+                         'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(scene, sol, S)
+        print(json.dumps(out), flush=True)
+    sol.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, sol, S):
+    """The CPU oracle (decision-identical C restatement of the reference, oracle/sca_oracle.c) timed on this box's host
+    cores on a bounded sample: policy passes over the current device state.  Also reports max |v_hip - v_oracle|."""
+    from oracle import oracle as orc
+    n = scene['n']
+    sc = scene['sc']
+    st = sol.get_state()
+    cores = os.cpu_count() or 1
+    perm = sol.get_kd_perm()
+    vmode = np.zeros(n, np.uint8)
+    args = (st['pos'], st['vel'], st['heading'], scene['radius'], scene['pref_speed'], st['flags'], sc['goal'][:, :3],
+            scene['policy'], scene['zaxis'], np.zeros((n, 3)), vmode, perm, sc['obs_pos'], sc['obs_radius'])
+    t0 = time.perf_counter()
+    ref = orc.policy_step(*args, nthreads=cores)
+    reps = 1
+    one = time.perf_counter() - t0
+    while time.perf_counter() - t0 < 10.0 and reps < 50:
+        orc.policy_step(*args, nthreads=cores)
+        reps += 1
+    dt = time.perf_counter() - t0
+    active = int(((st['flags'] & 7) == 0).sum())
+    # the same pass on the GPU for the parity number
+    sol.policy_pass(S.NBR_KDTREE)
+    a = sol.actions()
+    dv = float(np.abs(a[:, :3] - ref['action'][:, :3]).max())
+    return {'value': active * reps / dt, 'unit': 'agent-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} policy passes over the {n}-agent state after the timed steps ({one:.2f} s each), '
+                      f'OpenMP over agents', 'max_abs_dv_vs_hip': dv}
+
+
+if __name__ == '__main__':
+    main()

@@ -112,15 +112,27 @@ int sca_synchronize(sca_ctx *ctx);
 /* multi-GPU / interop ------------------------------------------------------------------------------ */
 /* This rank solves agents [begin, begin+count); all agents' public records must be present. */
 int sca_set_shard(sca_ctx *ctx, int begin, int count);
-/* Device address and byte size of the public-record array (48 B per agent: pos f64x3, vel f32x3, flags u32,
- * radius f64) so that an RCCL all-gather (torch.distributed) can exchange shards in place. */
-int sca_public_records(sca_ctx *ctx, void **device_ptr, int64_t *bytes_per_agent);
-/* Use caller-owned device memory (e.g. a torch tensor) for the public records; NULL restores the internal one. */
-int sca_bind_public_records(sca_ctx *ctx, void *device_ptr);
+/* Device address of a public-record array (48 B per agent: pos f64x3, vel f32x3, flags u32, radius f64).
+ * which = 0: the current records; which = 1: the "moved" records written by sca_step_begin, i.e. the buffer an
+ * RCCL all-gather (torch.distributed) exchanges between sca_step_begin and sca_step_end. */
+int sca_public_records(sca_ctx *ctx, int which, void **device_ptr, int64_t *bytes_per_agent);
+/* Use caller-owned device memory (e.g. two torch tensors of max_agents*48 bytes) for the two record arrays;
+ * NULL, NULL restores the internal ones. */
+int sca_bind_public_records(sca_ctx *ctx, void *current, void *moved);
+/* One step split around the exchange: begin = kd build + neighbours + solve + integrate for this rank's shard
+ * (writes the shard's moved records); [all-gather of the moved records]; end = collision / goal flags + publish. */
+int sca_step_begin(sca_ctx *ctx, int neighbor_mode);
+int sca_step_end(sca_ctx *ctx);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the internal stream. */
 int sca_set_stream(sca_ctx *ctx, void *hip_stream);
 /* average device time of the kernels of the last sca_policy_pass / sca_run_steps, measured with HIP events */
 int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float *update_ms);
+
+/* with profiling on, sca_run_steps brackets every kernel launch of the policy pass with HIP events on its stream;
+ * sca_synchronize() then folds them into the averages sca_last_kernel_ms() returns */
+int sca_set_profiling(sca_ctx *ctx, int on);
+/* number of agents that entered find_next_action since the last reset (the metric's "agent-steps") */
+int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 
 /* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
 /* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */

@@ -45,10 +45,14 @@ SIGNATURES = {
     'sca_run_steps': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'sca_synchronize': (C.c_int, [C.c_void_p]),
     'sca_set_shard': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    'sca_public_records': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
-    'sca_bind_public_records': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'sca_public_records': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'sca_bind_public_records': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sca_step_begin': (C.c_int, [C.c_void_p, C.c_int]),
+    'sca_step_end': (C.c_int, [C.c_void_p]),
     'sca_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
+    'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
+    'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     'sca_candidate_table': (C.c_int, [C.c_int, dp, dp]),
     'sca_kd_build_host': (C.c_int, [C.c_int, dp, ip, dp]),
 }

@@ -100,10 +100,14 @@ struct sca_ctx {
     int max_n = 0, max_m = 0, n = 0, m = 0;
     Params P{};
     DeviceView d{};
-    PubRec *rec_own = nullptr;
+    PubRec *rec_own = nullptr, *rec_new_own = nullptr;
     hipStream_t stream_own = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms_nbr = 0, ms_solve = 0, ms_update = 0;
+    // per-launch profiling of sca_run_steps: event pairs around every k_neighbors_kd / k_solve launch
+    bool profiling = false;
+    std::vector<hipEvent_t> pool;       // 3 events per step: before K1, before K2, after K2
+    int pool_used = 0;
     std::vector<double> h_pos;          // host mirror of positions for the kd build
     bool h_pos_valid = false;
     std::vector<int32_t> h_perm;
@@ -187,7 +191,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     DeviceView &d = c->d;
     int r = 0;
     r |= dalloc(c, &c->rec_own, N); d.rec = c->rec_own;
-    r |= dalloc(c, &d.rec_new, N);
+    r |= dalloc(c, &c->rec_new_own, N); d.rec_new = c->rec_new_own;
     r |= dalloc(c, &d.heading, 3 * N); r |= dalloc(c, &d.goal, 3 * N); r |= dalloc(c, &d.pref_speed, N);
     r |= dalloc(c, &d.vpref_ext, 3 * N); r |= dalloc(c, &d.total_dist, N); r |= dalloc(c, &d.max_run_dist, N);
     r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.policy, N);
@@ -197,7 +201,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
-    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 1);
+    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 1); r |= dalloc(c, &d.agent_steps, 1);
     if (r) return SCA_ERR_HIP;
     // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
     std::vector<double> tab(768 + 384 + 256 + 128);
@@ -215,12 +219,13 @@ void sca_destroy(sca_ctx *c) {
     if (!c) return;
     DeviceView &d = c->d;
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
-    void *ptrs[] = {c->rec_own, d.rec_new, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
+    void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.action, d.vpref_used, d.diag, d.status,
-                    d.done_count, c->tab};
+                    d.done_count, d.agent_steps, c->tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->pool) (void)hipEventDestroy(e);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
     delete c;
 }
@@ -355,32 +360,56 @@ static int build_agent_tree(sca_ctx *c) {
     return 0;
 }
 
+static int pool_event(sca_ctx *c, hipEvent_t *out) {
+    if (c->pool_used == (int)c->pool.size()) {
+        hipEvent_t e;
+        CHK(c, hipEventCreate(&e));
+        c->pool.push_back(e);
+    }
+    *out = c->pool[c->pool_used++];
+    return 0;
+}
+
 static int launch_policy(sca_ctx *c, int mode, bool timed) {
     const DeviceView &d = c->d;
     if (mode != SCA_NBR_KDTREE) { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     if (int r = build_agent_tree(c)) return r;
     CHK(c, hipMemsetAsync(d.status, 0, sizeof(int32_t) * c->n, c->stream));
     const int cnt = d.shard_count;
-    if (timed) CHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
+    const bool prof = !timed && c->profiling && c->pool_used + 3 <= 3 * 4096;
+    if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2)) return SCA_ERR_HIP; }
+    if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
     hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_THREADS - 1) / K1_THREADS), dim3(K1_THREADS), 0, c->stream, d, c->P);
-    if (timed) CHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-    if (timed) CHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
     return 0;
 }
 
-static int launch_update(sca_ctx *c, bool timed) {
+static int launch_integrate(sca_ctx *c) {
+    const DeviceView &d = c->d;
+    const int cnt = d.shard_count;
+    hipLaunchKernelGGL(k_integrate, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    CHK(c, hipGetLastError());
+    return 0;
+}
+static int launch_collide_finish(sca_ctx *c, bool timed) {
     const DeviceView &d = c->d;
     const int cnt = d.shard_count;
     CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(k_integrate, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     hipLaunchKernelGGL(k_collide, dim3((cnt + 3) / 4), dim3(256), 0, c->stream, d, c->P);
-    hipLaunchKernelGGL(k_finish, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    // every agent's record is republished: the shard's from this rank's flags, the others' with a replicated at-goal test
+    hipLaunchKernelGGL(k_finish, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
     CHK(c, hipGetLastError());
     c->h_pos_valid = false;
     return 0;
+}
+static int launch_update(sca_ctx *c, bool timed) {
+    if (int r = launch_integrate(c)) return r;
+    return launch_collide_finish(c, timed);
 }
 
 int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
@@ -418,9 +447,49 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     return 0;
 }
 
+int sca_step_begin(sca_ctx *c, int neighbor_mode) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    if (int r = launch_policy(c, neighbor_mode, false)) return r;
+    return launch_integrate(c);
+}
+int sca_step_end(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    return launch_collide_finish(c, false);
+}
+
 int sca_synchronize(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
     CHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling && c->pool_used >= 3) {
+        double a = 0, b = 0;
+        const int steps = c->pool_used / 3;
+        for (int s = 0; s < steps; s++) {
+            float t0 = 0, t1 = 0;
+            CHK(c, hipEventElapsedTime(&t0, c->pool[3 * s], c->pool[3 * s + 1]));
+            CHK(c, hipEventElapsedTime(&t1, c->pool[3 * s + 1], c->pool[3 * s + 2]));
+            a += t0; b += t1;
+        }
+        c->ms_nbr = (float)(a / steps); c->ms_solve = (float)(b / steps);
+        c->pool_used = 0;
+    }
+    return 0;
+}
+
+int sca_set_profiling(sca_ctx *c, int on) {
+    if (!c) return SCA_ERR_ARG;
+    c->profiling = on != 0;
+    c->pool_used = 0;
+    return 0;
+}
+
+int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
+    if (!c) return SCA_ERR_ARG;
+    unsigned long long v = 0;
+    CHK(c, hipMemcpyAsync(&v, c->d.agent_steps, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (count) *count = (int64_t)v;
+    if (reset) { CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(v), c->stream)); CHK(c, hipStreamSynchronize(c->stream)); }
     return 0;
 }
 
@@ -470,15 +539,21 @@ int sca_set_shard(sca_ctx *c, int begin, int count) {
     c->d.shard_begin = begin; c->d.shard_count = count;
     return 0;
 }
-int sca_public_records(sca_ctx *c, void **device_ptr, int64_t *bytes_per_agent) {
+int sca_public_records(sca_ctx *c, int which, void **device_ptr, int64_t *bytes_per_agent) {
     if (!c) return SCA_ERR_ARG;
-    if (device_ptr) *device_ptr = c->d.rec;
+    if (device_ptr) *device_ptr = which ? (void *)c->d.rec_new : (void *)c->d.rec;
     if (bytes_per_agent) *bytes_per_agent = (int64_t)sizeof(PubRec);
     return 0;
 }
-int sca_bind_public_records(sca_ctx *c, void *device_ptr) {
+int sca_bind_public_records(sca_ctx *c, void *current, void *moved) {
     if (!c) return SCA_ERR_ARG;
-    c->d.rec = device_ptr ? (PubRec *)device_ptr : c->rec_own;
+    ARG(c, (current == nullptr) == (moved == nullptr));
+    if (current) {
+        // carry the live records over into the caller's buffer
+        CHK(c, hipMemcpyAsync(current, c->d.rec, sizeof(PubRec) * c->max_n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+        c->d.rec = (PubRec *)current; c->d.rec_new = (PubRec *)moved;
+    } else { c->d.rec = c->rec_own; c->d.rec_new = c->rec_new_own; }
     return 0;
 }
 int sca_set_stream(sca_ctx *c, void *hip_stream) {

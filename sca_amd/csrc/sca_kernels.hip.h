@@ -55,6 +55,7 @@ struct DeviceView {
     // candidate tables (SoA [3][N]) and phi numerators
     const double *unit256, *unit128, *phi256, *phi128;
     int32_t *done_count;     // [1] number of agents not yet done (k_finish)
+    unsigned long long *agent_steps;   // [1] running count of agents that entered the policy (mampenv.py:35-40)
     int n, m, shard_begin, shard_count;
 };
 
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     }
     if (lane == 7) act_out[7] = 0.0f;
     if (lane == 0) {
+        atomicAdd(d.agent_steps, 1ull);
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         const int stw = __builtin_amdgcn_readfirstlane(st);
@@ -570,17 +572,20 @@ __global__ __launch_bounds__(256) void k_collide(DeviceView d, Params P) {
     }
 }
 
-// commit flags, is_done (mampenv.py:51-59), publish rec <- rec_new
+// commit flags, is_done (mampenv.py:51-59), publish rec <- rec_new.  Runs over ALL agents: agents of other shards
+// (multi-GPU: their moved records arrived by all-gather) get the replicated at-goal test, the only flag of another
+// agent the policy ever reads (scaPolicy.py:53); their collision / timeout bits stay with the owning rank.
 __global__ __launch_bounds__(256) void k_finish(DeviceView d, Params P) {
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.shard_begin + d.shard_count) return;
+    const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.n) return;
+    const bool mine = agent >= d.shard_begin && agent < d.shard_begin + d.shard_count;
     PubRec r = d.rec_new[agent];
-    uint32_t f = d.coll_new[agent];
+    uint32_t f = mine ? d.coll_new[agent] : r.flags;
     const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
     if (l3norm(v3(r.px, r.py, r.pz), g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;
     r.flags = f;
     d.rec[agent] = r;
-    if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(d.done_count, 1);
+    if (mine && !(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(d.done_count, 1);
 }
 
 }  // namespace sca

@@ -1,0 +1,61 @@
+"""Agents sharded over the GPUs of one node: one process per GPU, contiguous id ranges, ONE exchange per step.
+
+Per step and rank:
+    step_begin : kd-tree (replicated) -> neighbours -> solve -> integrate, for the rank's shard only
+    all-gather : the shard's moved 48-byte public records (RCCL over xGMI; torch.distributed backend "nccl")
+    step_end   : collision flags for the shard (needs everyone's moved records), at-goal flags for everyone, publish
+Every rank holds all N public records; private per-agent state is only meaningful for the owner's shard.
+The backend only has to offer set_shard / step_begin / step_end / run_steps / synchronize plus `moved_records()`
+returning (full tensor, this rank's slice) -- tests drive the same class on CPU with gloo and a checker backend.
+"""
+
+
+class ShardedStepper:
+    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0):
+        self.sol = solver
+        self.rank, self.world = int(rank), int(world)
+        self.torch = torch_mod
+        self.dist = dist_mod
+        self.mode = mode
+        n = solver.n
+        if self.world > 1:
+            if n % self.world:
+                raise ValueError(f'{n} agents do not split evenly over {self.world} ranks')
+            self.count = n // self.world
+            self.begin = self.rank * self.count
+            solver.set_shard(self.begin, self.count)
+            self._setup_exchange()
+        else:
+            self.begin, self.count = 0, n
+
+    def _setup_exchange(self):
+        sol = self.sol
+        if hasattr(sol, 'moved_records'):
+            return
+        torch = self.torch
+        nbytes = sol.public_records(1)[1] * sol.n
+        dev = torch.device('cuda', torch.cuda.current_device())
+        self._cur = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self._moved = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        sol.bind_public_records(self._cur.data_ptr(), self._moved.data_ptr())
+        sol.set_stream(torch.cuda.current_stream().cuda_stream)
+        per = nbytes // self.world
+        self._slice = self._moved[self.rank * per:(self.rank + 1) * per]
+
+    def _moved_records(self):
+        if hasattr(self.sol, 'moved_records'):
+            return self.sol.moved_records()
+        return self._moved, self._slice
+
+    def run(self, steps):
+        if self.world == 1:
+            self.sol.run_steps(steps, self.mode)
+            return
+        for _ in range(int(steps)):
+            self.sol.step_begin(self.mode)
+            full, mine = self._moved_records()
+            self.dist.all_gather_into_tensor(full, mine)
+            self.sol.step_end()
+
+    def sync(self):
+        self.sol.synchronize()

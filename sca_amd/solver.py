@@ -1,0 +1,192 @@
+"""BatchedSolver: numpy-facing wrapper of one libsca_hip context (include/sca_hip.h).
+
+All heavy lifting happens in the HIP kernels; this class only marshals arrays.  It mirrors the quantities the
+reference keeps on its Agent objects (mamp/agents/agent.py) as structure-of-arrays.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+POL_SCA, POL_RVO3D, POL_SRVO3D, POL_ORCA3D, POL_ORCA3D_LP, POL_RVO3D_DUBINS = range(6)
+FLAG_AT_GOAL, FLAG_COLLISION, FLAG_TIMEOUT = 1, 2, 4
+NBR_KDTREE, NBR_GRID = 0, 1
+K = _lib.K
+
+
+class ScaError(RuntimeError):
+    pass
+
+
+class BatchedSolver:
+    def __init__(self, max_agents, max_obstacles=0, device=0, params=None):
+        self.L = _lib.lib()
+        p = _lib.Params()
+        self.L.sca_default_params(C.byref(p))
+        for k, v in (params or {}).items():
+            setattr(p, k, v)
+        self.params = p
+        self.ctx = C.c_void_p()
+        rc = self.L.sca_create(C.byref(p), int(device), int(max_agents), int(max_obstacles), C.byref(self.ctx))
+        if rc != 0:
+            msg = self.L.sca_last_error(self.ctx).decode() if self.ctx else 'sca_create failed'
+            if self.ctx:
+                self.L.sca_destroy(self.ctx)
+                self.ctx = None
+            raise ScaError(f'sca_create: {msg} (rc={rc})')
+        self.n = 0
+        self.m = 0
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.L.sca_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise ScaError(f'{what}: {self.L.sca_last_error(self.ctx).decode()} (rc={rc})')
+
+    # ---- static scene ------------------------------------------------------------------------------
+    def set_obstacles(self, pos, radius):
+        pos = _lib.as_d(pos).reshape(-1, 3)
+        radius = _lib.as_d(radius).reshape(-1)
+        self.m = len(radius)
+        self._chk(self.L.sca_set_obstacles(self.ctx, self.m, _lib.ptr(pos, C.c_double), _lib.ptr(radius, C.c_double)),
+                  'sca_set_obstacles')
+
+    def set_agents(self, radius, pref_speed, goal, policy, zaxis=None, max_run_dist=None):
+        radius = _lib.as_d(radius).reshape(-1)
+        n = len(radius)
+        pref_speed = _lib.as_d(np.broadcast_to(pref_speed, (n,)))
+        goal = _lib.as_d(goal).reshape(n, 3)
+        policy = np.ascontiguousarray(np.broadcast_to(policy, (n,)), np.uint8)
+        zaxis = np.zeros(n, np.uint8) if zaxis is None else np.ascontiguousarray(zaxis, np.uint8)
+        mrd = np.full(n, np.inf) if max_run_dist is None else _lib.as_d(max_run_dist).reshape(n)
+        self.n = n
+        self._chk(self.L.sca_set_agents(self.ctx, n, _lib.ptr(radius, C.c_double), _lib.ptr(pref_speed, C.c_double),
+                                        _lib.ptr(goal, C.c_double), _lib.ptr(policy, C.c_uint8),
+                                        _lib.ptr(zaxis, C.c_uint8), _lib.ptr(mrd, C.c_double)), 'sca_set_agents')
+
+    # ---- dynamic state -------------------------------------------------------------------------------
+    def set_state(self, pos, vel, heading, flags, total_dist=None, step_num=None):
+        n = self.n
+        pos = _lib.as_d(pos).reshape(n, 3)
+        vel = np.ascontiguousarray(vel, np.float32).reshape(n, 3)
+        heading = _lib.as_d(heading).reshape(n, 3)
+        flags = np.ascontiguousarray(flags, np.uint8).reshape(n)
+        td = None if total_dist is None else _lib.as_d(total_dist).reshape(n)
+        sn = None if step_num is None else np.ascontiguousarray(step_num, np.int32).reshape(n)
+        self._chk(self.L.sca_set_state(self.ctx, _lib.ptr(pos, C.c_double), _lib.ptr(vel, C.c_float),
+                                       _lib.ptr(heading, C.c_double), _lib.ptr(flags, C.c_uint8),
+                                       None if td is None else _lib.ptr(td, C.c_double),
+                                       None if sn is None else _lib.ptr(sn, C.c_int32)), 'sca_set_state')
+
+    def get_state(self):
+        n = self.n
+        out = dict(pos=np.zeros((n, 3)), vel=np.zeros((n, 3), np.float32), heading=np.zeros((n, 3)),
+                   flags=np.zeros(n, np.uint8), total_dist=np.zeros(n), step_num=np.zeros(n, np.int32))
+        self._chk(self.L.sca_get_state(self.ctx, _lib.ptr(out['pos'], C.c_double), _lib.ptr(out['vel'], C.c_float),
+                                       _lib.ptr(out['heading'], C.c_double), _lib.ptr(out['flags'], C.c_uint8),
+                                       _lib.ptr(out['total_dist'], C.c_double), _lib.ptr(out['step_num'], C.c_int32)),
+                  'sca_get_state')
+        return out
+
+    def set_kd_perm(self, perm):
+        perm = np.ascontiguousarray(perm, np.int32).reshape(self.n)
+        self._chk(self.L.sca_set_kd_perm(self.ctx, _lib.ptr(perm, C.c_int32)), 'sca_set_kd_perm')
+
+    def get_kd_perm(self):
+        perm = np.zeros(self.n, np.int32)
+        self._chk(self.L.sca_get_kd_perm(self.ctx, _lib.ptr(perm, C.c_int32)), 'sca_get_kd_perm')
+        return perm
+
+    def set_vpref(self, vpref, mode):
+        vpref = _lib.as_d(np.nan_to_num(vpref)).reshape(self.n, 3)
+        mode = np.ascontiguousarray(np.broadcast_to(mode, (self.n,)), np.uint8)
+        self._chk(self.L.sca_set_vpref(self.ctx, _lib.ptr(vpref, C.c_double), _lib.ptr(mode, C.c_uint8)), 'sca_set_vpref')
+
+    # ---- hot path --------------------------------------------------------------------------------------
+    def policy_pass(self, mode=NBR_KDTREE):
+        self._chk(self.L.sca_policy_pass(self.ctx, int(mode)), 'sca_policy_pass')
+
+    def env_update(self, want_done=True):
+        done = C.c_int(0)
+        self._chk(self.L.sca_env_update(self.ctx, C.byref(done) if want_done else None), 'sca_env_update')
+        return bool(done.value)
+
+    def run_steps(self, steps, mode=NBR_KDTREE):
+        self._chk(self.L.sca_run_steps(self.ctx, int(steps), int(mode)), 'sca_run_steps')
+
+    def synchronize(self):
+        self._chk(self.L.sca_synchronize(self.ctx), 'sca_synchronize')
+
+    def actions(self):
+        a = np.zeros((self.n, 7), np.float32)
+        self._chk(self.L.sca_get_actions(self.ctx, _lib.ptr(a, C.c_float)), 'sca_get_actions')
+        return a
+
+    def neighbors(self):
+        n = self.n
+        out = dict(nbr_n=np.zeros(n, np.int32), nbr_id=np.zeros((n, K), np.int32), nbr_kind=np.zeros((n, K), np.uint8),
+                   nbr_dsq=np.zeros((n, K)), nbr_valid=np.zeros(n, np.uint8))
+        self._chk(self.L.sca_get_neighbors(self.ctx, _lib.ptr(out['nbr_n'], C.c_int32), _lib.ptr(out['nbr_id'], C.c_int32),
+                                           _lib.ptr(out['nbr_kind'], C.c_uint8), _lib.ptr(out['nbr_dsq'], C.c_double),
+                                           _lib.ptr(out['nbr_valid'], C.c_uint8)), 'sca_get_neighbors')
+        return out
+
+    def diag(self):
+        n = self.n
+        out = dict(diag=np.zeros((n, 5), np.int32), status=np.zeros(n, np.int32), vpref=np.zeros((n, 3)))
+        self._chk(self.L.sca_get_diag(self.ctx, _lib.ptr(out['diag'], C.c_int32), _lib.ptr(out['status'], C.c_int32),
+                                      _lib.ptr(out['vpref'], C.c_double)), 'sca_get_diag')
+        return out
+
+    def kernel_ms(self):
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        self._chk(self.L.sca_last_kernel_ms(self.ctx, C.byref(a), C.byref(b), C.byref(c)), 'sca_last_kernel_ms')
+        return dict(neighbors=a.value, solve=b.value, update=c.value)
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.sca_set_profiling(self.ctx, 1 if on else 0), 'sca_set_profiling')
+
+    def agent_steps(self, reset=False):
+        v = C.c_int64(0)
+        self._chk(self.L.sca_agent_steps(self.ctx, C.byref(v), 1 if reset else 0), 'sca_agent_steps')
+        return int(v.value)
+
+    # ---- multi-GPU --------------------------------------------------------------------------------------
+    def set_shard(self, begin, count):
+        self._chk(self.L.sca_set_shard(self.ctx, int(begin), int(count)), 'sca_set_shard')
+
+    def public_records(self, which=0):
+        p = C.c_void_p()
+        b = C.c_int64()
+        self._chk(self.L.sca_public_records(self.ctx, int(which), C.byref(p), C.byref(b)), 'sca_public_records')
+        return p.value, b.value
+
+    def bind_public_records(self, current_ptr, moved_ptr):
+        self._chk(self.L.sca_bind_public_records(self.ctx, C.c_void_p(current_ptr), C.c_void_p(moved_ptr)),
+                  'sca_bind_public_records')
+
+    def step_begin(self, mode=NBR_KDTREE):
+        self._chk(self.L.sca_step_begin(self.ctx, int(mode)), 'sca_step_begin')
+
+    def step_end(self):
+        self._chk(self.L.sca_step_end(self.ctx), 'sca_step_end')
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.sca_set_stream(self.ctx, C.c_void_p(stream_ptr)), 'sca_set_stream')
+
+
+def zaxis_flags(start, goal):
+    """is_zAxis of scaPolicy.py:188-189: start and goal share x and y."""
+    d = np.asarray(goal, float)[:, :3] - np.asarray(start, float)[:, :3]
+    return ((np.abs(d[:, 0]) <= 1e-5) & (np.abs(d[:, 1]) <= 1e-5)).astype(np.uint8)

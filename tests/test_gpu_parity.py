@@ -1,0 +1,204 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (1) the golden vectors recorded from the reference (tests/golden), and
+  (2) the CPU oracle on seeded synthetic swarms at BASELINE sizes.
+Bar: neighbour lists / decisions / velocities bit-exact (velocities are discrete picks, truncated to 5 dp);
+heading deltas within one float32 ulp (they pass through atan2); tolerance of the north star: 1e-5."""
+import numpy as np
+import pytest
+
+from golden_util import episode_fixtures, load, static_inputs
+
+pytestmark = pytest.mark.gpu
+
+ANG_TOL = 5e-7
+VEL_TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def S():
+    import sca_amd.solver as S
+    return S
+
+
+def make_solver(S, fx, st):
+    n = len(st['radius'])
+    m = len(st['obs_radius'])
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1))
+    sol.set_obstacles(st['obs_pos'], st['obs_radius'])
+    sol.set_agents(st['radius'], st['pref_speed'], fx['goal'][0], st['policy'], st['zaxis'], st['max_run_dist'])
+    return sol
+
+
+def check_actions(got, ref, ctx):
+    assert np.array_equal(got[:, :4], ref[:, :4]), ctx + ('velocity', np.abs(got[:, :4] - ref[:, :4]).max())
+    assert np.allclose(got[:, 4:], ref[:, 4:], rtol=0, atol=ANG_TOL), ctx + ('angles', np.abs(got[:, 4:] - ref[:, 4:]).max())
+
+
+@pytest.mark.parametrize('name', episode_fixtures())
+def test_policy_pass_vs_golden(S, name):
+    fx = load(name)
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    for t in range(T):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_kd_perm(fx['perm'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_KDTREE)
+        ctx = (name, t)
+        assert np.array_equal(sol.get_kd_perm(), fx['perm_after'][t]), ctx
+        nb = sol.neighbors()
+        valid = fx['nbr_valid'][t].astype(bool)
+        assert np.array_equal(nb['nbr_valid'].astype(bool), valid), ctx
+        assert np.array_equal(nb['nbr_n'][valid], fx['nbr_n'][t][valid]), ctx
+        assert np.array_equal(nb['nbr_id'][valid], fx['nbr_id'][t][valid]), ctx
+        assert np.array_equal(nb['nbr_kind'][valid], fx['nbr_kind'][t][valid]), ctx
+        assert np.array_equal(nb['nbr_dsq'][valid], fx['nbr_dsq'][t][valid]), ctx
+        dg = sol.diag()
+        assert not dg['status'].any(), ctx + (dg['status'][dg['status'] != 0],)
+        called = fx['called'][t].astype(bool)
+        own = called & ~st['vpref_mode'].astype(bool)
+        assert np.array_equal(dg['vpref'][own], fx['vpref'][t][own]), ctx + ('v_pref',)
+        sel = fx['n_suit'][t] >= 0
+        assert np.array_equal(dg['diag'][sel, 0], fx['n_suit'][t][sel]), ctx + ('n_suit',)
+        assert np.array_equal(dg['diag'][sel, 1], fx['fallback'][t][sel]), ctx + ('fallback',)
+        lp = fx['plane_fail'][t] >= 0
+        assert np.array_equal(dg['diag'][lp, 3], fx['plane_fail'][t][lp]), ctx + ('planeFail',)
+        assert np.array_equal(dg['diag'][lp, 4], fx['lp4'][t][lp]), ctx + ('lp4',)
+        check_actions(sol.actions(), fx['action'][t], ctx)
+        flags = sol.get_state()['flags']
+        assert np.array_equal((flags >> 1) & 1, fx['coll_after_policy'][t]), ctx + ('collision',)
+    sol.close()
+
+
+@pytest.mark.parametrize('name', episode_fixtures())
+def test_env_update_vs_golden(S, name):
+    fx = load(name)
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    for t in range(0, T, max(1, T // 40)):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_kd_perm(fx['perm'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_KDTREE)
+        sol.env_update()
+        s = sol.get_state()
+        ctx = (name, t)
+        assert np.allclose(s['pos'], fx['pos_after'][t], rtol=0, atol=1e-6), ctx + (np.abs(s['pos'] - fx['pos_after'][t]).max(),)
+        assert np.array_equal(s['vel'][:, :3], fx['vel_after'][t]), ctx
+        assert np.allclose(s['heading'], fx['heading_after'][t], rtol=0, atol=1e-6), ctx
+        assert np.allclose(s['total_dist'], fx['total_dist_after'][t], rtol=0, atol=1e-9), ctx
+        assert np.array_equal(s['flags'], fx['flags_after'][t]), ctx
+    sol.close()
+
+
+def test_closed_loop_episode_c1(S):
+    """BASELINE config 1: N=8 circle, SCA, the whole 246-step episode run on the GPU (state resident on the
+    device, only the Dubins-tracker v_pref of each step comes from the fixture)."""
+    fx = load('F1_sca_circle8')
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    sol.set_state(fx['pos'][0], fx['vel'][0], fx['heading'][0], fx['flags'][0], fx['total_dist'][0])
+    sol.set_kd_perm(fx['perm'][0])
+    maxdv = 0.0
+    for t in range(T):
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_KDTREE)
+        a = sol.actions()
+        maxdv = max(maxdv, float(np.abs(a[:, :3] - fx['action'][t][:, :3]).max()))
+        done = sol.env_update()
+        assert done == (t == int(fx['done_step'])), t
+    s = sol.get_state()
+    assert maxdv <= VEL_TOL, maxdv
+    assert np.allclose(s['pos'], fx['pos_after'][-1], rtol=0, atol=1e-6)
+    assert np.array_equal(s['flags'], fx['flags_after'][-1])
+    sol.close()
+
+
+def _scenario_state(S, sc, policy, seed=0):
+    from sca_amd import scenarios
+    n = len(sc['start'])
+    rng = np.random.default_rng(seed)
+    pos = sc['start'][:, :3].copy()
+    head = sc['start'][:, 3:6].copy()
+    # non-zero float32 velocities so the real (non-bootstrap) branch runs: unit-ish towards the goal + noise
+    d = sc['goal'][:, :3] - pos
+    v = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9) + rng.normal(0, 0.15, (n, 3))
+    vel = (v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0.5, 1.0, (n, 1))).astype(np.float32)
+    return dict(n=n, pos=pos, vel=vel, heading=head, flags=np.zeros(n, np.uint8), goal=sc['goal'][:, :3].copy(),
+                radius=np.full(n, 0.5), pref_speed=np.full(n, 1.0), policy=np.broadcast_to(policy, (n,)).astype(np.uint8),
+                zaxis=S.zaxis_flags(sc['start'], sc['goal']), max_run_dist=scenarios.max_run_dist(sc['start'], sc['goal']),
+                obs_pos=sc['obs_pos'], obs_radius=sc['obs_radius'])
+
+
+CASES = [
+    ('circle1024_sca', 'circle', 1024, 0),          # BASELINE config 2
+    ('random4096_orca', 'random', 4096, 3),         # BASELINE config 3
+    ('random4096_orcalp', 'random', 4096, 4),
+    ('takeoff1024_mixed', 'takeoff', 1024, -1),     # BASELINE config 5 (scaled), SCA even ids / S-RVO3D odd ids
+    ('circle2048_rvo', 'circle', 2048, 1),
+]
+
+
+@pytest.mark.parametrize('label,kind,n,pol', CASES)
+def test_policy_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
+    from sca_amd import scenarios
+    sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=0),
+          'takeoff': lambda: scenarios.takeoff_landing(n)}[kind]()
+    policy = np.where(np.arange(n) % 2 == 0, 0, 2) if pol < 0 else pol
+    s = _scenario_state(S, sc, policy)
+    # SCA's v_pref comes from the Dubins tracker in the reference; here the straight-line rule feeds both sides
+    vmode = np.zeros(n, np.uint8)
+    perm = np.arange(n, dtype=np.int32)
+    ref = oracle.policy_step(s['pos'], s['vel'], s['heading'], s['radius'], s['pref_speed'], s['flags'], s['goal'],
+                             s['policy'], s['zaxis'], np.zeros((n, 3)), vmode, perm, s['obs_pos'], s['obs_radius'],
+                             nthreads=8)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(s['obs_radius'])))
+    sol.set_obstacles(s['obs_pos'], s['obs_radius'])
+    sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+    sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+    sol.policy_pass(S.NBR_KDTREE)
+    nb = sol.neighbors()
+    assert np.array_equal(sol.get_kd_perm(), ref['perm'])
+    assert np.array_equal(nb['nbr_n'], ref['nbr_n'])
+    assert np.array_equal(nb['nbr_id'], ref['nbr_id'])
+    assert np.array_equal(nb['nbr_dsq'], ref['nbr_dsq'])
+    dg = sol.diag()
+    assert np.array_equal(dg['diag'][:, :2], ref['diag'][:, :2])
+    a = sol.actions()
+    dv = np.abs(a[:, :4] - ref['action'][:, :4]).max()
+    assert dv <= VEL_TOL, dv
+    assert np.array_equal(a[:, :4], ref['action'][:, :4])
+    assert np.allclose(a[:, 4:], ref['action'][:, 4:], rtol=0, atol=ANG_TOL)
+    sol.close()
+
+
+def test_resident_steps_match_stepwise_oracle(S, oracle):
+    """sca_run_steps (state never leaves HBM) vs the oracle stepped on the host: N=512 random, ORCA3D, 20 steps."""
+    from sca_amd import scenarios
+    n, steps = 512, 20
+    sc = scenarios.random_cube(n, seed=5)
+    s = _scenario_state(S, sc, 3)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+    sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+    sol.run_steps(steps, S.NBR_KDTREE)
+    sol.synchronize()
+    g = sol.get_state()
+    pos, vel, head, flags = s['pos'].copy(), s['vel'].copy(), s['heading'].copy(), s['flags'].copy()
+    td = np.zeros(n); sn = np.zeros(n, np.int32); perm = np.arange(n, dtype=np.int32)
+    for _ in range(steps):
+        r = oracle.policy_step(pos, vel, head, s['radius'], s['pref_speed'], flags, s['goal'], s['policy'], s['zaxis'],
+                               np.zeros((n, 3)), np.zeros(n, np.uint8), perm, s['obs_pos'], s['obs_radius'], nthreads=8)
+        perm = r['perm']
+        u = oracle.env_update(pos, vel, head, s['radius'], r['flags'], s['goal'], r['action'], td, s['max_run_dist'], sn,
+                              s['obs_pos'], s['obs_radius'])
+        pos, vel, head, flags, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+    assert np.abs(g['vel'] - vel).max() <= VEL_TOL
+    assert np.allclose(g['pos'], pos, rtol=0, atol=1e-6)
+    assert np.array_equal(g['flags'], flags)
+    assert np.array_equal(g['step_num'], sn)
+    sol.close()
