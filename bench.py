@@ -166,7 +166,7 @@ def cpu_baseline(scene, sol, S):
     n = scene['n']
     sc = scene['sc']
     st = sol.get_state()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     perm = sol.get_kd_perm()
     vmode = np.zeros(n, np.uint8)
     args = (st['pos'], st['vel'], st['heading'], scene['radius'], scene['pref_speed'], st['flags'], sc['goal'][:, :3],

@@ -133,12 +133,16 @@ __global__ __launch_bounds__(K1_THREADS) void k_neighbors_kd(DeviceView d, Param
     d.nbr_valid[agent] = 0;
     d.nbr_n[agent] = 0;
     int st = 0;
-    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) return;          // mampenv.py:35
+    bool skip = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
     const int pol = d.policy[agent];
     const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     // SCA / RVO / S-RVO skip computeNeighbors on the bootstrap step (scaPolicy.py:34); ORCA does not (orca3dPolicy.py:51)
-    if (!orca && l3norm_f32zero(vA, false) <= 1e-5) return;
+    if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;
+    if (skip) {
+        for (int k = 0; k < K_MAX; k++) { d.nbr_id[agent * K_MAX + k] = -1; d.nbr_dsq[agent * K_MAX + k] = 0.0; }
+        return;
+    }
     const V3 pA = v3(me.px, me.py, me.pz);
     const double rangeSq = P.neighbor_dist * P.neighbor_dist;                      // scaPolicy.py:112
     const int maxn = P.max_neighbors;
