@@ -1,6 +1,7 @@
 // sca_hip.hip -- host side of libsca_hip.so: context, HBM layout, launches, C-ABI (include/sca_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,7 @@ struct sca_ctx {
     std::vector<KdNode> h_tree;
     std::vector<PubRec> h_rec;
     bool agents_set = false, state_set = false;
+    double max_radius = 0, max_obs_radius = 0, max_pref_speed = 0;
     std::string err;
     double *tab = nullptr;
 };
@@ -201,7 +203,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
-    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 1); r |= dalloc(c, &d.agent_steps, 1);
+    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 64); r |= dalloc(c, &d.agent_steps, 256);
     if (r) return SCA_ERR_HIP;
     // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
     std::vector<double> tab(768 + 384 + 256 + 128);
@@ -235,6 +237,8 @@ int sca_set_obstacles(sca_ctx *c, int m, const double *pos, const double *radius
     ARG(c, m >= 0 && m <= c->max_m);
     ARG(c, m == 0 || (pos && radius));
     c->m = m; c->d.m = m;
+    c->max_obs_radius = 0;
+    for (int i = 0; i < m; i++) c->max_obs_radius = std::max(c->max_obs_radius, radius[i]);
     if (m == 0) return 0;
     std::vector<ObsRec> h(m);
     for (int i = 0; i < m; i++) { h[i].px = pos[3 * i]; h[i].py = pos[3 * i + 1]; h[i].pz = pos[3 * i + 2]; h[i].radius = radius[i]; }
@@ -256,7 +260,12 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     ARG(c, radius && pref_speed && goal && policy && max_run_dist);
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
     c->h_rec.assign(n, PubRec{});
-    for (int i = 0; i < n; i++) c->h_rec[i].radius = radius[i];
+    c->max_radius = 0; c->max_pref_speed = 0;
+    for (int i = 0; i < n; i++) {
+        c->h_rec[i].radius = radius[i];
+        c->max_radius = std::max(c->max_radius, radius[i]);
+        c->max_pref_speed = std::max(c->max_pref_speed, pref_speed[i]);
+    }
     c->h_perm.resize(n);
     for (int i = 0; i < n; i++) c->h_perm[i] = i;                     // kdTree.py:43-45
     std::vector<uint8_t> z(n, 0), mode(n, 0);
@@ -370,19 +379,21 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
     return 0;
 }
 
-static int launch_policy(sca_ctx *c, int mode, bool timed) {
+static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
     const DeviceView &d = c->d;
     if (mode != SCA_NBR_KDTREE) { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     if (int r = build_agent_tree(c)) return r;
-    CHK(c, hipMemsetAsync(d.status, 0, sizeof(int32_t) * c->n, c->stream));
     const int cnt = d.shard_count;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
     const bool prof = !timed && c->profiling && c->pool_used + 3 <= 3 * 4096;
     if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2)) return SCA_ERR_HIP; }
     if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_THREADS - 1) / K1_THREADS), dim3(K1_THREADS), 0, c->stream, d, c->P);
+    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
-    hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (fuse_integrate)
+        hipLaunchKernelGGL(k_solve<true>, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    else
+        hipLaunchKernelGGL(k_solve<false>, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
     return 0;
@@ -395,15 +406,21 @@ static int launch_integrate(sca_ctx *c) {
     CHK(c, hipGetLastError());
     return 0;
 }
+// check_agent_state + is_done; afterwards the moved records become the current ones (buffer swap, no copy)
 static int launch_collide_finish(sca_ctx *c, bool timed) {
-    const DeviceView &d = c->d;
+    DeviceView &d = c->d;
     const int cnt = d.shard_count;
-    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(k_collide, dim3((cnt + 3) / 4), dim3(256), 0, c->stream, d, c->P);
-    // every agent's record is republished: the shard's from this rank's flags, the others' with a replicated at-goal test
-    hipLaunchKernelGGL(k_finish, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 64, c->stream));
+    // a pair that touches after the move was within r_a + r_b + 2 * max_step before it; l3norm rounds to 5 dp
+    const double max_step = 1.01 * std::max(c->max_pref_speed, c->P.max_speed) * c->P.time_step;
+    const double agent_reach = c->max_radius + 2.0 * max_step + 1e-4;
+    const double obs_reach = c->max_obs_radius + 1e-4;
+    hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P,
+                       agent_reach, obs_reach);
+    if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
     CHK(c, hipGetLastError());
+    std::swap(d.rec, d.rec_new);
     c->h_pos_valid = false;
     return 0;
 }
@@ -415,7 +432,7 @@ static int launch_update(sca_ctx *c, bool timed) {
 int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
-    if (int r = launch_policy(c, neighbor_mode, true)) return r;
+    if (int r = launch_policy(c, neighbor_mode, true, false)) return r;
     CHK(c, hipStreamSynchronize(c->stream));
     CHK(c, hipEventElapsedTime(&c->ms_nbr, c->ev[0], c->ev[1]));
     CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[1], c->ev[2]));
@@ -428,10 +445,12 @@ int sca_env_update(sca_ctx *c, int *all_done) {
     CHK(c, hipEventRecord(c->ev[2], c->stream));
     if (int r = launch_update(c, true)) return r;
     if (all_done) {
-        int32_t active = 0;
-        CHK(c, hipMemcpyAsync(&active, c->d.done_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        int32_t parts[64];
+        CHK(c, hipMemcpyAsync(parts, c->d.done_count, sizeof(parts), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
         CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[2], c->ev[3]));
+        int active = 0;
+        for (int v : parts) active += v;
         *all_done = (active == 0);
     }
     return 0;
@@ -441,8 +460,8 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     for (int s = 0; s < steps; s++) {
-        if (int r = launch_policy(c, neighbor_mode, false)) return r;
-        if (int r = launch_update(c, false)) return r;
+        if (int r = launch_policy(c, neighbor_mode, false, true)) return r;     // integrate fused into k_solve
+        if (int r = launch_collide_finish(c, false)) return r;
     }
     return 0;
 }
@@ -450,8 +469,7 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
 int sca_step_begin(sca_ctx *c, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
-    if (int r = launch_policy(c, neighbor_mode, false)) return r;
-    return launch_integrate(c);
+    return launch_policy(c, neighbor_mode, false, true);
 }
 int sca_step_end(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
@@ -485,11 +503,13 @@ int sca_set_profiling(sca_ctx *c, int on) {
 
 int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
     if (!c) return SCA_ERR_ARG;
-    unsigned long long v = 0;
-    CHK(c, hipMemcpyAsync(&v, c->d.agent_steps, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long parts[256];
+    CHK(c, hipMemcpyAsync(parts, c->d.agent_steps, sizeof(parts), hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    for (unsigned long long x : parts) v += x;
     if (count) *count = (int64_t)v;
-    if (reset) { CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(v), c->stream)); CHK(c, hipStreamSynchronize(c->stream)); }
+    if (reset) { CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(parts), c->stream)); CHK(c, hipStreamSynchronize(c->stream)); }
     return 0;
 }
 
@@ -553,7 +573,11 @@ int sca_bind_public_records(sca_ctx *c, void *current, void *moved) {
         CHK(c, hipMemcpyAsync(current, c->d.rec, sizeof(PubRec) * c->max_n, hipMemcpyDeviceToDevice, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
         c->d.rec = (PubRec *)current; c->d.rec_new = (PubRec *)moved;
-    } else { c->d.rec = c->rec_own; c->d.rec_new = c->rec_new_own; }
+    } else {
+        CHK(c, hipMemcpyAsync(c->rec_own, c->d.rec, sizeof(PubRec) * c->max_n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+        c->d.rec = c->rec_own; c->d.rec_new = c->rec_new_own;
+    }
     return 0;
 }
 int sca_set_stream(sca_ctx *c, void *hip_stream) {

@@ -5,7 +5,8 @@
 //   k_solve        : cone / half-space construction + 513-candidate sweep + selection (or LP1-4),
 //                    ONE WAVEFRONT (64 lanes) PER AGENT, neighbour constants staged in LDS and read as
 //                    wave-uniform broadcasts, selection by wave-level tuple reductions / ballots.
-//   k_integrate / k_collide / k_finish : MACAEnv second loop (mampenv.py:42-59).
+//   k_integrate / k_collide_finish : MACAEnv second loop (mampenv.py:42-59); integrate is fused into k_solve
+//                    when the state stays resident (sca_run_steps).
 //
 // HBM layout: one 48-byte PubRec per agent (pos f64x3, vel f32x3, flags, radius) -- the only thing other
 // agents / other GPUs read; private per-agent arrays are SoA.  No MFMA: there is no contraction here.
@@ -54,8 +55,8 @@ struct DeviceView {
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
     const double *unit256, *unit128, *phi256, *phi128;
-    int32_t *done_count;     // [1] number of agents not yet done (k_finish)
-    unsigned long long *agent_steps;   // [1] running count of agents that entered the policy (mampenv.py:35-40)
+    int32_t *done_count;     // [64] sharded count of agents not yet done after the step
+    unsigned long long *agent_steps;   // [256] sharded running count of agents that entered the policy (mampenv.py:35-40)
     int n, m, shard_begin, shard_count;
 };
 
@@ -88,28 +89,27 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: kd-tree neighbour query, one lane per agent.
-constexpr int KD_STACK = 48;
-constexpr int K1_THREADS = 64;
+// K1: kd-tree neighbour query.  ONE WAVEFRONT PER AGENT: the traversal state (stack, current node) is
+// wave-uniform and lives in SGPRs / LDS, node records come through the scalar cache, a leaf's <= 10 members
+// are fetched and measured by 10 lanes at once, and the bounded sorted neighbour list of agent.py:87-99
+// is kept one entry per lane (lanes 0..15) so that an insertion is one ballot + one lane shift.
+constexpr int KD_STACK = 64;
+constexpr int K1_WAVES = 4;
 
-struct NbrListLds {                      // [slot][lane] layout: consecutive lanes hit consecutive banks
-    double dsq[K_MAX][K1_THREADS];
-    int id[K_MAX][K1_THREADS];
-    int stack[KD_STACK][K1_THREADS];
+struct WaveList {            // entry k of the sorted list lives in lane k
+    double dsq;
+    int id;
+    int cnt;                 // wave-uniform
 };
-
-// the `neighbors.pop(); append; sort(key=distSq)` sequence of agent.py:87-90: stable, new element after equals
-__device__ __forceinline__ void nbr_insert(NbrListLds &L, int lane, int &cnt, int maxn, int id, double dsq) {
-    if (cnt == maxn) cnt--;
-    int j = cnt;
-    while (j > 0 && L.dsq[j - 1][lane] > dsq) {
-        L.dsq[j][lane] = L.dsq[j - 1][lane];
-        L.id[j][lane] = L.id[j - 1][lane];
-        j--;
-    }
-    L.dsq[j][lane] = dsq;
-    L.id[j][lane] = id;
-    cnt++;
+// `neighbors.pop(); append; sort(key=distSq)` (agent.py:87-90): stable, so the newcomer lands after equal keys
+__device__ __forceinline__ void wave_insert(WaveList &L, int lane, int maxn, int id, double dsq) {
+    if (L.cnt == maxn) L.cnt--;
+    const int pos = __popcll(__ballot(lane < L.cnt && L.dsq <= dsq));
+    const double up_d = __shfl_up(L.dsq, 1);
+    const int up_i = __shfl_up(L.id, 1);
+    if (lane > pos && lane <= L.cnt) { L.dsq = up_d; L.id = up_i; }
+    if (lane == pos) { L.dsq = dsq; L.id = id; }
+    L.cnt++;
 }
 
 __device__ __forceinline__ double box_dist_sq(const KdNode &c, V3 p) {     // kdTree.py:132-145
@@ -123,15 +123,52 @@ __device__ __forceinline__ double box_dist_sq(const KdNode &c, V3 p) {     // kd
     return s;
 }
 
-__global__ __launch_bounds__(K1_THREADS) void k_neighbors_kd(DeviceView d, Params P) {
-    __shared__ NbrListLds L;
-    const int lane = threadIdx.x;
-    const int agent = d.shard_begin + blockIdx.x * K1_THREADS + lane;
+// Depth-first traversal of kdTree.py:127-156 (nearer child first, ties go right, constant rangeSq) with a
+// wave-uniform explicit stack.  leaf(begin, end) is called for every visited leaf in visit order.
+template <class LeafFn>
+__device__ __forceinline__ int kd_traverse(const KdNode *tree, V3 p, double rangeSq, int *stack, int lane, LeafFn leaf) {
+    int sp = 0, st = 0;
+    int node = 0;
+    bool have = true;
+    while (have) {
+        node = __builtin_amdgcn_readfirstlane(node);
+        const KdNode nd = tree[node];
+        have = false;
+        if (nd.end - nd.begin <= MAX_LEAF) {
+            leaf(nd.begin, nd.end);
+        } else {
+            const double dl = box_dist_sq(tree[nd.left], p);
+            const double dr = box_dist_sq(tree[nd.right], p);
+            int first, second;
+            double dfirst, dsecond;
+            if (dl < dr) { first = nd.left; second = nd.right; dfirst = dl; dsecond = dr; }
+            else { first = nd.right; second = nd.left; dfirst = dr; dsecond = dl; }
+            if (dfirst < rangeSq) {
+                if (dsecond < rangeSq) {
+                    if (sp < KD_STACK) { if (lane == 0) stack[sp] = second; sp++; }
+                    else st |= ST_KD_STACK;
+                }
+                node = first;
+                have = true;
+            }
+        }
+        if (!have && sp > 0) {
+            sp--;
+            __builtin_amdgcn_wave_barrier();
+            node = stack[sp];
+            have = true;
+        }
+    }
+    return st;
+}
+
+__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P) {
+    __shared__ int stacks[K1_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
     if (agent >= d.shard_begin + d.shard_count) return;
     const PubRec me = d.rec[agent];
-    d.coll_new[agent] = 0;
-    d.nbr_valid[agent] = 0;
-    d.nbr_n[agent] = 0;
     int st = 0;
     bool skip = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
     const int pol = d.policy[agent];
@@ -140,78 +177,79 @@ __global__ __launch_bounds__(K1_THREADS) void k_neighbors_kd(DeviceView d, Param
     // SCA / RVO / S-RVO skip computeNeighbors on the bootstrap step (scaPolicy.py:34); ORCA does not (orca3dPolicy.py:51)
     if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;
     if (skip) {
-        for (int k = 0; k < K_MAX; k++) { d.nbr_id[agent * K_MAX + k] = -1; d.nbr_dsq[agent * K_MAX + k] = 0.0; }
+        if (lane < K_MAX) { d.nbr_id[agent * K_MAX + lane] = -1; d.nbr_dsq[agent * K_MAX + lane] = 0.0; }
+        if (lane == 0) { d.coll_new[agent] = 0; d.nbr_valid[agent] = 0; d.nbr_n[agent] = 0; d.status[agent] = 0; }
         return;
     }
     const V3 pA = v3(me.px, me.py, me.pz);
     const double rangeSq = P.neighbor_dist * P.neighbor_dist;                      // scaPolicy.py:112
     const int maxn = P.max_neighbors;
-    int cnt = 0;
+    WaveList L; L.dsq = 0.0; L.id = -1; L.cnt = 0;
     bool coll = false;
-    for (int phase = 0; phase < 2; phase++) {                                      // obstacles first (scaPolicy.py:114-116)
-        const bool ob = (phase == 0);
-        const int total = ob ? d.m : d.n;
-        if (total <= 0) continue;
-        const KdNode *tree = ob ? d.otree : d.atree;
-        const int32_t *perm = ob ? d.operm : d.aperm;
-        int sp = 0;
-        L.stack[sp++][lane] = 0;
-        while (sp > 0) {
-            const int node = L.stack[--sp][lane];
-            const KdNode nd = tree[node];
-            if (nd.end - nd.begin <= MAX_LEAF) {
-                for (int i = nd.begin; i < nd.end; i++) {
-                    const int o = perm[i];
-                    if (ob) {                                                      // agent.py:101-124
-                        const ObsRec r = d.obs[o];
-                        const V3 pO = v3(r.px, r.py, r.pz);
-                        const double distSq1 = l3normsq(pA, pO);
-                        const double t = l3norm(pA, pO) - r.radius;
-                        const double distSq = t * t;
-                        const double rs = me.radius + r.radius;
-                        if (distSq1 < rs * rs && distSq < rangeSq) {
-                            if (!coll) { coll = true; cnt = 0; }
-                            nbr_insert(L, lane, cnt, maxn, o | NBR_OBSTACLE_BIT, distSq);
-                        } else if (!coll && distSq < rangeSq) {
-                            nbr_insert(L, lane, cnt, maxn, o | NBR_OBSTACLE_BIT, distSq);
-                        }
-                    } else if (o != agent) {                                       // agent.py:79-99
-                        const PubRec r = d.rec[o];
-                        const double distSq = l3normsq(pA, v3(r.px, r.py, r.pz));
-                        const double rs = me.radius + r.radius;
-                        if (distSq < rs * rs && distSq < rangeSq) {
-                            if (!coll) { coll = true; cnt = 0; }
-                            nbr_insert(L, lane, cnt, maxn, o, distSq);
-                        } else if (!coll && distSq < rangeSq) {
-                            nbr_insert(L, lane, cnt, maxn, o, distSq);
-                        }
-                    }
-                }
-            } else {                                                               // kdTree.py:147-156
-                const double dl = box_dist_sq(tree[nd.left], pA);
-                const double dr = box_dist_sq(tree[nd.right], pA);
-                int first, second;
-                double dfirst, dsecond;
-                if (dl < dr) { first = nd.left; second = nd.right; dfirst = dl; dsecond = dr; }
-                else { first = nd.right; second = nd.left; dfirst = dr; dsecond = dl; }
-                if (dfirst < rangeSq) {
-                    if (sp + 2 > KD_STACK) { st |= ST_KD_STACK; }
-                    else {
-                        if (dsecond < rangeSq) L.stack[sp++][lane] = second;
-                        L.stack[sp++][lane] = first;
-                    }
-                }
+    int *stack = stacks[wid];
+    // obstacles first (scaPolicy.py:114-116), agent.py:101-124
+    if (d.m > 0) {
+        st |= kd_traverse(d.otree, pA, rangeSq, stack, lane, [&](int begin, int end) {
+            const bool valid = lane < end - begin;
+            int o = 0; double distSq = 0.0; bool c = false, r = false;
+            if (valid) {
+                o = d.operm[begin + lane];
+                const ObsRec ob = d.obs[o];
+                const V3 pO = v3(ob.px, ob.py, ob.pz);
+                const double distSq1 = l3normsq(pA, pO);
+                const double t = l3norm(pA, pO) - ob.radius;
+                distSq = t * t;
+                const double rs = me.radius + ob.radius;
+                r = distSq < rangeSq;
+                c = r && distSq1 < rs * rs;
+            }
+            unsigned long long todo = __ballot(r);
+            while (todo) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const bool cb = __shfl((int)c, b) != 0;
+                const double db = __shfl(distSq, b);
+                const int ib = __shfl(o, b) | NBR_OBSTACLE_BIT;
+                if (cb) { if (!coll) { coll = true; L.cnt = 0; } wave_insert(L, lane, maxn, ib, db); }
+                else if (!coll) wave_insert(L, lane, maxn, ib, db);
+            }
+        });
+    }
+    // other agents, agent.py:79-99
+    st |= kd_traverse(d.atree, pA, rangeSq, stack, lane, [&](int begin, int end) {
+        const bool valid = lane < end - begin;
+        int o = -1; double distSq = 0.0; bool c = false, r = false;
+        if (valid) {
+            o = d.aperm[begin + lane];
+            if (o != agent) {
+                const PubRec ot = d.rec[o];
+                distSq = l3normsq(pA, v3(ot.px, ot.py, ot.pz));
+                const double rs = me.radius + ot.radius;
+                r = distSq < rangeSq;
+                c = r && distSq < rs * rs;
             }
         }
+        unsigned long long todo = __ballot(r);
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const bool cb = __shfl((int)c, b) != 0;
+            const double db = __shfl(distSq, b);
+            const int ib = __shfl(o, b);
+            if (cb) { if (!coll) { coll = true; L.cnt = 0; } wave_insert(L, lane, maxn, ib, db); }
+            else if (!coll) wave_insert(L, lane, maxn, ib, db);
+        }
+    });
+    if (lane < K_MAX) {
+        d.nbr_id[agent * K_MAX + lane] = (lane < L.cnt) ? L.id : -1;
+        d.nbr_dsq[agent * K_MAX + lane] = (lane < L.cnt) ? L.dsq : 0.0;
     }
-    d.nbr_n[agent] = cnt;
-    d.nbr_valid[agent] = 1;
-    d.coll_new[agent] = coll ? 1u : 0u;
-    for (int k = 0; k < K_MAX; k++) {
-        d.nbr_id[agent * K_MAX + k] = (k < cnt) ? L.id[k][lane] : -1;
-        d.nbr_dsq[agent * K_MAX + k] = (k < cnt) ? L.dsq[k][lane] : 0.0;
+    if (lane == 0) {
+        d.nbr_n[agent] = L.cnt;
+        d.nbr_valid[agent] = 1;
+        d.coll_new[agent] = coll ? 1u : 0u;
+        d.status[agent] = st;
     }
-    if (st) atomicOr(&d.status[agent], st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,10 +283,29 @@ __device__ __forceinline__ double phi_from_idx(const CandTab &T, int idx, V3 vpr
     return T.phi[n0];
 }
 
+// update_velocitie (mampenv.py:83-105) for one agent: the moved record goes to rec_new (positions of the
+// current step stay readable for everybody else until the host swaps the buffers).
+__device__ __forceinline__ void integrate_agent(const DeviceView &d, const Params &P, int agent, PubRec r, const float *act) {
+    const double speed = (double)act[3];
+    const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
+    const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
+    const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
+    const double dx = speed * cos(b) * cos(a) * P.time_step;
+    const double dy = speed * cos(b) * sin(a) * P.time_step;
+    const double dz = speed * sin(b) * P.time_step;
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    d.total_dist[agent] += len;
+    r.px += dx; r.py += dy; r.pz += dz;
+    r.vx = act[0]; r.vy = act[1]; r.vz = act[2];
+    d.heading[agent * 3 + 0] = a; d.heading[agent * 3 + 1] = b; d.heading[agent * 3 + 2] = g;
+    if (!(r.flags & FLAG_AT_GOAL)) d.step_num[agent] += 1;
+    d.rec_new[agent] = r;
+}
+
 // generalized pass-on-the-right (scaPolicy.py:119-145) on a list given as per-lane slots.
 // inlist/key/idx: NR table slots per lane + one extra slot (v_pref) that only lane 0 owns.
 // Order of the reference's sorted list == lexicographic (key, idx).
-__device__ int select_from_list(bool shunted, double thr, int count, const bool inl[NR + 1], const double key[NR + 1],
+__device__ __forceinline__ int select_from_list(bool shunted, double thr, int count, const bool inl[NR + 1], const double key[NR + 1],
                                 const int idx[NR + 1], const V3 cand[NR + 1], const CandTab &T, V3 vpref, V3 vA64) {
     Key3 best = key_invalid();
 #pragma unroll
@@ -293,10 +350,11 @@ __device__ int select_from_list(bool shunted, double thr, int count, const bool 
     return kmax.idx;
 }
 
+template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
     __shared__ SolveLds S;
     const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
     if (agent >= d.shard_begin + d.shard_count) return;                             // wave-uniform
     const PubRec me = d.rec[agent];
@@ -305,6 +363,10 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35: row stays zero
         if (lane < 8) { act_out[lane] = 0.0f; diag[lane] = -1; }
         if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
+        if (FUSE_INTEGRATE && lane == 0) {
+            const float zero[7] = {0, 0, 0, 0, 0, 0, 0};
+            integrate_agent(d, P, agent, me, zero);
+        }
         return;
     }
     const int pol = d.policy[agent];
@@ -496,20 +558,28 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     }
     double act[7];
     cartesian2spherical(yaw, pitch, vpost, pol == POL_ORCA_LP, act);
-    if (lane < 7) {
-        double a = act[0];
+    float actf[7];
 #pragma unroll
-        for (int k = 1; k < 7; k++) if (lane == k) a = act[k];
-        act_out[lane] = (float)a;                                                     // mampenv.py:31,40 float32 row
+    for (int k = 0; k < 7; k++) actf[k] = (float)act[k];                              // mampenv.py:31,40 float32 row
+    if (lane < 7) {
+        float a = actf[0];
+#pragma unroll
+        for (int k = 1; k < 7; k++) if (lane == k) a = actf[k];
+        act_out[lane] = a;
     }
     if (lane == 7) act_out[7] = 0.0f;
     if (lane == 0) {
-        atomicAdd(d.agent_steps, 1ull);
+        atomicAdd(&d.agent_steps[blockIdx.x & 255], 1ull);
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         const int stw = __builtin_amdgcn_readfirstlane(st);
         if (stw) atomicOr(&d.status[agent], stw);
-        if (d.coll_new[agent]) d.rec[agent].flags = me.flags | FLAG_COLLISION;        // agent.py:84 is_collision = True
+        PubRec mine = me;
+        if (d.coll_new[agent]) {                                                      // agent.py:84 is_collision = True
+            mine.flags = me.flags | FLAG_COLLISION;
+            d.rec[agent].flags = mine.flags;
+        }
+        if (FUSE_INTEGRATE) integrate_agent(d, P, agent, mine, actf);
     }
     // status bits raised by other lanes (fallback sqrt domain)
     if (lane != 0 && st) atomicOr(&d.status[agent], st);
@@ -522,74 +592,77 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.shard_begin + d.shard_count) return;
-    PubRec r = d.rec[agent];
-    const float *act = d.action + (size_t)agent * 8;
-    const double speed = (double)act[3];
-    const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
-    const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
-    const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
-    const double dx = speed * cos(b) * cos(a) * P.time_step;
-    const double dy = speed * cos(b) * sin(a) * P.time_step;
-    const double dz = speed * sin(b) * P.time_step;
-    const double len = sqrt(dx * dx + dy * dy + dz * dz);
-    d.total_dist[agent] += len;
-    r.px += dx; r.py += dy; r.pz += dz;
-    r.vx = act[0]; r.vy = act[1]; r.vz = act[2];
-    d.heading[agent * 3 + 0] = a; d.heading[agent * 3 + 1] = b; d.heading[agent * 3 + 2] = g;
-    if (!(r.flags & FLAG_AT_GOAL)) d.step_num[agent] += 1;
-    d.rec_new[agent] = r;
+    float act[7];
+    for (int k = 0; k < 7; k++) act[k] = d.action[(size_t)agent * 8 + k];
+    integrate_agent(d, P, agent, d.rec[agent], act);
 }
 
-// brute-force pair scan, one wave per agent (used while n is small; the grid variant replaces it for large n)
-__global__ __launch_bounds__(256) void k_collide(DeviceView d, Params P) {
+// check_agent_state (mampenv.py:61-80) + is_done (mampenv.py:51-59), one wave per agent, candidates from the
+// kd-tree of the step's OLD positions: any pair that touches after the move was within
+// r_a + r_b + 2 * max_step of each other before it.  The flags are committed into the moved record; the
+// host swaps the two record buffers afterwards.
+__global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
+    __shared__ int stacks[K1_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
-    const int agent = d.shard_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
     if (agent >= d.shard_begin + d.shard_count) return;
     const PubRec me = d.rec_new[agent];
+    const PubRec me_old = d.rec[agent];
     const V3 p = v3(me.px, me.py, me.pz);
-    const V3 p_old = v3(d.rec[agent].px, d.rec[agent].py, d.rec[agent].pz);
+    const V3 p_old = v3(me_old.px, me_old.py, me_old.pz);
     const bool me_goal = (me.flags & FLAG_AT_GOAL) != 0;
     bool hit = false;
-    for (int o = lane; o < d.m; o += 64) {
-        const ObsRec r = d.obs[o];
-        if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;       // mampenv.py:63-66
+    int *stack = stacks[wid];
+    if (d.m > 0) {
+        const double rq = me.radius + obs_reach;
+        kd_traverse(d.otree, p, rq * rq, stack, lane, [&](int begin, int end) {
+            if (lane < end - begin) {
+                const ObsRec r = d.obs[d.operm[begin + lane]];
+                if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;   // mampenv.py:63-66
+            }
+        });
     }
-    for (int j = lane; j < d.n; j += 64) {
-        if (j == agent) continue;
-        const PubRec rn = d.rec_new[j];
-        const PubRec ro = d.rec[j];
-        const double rs = me.radius + rn.radius;
-        const bool j_goal = (rn.flags & FLAG_AT_GOAL) != 0;
-        // new-new is seen by whichever of the two is checked second; mixed pairs by the first one
-        bool c = l3norm(p, v3(rn.px, rn.py, rn.pz)) <= rs;
-        if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);          // agent moved, j not yet
-        else c = c || (l3norm(v3(rn.px, rn.py, rn.pz), p_old) <= rs);                 // j moved, agent not yet
-        if (c && !me_goal) hit = true;                                                // mampenv.py:72-75
-        (void)j_goal;
+    {
+        const double rq = me.radius + agent_reach;
+        kd_traverse(d.atree, p_old, rq * rq, stack, lane, [&](int begin, int end) {
+            if (lane < end - begin) {
+                const int j = d.aperm[begin + lane];
+                if (j != agent) {
+                    const PubRec rn = d.rec_new[j];
+                    const PubRec ro = d.rec[j];
+                    const double rs = me.radius + rn.radius;
+                    const V3 pn = v3(rn.px, rn.py, rn.pz);
+                    // new-new is seen by whichever of the two is checked second; the mixed pair by the first one
+                    bool c = l3norm(p, pn) <= rs;
+                    if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);    // agent moved, j not yet
+                    else c = c || (l3norm(pn, p_old) <= rs);                               // j moved, agent not yet
+                    if (c && !me_goal) hit = true;                                         // mampenv.py:72-75
+                }
+            }
+        });
     }
     const bool any = __ballot(hit) != 0;
     if (lane == 0) {
         uint32_t f = me.flags;
         if (any) f |= FLAG_COLLISION;
-        if (d.total_dist[agent] > d.max_run_dist[agent]) f |= FLAG_TIMEOUT;           // mampenv.py:77-79
-        d.coll_new[agent] = f;                                                        // staged; k_finish commits
+        if (d.total_dist[agent] > d.max_run_dist[agent]) f |= FLAG_TIMEOUT;               // mampenv.py:77-79
+        const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
+        if (l3norm(p, g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;                     // mampenv.py:53-54
+        d.rec_new[agent].flags = f;
+        if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[blockIdx.x & 63], 1);
     }
 }
 
-// commit flags, is_done (mampenv.py:51-59), publish rec <- rec_new.  Runs over ALL agents: agents of other shards
-// (multi-GPU: their moved records arrived by all-gather) get the replicated at-goal test, the only flag of another
-// agent the policy ever reads (scaPolicy.py:53); their collision / timeout bits stay with the owning rank.
-__global__ __launch_bounds__(256) void k_finish(DeviceView d, Params P) {
+// multi-GPU only: agents of other shards arrived by all-gather with the flags their owner published one step ago;
+// replicate the at-goal test for them -- the only flag of another agent the policy reads (scaPolicy.py:53).
+__global__ __launch_bounds__(256) void k_goal_flags_others(DeviceView d, Params P) {
     const int agent = blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.n) return;
-    const bool mine = agent >= d.shard_begin && agent < d.shard_begin + d.shard_count;
-    PubRec r = d.rec_new[agent];
-    uint32_t f = mine ? d.coll_new[agent] : r.flags;
+    if (agent >= d.shard_begin && agent < d.shard_begin + d.shard_count) return;
+    const PubRec r = d.rec_new[agent];
     const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
-    if (l3norm(v3(r.px, r.py, r.pz), g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;
-    r.flags = f;
-    d.rec[agent] = r;
-    if (mine && !(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(d.done_count, 1);
+    if (l3norm(v3(r.px, r.py, r.pz), g) <= P.near_goal_threshold) d.rec_new[agent].flags = r.flags | FLAG_AT_GOAL;
 }
 
 }  // namespace sca

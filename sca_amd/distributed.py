@@ -39,13 +39,16 @@ class ShardedStepper:
         self._moved = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         sol.bind_public_records(self._cur.data_ptr(), self._moved.data_ptr())
         sol.set_stream(torch.cuda.current_stream().cuda_stream)
-        per = nbytes // self.world
-        self._slice = self._moved[self.rank * per:(self.rank + 1) * per]
+        self._per = nbytes // self.world
+        self._by_ptr = {self._cur.data_ptr(): self._cur, self._moved.data_ptr(): self._moved}
 
     def _moved_records(self):
+        """(full buffer, this rank's slice) of the records sca_step_begin has just written.  The library swaps its two
+        record buffers at the end of every step, so the buffer is looked up by address."""
         if hasattr(self.sol, 'moved_records'):
             return self.sol.moved_records()
-        return self._moved, self._slice
+        full = self._by_ptr[self.sol.public_records(1)[0]]
+        return full, full[self.rank * self._per:(self.rank + 1) * self._per]
 
     def run(self, steps):
         if self.world == 1:
