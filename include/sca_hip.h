@@ -58,8 +58,9 @@ enum sca_policy {                 /* which find_next_action the agent runs */
 enum sca_flag { SCA_FLAG_AT_GOAL = 1, SCA_FLAG_COLLISION = 2, SCA_FLAG_TIMEOUT = 4 };   /* agent.py:70-72 */
 
 enum sca_neighbor_mode {
-    SCA_NBR_KDTREE = 0,           /* replica of the reference kd-tree visit order (exact neighbour lists) */
-    SCA_NBR_GRID = 1              /* uniform grid; identical lists whenever <= max_neighbors objects are in range */
+    SCA_NBR_KDTREE = 0,           /* replica of the reference kd-tree (built and queried on the device): exact lists */
+    SCA_NBR_GRID = 1,             /* reserved: uniform grid (identical lists whenever <= max_neighbors are in range) */
+    SCA_NBR_KDTREE_HOSTBUILD = 2  /* same tree built on the host from a position read-back (debug / A-B reference) */
 };
 
 enum sca_status_bit {             /* per-agent status word of the last policy pass */
@@ -95,6 +96,8 @@ int sca_get_state(sca_ctx *ctx, double *pos, float *vel, double *heading, uint8_
 /* kdTree.agentIDs: the permutation the reference carries from step to step (kdTree.py:43-45,101-111) */
 int sca_set_kd_perm(sca_ctx *ctx, const int32_t *perm /*n*/);
 int sca_get_kd_perm(sca_ctx *ctx, int32_t *perm /*n*/);
+/* the agent kd-tree of the last policy pass, (2n-1) nodes x [begin,end,left,right,min3,max3] (kdTree.py:14-21) */
+int sca_get_kd_tree(sca_ctx *ctx, double *tree_out /*(2n-1)*10*/);
 /* externally computed preferred velocity (SCA / RVO3D+Dubins); mode[i]=1 uses vpref[i], 0 = straight line */
 int sca_set_vpref(sca_ctx *ctx, const double *vpref /*n*3*/, const uint8_t *mode /*n*/);
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     'sca_get_state': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, ip]),
     'sca_set_kd_perm': (C.c_int, [C.c_void_p, ip]),
     'sca_get_kd_perm': (C.c_int, [C.c_void_p, ip]),
+    'sca_get_kd_tree': (C.c_int, [C.c_void_p, dp]),
     'sca_set_vpref': (C.c_int, [C.c_void_p, dp, bp]),
     'sca_policy_pass': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_get_actions': (C.c_int, [C.c_void_p, fp]),

@@ -11,6 +11,7 @@
 
 #include "../../include/sca_hip.h"
 #include "sca_kernels.hip.h"
+#include "sca_kdbuild.hip.h"
 
 using namespace sca;
 
@@ -114,6 +115,8 @@ struct sca_ctx {
     std::vector<int32_t> h_perm;
     std::vector<KdNode> h_tree;
     std::vector<PubRec> h_rec;
+    KdScratch kd{};
+    bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
     double max_radius = 0, max_obs_radius = 0, max_pref_speed = 0;
     std::string err;
@@ -204,6 +207,11 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 64); r |= dalloc(c, &d.agent_steps, 256);
+    r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
+    r |= dalloc(c, &c->kd.ml, N); r |= dalloc(c, &c->kd.mr, N);
+    c->kd.job_cap = (int)(N / 64 + 64);
+    r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
+    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_MAX_LEVELS + 2);
     if (r) return SCA_ERR_HIP;
     // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
     std::vector<double> tab(768 + 384 + 256 + 128);
@@ -224,7 +232,8 @@ void sca_destroy(sca_ctx *c) {
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.action, d.vpref_used, d.diag, d.status,
-                    d.done_count, d.agent_steps, c->tab};
+                    d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -268,6 +277,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     }
     c->h_perm.resize(n);
     for (int i = 0; i < n; i++) c->h_perm[i] = i;                     // kdTree.py:43-45
+    c->perm_on_device = false;
     std::vector<uint8_t> z(n, 0), mode(n, 0);
     if (zaxis) z.assign(zaxis, zaxis + n);
     for (int i = 0; i < n; i++) ARG(c, policy[i] <= SCA_POLICY_RVO3D_DUBINS);
@@ -336,12 +346,32 @@ int sca_set_kd_perm(sca_ctx *c, const int32_t *perm) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, perm && c->agents_set);
     c->h_perm.assign(perm, perm + c->n);
+    c->perm_on_device = false;
     return 0;
 }
 int sca_get_kd_perm(sca_ctx *c, int32_t *perm) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, perm && c->agents_set);
+    if (c->perm_on_device) {
+        CHK(c, hipMemcpyAsync(c->h_perm.data(), c->d.aperm, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+    }
     std::memcpy(perm, c->h_perm.data(), sizeof(int32_t) * c->n);
+    return 0;
+}
+
+int sca_get_kd_tree(sca_ctx *c, double *tree_out) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, tree_out && c->agents_set);
+    const int n = c->n;
+    std::vector<KdNode> t((size_t)2 * n);
+    CHK(c, hipMemcpyAsync(t.data(), c->d.atree, sizeof(KdNode) * (2 * n - 1), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2 * n - 1; i++) {
+        double *o = tree_out + 10 * (size_t)i;
+        o[0] = t[i].begin; o[1] = t[i].end; o[2] = t[i].left; o[3] = t[i].right;
+        for (int k = 0; k < 3; k++) { o[4 + k] = t[i].mn[k]; o[7 + k] = t[i].mx[k]; }
+    }
     return 0;
 }
 
@@ -369,6 +399,43 @@ static int build_agent_tree(sca_ctx *c) {
     return 0;
 }
 
+// KDTree.buildAgentTree on the device (sca_kdbuild.hip.h): gather, one launch per level of large nodes, one launch
+// that finishes every small subtree.  Everything is enqueued on the context's stream; nothing comes back to the host.
+static int build_agent_tree_device(sca_ctx *c) {
+    const int n = c->n;
+    const DeviceView &d = c->d;
+    if (!c->perm_on_device) {
+        CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+        c->perm_on_device = true;
+    }
+    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd);
+    int levels = 0;
+    if (n > KD_WAVE_MAX) {
+        int need = 1;
+        while ((KD_WAVE_MAX << need) < n) need++;                    // balanced depth down to KD_WAVE_MAX
+        levels = std::min(need + 6, KD_MAX_LEVELS - 1);               // slack for uneven midpoint splits
+        for (int l = 0; l < levels; l++) {
+            const int grid = (int)std::min<long long>(1ll << std::min(l, 20), (long long)std::max(1, n / KD_WAVE_MAX));
+            hipLaunchKernelGGL(k_kd_level, dim3(grid), dim3(KD_LEVEL_THREADS), 0, c->stream, d, c->kd, l);
+        }
+    }
+    const int sgrid = std::max(1, std::min(2048, (n / 64 + KD_SMALL_WAVES) / KD_SMALL_WAVES));
+    hipLaunchKernelGGL(k_kd_small, dim3(sgrid), dim3(KD_SMALL_WAVES * 64), 0, c->stream, d, c->kd, levels);
+    CHK(c, hipGetLastError());
+    return 0;
+}
+static int check_kd_overflow(sca_ctx *c) {
+    int flag = 0;
+    CHK(c, hipMemcpyAsync(&flag, c->kd.counts + KD_MAX_LEVELS + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (flag) {
+        c->err = "device kd-tree build overflow (tree deeper than the level budget): results of this pass are invalid; "
+                 "use SCA_NBR_KDTREE_HOSTBUILD for this scene";
+        return SCA_ERR_STATE;
+    }
+    return 0;
+}
+
 static int pool_event(sca_ctx *c, hipEvent_t *out) {
     if (c->pool_used == (int)c->pool.size()) {
         hipEvent_t e;
@@ -381,8 +448,15 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
     const DeviceView &d = c->d;
-    if (mode != SCA_NBR_KDTREE) { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
-    if (int r = build_agent_tree(c)) return r;
+    if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
+    else if (mode == SCA_NBR_KDTREE_HOSTBUILD) {
+        if (c->perm_on_device) {
+            CHK(c, hipMemcpyAsync(c->h_perm.data(), c->d.aperm, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+            CHK(c, hipStreamSynchronize(c->stream));
+            c->perm_on_device = false;
+        }
+        if (int r = build_agent_tree(c)) return r;
+    } else { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     const int cnt = d.shard_count;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
     const bool prof = !timed && c->profiling && c->pool_used + 3 <= 3 * 4096;
@@ -434,6 +508,7 @@ int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (int r = launch_policy(c, neighbor_mode, true, false)) return r;
     CHK(c, hipStreamSynchronize(c->stream));
+    if (neighbor_mode == SCA_NBR_KDTREE) { if (int r = check_kd_overflow(c)) return r; }
     CHK(c, hipEventElapsedTime(&c->ms_nbr, c->ev[0], c->ev[1]));
     CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[1], c->ev[2]));
     return 0;
@@ -479,6 +554,7 @@ int sca_step_end(sca_ctx *c) {
 int sca_synchronize(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
     CHK(c, hipStreamSynchronize(c->stream));
+    if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
     if (c->profiling && c->pool_used >= 3) {
         double a = 0, b = 0;
         const int steps = c->pool_used / 3;

@@ -12,7 +12,7 @@ from . import _lib
 
 POL_SCA, POL_RVO3D, POL_SRVO3D, POL_ORCA3D, POL_ORCA3D_LP, POL_RVO3D_DUBINS = range(6)
 FLAG_AT_GOAL, FLAG_COLLISION, FLAG_TIMEOUT = 1, 2, 4
-NBR_KDTREE, NBR_GRID = 0, 1
+NBR_KDTREE, NBR_GRID, NBR_KDTREE_HOSTBUILD = 0, 1, 2
 K = _lib.K
 
 
@@ -107,6 +107,11 @@ class BatchedSolver:
         perm = np.zeros(self.n, np.int32)
         self._chk(self.L.sca_get_kd_perm(self.ctx, _lib.ptr(perm, C.c_int32)), 'sca_get_kd_perm')
         return perm
+
+    def get_kd_tree(self):
+        t = np.zeros((2 * self.n - 1, 10))
+        self._chk(self.L.sca_get_kd_tree(self.ctx, _lib.ptr(t, C.c_double)), 'sca_get_kd_tree')
+        return t
 
     def set_vpref(self, vpref, mode):
         vpref = _lib.as_d(np.nan_to_num(vpref)).reshape(self.n, 3)

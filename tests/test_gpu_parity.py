@@ -206,3 +206,63 @@ def test_resident_steps_match_stepwise_oracle(S, oracle):
     assert np.array_equal(g['flags'], flags)
     assert np.array_equal(g['step_num'], sn)
     sol.close()
+
+
+@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 200, 257, 300, 1000, 5000, 40000])
+def test_device_kd_build_matches_host_replica(S, n):
+    """K0: the kd-tree built on the device (nodes, boxes, permutation) against the sequential host replica of
+    kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent)."""
+    import ctypes as C
+    from sca_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(-60, 60, (n, 3))
+    if n >= 64:
+        pos[: n // 4] = np.round(pos[: n // 4], 0)            # duplicates and ties on split planes
+        pos[n // 4: n // 3, 2] = 10.0                          # a flat slab (degenerate axis)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), np.zeros((n, 3)), np.full(n, 1, np.uint8))
+    perm = rng.permutation(n).astype(np.int32)
+    sol.set_kd_perm(perm)
+    href = perm.copy()
+    for it in range(3):
+        vel = np.full((n, 3), 0.3, np.float32)
+        sol.set_state(pos, vel, np.zeros((n, 3)), np.zeros(n, np.uint8))
+        sol.policy_pass(S.NBR_KDTREE)
+        t_dev = sol.get_kd_tree()
+        t_ref = np.zeros((2 * n - 1, 10))
+        assert L.sca_kd_build_host(n, _lib.ptr(pos, C.c_double), _lib.ptr(href, C.c_int32), _lib.ptr(t_ref, C.c_double)) == 0
+        assert np.array_equal(sol.get_kd_perm(), href), (n, it)
+        used = np.zeros(2 * n - 1, bool)
+        stack = [0]
+        while stack:
+            i = stack.pop()
+            used[i] = True
+            if t_ref[i, 1] - t_ref[i, 0] > 10:
+                stack += [int(t_ref[i, 2]), int(t_ref[i, 3])]
+        assert np.array_equal(t_dev[used], t_ref[used]), (n, it)
+        pos = pos + rng.normal(0, 0.3, pos.shape)              # move a little, rebuild from the carried permutation
+    sol.close()
+
+
+def test_hostbuild_and_device_build_give_identical_passes(S):
+    from sca_amd import scenarios
+    n = 3000
+    sc = scenarios.random_cube(n, seed=9)
+    s = _scenario_state(S, sc, 2)
+    outs = []
+    for mode in (S.NBR_KDTREE, S.NBR_KDTREE_HOSTBUILD):
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+        sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+        sol.run_steps(5, mode)
+        sol.synchronize()
+        outs.append((sol.get_state(), sol.get_kd_perm(), sol.neighbors()))
+        sol.close()
+    a, b = outs
+    assert np.array_equal(a[1], b[1])
+    for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[2]['nbr_id'], b[2]['nbr_id'])
