@@ -118,6 +118,7 @@ struct sca_ctx {
     KdScratch kd{};
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
+    bool near_valid = false;            // K1's collision-candidate lists describe the current records
     double max_radius = 0, max_obs_radius = 0, max_pref_speed = 0;
     std::string err;
     double *tab = nullptr;
@@ -205,6 +206,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.otree, 2 * M); r |= dalloc(c, &d.operm, M);
     r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
+    r |= dalloc(c, &d.near_n, N); r |= dalloc(c, &d.near_id, N * NEAR_MAX);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 64); r |= dalloc(c, &d.agent_steps, 256);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
@@ -231,7 +233,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
-                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.action, d.vpref_used, d.diag, d.status,
+                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -308,6 +310,7 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
     }
     c->h_pos.assign(pos, pos + 3 * (size_t)n);
     c->h_pos_valid = true;
+    c->near_valid = false;
     CHK(c, hipMemcpyAsync(c->d.rec, c->h_rec.data(), sizeof(PubRec) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.heading, heading, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     if (total_dist) CHK(c, hipMemcpyAsync(c->d.total_dist, total_dist, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
@@ -436,6 +439,14 @@ static int check_kd_overflow(sca_ctx *c) {
     return 0;
 }
 
+// A pair that touches after the move was within r_a + r_b + 2 * max_step of each other before it (an obstacle:
+// r_a + r_o + max_step); l3norm rounds to 5 dp, hence the 1e-4.  The kernels add the agent's own radius.
+static void collide_reach(const sca_ctx *c, double &agent_reach, double &obs_reach) {
+    const double max_step = 1.01 * std::max(c->max_pref_speed, c->P.max_speed) * c->P.time_step;
+    agent_reach = c->max_radius + 2.0 * max_step + 1e-4;
+    obs_reach = c->max_obs_radius + max_step + 1e-4;
+}
+
 static int pool_event(sca_ctx *c, hipEvent_t *out) {
     if (c->pool_used == (int)c->pool.size()) {
         hipEvent_t e;
@@ -462,7 +473,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool prof = !timed && c->profiling && c->pool_used + 3 <= 3 * 4096;
     if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2)) return SCA_ERR_HIP; }
     if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P);
+    double agent_reach, obs_reach;
+    collide_reach(c, agent_reach, obs_reach);
+    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P,
+                       agent_reach, obs_reach);
+    c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     if (fuse_integrate)
         hipLaunchKernelGGL(k_solve<true>, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
@@ -485,10 +500,10 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     DeviceView &d = c->d;
     const int cnt = d.shard_count;
     CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 64, c->stream));
-    // a pair that touches after the move was within r_a + r_b + 2 * max_step before it; l3norm rounds to 5 dp
-    const double max_step = 1.01 * std::max(c->max_pref_speed, c->P.max_speed) * c->P.time_step;
-    const double agent_reach = c->max_radius + 2.0 * max_step + 1e-4;
-    const double obs_reach = c->max_obs_radius + 1e-4;
+    double agent_reach, obs_reach;
+    collide_reach(c, agent_reach, obs_reach);
+    if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
+    c->near_valid = false;
     hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P,
                        agent_reach, obs_reach);
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);

@@ -48,6 +48,8 @@ struct DeviceView {
     double *nbr_dsq;         // [n*16]
     uint32_t *coll_new;      // [n] collision detected by insert*Neighbor in this pass
     uint8_t *nbr_valid;      // [n]
+    int32_t *near_n;         // [n] collision candidates found by K1 (-1: not computed / overflow -> traversal)
+    int32_t *near_id;        // [n*NEAR_MAX] ids within collision reach at the step's old positions
     // outputs
     float *action;           // [n*8] (7 used)
     double *vpref_used;      // [n*3]
@@ -95,6 +97,7 @@ __device__ __forceinline__ double wave_min(double v) {
 // is kept one entry per lane (lanes 0..15) so that an insertion is one ballot + one lane shift.
 constexpr int KD_STACK = 64;
 constexpr int K1_WAVES = 4;
+constexpr int NEAR_MAX = 8;
 
 struct WaveList {            // entry k of the sorted list lives in lane k
     double dsq;
@@ -162,7 +165,9 @@ __device__ __forceinline__ int kd_traverse(const KdNode *tree, V3 p, double rang
     return st;
 }
 
-__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P) {
+// agent_reach / obs_reach: see k_collide_finish.  Every object that can touch this agent after the move is visited
+// here anyway (it is within neighborDist), so the few that are close enough are written down for K4.
+__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach) {
     __shared__ int stacks[K1_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,9 +183,12 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
     if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;
     if (skip) {
         if (lane < K_MAX) { d.nbr_id[agent * K_MAX + lane] = -1; d.nbr_dsq[agent * K_MAX + lane] = 0.0; }
-        if (lane == 0) { d.coll_new[agent] = 0; d.nbr_valid[agent] = 0; d.nbr_n[agent] = 0; d.status[agent] = 0; }
+        if (lane == 0) { d.coll_new[agent] = 0; d.nbr_valid[agent] = 0; d.nbr_n[agent] = 0; d.status[agent] = 0; d.near_n[agent] = -1; }
         return;
     }
+    int near_cnt = 0;                    // wave-uniform
+    int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
+    const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const V3 pA = v3(me.px, me.py, me.pz);
     const double rangeSq = P.neighbor_dist * P.neighbor_dist;                      // scaPolicy.py:112
     const int maxn = P.max_neighbors;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
     if (d.m > 0) {
         st |= kd_traverse(d.otree, pA, rangeSq, stack, lane, [&](int begin, int end) {
             const bool valid = lane < end - begin;
-            int o = 0; double distSq = 0.0; bool c = false, r = false;
+            int o = 0; double distSq = 0.0; bool c = false, r = false, nr = false;
             if (valid) {
                 o = d.operm[begin + lane];
                 const ObsRec ob = d.obs[o];
@@ -202,6 +210,13 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
                 const double rs = me.radius + ob.radius;
                 r = distSq < rangeSq;
                 c = r && distSq1 < rs * rs;
+                const V3 dd = pA - pO;
+                nr = (dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) < reach_o * reach_o;
+            }
+            {
+                const unsigned long long nm = __ballot(nr);
+                if (nr) { const int at = near_cnt + __popcll(nm & ((1ull << lane) - 1ull)); if (at < NEAR_MAX) near_out[at] = o | NBR_OBSTACLE_BIT; }
+                near_cnt += __popcll(nm);
             }
             unsigned long long todo = __ballot(r);
             while (todo) {
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
     // other agents, agent.py:79-99
     st |= kd_traverse(d.atree, pA, rangeSq, stack, lane, [&](int begin, int end) {
         const bool valid = lane < end - begin;
-        int o = -1; double distSq = 0.0; bool c = false, r = false;
+        int o = -1; double distSq = 0.0; bool c = false, r = false, nr = false;
         if (valid) {
             o = d.aperm[begin + lane];
             if (o != agent) {
@@ -227,7 +242,13 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
                 const double rs = me.radius + ot.radius;
                 r = distSq < rangeSq;
                 c = r && distSq < rs * rs;
+                nr = distSq < reach_a * reach_a;
             }
+        }
+        {
+            const unsigned long long nm = __ballot(nr);
+            if (nr) { const int at = near_cnt + __popcll(nm & ((1ull << lane) - 1ull)); if (at < NEAR_MAX) near_out[at] = o; }
+            near_cnt += __popcll(nm);
         }
         unsigned long long todo = __ballot(r);
         while (todo) {
@@ -249,6 +270,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
         d.nbr_valid[agent] = 1;
         d.coll_new[agent] = coll ? 1u : 0u;
         d.status[agent] = st;
+        // candidates are only complete if the whole reach lies inside the visited range
+        const bool complete = near_cnt <= NEAR_MAX && reach_a * reach_a <= rangeSq && reach_o * reach_o <= rangeSq;
+        d.near_n[agent] = complete ? near_cnt : -1;
     }
 }
 
@@ -614,32 +638,43 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, 
     const bool me_goal = (me.flags & FLAG_AT_GOAL) != 0;
     bool hit = false;
     int *stack = stacks[wid];
-    if (d.m > 0) {
-        const double rq = me.radius + obs_reach;
-        kd_traverse(d.otree, p, rq * rq, stack, lane, [&](int begin, int end) {
-            if (lane < end - begin) {
-                const ObsRec r = d.obs[d.operm[begin + lane]];
-                if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;   // mampenv.py:63-66
-            }
-        });
-    }
-    {
+    // the pair tests of mampenv.py:63-75 against object j (id as stored in the neighbour lists)
+    auto test_obstacle = [&](int o) {
+        const ObsRec r = d.obs[o];
+        if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;           // mampenv.py:63-66
+    };
+    auto test_agent = [&](int j) {
+        const PubRec rn = d.rec_new[j];
+        const PubRec ro = d.rec[j];
+        const double rs = me.radius + rn.radius;
+        const V3 pn = v3(rn.px, rn.py, rn.pz);
+        // new-new is seen by whichever of the two is checked second; the mixed pair by the first one
+        bool c = l3norm(p, pn) <= rs;
+        if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);                // agent moved, j not yet
+        else c = c || (l3norm(pn, p_old) <= rs);                                           // j moved, agent not yet
+        if (c && !me_goal) hit = true;                                                     // mampenv.py:72-75
+    };
+    const int near_n = d.near_n[agent];
+    // an agent that had arrived or collided before this step did not move and cannot gain a flag (mampenv.py:72-75
+    // never flags an agent at its goal; a collided one is flagged already)
+    const bool settled = (me_old.flags & (FLAG_AT_GOAL | FLAG_COLLISION)) != 0;
+    if (settled) {
+    } else if (near_n >= 0) {
+        if (lane < near_n) {
+            const int id = d.near_id[(size_t)agent * NEAR_MAX + lane];
+            if (id & NBR_OBSTACLE_BIT) test_obstacle(id & ~NBR_OBSTACLE_BIT);
+            else test_agent(id);
+        }
+    } else {
+        if (d.m > 0) {
+            const double rq = me.radius + obs_reach;
+            kd_traverse(d.otree, p, rq * rq, stack, lane, [&](int begin, int end) {
+                if (lane < end - begin) test_obstacle(d.operm[begin + lane]);
+            });
+        }
         const double rq = me.radius + agent_reach;
         kd_traverse(d.atree, p_old, rq * rq, stack, lane, [&](int begin, int end) {
-            if (lane < end - begin) {
-                const int j = d.aperm[begin + lane];
-                if (j != agent) {
-                    const PubRec rn = d.rec_new[j];
-                    const PubRec ro = d.rec[j];
-                    const double rs = me.radius + rn.radius;
-                    const V3 pn = v3(rn.px, rn.py, rn.pz);
-                    // new-new is seen by whichever of the two is checked second; the mixed pair by the first one
-                    bool c = l3norm(p, pn) <= rs;
-                    if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);    // agent moved, j not yet
-                    else c = c || (l3norm(pn, p_old) <= rs);                               // j moved, agent not yet
-                    if (c && !me_goal) hit = true;                                         // mampenv.py:72-75
-                }
-            }
+            if (lane < end - begin) { const int j = d.aperm[begin + lane]; if (j != agent) test_agent(j); }
         });
     }
     const bool any = __ballot(hit) != 0;
@@ -652,6 +687,12 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, 
         d.rec_new[agent].flags = f;
         if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[blockIdx.x & 63], 1);
     }
+}
+
+// the near lists belong to the policy pass of the same step; without one, k_collide_finish must traverse
+__global__ __launch_bounds__(256) void k_invalidate_near(DeviceView d) {
+    const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent < d.n) d.near_n[agent] = -1;
 }
 
 // multi-GPU only: agents of other shards arrived by all-gather with the flags their owner published one step ago;
