@@ -17,6 +17,9 @@ using namespace sca;
 
 namespace {
 
+// grid cap for the wave-per-agent kernels (they grid-stride): 256 CUs x 8 workgroups
+constexpr int MAX_GRID = 1 << 30;      // one agent per wavefront: measured faster than grid-striding (k_solve keeps 2 waves/SIMD)
+
 // libm calls that must not be folded by the compiler (the candidate table follows the reference's
 // Python expression literally: z ** 2 is pow(z, 2), not z * z)
 double (*volatile p_pow)(double, double) = std::pow;
@@ -208,7 +211,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.near_n, N); r |= dalloc(c, &d.near_id, N * NEAR_MAX);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.diag, N * 8);
-    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 64); r |= dalloc(c, &d.agent_steps, 256);
+    r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
     r |= dalloc(c, &c->kd.ml, N); r |= dalloc(c, &c->kd.mr, N);
     c->kd.job_cap = (int)(N / 64 + 64);
@@ -422,8 +425,8 @@ static int build_agent_tree_device(sca_ctx *c) {
             hipLaunchKernelGGL(k_kd_level, dim3(grid), dim3(KD_LEVEL_THREADS), 0, c->stream, d, c->kd, l);
         }
     }
-    const int sgrid = std::max(1, std::min(2048, (n / 64 + KD_SMALL_WAVES) / KD_SMALL_WAVES));
-    hipLaunchKernelGGL(k_kd_small, dim3(sgrid), dim3(KD_SMALL_WAVES * 64), 0, c->stream, d, c->kd, levels);
+    const int sgrid = std::max(1, std::min(1024, 4 * n / KB_MAX + 2));
+    hipLaunchKernelGGL(k_kd_block, dim3(sgrid), dim3(KB_T), 0, c->stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
     return 0;
 }
@@ -475,14 +478,16 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
-    hipLaunchKernelGGL(k_neighbors_kd, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P,
-                       agent_reach, obs_reach);
+    hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
+                       c->stream, d, c->P, agent_reach, obs_reach);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     if (fuse_integrate)
-        hipLaunchKernelGGL(k_solve<true>, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        hipLaunchKernelGGL(k_solve<true>, dim3(std::min((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES, MAX_GRID)), dim3(SOLVE_WAVES * 64), 0,
+                           c->stream, d, c->P);
     else
-        hipLaunchKernelGGL(k_solve<false>, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        hipLaunchKernelGGL(k_solve<false>, dim3(std::min((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES, MAX_GRID)), dim3(SOLVE_WAVES * 64), 0,
+                           c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
     return 0;
@@ -499,13 +504,13 @@ static int launch_integrate(sca_ctx *c) {
 static int launch_collide_finish(sca_ctx *c, bool timed) {
     DeviceView &d = c->d;
     const int cnt = d.shard_count;
-    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 64, c->stream));
+    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     c->near_valid = false;
-    hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * 64), 0, c->stream, d, c->P,
-                       agent_reach, obs_reach);
+    hipLaunchKernelGGL(k_collide_finish, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
+                       c->stream, d, c->P, agent_reach, obs_reach);
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
     CHK(c, hipGetLastError());
@@ -535,8 +540,8 @@ int sca_env_update(sca_ctx *c, int *all_done) {
     CHK(c, hipEventRecord(c->ev[2], c->stream));
     if (int r = launch_update(c, true)) return r;
     if (all_done) {
-        int32_t parts[64];
-        CHK(c, hipMemcpyAsync(parts, c->d.done_count, sizeof(parts), hipMemcpyDeviceToHost, c->stream));
+        std::vector<int32_t> parts(256 * 32);
+        CHK(c, hipMemcpyAsync(parts.data(), c->d.done_count, sizeof(int32_t) * parts.size(), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
         CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[2], c->ev[3]));
         int active = 0;
@@ -594,13 +599,16 @@ int sca_set_profiling(sca_ctx *c, int on) {
 
 int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
     if (!c) return SCA_ERR_ARG;
-    unsigned long long parts[256];
-    CHK(c, hipMemcpyAsync(parts, c->d.agent_steps, sizeof(parts), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> parts(256 * 16);
+    CHK(c, hipMemcpyAsync(parts.data(), c->d.agent_steps, sizeof(unsigned long long) * parts.size(), hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     unsigned long long v = 0;
     for (unsigned long long x : parts) v += x;
     if (count) *count = (int64_t)v;
-    if (reset) { CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(parts), c->stream)); CHK(c, hipStreamSynchronize(c->stream)); }
+    if (reset) {
+        CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(unsigned long long) * parts.size(), c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

@@ -14,13 +14,14 @@
 //   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced
 //   k_kd_level  : one launch per tree level for the nodes with more than KD_WAVE_MAX members, ONE WORKGROUP PER
 //                 NODE (block reductions for the box and the counts, ballot-based block scan for the ranks)
-//   k_kd_small  : every subtree of <= KD_WAVE_MAX members is finished by ONE WAVEFRONT in LDS, depth first
+//   k_kd_block  : every subtree of <= KD_WAVE_MAX members is finished by ONE WORKGROUP entirely in LDS, level by level,
+//                 all nodes of a level at once (element-parallel; boxes by LDS atomics on order-preserving keys)
 #pragma once
 #include "sca_kernels.hip.h"
 
 namespace sca {
 
-constexpr int KD_WAVE_MAX = 256;       // a node this small is finished (whole subtree) by one wavefront
+constexpr int KD_WAVE_MAX = 2048;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
 constexpr int KD_LEVEL_THREADS = 512;
 constexpr int KD_SMALL_WAVES = 4;
 constexpr int KD_SMALL_STACK = 64;
@@ -175,109 +176,199 @@ __global__ __launch_bounds__(KD_LEVEL_THREADS) void k_kd_level(DeviceView d, KdS
     }
 }
 
-// One wavefront finishes one subtree of <= KD_WAVE_MAX members, depth first, entirely in LDS.
-struct KdSmallLds {
-    double x[KD_SMALL_WAVES][KD_WAVE_MAX], y[KD_SMALL_WAVES][KD_WAVE_MAX], z[KD_SMALL_WAVES][KD_WAVE_MAX];
-    int id[KD_SMALL_WAVES][KD_WAVE_MAX];
-    int ml[KD_SMALL_WAVES][KD_WAVE_MAX], mr[KD_SMALL_WAVES][KD_WAVE_MAX];
-    int stk[KD_SMALL_WAVES][KD_SMALL_STACK][3];
+// ------------------------------------------------------------------------------------------------
+// One workgroup finishes one subtree of <= KB_MAX members in LDS.  Every level is one element-parallel pass over all
+// of the subtree's positions: each thread owns KB_E consecutive positions.
+constexpr int KB_MAX = KD_WAVE_MAX;
+constexpr int KB_T = 1024;
+constexpr int KB_E = KB_MAX / KB_T;     // 8 consecutive positions per thread
+constexpr int KB_NODES = 384;           // live nodes per level: <= 2 * KB_MAX / 11
+
+struct KbLds {
+    double x[KB_MAX], y[KB_MAX], z[KB_MAX];
+    int id[KB_MAX];
+    int slot[KB_MAX];                   // live-node slot of the position, -1 once its leaf is written
+    int mr[KB_MAX];                     // position of the k-th misplaced element of the right side (node-relative index)
+    int ps[KB_MAX];                     // inclusive prefix count of the ">= split" flags over all positions
+    int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES];
+    unsigned long long box[KB_NODES][6];
+    double split[KB_NODES];
+    int axis[KB_NODES], L[KB_NODES], child[KB_NODES], lfix[KB_NODES];
+    int count[2];
+    int wtot[KB_T / 64];
 };
 
-__global__ __launch_bounds__(KD_SMALL_WAVES * 64) void k_kd_small(DeviceView d, KdScratch s, int levels_run) {
-    __shared__ KdSmallLds S;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// order-preserving map double -> u64 so that LDS integer atomics give exact min / max
+__device__ __forceinline__ unsigned long long dkey(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+    __shared__ KbLds S;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int njobs = s.counts[KD_MAX_LEVELS];
-    // nodes still larger than KD_WAVE_MAX after the last level launch were never split: report, never guess
-    if (blockIdx.x == 0 && threadIdx.x == 0 && s.counts[levels_run] > 0) s.counts[KD_MAX_LEVELS + 1] = 1;
-    double *X = S.x[wid], *Y = S.y[wid], *Z = S.z[wid];
-    int *ID = S.id[wid], *ML = S.ml[wid], *MR = S.mr[wid];
-    for (int jb = blockIdx.x * KD_SMALL_WAVES + wid; jb < njobs; jb += gridDim.x * KD_SMALL_WAVES) {
+    // nodes still larger than KB_MAX after the last level launch were never split: report, never guess
+    if (blockIdx.x == 0 && tid == 0 && s.counts[levels_run] > 0) s.counts[KD_MAX_LEVELS + 1] = 1;
+    for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
         const KdJob job = s.small[jb];
         const int base = job.begin, size = job.end - job.begin;
-        if (size > KD_WAVE_MAX) { if (lane == 0) s.counts[KD_MAX_LEVELS + 1] = 1; continue; }
-        for (int i = lane; i < size; i += 64) {
-            X[i] = s.kx[base + i]; Y[i] = s.ky[base + i]; Z[i] = s.kz[base + i]; ID[i] = d.aperm[base + i];
+        if (size > KB_MAX) { if (tid == 0) s.counts[KD_MAX_LEVELS + 1] = 1; continue; }
+        __syncthreads();
+        for (int i = tid; i < size; i += KB_T) {
+            S.x[i] = s.kx[base + i]; S.y[i] = s.ky[base + i]; S.z[i] = s.kz[base + i]; S.id[i] = d.aperm[base + i];
+            S.slot[i] = 0;
         }
-        __builtin_amdgcn_wave_barrier();
-        int sp = 0;
-        int nb = 0, ne = size, nnode = job.node;          // current node, positions relative to base
-        bool have = true;
-        while (have) {
-            have = false;
-            // box
-            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int i = nb + lane; i < ne; i += 64) {
-                const double x = X[i], y = Y[i], z = Z[i];
-                mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
-                mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
-                mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+        if (tid == 0) { S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.count[0] = 1; S.count[1] = 0; }
+        int cur = 0;
+        const int p0 = tid * KB_E;
+        for (;;) {
+            __syncthreads();
+            const int nc = S.count[cur];
+            if (nc == 0) break;
+            const int nxt = cur ^ 1;
+            // (1) empty boxes
+            for (int i = tid; i < nc; i += KB_T) {
+                for (int k = 0; k < 3; k++) { S.box[i][k] = dkey(INFINITY); S.box[i][3 + k] = dkey(-INFINITY); }
             }
+            __syncthreads();
+            // (2) boxes: serial over the thread's own positions, one set of atomics per run of equal slots
+            {
+                int run = -1;
+                double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+                for (int k = 0; k <= KB_E; k++) {
+                    const int p = p0 + k;
+                    const int sl = (k < KB_E && p < size) ? S.slot[p] : -2;
+                    if (sl != run) {
+                        if (run >= 0) {
+                            for (int q = 0; q < 3; q++) { atomicMin(&S.box[run][q], dkey(mn[q])); atomicMax(&S.box[run][3 + q], dkey(mx[q])); }
+                        }
+                        run = sl;
+                        if (sl >= 0) { mn[0] = mx[0] = S.x[p]; mn[1] = mx[1] = S.y[p]; mn[2] = mx[2] = S.z[p]; }
+                    } else if (sl >= 0) {
+                        const double x = S.x[p], y = S.y[p], z = S.z[p];
+                        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
+                        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
+                        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+                    }
+                }
+            }
+            __syncthreads();
+            // (3) split plane per live node (kdTree.py:85-96); leaves (kdTree.py:85) get L = -1
+            for (int i = tid; i < nc; i += KB_T) {
+                if (S.ne[cur][i] - S.nb[cur][i] > MAX_LEAF) {
+                    double mn[3], mx[3];
+                    for (int k = 0; k < 3; k++) { mn[k] = dunkey(S.box[i][k]); mx[k] = dunkey(S.box[i][3 + k]); }
+                    int axis; double split;
+                    kd_split(mn, mx, axis, split);
+                    S.axis[i] = axis; S.split[i] = split; S.L[i] = 0;
+                } else S.L[i] = -1;
+            }
+            __syncthreads();
+            // (4) ">= split" flags and their inclusive prefix over all positions (block scan)
+            int flags = 0, tsum = 0;
+            for (int k = 0; k < KB_E; k++) {
+                const int p = p0 + k;
+                bool ge = false;
+                if (p < size) {
+                    const int sl = S.slot[p];
+                    if (sl >= 0 && S.L[sl] >= 0) {
+                        const int ax = S.axis[sl];
+                        const double c = ax == 0 ? S.x[p] : (ax == 1 ? S.y[p] : S.z[p]);
+                        ge = !(c < S.split[sl]);
+                    }
+                }
+                if (ge) { flags |= 1 << k; tsum++; }
+            }
+            int incl = tsum;                                   // wave inclusive scan of the per-thread totals
 #pragma unroll
-            for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
-            KdNode nd;
-            nd.begin = base + nb; nd.end = base + ne; nd.left = 0; nd.right = 0;
-            for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
-            int leftSize = 0;
-            if (ne - nb > MAX_LEAF) {
-                int axis; double split;
-                kd_split(mn, mx, axis, split);
-                const double *C = axis == 0 ? X : (axis == 1 ? Y : Z);
-                int cnt = 0;
-                for (int i = nb + lane; i < ne; i += 64) cnt += C[i] < split ? 1 : 0;
-                const int L = wave_sum_i(cnt);
-                // misplaced on the left, counted from the left
-                int carry = 0;
-                for (int t0 = nb; t0 < nb + L; t0 += 64) {
-                    const int i = t0 + lane;
-                    const bool ge = i < nb + L && !(C[i] < split);
-                    const unsigned long long m = __ballot(ge);
-                    if (ge) ML[carry + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                    carry += __popcll(m);
-                }
-                const int nswap = carry;
-                // misplaced on the right, counted from the right
-                carry = 0;
-                for (int t1 = ne; t1 > nb + L; t1 -= 64) {
-                    const int i = t1 - 1 - lane;                 // lane 0 takes the right-most element
-                    const bool lt = i >= nb + L && (C[i] < split);
-                    const unsigned long long m = __ballot(lt);
-                    if (lt) MR[carry + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                    carry += __popcll(m);
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (int k = lane; k < nswap; k += 64) {
-                    const int p = ML[k], q = MR[k];
-                    const int ip = ID[p]; ID[p] = ID[q]; ID[q] = ip;
-                    double t;
-                    t = X[p]; X[p] = X[q]; X[q] = t;
-                    t = Y[p]; Y[p] = Y[q]; Y[q] = t;
-                    t = Z[p]; Z[p] = Z[q]; Z[q] = t;
-                }
-                __builtin_amdgcn_wave_barrier();
-                leftSize = L == 0 ? 1 : L;
-                nd.left = nnode + 1; nd.right = nnode + 2 * leftSize;
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            if (lane == 63) S.wtot[wid] = incl;
+            __syncthreads();
+            int excl = incl - tsum;
+            for (int w = 0; w < wid; w++) excl += S.wtot[w];
+            {
+                int run = excl;
+                for (int k = 0; k < KB_E; k++) { const int p = p0 + k; if ((flags >> k) & 1) run++; if (p < size) S.ps[p] = run; }
             }
-            if (lane == 0) d.atree[nnode] = nd;
-            if (leftSize > 0) {
-                // right child later, left child now (the order is irrelevant for the result: disjoint ranges)
-                if (sp < KD_SMALL_STACK) {
-                    if (lane == 0) { S.stk[wid][sp][0] = nb + leftSize; S.stk[wid][sp][1] = ne; S.stk[wid][sp][2] = nd.right; }
-                    sp++;
-                } else if (lane == 0) s.counts[KD_MAX_LEVELS + 1] = 1;
-                ne = nb + leftSize; nnode = nd.left;
-                have = true;
-            } else if (sp > 0) {
-                sp--;
-                __builtin_amdgcn_wave_barrier();
-                nb = __builtin_amdgcn_readfirstlane(S.stk[wid][sp][0]);
-                ne = __builtin_amdgcn_readfirstlane(S.stk[wid][sp][1]);
-                nnode = __builtin_amdgcn_readfirstlane(S.stk[wid][sp][2]);
-                have = true;
+            __syncthreads();
+            // (5) L = #(members < split) per node
+            for (int i = tid; i < nc; i += KB_T) {
+                if (S.L[i] >= 0) {
+                    const int b = S.nb[cur][i], e = S.ne[cur][i];
+                    const int ge_cnt = S.ps[e - 1] - (b > 0 ? S.ps[b - 1] : 0);
+                    S.L[i] = (e - b) - ge_cnt;
+                }
             }
+            __syncthreads();
+            // (6) the k-th "< split" member of the right part, counted from the right
+            for (int k = 0; k < KB_E; k++) {
+                const int p = p0 + k;
+                if (p < size && !((flags >> k) & 1)) {
+                    const int sl = S.slot[p];
+                    if (sl >= 0 && S.L[sl] >= 0) {
+                        const int b = S.nb[cur][sl], L = S.L[sl];
+                        if (p >= b + L) {
+                            const int G = S.ps[p] - (b > 0 ? S.ps[b - 1] : 0);
+                            const int lt_incl = (p - b + 1) - G;
+                            S.mr[b + (L - lt_incl)] = p;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // (7) the swaps: the k-th ">= split" member of the left part takes its partner (kdTree.py:108-111)
+            for (int k = 0; k < KB_E; k++) {
+                const int p = p0 + k;
+                if (p < size && ((flags >> k) & 1)) {
+                    const int sl = S.slot[p];
+                    const int b = S.nb[cur][sl], L = S.L[sl];
+                    if (p < b + L) {
+                        const int G = S.ps[p] - (b > 0 ? S.ps[b - 1] : 0);
+                        const int q = S.mr[b + G - 1];
+                        const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
+                        double t;
+                        t = S.x[p]; S.x[p] = S.x[q]; S.x[q] = t;
+                        t = S.y[p]; S.y[p] = S.y[q]; S.y[q] = t;
+                        t = S.z[p]; S.z[p] = S.z[q]; S.z[q] = t;
+                    }
+                }
+            }
+            __syncthreads();
+            // (8) node records, children become the next level's live nodes (kdTree.py:112-122)
+            for (int i = tid; i < nc; i += KB_T) {
+                KdNode nd;
+                nd.begin = base + S.nb[cur][i]; nd.end = base + S.ne[cur][i]; nd.left = 0; nd.right = 0;
+                for (int k = 0; k < 3; k++) { nd.mn[k] = dunkey(S.box[i][k]); nd.mx[k] = dunkey(S.box[i][3 + k]); }
+                const int node = S.nnode[cur][i];
+                if (S.L[i] >= 0) {
+                    const int lf = S.L[i] == 0 ? 1 : S.L[i];
+                    nd.left = node + 1; nd.right = node + 2 * lf;
+                    const int c0 = atomicAdd(&S.count[nxt], 2);
+                    S.child[i] = c0; S.lfix[i] = lf;
+                    S.nb[nxt][c0] = S.nb[cur][i]; S.ne[nxt][c0] = S.nb[cur][i] + lf; S.nnode[nxt][c0] = nd.left;
+                    S.nb[nxt][c0 + 1] = S.nb[cur][i] + lf; S.ne[nxt][c0 + 1] = S.ne[cur][i]; S.nnode[nxt][c0 + 1] = nd.right;
+                }
+                d.atree[node] = nd;
+            }
+            __syncthreads();
+            // (9) positions move to their child's slot
+            for (int k = 0; k < KB_E; k++) {
+                const int p = p0 + k;
+                if (p < size) {
+                    const int sl = S.slot[p];
+                    if (sl >= 0) S.slot[p] = S.L[sl] < 0 ? -1 : S.child[sl] + (p >= S.nb[cur][sl] + S.lfix[sl] ? 1 : 0);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) S.count[cur] = 0;
+            cur = nxt;
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < size; i += 64) d.aperm[base + i] = ID[i];
+        for (int i = tid; i < size; i += KB_T) d.aperm[base + i] = S.id[i];
     }
 }
 

@@ -57,8 +57,10 @@ struct DeviceView {
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
     const double *unit256, *unit128, *phi256, *phi128;
-    int32_t *done_count;     // [64] sharded count of agents not yet done after the step
-    unsigned long long *agent_steps;   // [256] sharded running count of agents that entered the policy (mampenv.py:35-40)
+    // counters sharded 256 ways, ONE 128-BYTE LINE PER SHARD: atomics serialise per cache line at the L2
+    // (64 adjacent int counters in 2 lines cost 470 us per 100k-agent step; one line each: a few us)
+    int32_t *done_count;     // [256*32] count of agents not yet done after the step
+    unsigned long long *agent_steps;   // [256*16] running count of agents that entered the policy (mampenv.py:35-40)
     int n, m, shard_begin, shard_count;
 };
 
@@ -167,12 +169,8 @@ __device__ __forceinline__ int kd_traverse(const KdNode *tree, V3 p, double rang
 
 // agent_reach / obs_reach: see k_collide_finish.  Every object that can touch this agent after the move is visited
 // here anyway (it is within neighborDist), so the few that are close enough are written down for K4.
-__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach) {
-    __shared__ int stacks[K1_WAVES][KD_STACK];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent >= d.shard_begin + d.shard_count) return;
+__device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
+                                              int *stack, int agent, int lane) {
     const PubRec me = d.rec[agent];
     int st = 0;
     bool skip = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
@@ -194,7 +192,6 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
     const int maxn = P.max_neighbors;
     WaveList L; L.dsq = 0.0; L.id = -1; L.cnt = 0;
     bool coll = false;
-    int *stack = stacks[wid];
     // obstacles first (scaPolicy.py:114-116), agent.py:101-124
     if (d.m > 0) {
         st |= kd_traverse(d.otree, pA, rangeSq, stack, lane, [&](int begin, int end) {
@@ -274,6 +271,14 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
         const bool complete = near_cnt <= NEAR_MAX && reach_a * reach_a <= rangeSq && reach_o * reach_o <= rangeSq;
         d.near_n[agent] = complete ? near_cnt : -1;
     }
+}
+
+__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach) {
+    __shared__ int stacks[K1_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, stacks[wid], agent, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,12 +380,7 @@ __device__ __forceinline__ int select_from_list(bool shunted, double thr, int co
 }
 
 template <bool FUSE_INTEGRATE>
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
-    __shared__ SolveLds S;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent >= d.shard_begin + d.shard_count) return;                             // wave-uniform
+__device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, SolveLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
     float *act_out = d.action + (size_t)agent * 8;
     int32_t *diag = d.diag + (size_t)agent * 8;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     }
     if (lane == 7) act_out[7] = 0.0f;
     if (lane == 0) {
-        atomicAdd(&d.agent_steps[blockIdx.x & 255], 1ull);
+        atomicAdd(&d.agent_steps[(agent & 255) * 16], 1ull);
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         const int stw = __builtin_amdgcn_readfirstlane(st);
@@ -607,6 +607,16 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     }
     // status bits raised by other lanes (fallback sqrt domain)
     if (lane != 0 && st) atomicOr(&d.status[agent], st);
+}
+
+template <bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
+    __shared__ SolveLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one agent per wavefront, no grid-stride loop: the loop form costs 58 more VGPRs (1 wave/SIMD instead of 2)
+    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) solve_one<FUSE_INTEGRATE>(d, P, S, agent, lane, wid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -625,19 +635,14 @@ __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
 // kd-tree of the step's OLD positions: any pair that touches after the move was within
 // r_a + r_b + 2 * max_step of each other before it.  The flags are committed into the moved record; the
 // host swaps the two record buffers afterwards.
-__global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
-    __shared__ int stacks[K1_WAVES][KD_STACK];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent >= d.shard_begin + d.shard_count) return;
+__device__ __forceinline__ void collide_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
+                                            int *stack, int agent, int lane) {
     const PubRec me = d.rec_new[agent];
     const PubRec me_old = d.rec[agent];
     const V3 p = v3(me.px, me.py, me.pz);
     const V3 p_old = v3(me_old.px, me_old.py, me_old.pz);
     const bool me_goal = (me.flags & FLAG_AT_GOAL) != 0;
     bool hit = false;
-    int *stack = stacks[wid];
     // the pair tests of mampenv.py:63-75 against object j (id as stored in the neighbour lists)
     auto test_obstacle = [&](int o) {
         const ObsRec r = d.obs[o];
@@ -685,8 +690,16 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, 
         const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
         if (l3norm(p, g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;                     // mampenv.py:53-54
         d.rec_new[agent].flags = f;
-        if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[blockIdx.x & 63], 1);
+        if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[(agent & 255) * 32], 1);
     }
+}
+
+__global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
+    __shared__ int stacks[K1_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) collide_one(d, P, agent_reach, obs_reach, stacks[wid], agent, lane);
 }
 
 // the near lists belong to the policy pass of the same step; without one, k_collide_finish must traverse
