@@ -379,6 +379,35 @@ __device__ __forceinline__ int select_from_list(bool shunted, double thr, int co
     return kmax.idx;
 }
 
+// The hot loop: K neighbours x NROUND candidates per lane, branch-free.  Per pair (cone): 3 sub, 2x(mul+2 fma), 2 mul,
+// 2 compares -- all fp64, no transcendental (the asin/acos comparison of util.py:30-41 in algebraic form).
+template <int NROUND, bool ORCA>
+__device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, const V3 (&sh)[NR], const V3 (&cand)[NR + 1],
+                                          unsigned alive) {
+    for (int j = 0; j < K; j++) {
+        const double *s = slot[j];
+        const double a0 = s[0], a1 = s[1], a2 = s[2], b0 = s[3], b1 = s[4], b2 = s[5], g = s[6];
+        unsigned hits = 0;
+#pragma unroll
+        for (int r = 0; r < NROUND; r++) {
+            bool h;
+            if (!ORCA) {
+                const double vx = sh[r].x - a0, vy = sh[r].y - a1, vz = sh[r].z - a2;      // v_dif = (cand + pA) - apex
+                const double dt = fma(b2, vz, fma(b1, vy, b0 * vx));
+                const double n2 = fma(vz, vz, fma(vy, vy, vx * vx));
+                h = (dt * fabs(dt) > g * n2) | (n2 == 0.0);
+            } else {
+                const double rx = cand[r].x - a0, ry = cand[r].y - a1, rz = cand[r].z - a2; // is_inORCA: (v - point) . n >= 0
+                h = !(fma(rz, b2, fma(ry, b1, rx * b0)) >= 0.0);
+            }
+            hits |= (h ? 1u : 0u) << r;
+        }
+        alive &= ~hits;
+        if (__ballot(alive != 0) == 0) break;
+    }
+    return alive;
+}
+
 template <bool FUSE_INTEGRATE>
 __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, SolveLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
@@ -480,24 +509,10 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
             cand[NR] = vpref;
             idx[NR] = T.vp_idx;
             const bool vp_post = posture_ok(P, vA, nvA, pA.z, vpref);
-            unsigned alive = okp;
             // table candidates: neighbours outer (constants broadcast from LDS), candidates in registers
-            for (int j = 0; j < K; j++) {
-                const double *s = slot[j];
-                if (!orca) {
-                    Cone c;
-                    c.apex = v3(s[0], s[1], s[2]); c.pAB = v3(s[3], s[4], s[5]); c.g = s[6];
-#pragma unroll
-                    for (int r = 0; r < NR; r++)
-                        if (r < nround && cone_hit(c, sh[r])) alive &= ~(1u << r);
-                } else {
-                    Plane pl; pl.p = v3(s[0], s[1], s[2]); pl.n = v3(s[3], s[4], s[5]);
-#pragma unroll
-                    for (int r = 0; r < NR; r++)
-                        if (r < nround && !in_orca(pl, cand[r])) alive &= ~(1u << r);
-                }
-                if (__ballot(alive != 0) == 0) break;
-            }
+            unsigned alive;
+            if (nround == NR) alive = orca ? sweep<NR, true>(slot, K, sh, cand, okp) : sweep<NR, false>(slot, K, sh, cand, okp);
+            else alive = orca ? sweep<NR / 2, true>(slot, K, sh, cand, okp) : sweep<NR / 2, false>(slot, K, sh, cand, okp);
             // v_pref candidate: lane j tests neighbour j
             bool vp_hit = false;
             if (lane < K) {
