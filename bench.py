@@ -7,8 +7,9 @@ flags), with the state resident in HBM when the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workloads (BASELINE.json configs): c2 = circle N=1024 SCA (default at 1 GPU), c3 = random N=4096 ORCA3D,
-c4 = circle N=100000 SCA, c5 = take-off/landing N=16384 mixed SCA + S-RVO3D.
+Workloads (BASELINE.json configs): c4 = circle N=100000 SCA (default at every GPU count: the configuration the metric's
+"N-agent circle at 1/2/4/8 GPUs" clause names; it fits one GPU and keeps the scaling runs strong-scaling), c2 = circle
+N=1024 SCA, c3 = random N=4096 ORCA3D, c5 = take-off/landing N=16384 mixed SCA + S-RVO3D.
 SCA's preferred velocity comes from the reference's host-side Dubins tracker (scaPolicy.py:264-338), which is
 outside the kernel boundary; the bench feeds the straight-line rule (rvo3dPolicy.py:182-196)
 computed on the device instead, and says so in `config`.
@@ -62,7 +63,7 @@ def build_scene(w, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
     ap.add_argument('--agents', type=int, default=None)
@@ -85,7 +86,7 @@ def main():
     from sca_amd import solver as S
     from sca_amd.distributed import ShardedStepper
 
-    wname = args.workload or 'c2'
+    wname = args.workload or 'c4'
     w = WORKLOADS[wname]
     n_req = args.agents or w['n']
     if world > 1:
@@ -145,7 +146,7 @@ def main():
                        'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'
                        if world > 1 else 'single GPU', 'agent_steps_timed': total_steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_solve',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(wname), 'kernel': 'k_solve',
                          'kernel_ms': kms['solve'], 'neighbors_kernel_ms': kms['neighbors'],
                          'bytes_per_agent_step': BYTES_PER_AGENT_STEP,
                          'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
@@ -157,6 +158,17 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(wname):
+    """HBM bytes per k_solve launch from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    profiles/r01_pmc_traffic.json); None when no capture exists for this workload."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(wname, {}).get('k_solve_hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(scene, sol, S):

@@ -1,0 +1,291 @@
+"""Drop-in host side for mamp.envs / mamp.agents / mamp.policies of wuuya1/SCA, backed by libsca_hip.
+
+Same names, arguments and attribute surface as the reference (file:line cites are into wuuya1/SCA):
+    Agent(start_pos, goal_pos, vel, radius, pref_speed, policy, id, dt)      mamp/agents/agent.py:9
+    Obstacle(pos, shape_dict, id)                                            mamp/agents/obstacle.py:5
+    SCAPolicy / RVO3DPolicy / SRVO3DPolicy / ORCA3DPolicy / ORCA3DPolicyOfficial / RVO3dDubinsPolicy
+        .find_next_action(dict_comm, agent, kdTree) -> action[7]             e.g. mamp/policies/rvo3dPolicy.py:23
+    MACAEnv().set_agents(agents, obstacles=[...]); MACAEnv.step(actions) -> bool   mamp/envs/mampenv.py:16-25
+
+Differences that matter:
+  * the env makes ONE library call per step for all agents (the reference calls find_next_action per agent,
+    mampenv.py:34-40); `agent.policy.find_next_action(...)` still works for a single agent -- it runs the same
+    batched pass and returns that agent's row;
+  * per-agent state lives in structure-of-arrays owned by the env; the Agent attributes the reference exposes
+    (pos_global_frame, vel_global_frame, heading_global_frame, is_at_goal, ...) are views / properties over them;
+  * SCAPolicy and RVO3dDubinsPolicy need the reference's Dubins tracker for v_pref (scaPolicy.py:264-338). That
+    tracker is a host-side, per-agent stateful planner outside the kernel boundary (not built yet):
+    pass `v_pref_fn(env) -> [N,3]` to MACAEnv to supply it; without one the straight-line rule of
+    rvo3dPolicy.py:182-196 is used and `env.dubins_tracker` is False;
+  * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
+There is no CPU path: constructing the env without a GPU raises.
+"""
+import math
+
+import numpy as np
+
+from . import scenarios as _sc
+from . import solver as S
+
+DT = 0.1                      # mamp/configs/config.py:2
+NEAR_GOAL_THRESHOLD = 0.5     # mamp/configs/config.py:3
+
+
+class _Policy:
+    policy_id = None
+    needs_external_vpref = False
+
+    def __init__(self):                      # constructible with no arguments (agent.py:11 `policy()`)
+        self.now_goal = None
+        self.type = 'internal'
+        self._env = None
+
+    def find_next_action(self, dict_comm, agent, kdTree):
+        """Single-agent entry point of the reference API.  Runs the batched policy pass of the owning env (cached per
+        step) and returns this agent's [vx, vy, vz, speed, d_yaw, d_pitch, d_roll]."""
+        if self._env is None:
+            raise RuntimeError('policy is not attached to a MACAEnv (call env.set_agents first)')
+        self.now_goal = agent.goal_global_frame          # get_trajectory: agent.path is always empty (scaPolicy.py:89)
+        return self._env._policy_row(agent.id)
+
+
+class SCAPolicy(_Policy):
+    policy_id = S.POL_SCA
+    needs_external_vpref = True
+
+
+class RVO3DPolicy(_Policy):
+    policy_id = S.POL_RVO3D
+
+
+class SRVO3DPolicy(_Policy):
+    policy_id = S.POL_SRVO3D
+
+
+class ORCA3DPolicy(_Policy):                 # mamp/policies/orca3dPolicy.py (sampled, the one run_orca.py imports)
+    policy_id = S.POL_ORCA3D
+
+
+class ORCA3DPolicyOfficial(_Policy):         # mamp/policies/orca3dPolicyOfficial.py (linearProgram1-4)
+    policy_id = S.POL_ORCA3D_LP
+
+
+class RVO3dDubinsPolicy(_Policy):
+    policy_id = S.POL_RVO3D_DUBINS
+    needs_external_vpref = True
+
+
+class Obstacle:
+    def __init__(self, pos, shape_dict, id):
+        self.shape = shape_dict['shape']
+        self.feature = shape_dict['feature']
+        if self.shape == 'cube':                                    # obstacle.py:9-11: bounding sphere
+            self.length, self.width, self.height = shape_dict['feature']
+            self.radius = math.sqrt(self.length ** 2 + self.width ** 2 + self.height ** 2) / 2
+        elif self.shape == 'sphere':
+            self.radius = shape_dict['feature']
+        else:
+            raise NotImplementedError
+        self.pos_global_frame = np.array(pos, dtype='float64')
+        self.vel_global_frame = np.array([0.0, 0.0, 0.0])
+        self.pos = pos
+        self.id = id
+        self.is_at_goal = True
+        self.is_obstacle = True
+        self.is_collision = False
+
+
+class Agent:
+    def __init__(self, start_pos, goal_pos, vel, radius, pref_speed, policy, id, dt=0.1):
+        self.group = 0
+        self.policy = policy()
+        self.initial_pos = np.array(start_pos, dtype='float64')
+        self.goal_pos = np.array(goal_pos, dtype='float64')
+        self._pos = np.array(start_pos[:3], dtype='float64')
+        self.goal_global_frame = np.array(goal_pos[:3], dtype='float64')
+        self._heading = np.array(start_pos[3:], dtype='float64')
+        self.goal_heading_frame = np.array(goal_pos[3:], dtype='float64')
+        self.initial_heading = np.array(start_pos[3:], dtype='float64')
+        self._vel = np.array(vel, dtype=np.float32)
+        self.radius = radius
+        self.turning_radius = 1.5
+        self.id = id
+        self.pref_speed = pref_speed
+        self.pitchlims = [-math.pi / 4, math.pi / 4]
+        self.min_heading_change = self.pitchlims[0]
+        self.max_heading_change = self.pitchlims[1]
+        self.maxNeighbors = 16
+        self.neighborDist = 10.0
+        self.timeStep = DT
+        self.timeHorizon = 10.0
+        self.maxSpeed = 1.0
+        self.dt_nominal = DT
+        self.path = []
+        self.v_pref = np.zeros(3)
+        self.total_time = 0.0
+        self.is_obstacle = False
+        d = float(np.sqrt(((self.initial_pos[:3] - self.goal_pos[:3]) ** 2).sum()))
+        self.straight_path_length = round(d, 5) - 0.5               # agent.py:51
+        self.desire_steps = int(self.straight_path_length / (pref_speed * DT))
+        self.max_run_dist = 3.0 * round(d, 5)                       # agent.py:74
+        self._env = None
+        self._flags = 0
+        self._total_dist = 0.0
+        self._step_num = 0
+
+    # --- state: views over the env's arrays once attached -------------------------------------------------------------
+    def _get(self, name, local):
+        return local if self._env is None else getattr(self._env, name)[self.id]
+
+    @property
+    def pos_global_frame(self):
+        return self._get('pos', self._pos)
+
+    @property
+    def vel_global_frame(self):
+        return self._get('vel', self._vel)
+
+    @property
+    def heading_global_frame(self):
+        return self._get('heading', self._heading)
+
+    @property
+    def total_dist(self):
+        return float(self._get('total_dist', self._total_dist))
+
+    @property
+    def step_num(self):
+        return int(self._get('step_num', self._step_num))
+
+    def _flag(self, bit):
+        f = self._flags if self._env is None else int(self._env.flags[self.id])
+        return bool(f & bit)
+
+    @property
+    def is_at_goal(self):
+        return self._flag(S.FLAG_AT_GOAL)
+
+    @property
+    def is_collision(self):
+        return self._flag(S.FLAG_COLLISION)
+
+    @property
+    def is_out_of_max_time(self):
+        return self._flag(S.FLAG_TIMEOUT)
+
+    @property
+    def is_run_done(self):
+        return self.is_at_goal or self.is_collision or self.is_out_of_max_time
+
+    @property
+    def neighbors(self):
+        """[(object, distSq)] of the last policy pass, as agent.py:79-124 leaves it."""
+        if self._env is None:
+            return []
+        return self._env._neighbors_of(self.id)
+
+
+class _KdTreeView:
+    """Stand-in for mamp.policies.kdTree.KDTree: the tree itself lives on the device; the permutation the reference
+    carries from step to step (kdTree.py:43-45) is readable."""
+
+    def __init__(self, env):
+        self._env = env
+        self.max_leaf_size = 10
+
+    @property
+    def agentIDs(self):
+        return list(self._env.solver.get_kd_perm())
+
+
+class MACAEnv:
+    def __init__(self, v_pref_fn=None, device=0, neighbor_mode=S.NBR_KDTREE):
+        self.agents = None
+        self.obstacles = []
+        self.kdTree = None
+        self.solver = None
+        self.v_pref_fn = v_pref_fn
+        self.dubins_tracker = v_pref_fn is not None
+        self.device = device
+        self.neighbor_mode = neighbor_mode
+        self._row_cache = None
+
+    def set_agents(self, agents, obstacles=None):
+        if obstacles is None:
+            raise TypeError('obstacles must be a list (the reference crashes on None too, kdTree.py:48)')
+        for i, a in enumerate(agents):
+            if a.id != i:
+                raise ValueError('agent.id must equal its list index (kdTree.py:64)')
+        self.agents = agents
+        self.obstacles = obstacles
+        n, m = len(agents), len(obstacles)
+        self.pos = np.array([a._pos for a in agents], dtype=np.float64).reshape(n, 3)
+        self.vel = np.array([a._vel for a in agents], dtype=np.float32).reshape(n, 3)
+        self.heading = np.array([a._heading for a in agents], dtype=np.float64).reshape(n, 3)
+        self.flags = np.zeros(n, np.uint8)
+        self.total_dist = np.zeros(n)
+        self.step_num = np.zeros(n, np.int32)
+        self.goal = np.array([a.goal_global_frame for a in agents], dtype=np.float64).reshape(n, 3)
+        self.policy_ids = np.array([a.policy.policy_id for a in agents], np.uint8)
+        self._ext = np.array([a.policy.needs_external_vpref for a in agents], bool)
+        start = np.array([a.initial_pos for a in agents], dtype=np.float64)
+        goal6 = np.array([a.goal_pos for a in agents], dtype=np.float64)
+        self.solver = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), device=self.device)
+        self.solver.set_obstacles(np.array([o.pos_global_frame for o in obstacles], dtype=np.float64).reshape(m, 3),
+                                  np.array([o.radius for o in obstacles], dtype=np.float64))
+        self.solver.set_agents([a.radius for a in agents], [a.pref_speed for a in agents], self.goal, self.policy_ids,
+                               S.zaxis_flags(start, goal6), [a.max_run_dist for a in agents])
+        self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
+        for a in agents:
+            a._env = self
+            a.policy._env = self
+        self.kdTree = _KdTreeView(self)
+        self._row_cache = None
+        self._nbr_cache = None
+
+    # ---- one step = MACAEnv.step (mampenv.py:22-25) ---------------------------------------------------------------------
+    def _policy_pass(self):
+        if self._row_cache is None:
+            if self.v_pref_fn is not None and self._ext.any():
+                vp = np.asarray(self.v_pref_fn(self), dtype=np.float64).reshape(len(self.agents), 3)
+                self.solver.set_vpref(vp, self._ext.astype(np.uint8))
+            self.solver.policy_pass(self.neighbor_mode)
+            self._row_cache = self.solver.actions()
+            self._nbr_cache = None
+            self.flags[:] = self.solver.get_state()['flags']      # is_collision set inside insert*Neighbor (agent.py:84)
+        return self._row_cache
+
+    def _policy_row(self, i):
+        return list(self._policy_pass()[i])
+
+    def _neighbors_of(self, i):
+        if self._nbr_cache is None:
+            self._nbr_cache = self.solver.neighbors()
+        nb = self._nbr_cache
+        out = []
+        for k in range(int(nb['nbr_n'][i])):
+            j = int(nb['nbr_id'][i, k])
+            obj = self.obstacles[j] if nb['nbr_kind'][i, k] else self.agents[j]
+            out.append((obj, float(nb['nbr_dsq'][i, k])))
+        return out
+
+    def step(self, actions=None):
+        """`actions` is ignored, as in the reference (mampenv.py:22)."""
+        self._policy_pass()
+        done = self.solver.env_update()
+        st = self.solver.get_state()
+        self.pos[:] = st['pos']
+        self.vel[:] = st['vel']
+        self.heading[:] = st['heading']
+        self.flags[:] = st['flags']
+        self.total_dist[:] = st['total_dist']
+        self.step_num[:] = st['step_num']
+        self._row_cache = None
+        return done
+
+
+def build_circle_agents(n, policy=RVO3DPolicy, rad=None, radius=0.5, pref_speed=1.0):
+    """run_example/run_sca.py:106-126 build_agents for the circle scenario."""
+    sc = _sc.circle(n, rad=rad)
+    return [Agent(start_pos=list(sc['start'][i]), goal_pos=list(sc['goal'][i]), vel=[0.0, 0.0, 0.0], radius=radius,
+                  pref_speed=pref_speed, policy=policy, id=i, dt=DT) for i in range(n)]

@@ -266,3 +266,39 @@ def test_hostbuild_and_device_build_give_identical_passes(S):
     for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
         assert np.array_equal(a[0][k], b[0][k]), k
     assert np.array_equal(a[2]['nbr_id'], b[2]['nbr_id'])
+
+
+def test_drop_in_env_api_matches_oracle_episode(S, oracle):
+    """mamp.envs-style usage: Agent objects + MACAEnv.step(), RVO3D circle N=24, 60 steps, against the oracle stepped on
+    the host with the reference's loop structure."""
+    from sca_amd import env as E, scenarios
+    n = 24
+    agents = E.build_circle_agents(n, policy=E.RVO3DPolicy, rad=8.0)
+    env = E.MACAEnv()
+    env.set_agents(agents, obstacles=[])
+    sc = scenarios.circle(n, rad=8.0)
+    pos, vel, head = sc['start'][:, :3].copy(), np.zeros((n, 3), np.float32), sc['start'][:, 3:6].copy()
+    flags = np.zeros(n, np.uint8); td = np.zeros(n); sn = np.zeros(n, np.int32); perm = np.arange(n, dtype=np.int32)
+    rad = np.full(n, 0.5); ps = np.full(n, 1.0); pol = np.full(n, 1, np.uint8); z = np.zeros(n, np.uint8)
+    mrd = scenarios.max_run_dist(sc['start'], sc['goal'])
+    e3, e0 = np.zeros((0, 3)), np.zeros(0)
+    for t in range(60):
+        if t == 5:
+            a = agents[3]
+            row = a.policy.find_next_action({}, a, env.kdTree)       # single-agent entry point of the reference API
+            assert len(row) == 7
+        r = oracle.policy_step(pos, vel, head, rad, ps, flags, sc['goal'][:, :3], pol, z, np.zeros((n, 3)),
+                               np.zeros(n, np.uint8), perm, e3, e0)
+        perm = r['perm']
+        if t == 5:
+            assert np.array_equal(np.float32(row[:4]), r['action'][3, :4])
+            assert [o.id for o, _ in a.neighbors] == list(r['nbr_id'][3, :r['nbr_n'][3]])
+        u = oracle.env_update(pos, vel, head, rad, r['flags'], sc['goal'][:, :3], r['action'], td, mrd, sn, e3, e0)
+        pos, vel, head, flags, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+        done = env.step({})
+        assert done == u['done']
+        assert np.abs(env.vel - vel).max() <= VEL_TOL
+    assert np.allclose(env.pos, pos, rtol=0, atol=1e-6)
+    assert np.array_equal(env.flags, flags)
+    assert np.array_equal(agents[0].pos_global_frame, env.pos[0]) and agents[0].step_num == sn[0]
+    assert env.kdTree.agentIDs == list(perm)

@@ -1,0 +1,101 @@
+"""CPU tests of the host-side logic: scenario generators against the reference's own start states (golden fixtures),
+the drop-in API surface, and the 2-rank sharded stepping protocol (gloo) with a checker backend built on the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_circle_generator_matches_reference_start_state():
+    from sca_amd import scenarios
+    fx = load('F1_sca_circle8')                       # run_sca.set_circle_pos((0,0), 10.0, 8)
+    sc = scenarios.circle(8, rad=10.0)
+    assert np.array_equal(sc['start'], fx['start'])
+    assert np.array_equal(sc['goal'], fx['goal6'])
+    assert np.array_equal(scenarios.max_run_dist(sc['start'], sc['goal']), fx['max_run_dist'])
+    fx = load('F4_sca_circle16_obs')
+    sc = scenarios.circle(16, rad=10.0)
+    assert np.array_equal(sc['start'], fx['start'])
+
+
+def test_takeoff_generator_matches_reference_cell():
+    from sca_amd import scenarios
+    fx = load('F4_sca_takeoff16')                     # run_sca.set_takeoff_landing_pos(16) + build_obstacles
+    sc = scenarios.takeoff_landing(16)
+    assert np.array_equal(sc['start'], fx['start'])
+    assert np.array_equal(sc['goal'], fx['goal6'])
+    assert np.array_equal(sc['obs_pos'], fx['obs_pos'])
+    assert np.array_equal(sc['obs_radius'], fx['obs_radius'])
+    big = scenarios.takeoff_landing(64)
+    assert big['start'].shape == (64, 6) and big['obs_pos'].shape == (32, 3)
+
+
+def test_random_generator_is_seeded_and_separated():
+    from sca_amd import scenarios
+    a = scenarios.random_cube(300, seed=3)
+    b = scenarios.random_cube(300, seed=3)
+    assert np.array_equal(a['start'], b['start']) and np.array_equal(a['goal'], b['goal'])
+    p = a['start'][:, :3]
+    d = np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1)) + np.eye(300) * 1e9
+    assert d.min() >= 1.5
+
+
+def test_drop_in_api_surface():
+    from sca_amd import env as E
+    a = E.Agent(start_pos=[1, 2, 3, 0.5, 0, 0], goal_pos=[4, 6, 3, 0, 0, 0], vel=[0.0, 0.0, 0.0], radius=0.5,
+                pref_speed=1.0, policy=E.SCAPolicy, id=0, dt=0.1)
+    # agent.py:13-42,70-74
+    assert a.policy.type == 'internal' and a.policy.now_goal is None
+    assert np.array_equal(a.pos_global_frame, [1, 2, 3]) and np.array_equal(a.heading_global_frame, [0.5, 0, 0])
+    assert (a.maxNeighbors, a.neighborDist, a.timeHorizon, a.maxSpeed, a.timeStep) == (16, 10.0, 10.0, 1.0, 0.1)
+    assert a.max_run_dist == 15.0 and not a.is_at_goal and not a.is_collision and not a.is_out_of_max_time
+    ob = E.Obstacle(pos=[0, 0, 5], shape_dict={'shape': 'cube', 'feature': (2.0, 2.0, 2.0)}, id=0)
+    assert abs(ob.radius - 3 ** 0.5) < 1e-15 and ob.is_at_goal           # obstacle.py:9-11,22
+    for cls, pid in ((E.SCAPolicy, 0), (E.RVO3DPolicy, 1), (E.SRVO3DPolicy, 2), (E.ORCA3DPolicy, 3),
+                     (E.ORCA3DPolicyOfficial, 4), (E.RVO3dDubinsPolicy, 5)):
+        assert cls().policy_id == pid
+    env = E.MACAEnv()
+    with pytest.raises(TypeError):
+        env.set_agents([a], obstacles=None)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from sharded_checker import CheckerBackend, reference_run, scene
+from sca_amd.distributed import ShardedStepper
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+sc = scene()
+be = CheckerBackend(sc)
+st = ShardedStepper(be, rank, world, torch_mod=torch, dist_mod=dist)
+st.run(6)
+st.sync()
+ref = reference_run(sc, 6)
+lo, hi = be.begin, be.begin + be.count
+ok = (np.array_equal(be.pos[lo:hi], ref['pos'][lo:hi]) and np.array_equal(be.vel[lo:hi], ref['vel'][lo:hi])
+      and np.array_equal(be.flags[lo:hi], ref['flags'][lo:hi]) and np.array_equal(be.pos, ref['pos']))
+print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_two_rank_sharded_stepping_matches_single_process(tmp_path):
+    """world_size 2 over gloo: each rank steps its half with the checker backend, exchanges the moved 48-byte records
+    with all_gather_into_tensor exactly as the GPU path does, and must land on the single-process result bit for bit."""
+    import subprocess
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29531', str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('OK') == 2, r.stdout[-2000:]
