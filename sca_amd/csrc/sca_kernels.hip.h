@@ -53,6 +53,7 @@ struct DeviceView {
     // outputs
     float *action;           // [n*8] (7 used)
     double *vpref_used;      // [n*3]
+    double *vpost;           // [n*3] selected velocity (k_solve -> k_action)
     int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
@@ -408,18 +409,12 @@ __device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, con
     return alive;
 }
 
-template <bool FUSE_INTEGRATE>
 __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, SolveLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
-    float *act_out = d.action + (size_t)agent * 8;
     int32_t *diag = d.diag + (size_t)agent * 8;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35: row stays zero
-        if (lane < 8) { act_out[lane] = 0.0f; diag[lane] = -1; }
+        if (lane < 8) diag[lane] = -1;
         if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
-        if (FUSE_INTEGRATE && lane == 0) {
-            const float zero[7] = {0, 0, 0, 0, 0, 0, 0};
-            integrate_agent(d, P, agent, me, zero);
-        }
         return;
     }
     const int pol = d.policy[agent];
@@ -429,7 +424,6 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
     const double ps = d.pref_speed[agent];
-    const double yaw = d.heading[agent * 3 + 0], pitch = d.heading[agent * 3 + 1];
     int st = 0;
     V3 vpref;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
@@ -595,49 +589,56 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
             vpost = trunc5(cand_from_idx(T, chosen, vpref));                          // scaPolicy.py:239
         }
     }
-    double act[7];
-    cartesian2spherical(yaw, pitch, vpost, pol == POL_ORCA_LP, act);
-    float actf[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) actf[k] = (float)act[k];                              // mampenv.py:31,40 float32 row
-    if (lane < 7) {
-        float a = actf[0];
-#pragma unroll
-        for (int k = 1; k < 7; k++) if (lane == k) a = actf[k];
-        act_out[lane] = a;
-    }
-    if (lane == 7) act_out[7] = 0.0f;
+    // the per-agent scalar epilogue (cartesian2spherical, update_velocitie) runs one LANE per agent in k_action:
+    // inside this one-wave-per-agent kernel it would cost a full wave's issue slots (~1500 instructions per agent)
     if (lane == 0) {
+        d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z;
         atomicAdd(&d.agent_steps[(agent & 255) * 16], 1ull);
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         const int stw = __builtin_amdgcn_readfirstlane(st);
         if (stw) atomicOr(&d.status[agent], stw);
-        PubRec mine = me;
-        if (d.coll_new[agent]) {                                                      // agent.py:84 is_collision = True
-            mine.flags = me.flags | FLAG_COLLISION;
-            d.rec[agent].flags = mine.flags;
-        }
-        if (FUSE_INTEGRATE) integrate_agent(d, P, agent, mine, actf);
     }
     // status bits raised by other lanes (fallback sqrt domain)
     if (lane != 0 && st) atomicOr(&d.status[agent], st);
 }
 
-template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
     __shared__ SolveLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one agent per wavefront, no grid-stride loop: the loop form costs 58 more VGPRs (1 wave/SIMD instead of 2)
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_one<FUSE_INTEGRATE>(d, P, S, agent, lane, wid);
+    if (agent < d.shard_begin + d.shard_count) solve_one(d, P, S, agent, lane, wid);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K4: MACAEnv second loop.  update_velocitie (mampenv.py:83-105) writes the moved record to rec_new;
 // check_agent_state (mampenv.py:61-80) then needs, for a pair i<j, new_i vs OLD_j (j not yet moved when i is
 // checked) and new_j vs new_i -- so collide reads both buffers.
+// K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
+// is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
+template <bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    PubRec me = d.rec[agent];
+    float actf[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!(me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) {                // mampenv.py:35: else the row stays zero
+        double act[7];
+        const V3 v = v3(d.vpost[agent * 3], d.vpost[agent * 3 + 1], d.vpost[agent * 3 + 2]);
+        cartesian2spherical(d.heading[agent * 3 + 0], d.heading[agent * 3 + 1], v, d.policy[agent] == POL_ORCA_LP, act);
+#pragma unroll
+        for (int k = 0; k < 7; k++) actf[k] = (float)act[k];
+        if (d.coll_new[agent]) { me.flags |= FLAG_COLLISION; d.rec[agent].flags = me.flags; }
+    }
+    float *out = d.action + (size_t)agent * 8;
+#pragma unroll
+    for (int k = 0; k < 7; k++) out[k] = actf[k];
+    out[7] = 0.0f;
+    if (FUSE_INTEGRATE) integrate_agent(d, P, agent, me, actf);
+}
+
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.shard_begin + d.shard_count) return;
