@@ -210,7 +210,8 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.near_n, N); r |= dalloc(c, &d.near_id, N * NEAR_MAX);
-    r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.vpost, 3 * N); r |= dalloc(c, &d.diag, N * 8);
+    r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.vpost, 3 * N);
+    r |= dalloc(c, &d.fb_list, N); r |= dalloc(c, &d.fb_count, 1); r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
     r |= dalloc(c, &c->kd.ml, N); r |= dalloc(c, &c->kd.mr, N);
@@ -236,7 +237,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
-                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.diag, d.status,
+                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -482,7 +483,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                        c->stream, d, c->P, agent_reach, obs_reach);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
+    CHK(c, hipMemsetAsync(d.fb_count, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    // agents without any suitable candidate (rare): the complete sweep incl. compute_without_suitV
+    hipLaunchKernelGGL(k_solve_full, dim3(std::max(1, std::min(4096, (cnt + SOLVE_WAVES - 1) / SOLVE_WAVES))), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     else hipLaunchKernelGGL(k_action<false>, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));

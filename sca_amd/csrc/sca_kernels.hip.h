@@ -54,6 +54,8 @@ struct DeviceView {
     float *action;           // [n*8] (7 used)
     double *vpref_used;      // [n*3]
     double *vpost;           // [n*3] selected velocity (k_solve -> k_action)
+    int32_t *fb_list;        // [n] agents without a suitable candidate: finished by k_solve_full
+    int32_t *fb_count;       // [1]
     int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
@@ -382,8 +384,8 @@ __device__ __forceinline__ int select_from_list(bool shunted, double thr, int co
 
 // The hot loop: K neighbours x NROUND candidates per lane, branch-free.  Per pair (cone): 3 sub, 2x(mul+2 fma), 2 mul,
 // 2 compares -- all fp64, no transcendental (the asin/acos comparison of util.py:30-41 in algebraic form).
-template <int NROUND, bool ORCA>
-__device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, const V3 (&sh)[NR], const V3 (&cand)[NR + 1],
+template <int NROUND, bool ORCA, int NA, int NB>
+__device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, const V3 (&sh)[NA], const V3 (&cand)[NB],
                                           unsigned alive) {
     for (int j = 0; j < K; j++) {
         const double *s = slot[j];
@@ -505,8 +507,8 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
             const bool vp_post = posture_ok(P, vA, nvA, pA.z, vpref);
             // table candidates: neighbours outer (constants broadcast from LDS), candidates in registers
             unsigned alive;
-            if (nround == NR) alive = orca ? sweep<NR, true>(slot, K, sh, cand, okp) : sweep<NR, false>(slot, K, sh, cand, okp);
-            else alive = orca ? sweep<NR / 2, true>(slot, K, sh, cand, okp) : sweep<NR / 2, false>(slot, K, sh, cand, okp);
+            if (nround == NR) alive = orca ? sweep<NR, true, NR, NR + 1>(slot, K, sh, cand, okp) : sweep<NR, false, NR, NR + 1>(slot, K, sh, cand, okp);
+            else alive = orca ? sweep<NR / 2, true, NR, NR + 1>(slot, K, sh, cand, okp) : sweep<NR / 2, false, NR, NR + 1>(slot, K, sh, cand, okp);
             // v_pref candidate: lane j tests neighbour j
             bool vp_hit = false;
             if (lane < K) {
@@ -593,7 +595,6 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     // inside this one-wave-per-agent kernel it would cost a full wave's issue slots (~1500 instructions per agent)
     if (lane == 0) {
         d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z;
-        atomicAdd(&d.agent_steps[(agent & 255) * 16], 1ull);
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         const int stw = __builtin_amdgcn_readfirstlane(st);
@@ -603,19 +604,237 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     if (lane != 0 && st) atomicOr(&d.status[agent], st);
 }
 
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
+// The complete sweep (all 513 candidates per agent in registers, incl. compute_without_suitV).  It runs only for the
+// agents k_solve could not finish (no suitable candidate: scaPolicy.py:224-238), taken from the fallback list.
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_full(DeviceView d, Params P) {
     __shared__ SolveLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // one agent per wavefront, no grid-stride loop: the loop form costs 58 more VGPRs (1 wave/SIMD instead of 2)
-    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_one(d, P, S, agent, lane, wid);
+    const int n = *d.fb_count;
+    for (int i = blockIdx.x * SOLVE_WAVES + wid; i < n; i += gridDim.x * SOLVE_WAVES) {
+        solve_one(d, P, S, d.fb_list[i], lane, wid);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: MACAEnv second loop.  update_velocitie (mampenv.py:83-105) writes the moved record to rec_new;
-// check_agent_state (mampenv.py:61-80) then needs, for a pair i<j, new_i vs OLD_j (j not yet moved when i is
-// checked) and new_j vs new_i -- so collide reads both buffers.
+// K2 fast path.  The posture constraint (util.py:6-20: within max_heading_change of the current velocity) removes
+// ~85 % of the 512 directions before any cone is looked at, so the candidates that pass it are COMPACTED across the
+// wavefront (ballot + prefix into an LDS list) and only those are swept, two per lane at a time.  The survivors go to
+// a second LDS list with their sort key; the selection passes run over that list.
+struct FastLds {
+    double slot[SOLVE_WAVES][K_MAX][SLOT];
+    Plane planes[SOLVE_WAVES][K_MAX];
+    Plane proj[SOLVE_WAVES][K_MAX];
+    double keyS[SOLVE_WAVES][520];
+    unsigned short listA[SOLVE_WAVES][512];
+    unsigned short idxS[SOLVE_WAVES][520];
+};
+
+__device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
+    const PubRec me = d.rec[agent];
+    int32_t *diag = d.diag + (size_t)agent * 8;
+    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
+        if (lane < 8) diag[lane] = -1;
+        if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
+        return;
+    }
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    const V3 pA = v3(me.px, me.py, me.pz);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const V3 vA64 = to_v3(vA);
+    const double rA = me.radius;
+    const double ps = d.pref_speed[agent];
+    int st = 0;
+    V3 vpref;
+    if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
+    const bool first_step = l3norm_f32zero(vA, orca) <= 1e-5;                        // scaPolicy.py:34 / orca3dPolicy.py:53
+    int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
+    V3 vpost;
+    const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    if (first_step) {
+        vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
+    } else {
+        double (*slot)[SLOT] = S.slot[wid];
+        if (lane < K) {                                   // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
+            const int nid = d.nbr_id[agent * K_MAX + lane];
+            V3 pB; F3 vB; double rB; bool stat; const bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
+            if (isob) {
+                const ObsRec o = d.obs[nid & ~NBR_OBSTACLE_BIT];
+                pB = v3(o.px, o.py, o.pz); vB.x = vB.y = vB.z = 0.0f; rB = o.radius; stat = true;   // obstacle.py:22
+            } else {
+                const PubRec o = d.rec[nid];
+                pB = v3(o.px, o.py, o.pz); vB.x = o.vx; vB.y = o.vy; vB.z = o.vz; rB = o.radius;
+                stat = (o.flags & FLAG_AT_GOAL) != 0;
+            }
+            double *sl = slot[lane];
+            if (!orca) {
+                const Cone c = make_cone(pA, vA, rA, pB, vB, rB, stat);
+                sl[0] = c.apex.x; sl[1] = c.apex.y; sl[2] = c.apex.z; sl[3] = c.pAB.x; sl[4] = c.pAB.y; sl[5] = c.pAB.z; sl[6] = c.g;
+            } else {
+                const OrcaOb o = make_orca(P, pA, vA, rA, pB, vB, rB, isob);
+                sl[0] = o.pl.p.x; sl[1] = o.pl.p.y; sl[2] = o.pl.p.z; sl[3] = o.pl.n.x; sl[4] = o.pl.n.y; sl[5] = o.pl.n.z; sl[6] = 0.0;
+                Plane pl; pl.p = o.pl.p; pl.n = o.pl.n;
+                S.planes[wid][lane] = pl;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (pol == POL_ORCA_LP) {
+            // K3: LP3 (+LP4), orca3dPolicyOfficial.py:108-113.  Scalar chain, lane 0 drives.
+            V3 nv = v3(0, 0, 0);
+            int pf = 0, l4 = 0;
+            if (lane == 0) {
+                pf = lp3(S.planes[wid], K, P.max_speed, vpref, false, nv);
+                if (pf < K) { lp4(S.planes[wid], K, pf, P.max_speed, nv, S.proj[wid]); l4 = 1; }
+            }
+            vpost = v3(__shfl(nv.x, 0), __shfl(nv.y, 0), __shfl(nv.z, 0));
+            dg_pfail = __shfl(pf, 0);
+            dg_lp4 = __shfl(l4, 0);
+        } else {
+            CandTab T;
+            T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;                 // scaPolicy.py:188-190
+            T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
+            T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
+            T.vp_idx = 2 * T.num_N;
+            if (!candidate_speeds(ps, T.rad1)) { st |= ST_BAD_PREF_SPEED; T.rad1 = ps; }
+            const int nround = T.vp_idx >> 6;
+            const double nvA = (double)normf(vA);
+            unsigned short *listA = S.listA[wid];
+            unsigned short *idxS = S.idxS[wid];
+            double *keyS = S.keyS[wid];
+            // ---- posture filter (util.py:6-20) + compaction.  c >= thr is decided without sqrt / division whenever
+            //      dot^2 and (thr*|vA|)^2 |v|^2 are more than 1e-13 apart (relative); otherwise the exact expression runs.
+            const double thr = P.cos_heading_thr;
+            const double tn = thr * nvA;
+            const double T2 = tn * tn;
+            const bool filter_ok = thr > 0.0;
+            int nA = 0;
+            for (int r = 0; r < nround; r++) {
+                const int idx = r * 64 + lane;
+                const V3 c = cand_from_idx(T, idx, vpref);
+                const double dt = dot(vA64, c);
+                const double n2 = dot(c, c);
+                const double y = T2 * n2;
+                const double lhs = dt * dt;
+                const bool sure_pass = filter_ok & (dt > 0.0) & (lhs > y * (1.0 + 1e-13));
+                const bool sure_fail = filter_ok & ((dt <= 0.0) | (lhs < y * (1.0 - 1e-13)));
+                bool ok = sure_pass;
+                if (__ballot(!(sure_pass | sure_fail)) != 0) {
+                    if (!(sure_pass | sure_fail)) ok = posture_cos(vA, nvA, c) >= thr;
+                }
+                ok = ok & ((pA.z + P.time_step * c.z) >= 0.0);
+                const unsigned long long m = __ballot(ok);
+                if (ok) listA[nA + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)idx;
+                nA += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- sweep of the compacted candidates, two per lane and chunk; survivors -> (idxS, keyS)
+            int nS = 0;
+            for (int c0 = 0; c0 < nA; c0 += 128) {
+                V3 cd[2], sh[2];
+                int ix[2];
+                unsigned valid = 0;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int e = c0 + q * 64 + lane;
+                    ix[q] = e < nA ? (int)listA[e] : 0;
+                    if (e < nA) valid |= 1u << q;
+                    cd[q] = cand_from_idx(T, ix[q], vpref);
+                    sh[q] = cd[q] + pA;
+                }
+                const unsigned alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, valid) : sweep<2, false, 2, 2>(slot, K, sh, cd, valid);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const bool a = (alive >> q) & 1u;
+                    const unsigned long long m = __ballot(a);
+                    if (a) {
+                        const int at = nS + __popcll(m & ((1ull << lane) - 1ull));
+                        idxS[at] = (unsigned short)ix[q];
+                        keyS[at] = l3norm(cd[q], vpref);                                 // scaPolicy.py:219
+                    }
+                    nS += __popcll(m);
+                }
+            }
+            // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j
+            bool vp_hit = false;
+            if (lane < K) {
+                const double *sl = slot[lane];
+                if (!orca) {
+                    Cone c; c.apex = v3(sl[0], sl[1], sl[2]); c.pAB = v3(sl[3], sl[4], sl[5]); c.g = sl[6];
+                    vp_hit = cone_hit(c, vpref + pA);
+                } else {
+                    Plane pl; pl.p = v3(sl[0], sl[1], sl[2]); pl.n = v3(sl[3], sl[4], sl[5]);
+                    vp_hit = !in_orca(pl, vpref);
+                }
+            }
+            const bool vp_ok = posture_ok(P, vA, nvA, pA.z, vpref) && (__ballot(vp_hit) == 0);
+            if (vp_ok) {
+                if (lane == 0) { idxS[nS] = (unsigned short)T.vp_idx; keyS[nS] = l3norm(vpref, vpref); }
+                nS++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            dg_nsuit = nS;
+            if (nS == 0) {
+                // no suitable candidate: compute_without_suitV needs all 513 candidates -> k_solve_full finishes this agent
+                if (lane == 0) { const int at = atomicAdd(d.fb_count, 1); d.fb_list[at] = agent; }
+                return;
+            }
+            dg_fallback = 0;
+            // ---- selection over the survivor list; sorted order of the reference == lexicographic (key, generation index)
+            const bool shunted = (pol == POL_SCA || pol == POL_SRVO);
+            Key3 best = key_invalid();
+            for (int e = lane; e < nS; e += 64) { Key3 k; k.a = keyS[e]; k.b = 0.0; k.idx = idxS[e]; if (key_less(k, best)) best = k; }
+            best = wave_argmin(best);
+            int chosen = best.idx;
+            if (shunted && nS > 1) {                                                     // scaPolicy.py:119-145
+                const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
+                const double s0 = l3norm(cand_from_idx(T, best.idx, vpref), vA64);
+                Key3 fail = key_invalid();
+                for (int e = lane; e < nS; e += 64) {
+                    const int ie = idxS[e];
+                    const double sv = l3norm(cand_from_idx(T, ie, vpref), vA64);
+                    if (!(fabs(s0 - sv) < sthr)) { Key3 k; k.a = keyS[e]; k.b = 0.0; k.idx = ie; if (key_less(k, fail)) fail = k; }
+                }
+                fail = wave_argmin(fail);
+                Key3 kmin = key_invalid(), kmax = key_invalid();
+                for (int e = lane; e < nS; e += 64) {
+                    Key3 mk; mk.a = keyS[e]; mk.b = 0.0; mk.idx = idxS[e];
+                    if (key_less(mk, fail)) {
+                        const double ph = phi_from_idx(T, mk.idx, vpref);
+                        Key3 a; a.a = ph; a.b = mk.a; a.idx = mk.idx;
+                        Key3 b; b.a = -ph; b.b = mk.a; b.idx = mk.idx;
+                        if (key_less(a, kmin)) kmin = a;
+                        if (key_less(b, kmax)) kmax = b;
+                    }
+                }
+                kmin = wave_argmin(kmin);
+                kmax = wave_argmin(kmax);
+                const double phi_min = kmin.a / EPS5, phi_max = (-kmax.a) / EPS5;
+                chosen = (fabs(phi_max - phi_min) <= PI) ? kmin.idx : kmax.idx;
+            }
+            dg_chosen = chosen;
+            vpost = trunc5(cand_from_idx(T, chosen, vpref));                             // scaPolicy.py:239
+        }
+    }
+    if (lane == 0) {
+        d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z;
+        diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
+        d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
+        if (st) atomicOr(&d.status[agent], st);
+    }
+}
+
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
+    __shared__ FastLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
+    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) solve_fast(d, P, S, agent, lane, wid);
+}
+
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
 template <bool FUSE_INTEGRATE>
@@ -631,6 +850,7 @@ __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
 #pragma unroll
         for (int k = 0; k < 7; k++) actf[k] = (float)act[k];
         if (d.coll_new[agent]) { me.flags |= FLAG_COLLISION; d.rec[agent].flags = me.flags; }
+        atomicAdd(&d.agent_steps[(agent & 255) * 16], 1ull);
     }
     float *out = d.action + (size_t)agent * 8;
 #pragma unroll
