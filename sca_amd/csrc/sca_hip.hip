@@ -119,6 +119,11 @@ struct sca_ctx {
     std::vector<KdNode> h_tree;
     std::vector<PubRec> h_rec;
     KdScratch kd{};
+    // depth of the large-node part of the tree, read back asynchronously (never waited for) to size the next build
+    int *kd_host_counts = nullptr;      // pinned
+    hipEvent_t kd_ev = nullptr;
+    bool kd_ev_pending = false;
+    int kd_levels_hint = 0;
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
     bool near_valid = false;            // K1's collision-candidate lists describe the current records
@@ -196,6 +201,8 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     CHK(c, hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
     c->stream = c->stream_own;
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
+    CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
+    CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (KD_MAX_LEVELS + 2)));
     const size_t N = (size_t)max_agents, M = (size_t)max_obstacles;
     DeviceView &d = c->d;
     int r = 0;
@@ -218,6 +225,9 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
     r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_MAX_LEVELS + 2);
+    c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MAX + 8);
+    r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
+    r |= dalloc(c, &c->kd.chge, (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.ps, N);
     if (r) return SCA_ERR_HIP;
     // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
     std::vector<double> tab(768 + 384 + 256 + 128);
@@ -239,10 +249,12 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
+    if (c->kd_ev) (void)hipEventDestroy(c->kd_ev);
+    if (c->kd_host_counts) (void)hipHostFree(c->kd_host_counts);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
     delete c;
 }
@@ -421,14 +433,30 @@ static int build_agent_tree_device(sca_ctx *c) {
         int need = 1;
         while ((KD_WAVE_MAX << need) < n) need++;                    // balanced depth down to KD_WAVE_MAX
         levels = std::min(need + 6, KD_MAX_LEVELS - 1);               // slack for uneven midpoint splits
+        // the tree changes slowly from step to step: use the depth seen by an earlier build (+2) when it has arrived
+        if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess) {
+            int depth = 0;
+            while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
+            c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 2;
+            c->kd_ev_pending = false;
+        }
+        if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
+        const int grid = c->kd.chunk_cap;
         for (int l = 0; l < levels; l++) {
-            const int grid = (int)std::min<long long>(1ll << std::min(l, 20), (long long)std::max(1, n / KD_WAVE_MAX));
-            hipLaunchKernelGGL(k_kd_level, dim3(grid), dim3(KD_LEVEL_THREADS), 0, c->stream, d, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_box, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_count, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
         }
     }
     const int sgrid = std::max(1, std::min(1024, 4 * n / KB_MAX + 2));
     hipLaunchKernelGGL(k_kd_block, dim3(sgrid), dim3(KB_T), 0, c->stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
+    if (n > KD_WAVE_MAX && !c->kd_ev_pending) {
+        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (KD_MAX_LEVELS + 2), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipEventRecord(c->kd_ev, c->stream));
+        c->kd_ev_pending = true;
+    }
     return 0;
 }
 static int check_kd_overflow(sca_ctx *c) {
@@ -436,6 +464,7 @@ static int check_kd_overflow(sca_ctx *c) {
     CHK(c, hipMemcpyAsync(&flag, c->kd.counts + KD_MAX_LEVELS + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
+        c->kd_levels_hint = 0;
         c->err = "device kd-tree build overflow (tree deeper than the level budget): results of this pass are invalid; "
                  "use SCA_NBR_KDTREE_HOSTBUILD for this scene";
         return SCA_ERR_STATE;

@@ -12,8 +12,8 @@
 // That form is data-parallel: one prefix count per element.
 //
 //   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced
-//   k_kd_level  : one launch per tree level for the nodes with more than KD_WAVE_MAX members, ONE WORKGROUP PER
-//                 NODE (block reductions for the box and the counts, ballot-based block scan for the ranks)
+//   k_kd_lv_*   : four launches per tree level for the nodes with more than KD_WAVE_MAX members; a node is cut into
+//                 chunks of KD_CHUNK positions, one workgroup per chunk: (box) -> (count) -> (rank) -> (swap + children)
 //   k_kd_block  : every subtree of <= KD_WAVE_MAX members is finished by ONE WORKGROUP entirely in LDS, level by level,
 //                 all nodes of a level at once (element-parallel; boxes by LDS atomics on order-preserving keys)
 #pragma once
@@ -33,18 +33,37 @@ struct KdScratch {
     double *kx, *ky, *kz;     // [n] coordinates in position order
     int *ml, *mr;             // [n] positions of the k-th misplaced element on the left / right side
     KdJob *jobs[2];           // ping-pong lists of nodes with > KD_WAVE_MAX members
-    KdJob *small;             // [n] subtrees handed to k_kd_small
+    KdJob *small;             // [n] subtrees handed to k_kd_block
     int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag
     int job_cap;
+    // multi-workgroup level passes
+    unsigned long long *nbox; // [2][job_cap][6] order-preserving keys of the node boxes (per level parity)
+    int *nge;                 // [2][job_cap] number of members >= split per node
+    int *chge;                // [chunk_cap] the same per chunk
+    int *ps;                  // [n] inclusive count of ">= split" members inside the node up to the position
+    int chunk_cap;
 };
+
+// order-preserving map double -> u64 so that integer atomics give exact min / max
+__device__ __forceinline__ unsigned long long dkey(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    return __longlong_as_double((long long)u);
+}
 
 __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) {
         for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
         KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = 0;
-        if (d.n > KD_WAVE_MAX) { s.jobs[0][0] = j; s.counts[0] = 1; }
-        else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
+        if (d.n > KD_WAVE_MAX) {
+            s.jobs[0][0] = j; s.counts[0] = 1;
+            for (int k = 0; k < 3; k++) { s.nbox[k] = dkey(INFINITY); s.nbox[3 + k] = dkey(-INFINITY); }
+            s.nge[0] = 0;
+        } else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
     }
     if (p >= d.n) return;
     const PubRec r = d.rec[d.aperm[p]];
@@ -74,103 +93,167 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
     split = 0.5 * (mx[axis] + mn[axis]);
 }
 
-__global__ __launch_bounds__(KD_LEVEL_THREADS) void k_kd_level(DeviceView d, KdScratch s, int level) {
-    constexpr int T = KD_LEVEL_THREADS, W = T / 64;
+// ---- level passes over the large nodes, one workgroup per chunk of KD_CHUNK positions ---------------------------------
+constexpr int KD_CHUNK = 4096;
+constexpr int KD_LV_T = 512;
+constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
+
+struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid; };
+
+// workgroup -> (node, chunk): the node list of a level is short (<= n / KD_WAVE_MAX), every workgroup walks it
+__device__ __forceinline__ KdChunk kd_find_chunk(const KdJob *jobs, int njobs, int blk) {
+    KdChunk c; c.valid = 0; c.job = 0; c.begin = c.end = c.node_begin = c.node_end = c.first_chunk = 0;
+    int acc = 0;
+    for (int j = 0; j < njobs; j++) {
+        const int b = jobs[j].begin, e = jobs[j].end;
+        const int nch = (e - b + KD_CHUNK - 1) / KD_CHUNK;
+        if (blk < acc + nch) {
+            c.valid = 1; c.job = j; c.node_begin = b; c.node_end = e; c.first_chunk = acc;
+            c.begin = b + (blk - acc) * KD_CHUNK;
+            c.end = c.begin + KD_CHUNK < e ? c.begin + KD_CHUNK : e;
+            return c;
+        }
+        acc += nch;
+    }
+    return c;
+}
+
+// (1) box of every large node: block reduction per chunk, then 6 atomics on order-preserving keys
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_box(KdScratch s, int level) {
+    constexpr int W = KD_LV_T / 64;
     __shared__ double red[W][6];
-    __shared__ int wtot[W];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
+    if (!c.valid) return;
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int p = c.begin + tid; p < c.end; p += KD_LV_T) {
+        const double x = s.kx[p], y = s.ky[p], z = s.kz[p];
+        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
+        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
+        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
+    if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (tid < 6) {
+        double v = red[0][tid];
+        for (int w = 1; w < W; w++) v = tid < 3 ? (red[w][tid] < v ? red[w][tid] : v) : (red[w][tid] > v ? red[w][tid] : v);
+        unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + c.job) * 6;
+        if (tid < 3) atomicMin(&box[tid], dkey(v)); else atomicMax(&box[tid], dkey(v));
+    }
+}
+
+__device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int job, int &axis, double &split, double mn[3], double mx[3]) {
+    const unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + job) * 6;
+    for (int k = 0; k < 3; k++) { mn[k] = dunkey(box[k]); mx[k] = dunkey(box[3 + k]); }
+    kd_split(mn, mx, axis, split);
+}
+
+// (2) number of members >= split, per chunk and per node
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_count(KdScratch s, int level) {
+    constexpr int W = KD_LV_T / 64;
     __shared__ int itot[W];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
+    if (!c.valid) return;
+    int axis; double split, mn[3], mx[3];
+    kd_node_split(s, level, c.job, axis, split, mn, mx);
+    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
+    int cnt = 0;
+    for (int p = c.begin + tid; p < c.end; p += KD_LV_T) cnt += kc[p] < split ? 0 : 1;
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) itot[wid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < W; w++) t += itot[w];
+        s.chge[blockIdx.x] = t;
+        atomicAdd(&s.nge[(level & 1) * s.job_cap + c.job], t);
+    }
+}
+
+// (3) ranks: inclusive ">= split" count inside the node (ps), and the k-th misplaced member of the right part (mr)
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level) {
+    constexpr int W = KD_LV_T / 64;
+    __shared__ int wtot[W];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
+    if (!c.valid) return;
+    int axis; double split, mn[3], mx[3];
+    kd_node_split(s, level, c.job, axis, split, mn, mx);
+    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
+    const int b = c.node_begin, e = c.node_end;
+    const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
+    int carry = 0;
+    for (int ch = c.first_chunk; ch < (int)blockIdx.x; ch++) carry += s.chge[ch];
+    for (int t0 = c.begin; t0 < c.end; t0 += KD_LV_T) {
+        const int p = t0 + tid;
+        const bool in_range = p < c.end;
+        const bool ge = in_range && !(kc[p] < split);
+        const unsigned long long m = __ballot(ge);
+        const int incl_w = __popcll(m & ((2ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wtot[wid] = __popcll(m);
+        __syncthreads();
+        int woff = 0, ttot = 0;
+        for (int w = 0; w < W; w++) { const int v = wtot[w]; if (w < wid) woff += v; ttot += v; }
+        const int G = carry + woff + incl_w;
+        if (in_range) {
+            s.ps[p] = G;
+            if (p >= b + L && !ge) { const int lt_incl = (p - b + 1) - G; s.mr[b + (L - lt_incl)] = p; }
+        }
+        carry += ttot;
+    }
+}
+
+// (4) swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+    const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
     KdJob *out = s.jobs[(level + 1) & 1];
-    const int njobs = s.counts[level];
-    for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
-        const KdJob job = in[jb];
-        const int b = job.begin, e = job.end;
-        // ---- box (kdTree.py:63-83)
-        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int p = b + tid; p < e; p += T) {
-            const double x = s.kx[p], y = s.ky[p], z = s.kz[p];
-            mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
-            mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
-            mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
-        __syncthreads();                                   // red/wtot free again (previous job)
-        if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double a = red[0][k], c = red[0][3 + k];
-            for (int w = 1; w < W; w++) { a = red[w][k] < a ? red[w][k] : a; c = red[w][3 + k] > c ? red[w][3 + k] : c; }
-            mn[k] = a; mx[k] = c;
-        }
-        int axis; double split;
-        kd_split(mn, mx, axis, split);
-        const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
-        // ---- L = #(coord < split)
-        int cnt = 0;
-        for (int p = b + tid; p < e; p += T) cnt += kc[p] < split ? 1 : 0;
-        cnt = wave_sum_i(cnt);
-        if (lane == 0) itot[wid] = cnt;
-        __syncthreads();
-        int L = 0;
-        for (int w = 0; w < W; w++) L += itot[w];
-        // ---- ranks of the misplaced elements (block scan of the >= split flags, tile by tile)
-        int carry = 0, nmis = 0;
-        for (int t0 = b; t0 < e; t0 += T) {
-            const int p = t0 + tid;
-            const bool in_range = p < e;
-            const bool ge = in_range && !(kc[p] < split);
-            const unsigned long long m = __ballot(ge);
-            const int incl_w = __popcll(m & ((2ull << lane) - 1ull));
-            __syncthreads();
-            if (lane == 0) wtot[wid] = __popcll(m);
-            __syncthreads();
-            int woff = 0, ttot = 0;
-            for (int w = 0; w < W; w++) { const int v = wtot[w]; if (w < wid) woff += v; ttot += v; }
-            const int G = carry + woff + incl_w;            // # of >= split in [b, p]
-            if (in_range) {
-                if (p < b + L) { if (ge) { s.ml[b + G - 1] = p; nmis++; } }
-                else if (!ge) { const int lt_incl = (p - b + 1) - G; s.mr[b + (L - lt_incl)] = p; }
-            }
-            carry += ttot;
-        }
-        nmis = wave_sum_i(nmis);
-        __syncthreads();
-        if (lane == 0) itot[wid] = nmis;
-        __syncthreads();                                    // also publishes ml / mr inside the workgroup
-        int nswap = 0;
-        for (int w = 0; w < W; w++) nswap += itot[w];
-        // ---- the swaps (kdTree.py:108-111)
-        for (int k = tid; k < nswap; k += T) {
-            const int p = s.ml[b + k], q = s.mr[b + k];
+    const KdChunk c = kd_find_chunk(in, s.counts[level], blockIdx.x);
+    if (!c.valid) return;
+    int axis; double split, mn[3], mx[3];
+    kd_node_split(s, level, c.job, axis, split, mn, mx);
+    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
+    const int b = c.node_begin, e = c.node_end;
+    const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
+    const int lim = c.end < b + L ? c.end : b + L;
+    for (int p = c.begin + tid; p < lim; p += KD_LV_T) {
+        if (!(kc[p] < split)) {                              // misplaced on the left: take the partner from the right
+            const int q = s.mr[b + s.ps[p] - 1];
             const int ip = d.aperm[p], iq = d.aperm[q];
             d.aperm[p] = iq; d.aperm[q] = ip;
             const double xp = s.kx[p], yp = s.ky[p], zp = s.kz[p];
             s.kx[p] = s.kx[q]; s.ky[p] = s.ky[q]; s.kz[p] = s.kz[q];
             s.kx[q] = xp; s.ky[q] = yp; s.kz[q] = zp;
         }
-        // ---- node record + children (kdTree.py:112-122)
-        if (tid == 0) {
-            const int leftSize = L == 0 ? 1 : L;            // degenerate: every member on the split plane
-            KdNode nd;
-            nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
-            for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
-            d.atree[job.node] = nd;
-            KdJob c[2];
-            c[0].begin = b; c[0].end = b + leftSize; c[0].node = nd.left; c[0].pad = 0;
-            c[1].begin = b + leftSize; c[1].end = e; c[1].node = nd.right; c[1].pad = 0;
-            for (int k = 0; k < 2; k++) {
-                if (c[k].end - c[k].begin > KD_WAVE_MAX) {
-                    if (level + 1 < KD_MAX_LEVELS) {
-                        const int at = atomicAdd(&s.counts[level + 1], 1);
-                        if (at < s.job_cap) out[at] = c[k]; else s.counts[KD_MAX_LEVELS + 1] = 1;
+    }
+    if (tid == 0 && c.begin == b) {
+        const KdJob job = in[c.job];
+        const int leftSize = L == 0 ? 1 : L;                 // degenerate: every member on the split plane
+        KdNode nd;
+        nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
+        for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
+        d.atree[job.node] = nd;
+        KdJob ch[2];
+        ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 0;
+        ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 0;
+        for (int k = 0; k < 2; k++) {
+            if (ch[k].end - ch[k].begin > KD_WAVE_MAX) {
+                if (level + 1 < KD_MAX_LEVELS) {
+                    const int at = atomicAdd(&s.counts[level + 1], 1);
+                    if (at < s.job_cap) {
+                        out[at] = ch[k];
+                        unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
+                        for (int q = 0; q < 3; q++) { box[q] = dkey(INFINITY); box[3 + q] = dkey(-INFINITY); }
+                        s.nge[((level + 1) & 1) * s.job_cap + at] = 0;
                     } else s.counts[KD_MAX_LEVELS + 1] = 1;
-                } else {
-                    const int at = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
-                    s.small[at] = c[k];
-                }
+                } else s.counts[KD_MAX_LEVELS + 1] = 1;
+            } else {
+                const int at = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
+                s.small[at] = ch[k];
             }
         }
     }
@@ -197,16 +280,6 @@ struct KbLds {
     int count[2];
     int wtot[KB_T / 64];
 };
-
-// order-preserving map double -> u64 so that LDS integer atomics give exact min / max
-__device__ __forceinline__ unsigned long long dkey(double x) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dunkey(unsigned long long k) {
-    const unsigned long long u = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
-    return __longlong_as_double((long long)u);
-}
 
 __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
     __shared__ KbLds S;
