@@ -271,17 +271,17 @@ struct KbLds {
     double x[KB_MAX], y[KB_MAX], z[KB_MAX];
     int id[KB_MAX];
     int slot[KB_MAX];                   // live-node slot of the position, -1 once its leaf is written
-    int mr[KB_MAX];                     // position of the k-th misplaced element of the right side (node-relative index)
+    int mr[KB_MAX];                     // position of the k-th misplaced member of the right part
     int ps[KB_MAX];                     // inclusive prefix count of the ">= split" flags over all positions
     int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES];
-    unsigned long long box[KB_NODES][6];
-    double split[KB_NODES];
-    int axis[KB_NODES], L[KB_NODES], child[KB_NODES], lfix[KB_NODES];
+    unsigned long long box[2][KB_NODES][6];
+    int child[KB_NODES], lfix[KB_NODES];
     int count[2];
     int wtot[KB_T / 64];
 };
 
 __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+    static_assert(KB_E == 2, "k_kd_block is written for two consecutive positions per thread");
     __shared__ KbLds S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int njobs = s.counts[KD_MAX_LEVELS];
@@ -296,152 +296,142 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
             S.x[i] = s.kx[base + i]; S.y[i] = s.ky[base + i]; S.z[i] = s.kz[base + i]; S.id[i] = d.aperm[base + i];
             S.slot[i] = 0;
         }
-        if (tid == 0) { S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.count[0] = 1; S.count[1] = 0; }
+        if (tid == 0) {
+            S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.count[0] = 1; S.count[1] = 0;
+            for (int k = 0; k < 3; k++) { S.box[0][0][k] = dkey(INFINITY); S.box[0][0][3 + k] = dkey(-INFINITY); }
+        }
+        __syncthreads();
         int cur = 0;
         const int p0 = tid * KB_E;
         for (;;) {
-            __syncthreads();
             const int nc = S.count[cur];
             if (nc == 0) break;
             const int nxt = cur ^ 1;
-            // (1) empty boxes
-            for (int i = tid; i < nc; i += KB_T) {
-                for (int k = 0; k < 3; k++) { S.box[i][k] = dkey(INFINITY); S.box[i][3 + k] = dkey(-INFINITY); }
-            }
-            __syncthreads();
-            // (2) boxes: serial over the thread's own positions, one set of atomics per run of equal slots
+            const bool v0 = p0 < size, v1 = p0 + 1 < size;
+            const int s0 = v0 ? S.slot[p0] : -1, s1 = v1 ? S.slot[p0 + 1] : -1;
+            // ---- A: boxes (kdTree.py:63-83).  A wave whose 128 positions sit in one node reduces first, then 6 atomics.
             {
-                int run = -1;
-                double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-                for (int k = 0; k <= KB_E; k++) {
-                    const int p = p0 + k;
-                    const int sl = (k < KB_E && p < size) ? S.slot[p] : -2;
-                    if (sl != run) {
-                        if (run >= 0) {
-                            for (int q = 0; q < 3; q++) { atomicMin(&S.box[run][q], dkey(mn[q])); atomicMax(&S.box[run][3 + q], dkey(mx[q])); }
-                        }
-                        run = sl;
-                        if (sl >= 0) { mn[0] = mx[0] = S.x[p]; mn[1] = mx[1] = S.y[p]; mn[2] = mx[2] = S.z[p]; }
-                    } else if (sl >= 0) {
-                        const double x = S.x[p], y = S.y[p], z = S.z[p];
+                const int ref = __shfl(s0, 0);
+                const bool uni = __all(s0 == ref && s1 == ref) && ref >= 0;
+                double mn[3], mx[3];
+                if (s0 >= 0) { mn[0] = mx[0] = S.x[p0]; mn[1] = mx[1] = S.y[p0]; mn[2] = mx[2] = S.z[p0]; }
+                if (s1 >= 0) {
+                    const double x = S.x[p0 + 1], y = S.y[p0 + 1], z = S.z[p0 + 1];
+                    if (s0 == s1) {
                         mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
                         mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
                         mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+                    } else {
+                        atomicMin(&S.box[cur][s1][0], dkey(x)); atomicMax(&S.box[cur][s1][3], dkey(x));
+                        atomicMin(&S.box[cur][s1][1], dkey(y)); atomicMax(&S.box[cur][s1][4], dkey(y));
+                        atomicMin(&S.box[cur][s1][2], dkey(z)); atomicMax(&S.box[cur][s1][5], dkey(z));
                     }
+                }
+                if (uni) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
+                    if (lane == 0)
+                        for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][ref][k], dkey(mn[k])); atomicMax(&S.box[cur][ref][3 + k], dkey(mx[k])); }
+                } else if (s0 >= 0) {
+                    for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][s0][k], dkey(mn[k])); atomicMax(&S.box[cur][s0][3 + k], dkey(mx[k])); }
                 }
             }
             __syncthreads();
-            // (3) split plane per live node (kdTree.py:85-96); leaves (kdTree.py:85) get L = -1
-            for (int i = tid; i < nc; i += KB_T) {
-                if (S.ne[cur][i] - S.nb[cur][i] > MAX_LEAF) {
-                    double mn[3], mx[3];
-                    for (int k = 0; k < 3; k++) { mn[k] = dunkey(S.box[i][k]); mx[k] = dunkey(S.box[i][3 + k]); }
-                    int axis; double split;
-                    kd_split(mn, mx, axis, split);
-                    S.axis[i] = axis; S.split[i] = split; S.L[i] = 0;
-                } else S.L[i] = -1;
-            }
-            __syncthreads();
-            // (4) ">= split" flags and their inclusive prefix over all positions (block scan)
-            int flags = 0, tsum = 0;
-            for (int k = 0; k < KB_E; k++) {
-                const int p = p0 + k;
-                bool ge = false;
-                if (p < size) {
-                    const int sl = S.slot[p];
-                    if (sl >= 0 && S.L[sl] >= 0) {
-                        const int ax = S.axis[sl];
-                        const double c = ax == 0 ? S.x[p] : (ax == 1 ? S.y[p] : S.z[p]);
-                        ge = !(c < S.split[sl]);
+            // ---- B: split plane of the element's node (kdTree.py:85-96), ">= split" flags, block scan
+            int nb_[2] = {0, 0}, ne_[2] = {0, 0};
+            bool live[2] = {false, false}, ge[2] = {false, false};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int sl = k == 0 ? s0 : s1;
+                if (sl >= 0) {
+                    nb_[k] = S.nb[cur][sl]; ne_[k] = S.ne[cur][sl];
+                    if (ne_[k] - nb_[k] > MAX_LEAF) {
+                        live[k] = true;
+                        double mn[3], mx[3];
+                        for (int q = 0; q < 3; q++) { mn[q] = dunkey(S.box[cur][sl][q]); mx[q] = dunkey(S.box[cur][sl][3 + q]); }
+                        int axis; double split;
+                        kd_split(mn, mx, axis, split);
+                        const int p = p0 + k;
+                        const double c = axis == 0 ? S.x[p] : (axis == 1 ? S.y[p] : S.z[p]);
+                        ge[k] = !(c < split);
                     }
                 }
-                if (ge) { flags |= 1 << k; tsum++; }
             }
-            int incl = tsum;                                   // wave inclusive scan of the per-thread totals
+            const int tsum = (ge[0] ? 1 : 0) + (ge[1] ? 1 : 0);
+            int incl = tsum;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
             if (lane == 63) S.wtot[wid] = incl;
             __syncthreads();
-            int excl = incl - tsum;
-            for (int w = 0; w < wid; w++) excl += S.wtot[w];
             {
-                int run = excl;
-                for (int k = 0; k < KB_E; k++) { const int p = p0 + k; if ((flags >> k) & 1) run++; if (p < size) S.ps[p] = run; }
+                int excl = incl - tsum;
+                for (int w = 0; w < wid; w++) excl += S.wtot[w];
+                if (v0) S.ps[p0] = excl + (ge[0] ? 1 : 0);
+                if (v1) S.ps[p0 + 1] = excl + tsum;
             }
             __syncthreads();
-            // (5) L = #(members < split) per node
-            for (int i = tid; i < nc; i += KB_T) {
-                if (S.L[i] >= 0) {
-                    const int b = S.nb[cur][i], e = S.ne[cur][i];
-                    const int ge_cnt = S.ps[e - 1] - (b > 0 ? S.ps[b - 1] : 0);
-                    S.L[i] = (e - b) - ge_cnt;
+            // ---- C: L = #(members < split); the k-th "< split" member of the right part counted from the right
+            int L_[2] = {0, 0}, G_[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (live[k]) {
+                    const int p = p0 + k, b = nb_[k], e = ne_[k];
+                    const int pb = b > 0 ? S.ps[b - 1] : 0;
+                    L_[k] = (e - b) - (S.ps[e - 1] - pb);
+                    G_[k] = S.ps[p] - pb;
+                    if (!ge[k] && p >= b + L_[k]) S.mr[b + (L_[k] - ((p - b + 1) - G_[k]))] = p;
                 }
             }
             __syncthreads();
-            // (6) the k-th "< split" member of the right part, counted from the right
-            for (int k = 0; k < KB_E; k++) {
+            // ---- D: the swaps (kdTree.py:108-111); node records and children (kdTree.py:112-122) by the owner of
+            //         the node's first position
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int sl = k == 0 ? s0 : s1;
                 const int p = p0 + k;
-                if (p < size && !((flags >> k) & 1)) {
-                    const int sl = S.slot[p];
-                    if (sl >= 0 && S.L[sl] >= 0) {
-                        const int b = S.nb[cur][sl], L = S.L[sl];
-                        if (p >= b + L) {
-                            const int G = S.ps[p] - (b > 0 ? S.ps[b - 1] : 0);
-                            const int lt_incl = (p - b + 1) - G;
-                            S.mr[b + (L - lt_incl)] = p;
+                if (live[k] && ge[k] && p < nb_[k] + L_[k]) {
+                    const int q = S.mr[nb_[k] + G_[k] - 1];
+                    const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
+                    double t;
+                    t = S.x[p]; S.x[p] = S.x[q]; S.x[q] = t;
+                    t = S.y[p]; S.y[p] = S.y[q]; S.y[q] = t;
+                    t = S.z[p]; S.z[p] = S.z[q]; S.z[q] = t;
+                }
+                if (sl >= 0 && p == nb_[k]) {
+                    KdNode nd;
+                    nd.begin = base + nb_[k]; nd.end = base + ne_[k]; nd.left = 0; nd.right = 0;
+                    for (int q = 0; q < 3; q++) { nd.mn[q] = dunkey(S.box[cur][sl][q]); nd.mx[q] = dunkey(S.box[cur][sl][3 + q]); }
+                    const int node = S.nnode[cur][sl];
+                    if (live[k]) {
+                        const int lf = L_[k] == 0 ? 1 : L_[k];
+                        nd.left = node + 1; nd.right = node + 2 * lf;
+                        const int c0 = atomicAdd(&S.count[nxt], 2);
+                        S.child[sl] = c0; S.lfix[sl] = lf;
+                        S.nb[nxt][c0] = nb_[k]; S.ne[nxt][c0] = nb_[k] + lf; S.nnode[nxt][c0] = nd.left;
+                        S.nb[nxt][c0 + 1] = nb_[k] + lf; S.ne[nxt][c0 + 1] = ne_[k]; S.nnode[nxt][c0 + 1] = nd.right;
+                        for (int q = 0; q < 3; q++) {
+                            S.box[nxt][c0][q] = dkey(INFINITY); S.box[nxt][c0][3 + q] = dkey(-INFINITY);
+                            S.box[nxt][c0 + 1][q] = dkey(INFINITY); S.box[nxt][c0 + 1][3 + q] = dkey(-INFINITY);
                         }
                     }
+                    d.atree[node] = nd;
                 }
             }
             __syncthreads();
-            // (7) the swaps: the k-th ">= split" member of the left part takes its partner (kdTree.py:108-111)
-            for (int k = 0; k < KB_E; k++) {
-                const int p = p0 + k;
-                if (p < size && ((flags >> k) & 1)) {
-                    const int sl = S.slot[p];
-                    const int b = S.nb[cur][sl], L = S.L[sl];
-                    if (p < b + L) {
-                        const int G = S.ps[p] - (b > 0 ? S.ps[b - 1] : 0);
-                        const int q = S.mr[b + G - 1];
-                        const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
-                        double t;
-                        t = S.x[p]; S.x[p] = S.x[q]; S.x[q] = t;
-                        t = S.y[p]; S.y[p] = S.y[q]; S.y[q] = t;
-                        t = S.z[p]; S.z[p] = S.z[q]; S.z[q] = t;
-                    }
-                }
+            // ---- E: positions move to their child's slot (own positions only: no barrier needed before the next A)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int sl = k == 0 ? s0 : s1;
+                if (sl >= 0) S.slot[p0 + k] = live[k] ? S.child[sl] + (p0 + k >= nb_[k] + S.lfix[sl] ? 1 : 0) : -1;
             }
-            __syncthreads();
-            // (8) node records, children become the next level's live nodes (kdTree.py:112-122)
-            for (int i = tid; i < nc; i += KB_T) {
-                KdNode nd;
-                nd.begin = base + S.nb[cur][i]; nd.end = base + S.ne[cur][i]; nd.left = 0; nd.right = 0;
-                for (int k = 0; k < 3; k++) { nd.mn[k] = dunkey(S.box[i][k]); nd.mx[k] = dunkey(S.box[i][3 + k]); }
-                const int node = S.nnode[cur][i];
-                if (S.L[i] >= 0) {
-                    const int lf = S.L[i] == 0 ? 1 : S.L[i];
-                    nd.left = node + 1; nd.right = node + 2 * lf;
-                    const int c0 = atomicAdd(&S.count[nxt], 2);
-                    S.child[i] = c0; S.lfix[i] = lf;
-                    S.nb[nxt][c0] = S.nb[cur][i]; S.ne[nxt][c0] = S.nb[cur][i] + lf; S.nnode[nxt][c0] = nd.left;
-                    S.nb[nxt][c0 + 1] = S.nb[cur][i] + lf; S.ne[nxt][c0 + 1] = S.ne[cur][i]; S.nnode[nxt][c0 + 1] = nd.right;
-                }
-                d.atree[node] = nd;
-            }
-            __syncthreads();
-            // (9) positions move to their child's slot
-            for (int k = 0; k < KB_E; k++) {
-                const int p = p0 + k;
-                if (p < size) {
-                    const int sl = S.slot[p];
-                    if (sl >= 0) S.slot[p] = S.L[sl] < 0 ? -1 : S.child[sl] + (p >= S.nb[cur][sl] + S.lfix[sl] ? 1 : 0);
-                }
-            }
-            __syncthreads();
             if (tid == 0) S.count[cur] = 0;
             cur = nxt;
         }
-        for (int i = tid; i < size; i += KB_T) d.aperm[base + i] = S.id[i];
+        __syncthreads();
+        for (int i = tid; i < size; i += KB_T) {
+            d.aperm[base + i] = S.id[i];
+            s.kx[base + i] = S.x[i]; s.ky[base + i] = S.y[i]; s.kz[base + i] = S.z[i];     // final position order: K1 reads leaves from here
+        }
     }
 }
 
