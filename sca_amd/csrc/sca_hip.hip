@@ -68,6 +68,27 @@ void kd_build_host(int n, const double *pos, int32_t *ids, std::vector<KdNode> &
     }
 }
 
+// query view of a host-built tree: node headers + both children's boxes (KdWide)
+void kd_widen_host(int n, const std::vector<KdNode> &tree, std::vector<KdWide> &wide) {
+    wide.assign(n > 0 ? (size_t)(2 * n) : 1, KdWide{});
+    if (n <= 0) return;
+    std::vector<int> st{0};
+    while (!st.empty()) {
+        const int i = st.back();
+        st.pop_back();
+        const KdNode &nd = tree[i];
+        KdWide &w = wide[i];
+        w.begin = nd.begin; w.end = nd.end; w.left = nd.left; w.right = nd.right;
+        if (nd.end - nd.begin > MAX_LEAF) {
+            for (int k = 0; k < 3; k++) {
+                w.lmn[k] = tree[nd.left].mn[k]; w.lmx[k] = tree[nd.left].mx[k];
+                w.rmn[k] = tree[nd.right].mn[k]; w.rmx[k] = tree[nd.right].mx[k];
+            }
+            st.push_back(nd.left); st.push_back(nd.right);
+        }
+    }
+}
+
 void candidate_table_host(int num_N, double *unit, double *phi) {
     const double param_phi = (std::sqrt(5.0) - 1.0) / 2.0;                         // scaPolicy.py:191
     for (int n = 1; n <= num_N; n++) {
@@ -213,6 +234,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.policy, N);
     r |= dalloc(c, &d.zaxis, N);
     r |= dalloc(c, &d.obs, M); r |= dalloc(c, &d.atree, 2 * N); r |= dalloc(c, &d.aperm, N);
+    r |= dalloc(c, &d.obs_sorted, M); r |= dalloc(c, &d.awide, 2 * N); r |= dalloc(c, &d.owide, 2 * M);
     r |= dalloc(c, &d.otree, 2 * M); r |= dalloc(c, &d.operm, M);
     r |= dalloc(c, &d.nbr_n, N); r |= dalloc(c, &d.nbr_id, N * K_MAX); r |= dalloc(c, &d.nbr_dsq, N * K_MAX);
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
@@ -222,6 +244,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
     r |= dalloc(c, &c->kd.ml, N); r |= dalloc(c, &c->kd.mr, N);
+    d.kx = c->kd.kx; d.ky = c->kd.ky; d.kz = c->kd.kz;
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
     r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_MAX_LEVELS + 2);
@@ -246,7 +269,7 @@ void sca_destroy(sca_ctx *c) {
     DeviceView &d = c->d;
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
-                    d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
+                    d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps};
@@ -276,6 +299,12 @@ int sca_set_obstacles(sca_ctx *c, int m, const double *pos, const double *radius
     CHK(c, hipMemcpyAsync(c->d.obs, h.data(), sizeof(ObsRec) * m, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.operm, perm.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.otree, tree.data(), sizeof(KdNode) * (2 * m - 1), hipMemcpyHostToDevice, c->stream));
+    std::vector<KdWide> wide;
+    kd_widen_host(m, tree, wide);
+    std::vector<ObsRec> sorted(m);
+    for (int i = 0; i < m; i++) sorted[i] = h[perm[i]];
+    CHK(c, hipMemcpyAsync(c->d.owide, wide.data(), sizeof(KdWide) * (2 * m - 1), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d.obs_sorted, sorted.data(), sizeof(ObsRec) * m, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -415,6 +444,17 @@ static int build_agent_tree(sca_ctx *c) {
     kd_build_host(n, c->h_pos.data(), c->h_perm.data(), c->h_tree);
     CHK(c, hipMemcpyAsync(c->d.atree, c->h_tree.data(), sizeof(KdNode) * (2 * n - 1), hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<KdWide> wide;
+    kd_widen_host(n, c->h_tree, wide);
+    std::vector<double> k((size_t)3 * n);
+    for (int p = 0; p < n; p++)
+        for (int a = 0; a < 3; a++) k[(size_t)a * n + p] = c->h_pos[3 * (size_t)c->h_perm[p] + a];
+    CHK(c, hipMemcpyAsync(c->d.awide, wide.data(), sizeof(KdWide) * (2 * n - 1), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->kd.kx, k.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->kd.ky, k.data() + n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->kd.kz, k.data() + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));                             // the staging vectors die with this scope
+    CHK(c, hipMemsetAsync(c->d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));
     return 0;
 }
 
@@ -509,10 +549,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
     hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
-                       c->stream, d, c->P, agent_reach, obs_reach);
+                       c->stream, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
-    CHK(c, hipMemsetAsync(d.fb_count, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     // agents without any suitable candidate (rare): the complete sweep incl. compute_without_suitV
     hipLaunchKernelGGL(k_solve_full, dim3(std::max(1, std::min(4096, (cnt + SOLVE_WAVES - 1) / SOLVE_WAVES))), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
@@ -534,9 +573,9 @@ static int launch_integrate(sca_ctx *c) {
 static int launch_collide_finish(sca_ctx *c, bool timed) {
     DeviceView &d = c->d;
     const int cnt = d.shard_count;
-    CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
+    if (!c->near_valid) CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));   // no policy pass before
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     c->near_valid = false;
     hipLaunchKernelGGL(k_collide_finish, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,

@@ -58,16 +58,29 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) {
         for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
-        KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = 0;
+        KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
         if (d.n > KD_WAVE_MAX) {
             s.jobs[0][0] = j; s.counts[0] = 1;
             for (int k = 0; k < 3; k++) { s.nbox[k] = dkey(INFINITY); s.nbox[3 + k] = dkey(-INFINITY); }
             s.nge[0] = 0;
         } else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
     }
+    if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
     if (p >= d.n) return;
     const PubRec r = d.rec[d.aperm[p]];
     s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
+}
+
+// every node publishes its header in its own query record and its box in its parent's (KdWide)
+__device__ __forceinline__ void kd_publish(KdWide *wide, const KdNode &nd, int node, int parent_code) {
+    KdWide *w = &wide[node];
+    w->begin = nd.begin; w->end = nd.end; w->left = nd.left; w->right = nd.right;
+    if (parent_code >= 0) {
+        KdWide *pw = &wide[parent_code >> 1];
+        double *mn = (parent_code & 1) ? pw->rmn : pw->lmn;
+        double *mx = (parent_code & 1) ? pw->rmx : pw->lmx;
+        for (int k = 0; k < 3; k++) { mn[k] = nd.mn[k]; mx[k] = nd.mx[k]; }
+    }
 }
 
 __device__ __forceinline__ double wave_min_d(double v) {
@@ -237,9 +250,10 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
         nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
         for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
         d.atree[job.node] = nd;
+        kd_publish(d.awide, nd, job.node, job.pad);
         KdJob ch[2];
-        ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 0;
-        ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 0;
+        ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
+        ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
         for (int k = 0; k < 2; k++) {
             if (ch[k].end - ch[k].begin > KD_WAVE_MAX) {
                 if (level + 1 < KD_MAX_LEVELS) {
@@ -273,7 +287,7 @@ struct KbLds {
     int slot[KB_MAX];                   // live-node slot of the position, -1 once its leaf is written
     int mr[KB_MAX];                     // position of the k-th misplaced member of the right part
     int ps[KB_MAX];                     // inclusive prefix count of the ">= split" flags over all positions
-    int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES];
+    int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES], npar[2][KB_NODES];
     unsigned long long box[2][KB_NODES][6];
     int child[KB_NODES], lfix[KB_NODES];
     int count[2];
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
             S.slot[i] = 0;
         }
         if (tid == 0) {
-            S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.count[0] = 1; S.count[1] = 0;
+            S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.npar[0][0] = job.pad; S.count[0] = 1; S.count[1] = 0;
             for (int k = 0; k < 3; k++) { S.box[0][0][k] = dkey(INFINITY); S.box[0][0][3 + k] = dkey(-INFINITY); }
         }
         __syncthreads();
@@ -407,14 +421,16 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                         nd.left = node + 1; nd.right = node + 2 * lf;
                         const int c0 = atomicAdd(&S.count[nxt], 2);
                         S.child[sl] = c0; S.lfix[sl] = lf;
-                        S.nb[nxt][c0] = nb_[k]; S.ne[nxt][c0] = nb_[k] + lf; S.nnode[nxt][c0] = nd.left;
+                        S.nb[nxt][c0] = nb_[k]; S.ne[nxt][c0] = nb_[k] + lf; S.nnode[nxt][c0] = nd.left; S.npar[nxt][c0] = 2 * node;
                         S.nb[nxt][c0 + 1] = nb_[k] + lf; S.ne[nxt][c0 + 1] = ne_[k]; S.nnode[nxt][c0 + 1] = nd.right;
+                        S.npar[nxt][c0 + 1] = 2 * node + 1;
                         for (int q = 0; q < 3; q++) {
                             S.box[nxt][c0][q] = dkey(INFINITY); S.box[nxt][c0][3 + q] = dkey(-INFINITY);
                             S.box[nxt][c0 + 1][q] = dkey(INFINITY); S.box[nxt][c0 + 1][3 + q] = dkey(-INFINITY);
                         }
                     }
                     d.atree[node] = nd;
+                    kd_publish(d.awide, nd, node, S.npar[cur][sl]);
                 }
             }
             __syncthreads();

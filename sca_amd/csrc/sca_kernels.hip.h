@@ -19,6 +19,10 @@
 namespace sca {
 
 struct KdNode { int begin, end, left, right; double mn[3], mx[3]; };   // 64 B, kdTree.py:14-21
+// What the query reads: the node header plus BOTH children's boxes, so that a level of the descent costs one
+// (scalar) load instead of two dependent ones.  128 B.
+struct alignas(16) KdWide { int begin, end, left, right; double lmn[3], lmx[3], rmn[3], rmx[3]; double pad[2]; };
+static_assert(sizeof(KdWide) == 128, "KdWide must be 128 bytes");
 struct ObsRec { double px, py, pz, radius; };                          // obstacle.py:5-28 (sphere)
 
 struct DeviceView {
@@ -38,6 +42,10 @@ struct DeviceView {
     uint8_t *zaxis;          // [n]
     // obstacles + trees
     ObsRec *obs;             // [m]
+    ObsRec *obs_sorted;      // [m] obstacles in obstacle-tree position order (leaf members are contiguous)
+    KdWide *awide;           // [2n] query view of the agent tree
+    KdWide *owide;           // [2m] query view of the obstacle tree
+    double *kx, *ky, *kz;    // [n] agent coordinates in agent-tree position order (written by the build)
     KdNode *atree;           // [2n]
     int32_t *aperm;          // [n]
     KdNode *otree;           // [2m]
@@ -120,33 +128,33 @@ __device__ __forceinline__ void wave_insert(WaveList &L, int lane, int maxn, int
     L.cnt++;
 }
 
-__device__ __forceinline__ double box_dist_sq(const KdNode &c, V3 p) {     // kdTree.py:132-145
+// Depth-first traversal of kdTree.py:127-156 (nearer child first, ties go right, constant rangeSq) with a
+// wave-uniform explicit stack.  leaf(begin, end) is called for every visited leaf in visit order.
+__device__ __forceinline__ double box_dist_sq(const double mn[3], const double mx[3], V3 p) {   // kdTree.py:132-145
     double t, s;
-    t = fmax(0.0, c.mn[0] - p.x); s = t * t;
-    t = fmax(0.0, p.x - c.mx[0]); s = s + t * t;
-    t = fmax(0.0, c.mn[1] - p.y); s = s + t * t;
-    t = fmax(0.0, p.y - c.mx[1]); s = s + t * t;
-    t = fmax(0.0, c.mn[2] - p.z); s = s + t * t;
-    t = fmax(0.0, p.z - c.mx[2]); s = s + t * t;
+    t = fmax(0.0, mn[0] - p.x); s = t * t;
+    t = fmax(0.0, p.x - mx[0]); s = s + t * t;
+    t = fmax(0.0, mn[1] - p.y); s = s + t * t;
+    t = fmax(0.0, p.y - mx[1]); s = s + t * t;
+    t = fmax(0.0, mn[2] - p.z); s = s + t * t;
+    t = fmax(0.0, p.z - mx[2]); s = s + t * t;
     return s;
 }
 
-// Depth-first traversal of kdTree.py:127-156 (nearer child first, ties go right, constant rangeSq) with a
-// wave-uniform explicit stack.  leaf(begin, end) is called for every visited leaf in visit order.
 template <class LeafFn>
-__device__ __forceinline__ int kd_traverse(const KdNode *tree, V3 p, double rangeSq, int *stack, int lane, LeafFn leaf) {
+__device__ __forceinline__ int kd_traverse(const KdWide *tree, V3 p, double rangeSq, int *stack, int lane, LeafFn leaf) {
     int sp = 0, st = 0;
     int node = 0;
     bool have = true;
     while (have) {
         node = __builtin_amdgcn_readfirstlane(node);
-        const KdNode nd = tree[node];
+        const KdWide nd = tree[node];
         have = false;
         if (nd.end - nd.begin <= MAX_LEAF) {
             leaf(nd.begin, nd.end);
         } else {
-            const double dl = box_dist_sq(tree[nd.left], p);
-            const double dr = box_dist_sq(tree[nd.right], p);
+            const double dl = box_dist_sq(nd.lmn, nd.lmx, p);
+            const double dr = box_dist_sq(nd.rmn, nd.rmx, p);
             int first, second;
             double dfirst, dsecond;
             if (dl < dr) { first = nd.left; second = nd.right; dfirst = dl; dsecond = dr; }
@@ -173,7 +181,7 @@ __device__ __forceinline__ int kd_traverse(const KdNode *tree, V3 p, double rang
 // agent_reach / obs_reach: see k_collide_finish.  Every object that can touch this agent after the move is visited
 // here anyway (it is within neighborDist), so the few that are close enough are written down for K4.
 __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
-                                              int *stack, int agent, int lane) {
+                                              double max_radius, int *stack, int agent, int lane) {
     const PubRec me = d.rec[agent];
     int st = 0;
     bool skip = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
@@ -197,12 +205,12 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     bool coll = false;
     // obstacles first (scaPolicy.py:114-116), agent.py:101-124
     if (d.m > 0) {
-        st |= kd_traverse(d.otree, pA, rangeSq, stack, lane, [&](int begin, int end) {
+        st |= kd_traverse(d.owide, pA, rangeSq, stack, lane, [&](int begin, int end) {
             const bool valid = lane < end - begin;
             int o = 0; double distSq = 0.0; bool c = false, r = false, nr = false;
             if (valid) {
                 o = d.operm[begin + lane];
-                const ObsRec ob = d.obs[o];
+                const ObsRec ob = d.obs_sorted[begin + lane];
                 const V3 pO = v3(ob.px, ob.py, ob.pz);
                 const double distSq1 = l3normsq(pA, pO);
                 const double t = l3norm(pA, pO) - ob.radius;
@@ -231,17 +239,18 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
         });
     }
     // other agents, agent.py:79-99
-    st |= kd_traverse(d.atree, pA, rangeSq, stack, lane, [&](int begin, int end) {
+    // leaf members are contiguous in position order: ids and coordinates come in one coalesced round trip; the other
+    // agent's radius is only fetched when the pair is close enough for the collision test to matter
+    const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
+    st |= kd_traverse(d.awide, pA, rangeSq, stack, lane, [&](int begin, int end) {
         const bool valid = lane < end - begin;
         int o = -1; double distSq = 0.0; bool c = false, r = false, nr = false;
         if (valid) {
             o = d.aperm[begin + lane];
             if (o != agent) {
-                const PubRec ot = d.rec[o];
-                distSq = l3normsq(pA, v3(ot.px, ot.py, ot.pz));
-                const double rs = me.radius + ot.radius;
+                distSq = l3normsq(pA, v3(d.kx[begin + lane], d.ky[begin + lane], d.kz[begin + lane]));
                 r = distSq < rangeSq;
-                c = r && distSq < rs * rs;
+                if (r && distSq < rmax2) { const double rs = me.radius + d.rec[o].radius; c = distSq < rs * rs; }
                 nr = distSq < reach_a * reach_a;
             }
         }
@@ -276,12 +285,13 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     }
 }
 
-__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach) {
+__global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach,
+                                                                double max_radius) {
     __shared__ int stacks[K1_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, stacks[wid], agent, lane);
+    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, max_radius, stacks[wid], agent, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -840,6 +850,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d.fb_count = 0;            // k_solve_full has run: ready for the next pass
     if (agent >= d.shard_begin + d.shard_count) return;
     PubRec me = d.rec[agent];
     float actf[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -909,12 +920,12 @@ __device__ __forceinline__ void collide_one(const DeviceView &d, const Params &P
     } else {
         if (d.m > 0) {
             const double rq = me.radius + obs_reach;
-            kd_traverse(d.otree, p, rq * rq, stack, lane, [&](int begin, int end) {
+            kd_traverse(d.owide, p, rq * rq, stack, lane, [&](int begin, int end) {
                 if (lane < end - begin) test_obstacle(d.operm[begin + lane]);
             });
         }
         const double rq = me.radius + agent_reach;
-        kd_traverse(d.atree, p_old, rq * rq, stack, lane, [&](int begin, int end) {
+        kd_traverse(d.awide, p_old, rq * rq, stack, lane, [&](int begin, int end) {
             if (lane < end - begin) { const int j = d.aperm[begin + lane]; if (j != agent) test_agent(j); }
         });
     }
