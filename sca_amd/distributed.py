@@ -11,7 +11,10 @@ returning (full tensor, this rank's slice) -- tests drive the same class on CPU 
 
 
 class ShardedStepper:
-    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0):
+    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0, staged=False):
+        """staged=True exchanges through host memory (for backends without GPU collectives, e.g. gloo when several
+        ranks share one GPU in tests); the default hands the device buffers to the collective directly (RCCL)."""
+        self.staged = staged
         self.sol = solver
         self.rank, self.world = int(rank), int(world)
         self.torch = torch_mod
@@ -57,7 +60,15 @@ class ShardedStepper:
         for _ in range(int(steps)):
             self.sol.step_begin(self.mode)
             full, mine = self._moved_records()
-            self.dist.all_gather_into_tensor(full, mine)
+            if self.staged:
+                self.sol.synchronize()
+                h_mine = mine.cpu()
+                h_full = self.torch.empty(full.numel(), dtype=full.dtype)
+                self.dist.all_gather_into_tensor(h_full, h_mine)
+                full.copy_(h_full)
+                self.torch.cuda.synchronize()
+            else:
+                self.dist.all_gather_into_tensor(full, mine)
             self.sol.step_end()
 
     def sync(self):

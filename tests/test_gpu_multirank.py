@@ -1,0 +1,60 @@
+"""Two ranks on ONE GPU (gloo, host-staged exchange): the real libsca_hip step_begin / exchange / step_end path with
+sharded agents must reproduce the single-rank resident run bit for bit.  (The 8-GPU runs use RCCL on the same code.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sca_amd import scenarios, solver as S
+from sca_amd.distributed import ShardedStepper
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo')
+n, steps = 3000, 12
+sc = scenarios.random_cube(n, seed=2)
+pol = np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 3 == 1, 3, 4)).astype(np.uint8)
+
+def make():
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1, device=0)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                   scenarios.max_run_dist(sc['start'], sc['goal']))
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    return sol
+
+sol = make()
+st = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=True)
+st.run(steps); st.sync()
+got = sol.get_state()
+ref_sol = make()
+ref_sol.run_steps(steps); ref_sol.synchronize()
+ref = ref_sol.get_state()
+lo, hi = st.begin, st.begin + st.count
+ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['vel'])
+ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
+ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
+ok = ok and np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm())
+print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_two_ranks_one_gpu_match_single_rank(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29541', str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('OK') == 2, r.stdout[-3000:]
