@@ -137,6 +137,22 @@ int sca_set_profiling(sca_ctx *ctx, int on);
 /* number of agents that entered find_next_action since the last reset (the metric's "agent-steps") */
 int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 
+/* native preferred-velocity tracker for SCAPolicy / RVO3dDubinsPolicy (host side, thread-parallel over agents):
+ * replaces compute_v_pref / compute_dubins / update_dubins (mamp/policies/sca/scaPolicy.py:92-104,243-338) and the 3-D
+ * Dubins planner (dubinsmaneuver3d.py:34-162, dubinsmaneuver2d.py:33-218,260-297).  Feed its output to sca_set_vpref. */
+void *sca_tracker_create(int n, const double *goal /*n*3*/, const double *goal_heading /*n*3*/, const double *pref_speed /*n*/,
+                         const uint8_t *zaxis /*n, nullable*/, double turning_radius /*agent.py:24 1.5*/,
+                         double pitch_min, double pitch_max /*agent.py:27*/, double neighbor_dist /*agent.py:33*/);
+void sca_tracker_destroy(void *tracker);
+/* one compute_v_pref per agent with active[i] != 0; nbr0_dsq[i] = distSq of agent.neighbors[0] as left by the previous
+ * policy pass, negative when the list is empty (scaPolicy.py:299) */
+int sca_tracker_vpref(void *tracker, const double *pos /*n*3*/, const float *vel /*n*3*/, const double *heading /*n*3*/,
+                      const uint8_t *active /*n*/, const double *nbr0_dsq /*n*/, double *vpref_out /*n*3*/, int nthreads);
+int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
+/* dubinsmaneuver3d (dubinsmaneuver3d.py:34): q = [x, y, z, yaw, pitch]; samples = [x, y, z, psi, gamma] rows */
+int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
+                    char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
+
 /* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
 /* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */
 int sca_candidate_table(int num_N, double *unit /*3*num_N*/, double *phi_num /*num_N*/);

@@ -54,6 +54,11 @@ SIGNATURES = {
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
     'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    'sca_tracker_create': (C.c_void_p, [C.c_int, dp, dp, dp, bp, C.c_double, C.c_double, C.c_double, C.c_double]),
+    'sca_tracker_destroy': (None, [C.c_void_p]),
+    'sca_tracker_vpref': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, dp, C.c_int]),
+    'sca_tracker_replans': (C.c_int, [C.c_void_p, ip]),
+    'sca_dubins_plan': (C.c_int, [dp, dp, C.c_double, C.c_double, C.c_double, dp, C.c_char_p, ip, dp, C.c_int]),
     'sca_candidate_table': (C.c_int, [C.c_int, dp, dp]),
     'sca_kd_build_host': (C.c_int, [C.c_int, dp, ip, dp]),
 }

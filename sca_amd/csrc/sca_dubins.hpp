@@ -1,0 +1,342 @@
+// sca_dubins.hpp -- native host-side replacement of SCA's preferred-velocity tracker.
+//
+// The reference computes v_pref for SCAPolicy / RVO3dDubinsPolicy with a per-agent, stateful tracker over a sampled 3-D
+// Dubins path (mamp/policies/sca/scaPolicy.py:92-104,243-338), planned by dubinsmaneuver3d.py:34-162 on top of the 2-D
+// planner dubinsmaneuver2d.py:33-218,260-297.  It is scalar, branchy and stateful, so it stays on the host; this file is
+// a C++ restatement that follows the Python statement by statement (same libm calls through function pointers so that the
+// compiler cannot fold pow(x, 2) or fuse sin/cos), thread-parallel over agents.
+// generate_course (dubinsmaneuver2d.py:221-257) is not reproduced: the 3-D planner never reads its output.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace sca_dubins {
+
+// libm through volatile pointers: literal evaluation, no folding / fusing
+static double (*volatile m_pow)(double, double) = std::pow;
+static double (*volatile m_sin)(double) = std::sin;
+static double (*volatile m_cos)(double) = std::cos;
+static double (*volatile m_acos)(double) = std::acos;
+static double (*volatile m_atan2)(double, double) = std::atan2;
+
+static const double PI = 3.141592653589793;
+static inline double fma3(const double *a, const double *b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); }
+static inline double mod2pi(double t) { return t - 2.0 * PI * std::floor(t / 2.0 / PI); }                    // util.py:113
+// Python round(x, 5): correctly rounded (see sca_core.h round5_py)
+static inline double round5_py(double x) {
+    const double y = x * 100000.0;
+    const double e = std::fma(x, 100000.0, -y);
+    double r = std::rint(y);
+    const double d = y - r;
+    if (d == 0.5) { if (e > 0.0) r += 1.0; }
+    else if (d == -0.5) { if (e < 0.0) r -= 1.0; }
+    return r / 100000.0;
+}
+static inline double round5_np(double x) { return std::rint(x * 100000.0) / 100000.0; }
+static inline double trunc5(double x) { double t = std::trunc(x * 100000.0); if (t == 0.0) t = 0.0; return t / 100000.0; }
+static inline double l3norm(const double *a, const double *b) {                                              // util.py:104
+    return round5_py(std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0)));
+}
+
+struct Maneuver2D { double qi[3]; double r_min, t, p, q, length; char mode[3]; bool ok; };
+
+// dubinsmaneuver2d.py:33-145: one candidate word
+static bool word(int which, double alpha, double beta, double d, double &t, double &p, double &q, char mode[3]) {
+    const double sa = m_sin(alpha), sb = m_sin(beta), ca = m_cos(alpha), cb = m_cos(beta), c_ab = m_cos(alpha - beta);
+    switch (which) {
+    case 0: {                                                                                                // LSL :33-51
+        mode[0] = 'L'; mode[1] = 'S'; mode[2] = 'L';
+        const double tmp0 = d + sa - sb;
+        const double p2 = 2 + (d * d) - (2 * c_ab) + (2 * d * (sa - sb));
+        if (p2 < 0) return false;
+        const double tmp1 = m_atan2((cb - ca), tmp0);
+        t = mod2pi(-alpha + tmp1); p = std::sqrt(p2); q = mod2pi(beta - tmp1);
+        return true;
+    }
+    case 1: {                                                                                                // RSR :54-71
+        mode[0] = 'R'; mode[1] = 'S'; mode[2] = 'R';
+        const double tmp0 = d - sa + sb;
+        const double p2 = 2 + (d * d) - (2 * c_ab) + (2 * d * (sb - sa));
+        if (p2 < 0) return false;
+        const double tmp1 = m_atan2((ca - cb), tmp0);
+        t = mod2pi(alpha - tmp1); p = std::sqrt(p2); q = mod2pi(-beta + tmp1);
+        return true;
+    }
+    case 2: {                                                                                                // LSR :74-90
+        mode[0] = 'L'; mode[1] = 'S'; mode[2] = 'R';
+        const double p2 = -2 + (d * d) + (2 * c_ab) + (2 * d * (sa + sb));
+        if (p2 < 0) return false;
+        p = std::sqrt(p2);
+        const double tmp2 = m_atan2((-ca - cb), (d + sa + sb)) - m_atan2(-2.0, p);
+        t = mod2pi(-alpha + tmp2); q = mod2pi(-mod2pi(beta) + tmp2);
+        return true;
+    }
+    case 3: {                                                                                                // RSL :93-109
+        mode[0] = 'R'; mode[1] = 'S'; mode[2] = 'L';
+        const double p2 = (d * d) - 2 + (2 * c_ab) - (2 * d * (sa + sb));
+        if (p2 < 0) return false;
+        p = std::sqrt(p2);
+        const double tmp2 = m_atan2((ca + cb), (d - sa - sb)) - m_atan2(2.0, p);
+        t = mod2pi(alpha - tmp2); q = mod2pi(beta - tmp2);
+        return true;
+    }
+    case 4: {                                                                                                // RLR :112-127
+        mode[0] = 'R'; mode[1] = 'L'; mode[2] = 'R';
+        const double tmp = (6.0 - d * d + 2.0 * c_ab + 2.0 * d * (sa - sb)) / 8.0;
+        if (std::fabs(tmp) > 1.0) return false;
+        p = mod2pi(2 * PI - m_acos(tmp));
+        t = mod2pi(alpha - m_atan2(ca - cb, d - sa + sb) + mod2pi(p / 2.0));
+        q = mod2pi(alpha - beta - t + mod2pi(p));
+        return true;
+    }
+    default: {                                                                                               // LRL :130-145
+        mode[0] = 'L'; mode[1] = 'R'; mode[2] = 'L';
+        const double tmp = (6. - d * d + 2 * c_ab + 2 * d * (-sa + sb)) / 8.;
+        if (std::fabs(tmp) > 1) return false;
+        p = mod2pi(2 * PI - m_acos(tmp));
+        t = mod2pi(-alpha - m_atan2(ca - cb, d + sa - sb) + p / 2.);
+        q = mod2pi(mod2pi(beta) - alpha - t + mod2pi(p));
+        return true;
+    }
+    }
+}
+
+// dubins_path_planning (:179-218) + dubins_path_planning_from_origin (:148-176)
+static Maneuver2D plan2d(const double start[3], const double end[3], double c) {
+    Maneuver2D m;
+    m.qi[0] = start[0]; m.qi[1] = start[1]; m.qi[2] = start[2];
+    m.r_min = c; m.t = m.p = m.q = -1.0; m.length = INFINITY; m.ok = false;
+    const double ex = end[0] - start[0], ey = end[1] - start[1];
+    const double syaw = start[2], eyaw = end[2];
+    const double D = std::sqrt(m_pow(ex, 2.0) + m_pow(ey, 2.0));
+    const double d = D / c;
+    const double theta = mod2pi(m_atan2(ey, ex));
+    const double alpha = mod2pi(syaw - theta);
+    const double beta = mod2pi(eyaw - theta);
+    double bcost = INFINITY;
+    for (int w = 0; w < 6; w++) {                                     // planners = [LSL, RSR, LSR, RSL, RLR, LRL]
+        double t, p, q; char mode[3];
+        if (!word(w, alpha, beta, d, t, p, q, mode)) continue;
+        const double cost = c * (std::fabs(t) + std::fabs(p) + std::fabs(q));
+        if (bcost > cost) { m.t = t; m.p = p; m.q = q; std::memcpy(m.mode, mode, 3); bcost = cost; m.ok = true; }
+    }
+    m.length = bcost;
+    return m;
+}
+
+// get_position_in_segment (:283-297) / get_coordinates (:260-280)
+static void seg(double offset, const double qi[3], char mode, double q[3]) {
+    q[0] = q[1] = q[2] = 0.0;
+    if (mode == 'L') {
+        q[0] = qi[0] + m_sin(qi[2] + offset) - m_sin(qi[2]);
+        q[1] = qi[1] - m_cos(qi[2] + offset) + m_cos(qi[2]);
+        q[2] = qi[2] + offset;
+    } else if (mode == 'R') {
+        q[0] = qi[0] - m_sin(qi[2] - offset) + m_sin(qi[2]);
+        q[1] = qi[1] + m_cos(qi[2] - offset) - m_cos(qi[2]);
+        q[2] = qi[2] - offset;
+    } else if (mode == 'S') {
+        q[0] = qi[0] + m_cos(qi[2]) * offset;
+        q[1] = qi[1] + m_sin(qi[2]) * offset;
+        q[2] = qi[2];
+    }
+}
+static void get_coordinates(const Maneuver2D &m, double offset, double q[3]) {
+    const double noffset = offset / m.r_min;
+    const double qi[3] = {0., 0., m.qi[2]};
+    const double l1 = m.t, l2 = m.p;
+    double q1[3], q2[3];
+    seg(l1, qi, m.mode[0], q1);
+    seg(l2, q1, m.mode[1], q2);
+    if (noffset < l1) seg(noffset, qi, m.mode[0], q);
+    else if (noffset < (l1 + l2)) seg(noffset - l1, q1, m.mode[1], q);
+    else seg(noffset - l1 - l2, q2, m.mode[2], q);
+    q[0] = q[0] * m.r_min + qi[0];
+    q[1] = q[1] * m.r_min + qi[1];
+    q[2] = mod2pi(q[2]);
+}
+
+struct Plan3D {
+    Maneuver2D h, v;
+    double length = -1.0, sampling_size = 0.1;
+    char mode[7] = {0};
+    bool ok = false;
+    std::vector<double> path;            // samples [x, y, z, psi, gamma] in path order
+};
+
+// try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
+static int try_to_construct(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2], double hr,
+                            Maneuver2D &mh, Maneuver2D &mv) {
+    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
+    mh = plan2d(qi2D, qf2D, hr);
+    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
+    const double vc = std::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
+    if (vc < 1e-5) return 0;
+    const double vr = 1.0 / vc;
+    mv = plan2d(qi3D, qf3D, vr);
+    if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
+    if (mv.mode[0] == 'R') { if (qi[4] - mv.t < pitchlims[0]) return 0; }
+    else { if (qi[4] + mv.t > pitchlims[1]) return 0; }
+    return 2;
+}
+
+// dubinsmaneuver3d (dubinsmaneuver3d.py:34-113) + compute_sampling (:116-132)
+static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2]) {
+    Plan3D P;
+    double b = 1.0;
+    Maneuver2D fbh, fbv, fch, fcv;
+    int nfb = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+    int guard = 0;
+    while (nfb < 2) {
+        b *= 2.0;
+        nfb = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+        if (++guard > 200) return P;                                   // the reference would loop forever
+    }
+    double step = 0.1;
+    while (std::fabs(step) > 1e-10) {
+        double c = b + step;
+        if (c < 1.0) c = 1.0;
+        const int nfc = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
+        if (nfc > 0) {
+            if (fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
+        }
+        step *= -0.1;
+    }
+    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
+    std::memcpy(P.mode, fbh.mode, 3); std::memcpy(P.mode + 3, fbv.mode, 3); P.mode[6] = 0;
+    double ss = 0.1;
+    if (P.length > 100) ss = P.length / 1000;
+    P.sampling_size = ss;
+    const double stop = P.length + ss;
+    const long cnt = (long)std::ceil(stop / ss);                        // np.arange(0, stop, ss)
+    P.path.reserve((size_t)(cnt > 0 ? cnt : 0) * 5);
+    for (long i = 0; i < cnt; i++) {
+        const double ran = (double)i * ss;
+        double qSZ[3], qXY[3];
+        get_coordinates(P.v, ran, qSZ);
+        get_coordinates(P.h, qSZ[0], qXY);
+        const double s[5] = {qXY[0] + qi[0], qXY[1] + qi[1], qSZ[1] + qi[2], qXY[2], qSZ[2]};
+        P.path.insert(P.path.end(), s, s + 5);
+    }
+    return P;
+}
+
+// ---- the tracker (scaPolicy.py:243-338) ------------------------------------------------------------------------------
+struct AgentTrack {
+    bool is_use_dubins = false;
+    std::vector<double> path;           // remaining samples (x,y,z), stored so that pop() == pop_back()
+    double now_goal[3] = {0, 0, 0};
+    double sampling_size = 0.1;
+    double v_pref[3] = {0, 0, 0};       // agent.v_pref (not truncated), read by is_parallel on the next call
+    int replans = 0;
+};
+
+struct Tracker {
+    int n = 0;
+    std::vector<double> goal, goal_heading, pref_speed;
+    std::vector<uint8_t> zaxis;
+    double turning_radius = 1.5, pitchlims[2] = {-PI / 4, PI / 4}, neighbor_dist = 10.0;
+    std::vector<AgentTrack> st;
+};
+
+static void compute_dubins(const Tracker &T, AgentTrack &a, int i, const double *pos, const double *heading) {     // :92-104
+    const double qi[5] = {pos[0], pos[1], pos[2], heading[0], heading[1]};
+    const double qf[5] = {T.goal[3 * i], T.goal[3 * i + 1], T.goal[3 * i + 2], T.goal_heading[3 * i], T.goal_heading[3 * i + 1]};
+    Plan3D P = plan3d(qi, qf, T.turning_radius, T.pitchlims);
+    a.sampling_size = P.sampling_size;
+    const size_t cnt = P.path.size() / 5;
+    a.path.clear();
+    for (size_t k = cnt; k-- > 0;) { a.path.push_back(P.path[5 * k]); a.path.push_back(P.path[5 * k + 1]); a.path.push_back(P.path[5 * k + 2]); }
+    a.replans++;
+}
+static bool path_pop(AgentTrack &a, double out[3]) {
+    if (a.path.empty()) return false;
+    const size_t m = a.path.size();
+    out[0] = a.path[m - 3]; out[1] = a.path[m - 2]; out[2] = a.path[m - 1];
+    a.path.resize(m - 3);
+    return true;
+}
+static void node_pop4(AgentTrack &a) { double t[3]; for (int k = 0; k < 4; k++) path_pop(a, t); }                // :253-261
+static void update_dubins(const Tracker &T, AgentTrack &a, int i, const double *pos) {                            // :243-250
+    const double dis = l3norm(pos, a.now_goal);
+    if (dis < a.sampling_size * 2) {
+        if (!path_pop(a, a.now_goal)) { a.now_goal[0] = T.goal[3 * i]; a.now_goal[1] = T.goal[3 * i + 1]; a.now_goal[2] = T.goal[3 * i + 2]; }
+    }
+}
+// util.py:125-137 is_parallel(vA float32, v_pref float64)
+static bool is_parallel(const float *vA, const double *vp) {
+    const float n1 = std::sqrt((float)((double)(float)(vA[0] * vA[0]) + (double)(float)(vA[1] * vA[1]) + (double)(float)(vA[2] * vA[2])));
+    const double n2 = std::sqrt(fma3(vp, vp));
+    const float v1[3] = {vA[0] / n1, vA[1] / n1, vA[2] / n1};
+    const double v2[3] = {vp[0] / n2, vp[1] / n2, vp[2] / n2};
+    if (n1 <= (float)1e-5 || n2 <= 1e-5) return true;
+    const double v1d[3] = {(double)v1[0], (double)v1[1], (double)v1[2]};
+    return round5_np(1.0 - std::fabs(fma3(v1d, v2))) < 3e-3;
+}
+
+// compute_v_pref (scaPolicy.py:264-338) for one agent; nbr0_dsq < 0 means agent.neighbors is empty
+static void compute_v_pref(const Tracker &T, AgentTrack &a, int i, const double *pos, const float *vel, const double *heading,
+                           double nbr0_dsq, double *V_des) {
+    const double *goal = &T.goal[3 * i];
+    const double dis_goal = l3norm(pos, goal);
+    const double k = 3.0 * T.turning_radius;
+    double dif[3];
+    if (!a.is_use_dubins) {
+        a.is_use_dubins = true;
+        compute_dubins(T, a, i, pos, heading);
+        node_pop4(a);
+        path_pop(a, a.now_goal);
+        for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+    } else {
+        update_dubins(T, a, i, pos);
+        const double dis = l3norm(pos, a.now_goal);
+        const double max_size = round5_py(6 * a.sampling_size);
+        const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
+        const double vA64[3] = {(double)vel[0], (double)vel[1], (double)vel[2]};
+        const float nvA = std::sqrt((float)((double)(float)(vel[0] * vel[0]) + (double)(float)(vel[1] * vel[1]) + (double)(float)(vel[2] * vel[2])));
+        double cs = fma3(vA64, pApG) / ((double)nvA * std::sqrt(fma3(pApG, pApG)));
+        if (!(cs < 1.0)) cs = 1.0;                                       // min(x, 1.0); nan -> 1.0 as Python's min does here
+        if (cs < -1.0) cs = -1.0;                                        // the reference would raise; clamp
+        const double theta = round5_py(m_acos(cs));
+        const double deg100 = round5_np(100.0 * (PI / 180.0));
+        const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
+        const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
+        if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
+            update_dubins(T, a, i, pos);
+            if (!a.path.empty()) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+            else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
+        } else {
+            compute_dubins(T, a, i, pos, heading);
+            node_pop4(a);
+            path_pop(a, a.now_goal);
+            for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+        }
+    }
+    const double zero[3] = {0, 0, 0};
+    const double norm = l3norm(dif, zero);
+    double v[3];
+    for (int q = 0; q < 3; q++) v[q] = dif[q] * T.pref_speed[i] / norm;
+    if (l3norm(goal, pos) < 0.2) v[0] = v[1] = v[2] = 0.0;               // util.reached, bound 0.2
+    for (int q = 0; q < 3; q++) { a.v_pref[q] = v[q]; V_des[q] = trunc5(v[q]); }
+}
+
+static void step_all(Tracker &T, const double *pos, const float *vel, const double *heading, const uint8_t *active,
+                     const double *nbr0_dsq, double *vpref_out, int nthreads) {
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi; i++)
+            if (active[i]) compute_v_pref(T, T.st[i], i, pos + 3 * i, vel + 3 * i, heading + 3 * i, nbr0_dsq[i], vpref_out + 3 * i);
+    };
+    if (nthreads <= 1 || T.n < 64) { work(0, T.n); return; }
+    std::vector<std::thread> th;
+    const int chunk = (T.n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        const int lo = t * chunk, hi = std::min(T.n, lo + chunk);
+        if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    for (auto &x : th) x.join();
+}
+
+}  // namespace sca_dubins

@@ -12,6 +12,7 @@
 #include "../../include/sca_hip.h"
 #include "sca_kernels.hip.h"
 #include "sca_kdbuild.hip.h"
+#include "sca_dubins.hpp"
 
 using namespace sca;
 
@@ -199,6 +200,50 @@ int sca_kd_build_host(int n, const double *pos, int32_t *perm, double *tree_out)
             t[0] = tree[i].begin; t[1] = tree[i].end; t[2] = tree[i].left; t[3] = tree[i].right;
             for (int k = 0; k < 3; k++) { t[4 + k] = tree[i].mn[k]; t[7 + k] = tree[i].mx[k]; }
         }
+    return 0;
+}
+
+// ---- native v_pref tracker (host only, no GPU needed): scaPolicy.py:264-338 + dubinsmaneuver2d/3d.py ----------------
+void *sca_tracker_create(int n, const double *goal, const double *goal_heading, const double *pref_speed,
+                         const uint8_t *zaxis, double turning_radius, double pitch_min, double pitch_max,
+                         double neighbor_dist) {
+    if (n <= 0 || !goal || !goal_heading || !pref_speed) return nullptr;
+    auto *T = new sca_dubins::Tracker();
+    T->n = n;
+    T->goal.assign(goal, goal + 3 * (size_t)n);
+    T->goal_heading.assign(goal_heading, goal_heading + 3 * (size_t)n);
+    T->pref_speed.assign(pref_speed, pref_speed + n);
+    T->zaxis.assign((size_t)n, 0);
+    if (zaxis) T->zaxis.assign(zaxis, zaxis + n);
+    T->turning_radius = turning_radius; T->pitchlims[0] = pitch_min; T->pitchlims[1] = pitch_max;
+    T->neighbor_dist = neighbor_dist;
+    T->st.assign((size_t)n, sca_dubins::AgentTrack());
+    return T;
+}
+void sca_tracker_destroy(void *tr) { delete (sca_dubins::Tracker *)tr; }
+int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const double *heading, const uint8_t *active,
+                      const double *nbr0_dsq, double *vpref_out, int nthreads) {
+    if (!tr || !pos || !vel || !heading || !active || !nbr0_dsq || !vpref_out) return SCA_ERR_ARG;
+    sca_dubins::step_all(*(sca_dubins::Tracker *)tr, pos, vel, heading, active, nbr0_dsq, vpref_out, nthreads);
+    return 0;
+}
+int sca_tracker_replans(void *tr, int32_t *replans) {
+    if (!tr || !replans) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    for (int i = 0; i < T->n; i++) replans[i] = T->st[i].replans;
+    return 0;
+}
+int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
+                    char *mode7, int32_t *n_samples, double *samples, int cap) {
+    if (!qi5 || !qf5 || !length || !mode7) return SCA_ERR_ARG;
+    const double pl[2] = {pitch_min, pitch_max};
+    const sca_dubins::Plan3D P = sca_dubins::plan3d(qi5, qf5, rmin, pl);
+    if (!P.ok) return SCA_ERR_STATE;
+    *length = P.length;
+    std::memcpy(mode7, P.mode, 7);
+    const int cnt = (int)(P.path.size() / 5);
+    if (n_samples) *n_samples = cnt;
+    if (samples) std::memcpy(samples, P.path.data(), sizeof(double) * 5 * (size_t)std::min(cnt, cap));
     return 0;
 }
 

@@ -209,6 +209,7 @@ class MACAEnv:
         self.device = device
         self.neighbor_mode = neighbor_mode
         self._row_cache = None
+        self._last_neighbors = None     # neighbour lists of the previous policy pass (read by the v_pref tracker)
 
     def set_agents(self, agents, obstacles=None):
         if obstacles is None:
@@ -252,6 +253,8 @@ class MACAEnv:
             self.solver.policy_pass(self.neighbor_mode)
             self._row_cache = self.solver.actions()
             self._nbr_cache = None
+            if self.v_pref_fn is not None:
+                self._nbr_cache = self._last_neighbors = self.solver.neighbors()
             self.flags[:] = self.solver.get_state()['flags']      # is_collision set inside insert*Neighbor (agent.py:84)
         return self._row_cache
 

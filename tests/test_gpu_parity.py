@@ -302,3 +302,48 @@ def test_drop_in_env_api_matches_oracle_episode(S, oracle):
     assert np.array_equal(env.flags, flags)
     assert np.array_equal(agents[0].pos_global_frame, env.pos[0]) and agents[0].step_num == sn[0]
     assert env.kdTree.agentIDs == list(perm)
+
+
+def test_sca_end_to_end_with_native_tracker_c1(S):
+    """BASELINE config 1 end to end with NOTHING from the fixture but the start state: SCAPolicy agents in the drop-in
+    MACAEnv, v_pref from the native Dubins tracker, solver + env update on the GPU.  The whole 246-step episode must
+    follow the reference (velocities within 1e-5, same termination step)."""
+    from sca_amd import env as E, tracker
+    fx = load('F1_sca_circle8')
+    st = static_inputs(fx)
+    n = 8
+    agents = E.build_circle_agents(n, policy=E.SCAPolicy, rad=10.0)
+    tr = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=1)
+    env = E.MACAEnv(v_pref_fn=tr)
+    env.set_agents(agents, obstacles=[])
+    T = len(fx['step'])
+    worst = 0.0
+    for t in range(T):
+        done = env.step({})
+        worst = max(worst, float(np.abs(env.vel - fx['vel_after'][t]).max()))
+        assert done == (t == int(fx['done_step'])), t
+    assert worst <= VEL_TOL, worst
+    assert np.allclose(env.pos, fx['pos_after'][-1], rtol=0, atol=1e-6)
+    assert all(a.is_at_goal for a in agents)
+    assert tr.replans().sum() >= n
+
+
+def test_sca_takeoff_with_obstacles_end_to_end(S):
+    """N=16 take-off/landing + 8 obstacles (run_sca.py exp2), SCA with the native tracker, full episode vs fixture F4."""
+    from sca_amd import env as E, scenarios, tracker
+    fx = load('F4_sca_takeoff16')
+    st = static_inputs(fx)
+    sc = scenarios.takeoff_landing(16)
+    agents = [E.Agent(start_pos=list(sc['start'][i]), goal_pos=list(sc['goal'][i]), vel=[0.0, 0.0, 0.0], radius=0.5,
+                      pref_speed=1.0, policy=E.SCAPolicy, id=i) for i in range(16)]
+    obstacles = [E.Obstacle(pos=list(sc['obs_pos'][j]), shape_dict={'shape': 'sphere', 'feature': 1.0}, id=j) for j in range(8)]
+    tr = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=1)
+    env = E.MACAEnv(v_pref_fn=tr)
+    env.set_agents(agents, obstacles=obstacles)
+    T = len(fx['step'])
+    worst = 0.0
+    for t in range(T):
+        done = env.step({})
+        worst = max(worst, float(np.abs(env.vel - fx['vel_after'][t]).max()))
+        assert np.array_equal(env.flags, fx['flags_after'][t]), t
+    assert done and worst <= VEL_TOL, worst

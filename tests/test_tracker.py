@@ -1,0 +1,46 @@
+"""The native v_pref tracker / 3-D Dubins planner (sca_amd/csrc/sca_dubins.hpp, host code in libsca_hip.so) against
+golden vectors recorded from the reference: planner KATs (F7, incl. the paper instance RLRRSL / 976.79 of
+dubinsmaneuver3d.py:230) and the per-step v_pref of whole SCA episodes (F1, F2, F4).  Bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, load, static_inputs
+
+
+def test_dubins_planner_kats():
+    from sca_amd import tracker
+    kats = json.load(open(os.path.join(GOLDEN, 'F7_dubins_kat.json')))
+    assert kats[0]['mode'] == 'RLRRSL' and abs(kats[0]['length'] - 976.7927) < 1e-3      # the paper instance
+    for k in kats:
+        length, mode, samples, n = tracker.dubins_plan(k['qi'], k['qf'], k['R'], k['pl'], max_samples=5000)
+        assert mode == k['mode'], (mode, k['mode'])
+        assert length == k['length']
+        assert n == k['n']
+        assert np.array_equal(samples[0], k['first'])
+        assert np.array_equal(samples[n // 2], k['mid'])
+        assert np.array_equal(samples[n - 1], k['last'])
+
+
+@pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
+                                  'F4_mixed_takeoff16'])
+def test_tracker_reproduces_reference_v_pref(name):
+    """Open loop on the solver (states come from the fixture), closed loop on the tracker's own state: every
+    compute_v_pref of the episode, including all re-plans, must return the reference's V_des bit for bit."""
+    from sca_amd import tracker
+    fx = load(name)
+    st = static_inputs(fx)
+    n = len(st['radius'])
+    ext = st['vpref_mode'].astype(bool)
+    tr = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=4)
+    T = len(fx['step'])
+    assert np.array_equal(fx['step'], np.arange(T))           # every step recorded: the tracker state can be replayed
+    for t in range(T):
+        active = fx['called'][t].astype(bool) & ext
+        got = tr.vpref(fx['pos'][t], fx['vel'][t], fx['heading'][t], active.astype(np.uint8))
+        assert np.array_equal(got[active], fx['vpref'][t][active]), (name, t, np.abs(got[active] - fx['vpref'][t][active]).max())
+        tr.note_neighbors(fx['nbr_valid'][t], fx['nbr_n'][t], fx['nbr_dsq'][t])
+    assert tr.replans()[ext].min() >= 1
+    tr.close()
