@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
     ap.add_argument('--agents', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins'],
+                    help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -102,6 +104,28 @@ def main():
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
     stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist)
 
+    if args.vpref == 'dubins':
+        if world > 1:
+            raise SystemExit('--vpref dubins is a single-GPU measurement')
+        from sca_amd import tracker as trk
+        tr = trk.DubinsTracker(sc['goal'][:, :3], sc['goal'][:, 3:6], scene['pref_speed'], scene['zaxis'])
+        ext = np.isin(scene['policy'], (0, 5))
+
+        class TrackedStepper:
+            """one step = read back state -> native tracker (host threads) -> upload v_pref -> resident GPU step"""
+
+            def run(self, k):
+                for _ in range(k):
+                    st = sol.get_state()
+                    active = ((st['flags'] & 7) == 0) & ext
+                    vp = tr.vpref(st['pos'], st['vel'], st['heading'], active.astype(np.uint8))
+                    sol.set_vpref(vp, ext.astype(np.uint8))
+                    sol.run_steps(1)
+                    tr.note_nbr0(sol.nbr0())
+
+            def sync(self):
+                sol.synchronize()
+        stepper = TrackedStepper()
     # warm-up (untimed): includes the bootstrap step (velocity 0 -> 0.3 v_pref) so the real branch runs afterwards
     stepper.run(args.warmup)
     stepper.sync()
@@ -142,7 +166,8 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': w['desc'], 'agents': n, 'neighbor_search': 'kd-tree replica (host build, device query)',
-                       'v_pref': 'straight-line rule on device (Dubins tracker is outside the kernel boundary)',
+                       'v_pref': ('straight-line rule on device (the Dubins tracker is host-side, outside the kernel boundary)'
+                                  if args.vpref == 'straight' else 'native Dubins tracker on the host every step (end-to-end SCA)'),
                        'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'
                        if world > 1 else 'single GPU', 'agent_steps_timed': total_steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -106,6 +106,8 @@ int sca_policy_pass(sca_ctx *ctx, int neighbor_mode);
 int sca_get_actions(sca_ctx *ctx, float *action /*n*7*/);
 int sca_get_neighbors(sca_ctx *ctx, int32_t *nbr_n /*n*/, int32_t *nbr_id /*n*16*/, uint8_t *nbr_kind /*n*16*/,
                       double *nbr_dsq /*n*16*/, uint8_t *nbr_valid /*n*/);
+/* distSq of agent.neighbors[0] after the last pass: >= 0 value, -1 empty list, -2 list not touched by the pass */
+int sca_get_nbr0(sca_ctx *ctx, double *dsq0 /*n*/);
 int sca_get_diag(sca_ctx *ctx, int32_t *diag /*n*5*/, int32_t *status /*n*/, double *vpref_used /*n*3*/);
 int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/);
 /* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising */

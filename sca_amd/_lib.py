@@ -41,6 +41,7 @@ SIGNATURES = {
     'sca_policy_pass': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_get_actions': (C.c_int, [C.c_void_p, fp]),
     'sca_get_neighbors': (C.c_int, [C.c_void_p, ip, ip, bp, dp, bp]),
+    'sca_get_nbr0': (C.c_int, [C.c_void_p, dp]),
     'sca_get_diag': (C.c_int, [C.c_void_p, ip, ip, dp]),
     'sca_env_update': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_run_steps': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

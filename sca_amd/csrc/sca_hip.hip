@@ -754,6 +754,16 @@ int sca_get_neighbors(sca_ctx *c, int32_t *nbr_n, int32_t *nbr_id, uint8_t *nbr_
     return 0;
 }
 
+int sca_get_nbr0(sca_ctx *c, double *dsq0) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, dsq0 && c->agents_set);
+    double *tmp = c->kd.kx;      // build scratch, free between passes
+    hipLaunchKernelGGL(k_nbr0, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d, tmp);
+    CHK(c, hipMemcpyAsync(dsq0, tmp, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int sca_get_diag(sca_ctx *c, int32_t *diag, int32_t *status, double *vpref_used) {
     if (!c) return SCA_ERR_ARG;
     const int n = c->n;

@@ -955,6 +955,14 @@ __global__ __launch_bounds__(256) void k_invalidate_near(DeviceView d) {
     if (agent < d.n) d.near_n[agent] = -1;
 }
 
+// agent.neighbors[0][1] of the last pass (what the v_pref tracker reads, scaPolicy.py:299): -1 = empty list, -2 = the pass
+// did not touch the list (agent skipped: keep the previous value)
+__global__ __launch_bounds__(256) void k_nbr0(DeviceView d, double *out) {
+    const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.n) return;
+    out[agent] = d.nbr_valid[agent] ? (d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0) : -2.0;
+}
+
 // multi-GPU only: agents of other shards arrived by all-gather with the flags their owner published one step ago;
 // replicate the at-goal test for them -- the only flag of another agent the policy reads (scaPolicy.py:53).
 __global__ __launch_bounds__(256) void k_goal_flags_others(DeviceView d, Params P) {

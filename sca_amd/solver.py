@@ -147,6 +147,11 @@ class BatchedSolver:
                                            _lib.ptr(out['nbr_valid'], C.c_uint8)), 'sca_get_neighbors')
         return out
 
+    def nbr0(self):
+        a = np.zeros(self.n)
+        self._chk(self.L.sca_get_nbr0(self.ctx, _lib.ptr(a, C.c_double)), 'sca_get_nbr0')
+        return a
+
     def diag(self):
         n = self.n
         out = dict(diag=np.zeros((n, 5), np.int32), status=np.zeros(n, np.int32), vpref=np.zeros((n, 3)))

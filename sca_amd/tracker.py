@@ -24,7 +24,7 @@ class DubinsTracker:
                                            float(turning_radius), float(pitchlims[0]), float(pitchlims[1]), float(neighbor_dist))
         if not self.h:
             raise RuntimeError('sca_tracker_create failed')
-        self.nthreads = nthreads or min(os.cpu_count() or 1, 32)
+        self.nthreads = nthreads or min(os.cpu_count() or 1, 64)
         self._nbr0 = np.full(n, -1.0)          # agent.neighbors[0][1] as the last computeNeighbors left it
 
     def close(self):
@@ -43,6 +43,12 @@ class DubinsTracker:
         v = np.asarray(nbr_valid).astype(bool)
         first = np.where(np.asarray(nbr_n) > 0, np.asarray(nbr_dsq)[:, 0], -1.0)
         self._nbr0[v] = first[v]
+
+    def note_nbr0(self, nbr0):
+        """Same from the compact form of sca_get_nbr0 (-2 = list untouched by the pass)."""
+        nbr0 = np.asarray(nbr0)
+        m = nbr0 > -2.0
+        self._nbr0[m] = nbr0[m]
 
     def vpref(self, pos, vel, heading, active):
         n = self.n
