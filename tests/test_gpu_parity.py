@@ -347,3 +347,60 @@ def test_sca_takeoff_with_obstacles_end_to_end(S):
         worst = max(worst, float(np.abs(env.vel - fx['vel_after'][t]).max()))
         assert np.array_equal(env.flags, fx['flags_after'][t]), t
     assert done and worst <= VEL_TOL, worst
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 11, 63, 65, 257])
+@pytest.mark.parametrize('pol', [0, 2, 3, 4])
+def test_small_and_ragged_agent_counts(S, oracle, n, pol):
+    """Edge sizes: a single agent (empty neighbour list, one-leaf tree), counts that do not fill a wavefront / workgroup,
+    counts just past the kd leaf size (10) and past one wave-chunk."""
+    rng = np.random.default_rng(100 * n + pol)
+    pos = rng.uniform(-6, 6, (n, 3)) + np.array([0, 0, 20.0])
+    goal = -pos + np.array([0, 0, 40.0])
+    v = rng.normal(size=(n, 3))
+    vel = (v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0.4, 1.0, (n, 1))).astype(np.float32)
+    if n > 2:
+        vel[1] = 0.0                                             # one agent on the bootstrap branch
+    head = np.zeros((n, 3)); head[:, 0] = rng.uniform(-3, 3, n)
+    flags = np.zeros(n, np.uint8)
+    if n > 3:
+        flags[2] = 1                                             # one agent already at its goal (static neighbour, skipped)
+    rad = np.full(n, 0.5); ps = np.full(n, 1.0); policy = np.full(n, pol, np.uint8); z = np.zeros(n, np.uint8)
+    e3, e0 = np.zeros((0, 3)), np.zeros(0)
+    perm = rng.permutation(n).astype(np.int32)
+    ref = oracle.policy_step(pos, vel, head, rad, ps, flags, goal, policy, z, np.zeros((n, 3)), np.zeros(n, np.uint8), perm, e3, e0)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(e3, e0)
+    sol.set_agents(rad, ps, goal, policy, z, np.full(n, 1e9))
+    sol.set_state(pos, vel, head, flags)
+    sol.set_kd_perm(perm)
+    sol.policy_pass(S.NBR_KDTREE)
+    nb = sol.neighbors()
+    assert np.array_equal(sol.get_kd_perm(), ref['perm'])
+    assert np.array_equal(nb['nbr_valid'], ref['nbr_valid']) and np.array_equal(nb['nbr_n'], ref['nbr_n'])
+    assert np.array_equal(nb['nbr_id'], ref['nbr_id'])
+    a = sol.actions()
+    assert np.array_equal(a[:, :4], ref['action'][:, :4]), np.abs(a[:, :4] - ref['action'][:, :4]).max()
+    assert np.allclose(a[:, 4:], ref['action'][:, 4:], rtol=0, atol=ANG_TOL)
+    u = oracle.env_update(pos, vel, head, rad, ref['flags'], goal, ref['action'], np.zeros(n), np.full(n, 1e9),
+                          np.zeros(n, np.int32), e3, e0)
+    sol.env_update()
+    s = sol.get_state()
+    assert np.allclose(s['pos'], u['pos'], rtol=0, atol=1e-9) and np.array_equal(s['flags'], u['flags'])
+    sol.close()
+
+
+def test_unsupported_pref_speed_is_reported_not_hidden(S):
+    """pref_speed = 0.5 makes np.arange(0.5, ps + 0.03, ps - 0.5) divide by zero in the reference (scaPolicy.py:195): the
+    library must flag it in the status word instead of inventing a result silently."""
+    n = 4
+    pos = np.array([[0, 0, 10.0], [3, 0, 10], [0, 3, 10], [3, 3, 10]])
+    vel = np.full((n, 3), 0.2, np.float32)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.array([0.5, 1.0, 1.0, 1.0]), pos + 5.0, np.full(n, 1, np.uint8))
+    sol.set_state(pos, vel, np.zeros((n, 3)), np.zeros(n, np.uint8))
+    sol.policy_pass(S.NBR_KDTREE)
+    st = sol.diag()['status']
+    assert st[0] & 4 and not (st[1:] & 4).any()
+    sol.close()

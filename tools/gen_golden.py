@@ -175,13 +175,16 @@ def _snapshot(agents):
 
 def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, obstacles_spec, max_steps,
                     record_every=1, record_first=0, radius=0.5, pref_speed=1.0, outdir='tests/golden'):
+    """radius / pref_speed may be scalars or per-agent sequences."""
     """Runs MACAEnv.step (mampenv.py:22) and records every `record_every`-th step (and the first
     `record_first` steps) completely."""
     global REC
     from mamp.agents.obstacle import Obstacle
     n = len(pos)
-    agents = [agent_mod.Agent(start_pos=list(pos[i]), goal_pos=list(goal[i]), vel=[0.0, 0.0, 0.0], radius=radius,
-                              pref_speed=pref_speed, policy=classes[int(policy_ids[i])], id=i, dt=0.1)
+    radius_l = [float(x) for x in np.broadcast_to(radius, (n,))]
+    ps_l = [float(x) for x in np.broadcast_to(pref_speed, (n,))]
+    agents = [agent_mod.Agent(start_pos=list(pos[i]), goal_pos=list(goal[i]), vel=[0.0, 0.0, 0.0], radius=radius_l[i],
+                              pref_speed=ps_l[i], policy=classes[int(policy_ids[i])], id=i, dt=0.1)
               for i in range(n)]
     obstacles = [Obstacle(pos=list(p), shape_dict={'shape': 'sphere', 'feature': r}, id=i)
                  for i, (p, r) in enumerate(obstacles_spec)]
@@ -243,7 +246,7 @@ def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, ob
     out.update(dict(
         name=name, n_steps_run=step + 1, done_step=done_step,
         start=np.array([np.asarray(p, dtype=np.float64) for p in pos]), goal6=np.array([np.asarray(g, dtype=np.float64) for g in goal]),
-        radius=np.full(n, radius), pref_speed=np.full(n, pref_speed), policy=np.array(policy_ids, np.uint8),
+        radius=np.array(radius_l), pref_speed=np.array(ps_l), policy=np.array(policy_ids, np.uint8),
         max_run_dist=np.array([a.max_run_dist for a in agents]),
         obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
         obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64),
@@ -488,6 +491,19 @@ def main():
         if want(nm):
             single_step_cluster(agent_mod, env_mod, classes, nm, 60, 9.0, pid, seed=31 + pid, n_obs=14, min_sep=1.05,
                                 outdir=od)
+    # F9: heterogeneous radii and preferred speeds, mixed policies, obstacles of different sizes
+    if want('F9_hetero_mixed60'):
+        random.seed(23)
+        rng = np.random.default_rng(23)
+        r = 9.0
+        pos = [np.array([random.uniform(-r, r), random.uniform(-r, r), random.uniform(-r, r) + 30.0, random.uniform(0, 6.28), 0.0, 0.0]) for _ in range(60)]
+        goal = [np.array([random.uniform(-r, r), random.uniform(-r, r), random.uniform(-r, r) + 30.0, 0.0, 0.0, 0.0]) for _ in range(60)]
+        pol = [[POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP][i % 4] for i in range(60)]
+        rad = rng.choice([0.3, 0.5, 0.8], 60)
+        psp = rng.choice([0.8, 1.0, 1.5], 60)
+        obs9 = [([4.0, 1.0, 31.0], 1.5), ([-5.0, -3.0, 27.0], 0.6), ([0.0, 6.0, 34.0], 2.5)]
+        run_env_episode(agent_mod, env_mod, classes, 'F9_hetero_mixed60', pos, goal, pol, obs9, 30, radius=rad,
+                        pref_speed=psp, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
