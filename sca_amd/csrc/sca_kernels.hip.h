@@ -636,10 +636,20 @@ struct FastLds {
     double slot[SOLVE_WAVES][K_MAX][SLOT];
     Plane planes[SOLVE_WAVES][K_MAX];
     Plane proj[SOLVE_WAVES][K_MAX];
-    double keyS[SOLVE_WAVES][520];
+    unsigned int pkS[SOLVE_WAVES][520];          // survivors: (round5 numerator of |v - v_pref|) << 10 | generation index
     unsigned short listA[SOLVE_WAVES][512];
-    unsigned short idxS[SOLVE_WAVES][520];
 };
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
 
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
@@ -712,8 +722,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             const int nround = T.vp_idx >> 6;
             const double nvA = (double)normf(vA);
             unsigned short *listA = S.listA[wid];
-            unsigned short *idxS = S.idxS[wid];
-            double *keyS = S.keyS[wid];
+            unsigned int *pkS = S.pkS[wid];
             // ---- posture filter (util.py:6-20) + compaction.  c >= thr is decided without sqrt / division whenever
             //      dot^2 and (thr*|vA|)^2 |v|^2 are more than 1e-13 apart (relative); otherwise the exact expression runs.
             const double thr = P.cos_heading_thr;
@@ -754,15 +763,17 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     cd[q] = cand_from_idx(T, ix[q], vpref);
                     sh[q] = cd[q] + pA;
                 }
-                const unsigned alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, valid) : sweep<2, false, 2, 2>(slot, K, sh, cd, valid);
+                unsigned alive;
+                if (nA - c0 > 64) alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, valid) : sweep<2, false, 2, 2>(slot, K, sh, cd, valid);
+                else alive = orca ? sweep<1, true, 2, 2>(slot, K, sh, cd, valid) : sweep<1, false, 2, 2>(slot, K, sh, cd, valid);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const bool a = (alive >> q) & 1u;
                     const unsigned long long m = __ballot(a);
                     if (a) {
-                        const int at = nS + __popcll(m & ((1ull << lane) - 1ull));
-                        idxS[at] = (unsigned short)ix[q];
-                        keyS[at] = l3norm(cd[q], vpref);                                 // scaPolicy.py:219
+                        double kn;
+                        l3norm(cd[q], vpref, &kn);                                       // scaPolicy.py:219, as integer numerator
+                        pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(kn, ix[q]);
                     }
                     nS += __popcll(m);
                 }
@@ -781,7 +792,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             }
             const bool vp_ok = posture_ok(P, vA, nvA, pA.z, vpref) && (__ballot(vp_hit) == 0);
             if (vp_ok) {
-                if (lane == 0) { idxS[nS] = (unsigned short)T.vp_idx; keyS[nS] = l3norm(vpref, vpref); }
+                if (lane == 0) { double kn; l3norm(vpref, vpref, &kn); pkS[nS] = pack_key(kn, T.vp_idx); }
                 nS++;
             }
             __builtin_amdgcn_wave_barrier();
@@ -792,37 +803,38 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 return;
             }
             dg_fallback = 0;
-            // ---- selection over the survivor list; sorted order of the reference == lexicographic (key, generation index)
+            // ---- selection over the survivor list.  The reference's stable sort by round5(|v - v_pref|) (scaPolicy.py:219)
+            //      is the order of the packed integer (numerator << 10 | generation index): one 32-bit wave reduction each.
             const bool shunted = (pol == POL_SCA || pol == POL_SRVO);
-            Key3 best = key_invalid();
-            for (int e = lane; e < nS; e += 64) { Key3 k; k.a = keyS[e]; k.b = 0.0; k.idx = idxS[e]; if (key_less(k, best)) best = k; }
-            best = wave_argmin(best);
-            int chosen = best.idx;
+            unsigned best = 0xffffffffu;
+            for (int e = lane; e < nS; e += 64) { const unsigned k = pkS[e]; best = k < best ? k : best; }
+            best = wave_min_u32(best);
+            int chosen = (int)(best & 1023u);
             if (shunted && nS > 1) {                                                     // scaPolicy.py:119-145
                 const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
-                const double s0 = l3norm(cand_from_idx(T, best.idx, vpref), vA64);
-                Key3 fail = key_invalid();
+                const double s0 = l3norm(cand_from_idx(T, chosen, vpref), vA64);
+                unsigned fail = 0xffffffffu;                                             // first list element that breaks the prefix
                 for (int e = lane; e < nS; e += 64) {
-                    const int ie = idxS[e];
-                    const double sv = l3norm(cand_from_idx(T, ie, vpref), vA64);
-                    if (!(fabs(s0 - sv) < sthr)) { Key3 k; k.a = keyS[e]; k.b = 0.0; k.idx = ie; if (key_less(k, fail)) fail = k; }
+                    const unsigned k = pkS[e];
+                    const double sv = l3norm(cand_from_idx(T, (int)(k & 1023u), vpref), vA64);
+                    if (!(fabs(s0 - sv) < sthr)) fail = k < fail ? k : fail;
                 }
-                fail = wave_argmin(fail);
-                Key3 kmin = key_invalid(), kmax = key_invalid();
+                fail = wave_min_u32(fail);
+                // first minimal / first maximal get_phi inside the prefix: (phi numerator, list position) as one 64-bit key
+                unsigned long long kmin = ~0ull, kmax = ~0ull;
                 for (int e = lane; e < nS; e += 64) {
-                    Key3 mk; mk.a = keyS[e]; mk.b = 0.0; mk.idx = idxS[e];
-                    if (key_less(mk, fail)) {
-                        const double ph = phi_from_idx(T, mk.idx, vpref);
-                        Key3 a; a.a = ph; a.b = mk.a; a.idx = mk.idx;
-                        Key3 b; b.a = -ph; b.b = mk.a; b.idx = mk.idx;
-                        if (key_less(a, kmin)) kmin = a;
-                        if (key_less(b, kmax)) kmax = b;
+                    const unsigned k = pkS[e];
+                    if (k < fail) {
+                        const unsigned long long ph = (unsigned long long)phi_from_idx(T, (int)(k & 1023u), vpref);   // <= 628318
+                        const unsigned long long a = (ph << 32) | k, b = ((0xfffffull - ph) << 32) | k;
+                        kmin = a < kmin ? a : kmin;
+                        kmax = b < kmax ? b : kmax;
                     }
                 }
-                kmin = wave_argmin(kmin);
-                kmax = wave_argmin(kmax);
-                const double phi_min = kmin.a / EPS5, phi_max = (-kmax.a) / EPS5;
-                chosen = (fabs(phi_max - phi_min) <= PI) ? kmin.idx : kmax.idx;
+                kmin = wave_min_u64(kmin);
+                kmax = wave_min_u64(kmax);
+                const double phi_min = (double)(kmin >> 32) / EPS5, phi_max = (double)(0xfffffull - (kmax >> 32)) / EPS5;
+                chosen = (fabs(phi_max - phi_min) <= PI) ? (int)(kmin & 1023u) : (int)(kmax & 1023u);
             }
             dg_chosen = chosen;
             vpost = trunc5(cand_from_idx(T, chosen, vpref));                             // scaPolicy.py:239
