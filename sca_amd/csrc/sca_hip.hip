@@ -146,6 +146,7 @@ struct sca_ctx {
     hipEvent_t kd_ev = nullptr;
     bool kd_ev_pending = false;
     int kd_levels_hint = 0;
+    unsigned kd_token = 0;              // launch token of the chained scan (never reused)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
     bool near_valid = false;            // K1's collision-candidate lists describe the current records
@@ -296,6 +297,18 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MAX + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.chge, (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.ps, N);
+    r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
+    if (!r) {   // the root's accumulators start empty (every build's last kernel resets them for the next one)
+        unsigned long long h[12];
+        const double pinf = INFINITY, ninf = -INFINITY;
+        unsigned long long kp, kn;
+        { unsigned long long u; std::memcpy(&u, &pinf, 8); kp = (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
+        { unsigned long long u; std::memcpy(&u, &ninf, 8); kn = (u >> 63) ? ~u : (u | 0x8000000000000000ull); }
+        for (int q = 0; q < 12; q++) h[q] = (q % 6) < 3 ? kp : kn;
+        CHK(c, hipMemcpyAsync(c->kd.nbox, h, sizeof(unsigned long long) * 6, hipMemcpyHostToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(c->kd.cbox, h, sizeof(unsigned long long) * 12, hipMemcpyHostToDevice, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+    }
     if (r) return SCA_ERR_HIP;
     // candidate tables: [unit256 (768) | unit128 (384) | phi256 (256) | phi128 (128)]
     std::vector<double> tab(768 + 384 + 256 + 128);
@@ -317,7 +330,7 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps, c->kd.cbox, c->kd.chain};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -528,9 +541,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
         const int grid = c->kd.chunk_cap;
         for (int l = 0; l < levels; l++) {
-            hipLaunchKernelGGL(k_kd_lv_box, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
-            hipLaunchKernelGGL(k_kd_lv_count, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
-            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
             hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
         }
     }

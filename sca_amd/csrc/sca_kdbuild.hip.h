@@ -12,8 +12,9 @@
 // That form is data-parallel: one prefix count per element.
 //
 //   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced
-//   k_kd_lv_*   : four launches per tree level for the nodes with more than KD_WAVE_MAX members; a node is cut into
-//                 chunks of KD_CHUNK positions, one workgroup per chunk: (box) -> (count) -> (rank) -> (swap + children)
+//   k_kd_lv_*   : two launches per tree level for the nodes with more than KD_WAVE_MAX members; a node is cut into
+//                 chunks of KD_CHUNK positions, one workgroup per chunk: (flags + chained scan + ranks + children's
+//                 boxes) -> (swaps + node record + children)
 //   k_kd_block  : every subtree of <= KD_WAVE_MAX members is finished by ONE WORKGROUP entirely in LDS, level by level,
 //                 all nodes of a level at once (element-parallel; boxes by LDS atomics on order-preserving keys)
 #pragma once
@@ -42,6 +43,8 @@ struct KdScratch {
     int *chge;                // [chunk_cap] the same per chunk
     int *ps;                  // [n] inclusive count of ">= split" members inside the node up to the position
     int chunk_cap;
+    unsigned long long *cbox; // [2][job_cap][2][6] boxes of the two children, accumulated while the parent is partitioned
+    unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
 };
 
 // order-preserving map double -> u64 so that integer atomics give exact min / max
@@ -52,35 +55,6 @@ __device__ __forceinline__ unsigned long long dkey(double x) {
 __device__ __forceinline__ double dunkey(unsigned long long k) {
     const unsigned long long u = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
     return __longlong_as_double((long long)u);
-}
-
-__global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) {
-        for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
-        KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
-        if (d.n > KD_WAVE_MAX) {
-            s.jobs[0][0] = j; s.counts[0] = 1;
-            for (int k = 0; k < 3; k++) { s.nbox[k] = dkey(INFINITY); s.nbox[3 + k] = dkey(-INFINITY); }
-            s.nge[0] = 0;
-        } else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
-    }
-    if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
-    if (p >= d.n) return;
-    const PubRec r = d.rec[d.aperm[p]];
-    s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
-}
-
-// every node publishes its header in its own query record and its box in its parent's (KdWide)
-__device__ __forceinline__ void kd_publish(KdWide *wide, const KdNode &nd, int node, int parent_code) {
-    KdWide *w = &wide[node];
-    w->begin = nd.begin; w->end = nd.end; w->left = nd.left; w->right = nd.right;
-    if (parent_code >= 0) {
-        KdWide *pw = &wide[parent_code >> 1];
-        double *mn = (parent_code & 1) ? pw->rmn : pw->lmn;
-        double *mx = (parent_code & 1) ? pw->rmx : pw->lmx;
-        for (int k = 0; k < 3; k++) { mn[k] = nd.mn[k]; mx[k] = nd.mx[k]; }
-    }
 }
 
 __device__ __forceinline__ double wave_min_d(double v) {
@@ -97,6 +71,50 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
+__global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
+    __shared__ double red[4][6];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (p == 0) {
+        for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
+        KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
+        if (d.n > KD_WAVE_MAX) { s.jobs[0][0] = j; s.counts[0] = 1; }
+        else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
+    }
+    if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (p < d.n) {
+        const PubRec r = d.rec[d.aperm[p]];
+        s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
+        mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
+    }
+    if (d.n > KD_WAVE_MAX) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
+        if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int t = threadIdx.x;
+            double v = red[0][t];
+            for (int w = 1; w < 4; w++) v = t < 3 ? (red[w][t] < v ? red[w][t] : v) : (red[w][t] > v ? red[w][t] : v);
+            if (t < 3) atomicMin(&s.nbox[t], dkey(v)); else atomicMax(&s.nbox[t], dkey(v));
+        }
+    }
+}
+
+// every node publishes its header in its own query record and its box in its parent's (KdWide)
+__device__ __forceinline__ void kd_publish(KdWide *wide, const KdNode &nd, int node, int parent_code) {
+    KdWide *w = &wide[node];
+    w->begin = nd.begin; w->end = nd.end; w->left = nd.left; w->right = nd.right;
+    if (parent_code >= 0) {
+        KdWide *pw = &wide[parent_code >> 1];
+        double *mn = (parent_code & 1) ? pw->rmn : pw->lmn;
+        double *mx = (parent_code & 1) ? pw->rmx : pw->lmx;
+        for (int k = 0; k < 3; k++) { mn[k] = nd.mn[k]; mx[k] = nd.mx[k]; }
+    }
 }
 
 // kdTree.py:89-96: split axis and plane from the box
@@ -131,79 +149,92 @@ __device__ __forceinline__ KdChunk kd_find_chunk(const KdJob *jobs, int njobs, i
     return c;
 }
 
-// (1) box of every large node: block reduction per chunk, then 6 atomics on order-preserving keys
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_box(KdScratch s, int level) {
-    constexpr int W = KD_LV_T / 64;
-    __shared__ double red[W][6];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
-    if (!c.valid) return;
-    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int p = c.begin + tid; p < c.end; p += KD_LV_T) {
-        const double x = s.kx[p], y = s.ky[p], z = s.kz[p];
-        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
-        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
-        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
-    if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
-    __syncthreads();
-    if (tid < 6) {
-        double v = red[0][tid];
-        for (int w = 1; w < W; w++) v = tid < 3 ? (red[w][tid] < v ? red[w][tid] : v) : (red[w][tid] > v ? red[w][tid] : v);
-        unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + c.job) * 6;
-        if (tid < 3) atomicMin(&box[tid], dkey(v)); else atomicMax(&box[tid], dkey(v));
-    }
-}
-
 __device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int job, int &axis, double &split, double mn[3], double mx[3]) {
     const unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + job) * 6;
     for (int k = 0; k < 3; k++) { mn[k] = dunkey(box[k]); mx[k] = dunkey(box[3 + k]); }
     kd_split(mn, mx, axis, split);
 }
 
-// (2) number of members >= split, per chunk and per node
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_count(KdScratch s, int level) {
-    constexpr int W = KD_LV_T / 64;
-    __shared__ int itot[W];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
-    if (!c.valid) return;
-    int axis; double split, mn[3], mx[3];
-    kd_node_split(s, level, c.job, axis, split, mn, mx);
-    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
-    int cnt = 0;
-    for (int p = c.begin + tid; p < c.end; p += KD_LV_T) cnt += kc[p] < split ? 0 : 1;
-    cnt = wave_sum_i(cnt);
-    if (lane == 0) itot[wid] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < W; w++) t += itot[w];
-        s.chge[blockIdx.x] = t;
-        atomicAdd(&s.nge[(level & 1) * s.job_cap + c.job], t);
-    }
-}
-
-// (3) ranks: inclusive ">= split" count inside the node (ps), and the k-th misplaced member of the right part (mr)
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level) {
+// Level pass A: one workgroup per chunk.  The node's box is complete (accumulated by the parent's pass), so the chunk
+// can flag its members against the split plane, scan the flags (chained across the chunks of the node through one
+// 64-bit word per chunk: launch token | count), write the in-node ranks, and accumulate the boxes of the two children.
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
     constexpr int W = KD_LV_T / 64;
     __shared__ int wtot[W];
+    __shared__ int carry_sh;
+    __shared__ double red[W][12];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
     if (!c.valid) return;
-    int axis; double split, mn[3], mx[3];
-    kd_node_split(s, level, c.job, axis, split, mn, mx);
+    int axis; double split, bmn[3], bmx[3];
+    kd_node_split(s, level, c.job, axis, split, bmn, bmx);
     const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
-    const int b = c.node_begin, e = c.node_end;
-    const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
-    int carry = 0;
-    for (int ch = c.first_chunk; ch < (int)blockIdx.x; ch++) carry += s.chge[ch];
-    for (int t0 = c.begin; t0 < c.end; t0 += KD_LV_T) {
-        const int p = t0 + tid;
-        const bool in_range = p < c.end;
-        const bool ge = in_range && !(kc[p] < split);
+    const int b = c.node_begin;
+    // ---- flags of this thread's positions (tile t covers [begin + t*T, begin + (t+1)*T)), chunk total
+    unsigned flags = 0;
+    int mine = 0;
+    double cmn[2][3] = {{INFINITY, INFINITY, INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    double cmx[2][3] = {{-INFINITY, -INFINITY, -INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+#pragma unroll
+    for (int t = 0; t < KD_LV_E; t++) {
+        const int p = c.begin + t * KD_LV_T + tid;
+        if (p < c.end) {
+            const double x = s.kx[p], y = s.ky[p], z = s.kz[p];
+            const double cv = axis == 0 ? x : (axis == 1 ? y : z);
+            const int side = cv < split ? 0 : 1;
+            if (side) { flags |= 1u << t; mine++; }
+            cmn[side][0] = x < cmn[side][0] ? x : cmn[side][0]; cmx[side][0] = x > cmx[side][0] ? x : cmx[side][0];
+            cmn[side][1] = y < cmn[side][1] ? y : cmn[side][1]; cmx[side][1] = y > cmx[side][1] ? y : cmx[side][1];
+            cmn[side][2] = z < cmn[side][2] ? z : cmn[side][2]; cmx[side][2] = z > cmx[side][2] ? z : cmx[side][2];
+        }
+    }
+    const int wsum = wave_sum_i(mine);
+    if (lane == 0) wtot[wid] = wsum;
+    // children boxes: wave reduce, then one set of atomics per workgroup
+#pragma unroll
+    for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cmn[sd][k] = wave_min_d(cmn[sd][k]); cmx[sd][k] = wave_max_d(cmx[sd][k]); }
+    if (lane == 0)
+        for (int sd = 0; sd < 2; sd++)
+            for (int k = 0; k < 3; k++) { red[wid][sd * 6 + k] = cmn[sd][k]; red[wid][sd * 6 + 3 + k] = cmx[sd][k]; }
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < W; w++) total += wtot[w];
+    if (tid < 12) {
+        const bool is_min = (tid % 6) < 3;
+        double v = red[0][tid];
+        for (int w = 1; w < W; w++) v = is_min ? (red[w][tid] < v ? red[w][tid] : v) : (red[w][tid] > v ? red[w][tid] : v);
+        unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
+        if (is_min) atomicMin(&cb[tid], dkey(v)); else atomicMax(&cb[tid], dkey(v));
+    }
+    // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident)
+    if (tid == 0) {
+        __hip_atomic_store(&s.chain[blockIdx.x], ((unsigned long long)token << 32) | (unsigned)total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        int carry = 0;
+        for (int ch = c.first_chunk; ch < (int)blockIdx.x; ch++) {
+            unsigned long long v = 0;
+            int spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(&s.chain[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == token) break;
+                if (++spins > (1 << 24)) { s.counts[KD_MAX_LEVELS + 1] = 1; break; }     // never hang the GPU: report
+                __builtin_amdgcn_s_sleep(2);
+            }
+            carry += (int)(unsigned)v;
+        }
+        carry_sh = carry;
+        const int nch = (c.node_end - b + KD_CHUNK - 1) / KD_CHUNK;
+        if ((int)blockIdx.x == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
+    }
+    __syncthreads();
+    int carry = carry_sh;
+    // ---- ranks: ps = inclusive ">= split" count inside the node; mr[b + j - 1] = position of the j-th "< split" member
+#pragma unroll
+    for (int t = 0; t < KD_LV_E; t++) {
+        const int p = c.begin + t * KD_LV_T + tid;
+        const bool ge = (flags >> t) & 1u;
         const unsigned long long m = __ballot(ge);
         const int incl_w = __popcll(m & ((2ull << lane) - 1ull));
         __syncthreads();
@@ -212,15 +243,15 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level) 
         int woff = 0, ttot = 0;
         for (int w = 0; w < W; w++) { const int v = wtot[w]; if (w < wid) woff += v; ttot += v; }
         const int G = carry + woff + incl_w;
-        if (in_range) {
+        if (p < c.end) {
             s.ps[p] = G;
-            if (p >= b + L && !ge) { const int lt_incl = (p - b + 1) - G; s.mr[b + (L - lt_incl)] = p; }
+            if (!ge) s.mr[b + ((p - b + 1) - G) - 1] = p;
         }
         carry += ttot;
     }
 }
 
-// (4) swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
+// Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
 __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
     const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
@@ -234,8 +265,10 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
     const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
     const int lim = c.end < b + L ? c.end : b + L;
     for (int p = c.begin + tid; p < lim; p += KD_LV_T) {
-        if (!(kc[p] < split)) {                              // misplaced on the left: take the partner from the right
-            const int q = s.mr[b + s.ps[p] - 1];
+        if (!(kc[p] < split)) {
+            // the k-th ">= split" member of the left part (k = ps - 1) takes the k-th "< split" member from the right,
+            // i.e. the (L - k)-th "< split" member of the node
+            const int q = s.mr[b + (L - (s.ps[p] - 1)) - 1];
             const int ip = d.aperm[p], iq = d.aperm[q];
             d.aperm[p] = iq; d.aperm[q] = ip;
             const double xp = s.kx[p], yp = s.ky[p], zp = s.kz[p];
@@ -251,6 +284,8 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
         for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
         d.atree[job.node] = nd;
         kd_publish(d.awide, nd, job.node, job.pad);
+        unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
+        if (L == 0) s.counts[KD_MAX_LEVELS + 1] = 1;         // children boxes by side do not apply: report (never seen)
         KdJob ch[2];
         ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
         ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
@@ -261,8 +296,9 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
                     if (at < s.job_cap) {
                         out[at] = ch[k];
                         unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
-                        for (int q = 0; q < 3; q++) { box[q] = dkey(INFINITY); box[3 + q] = dkey(-INFINITY); }
-                        s.nge[((level + 1) & 1) * s.job_cap + at] = 0;
+                        for (int q = 0; q < 6; q++) box[q] = cb[k * 6 + q];          // the child's box is already known
+                        unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
+                        for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
                     } else s.counts[KD_MAX_LEVELS + 1] = 1;
                 } else s.counts[KD_MAX_LEVELS + 1] = 1;
             } else {
@@ -301,6 +337,11 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
     const int njobs = s.counts[KD_MAX_LEVELS];
     // nodes still larger than KB_MAX after the last level launch were never split: report, never guess
     if (blockIdx.x == 0 && tid == 0 && s.counts[levels_run] > 0) s.counts[KD_MAX_LEVELS + 1] = 1;
+    // the level passes are over: reset the root's accumulators (box, children boxes) for the next build
+    if (blockIdx.x == 0 && tid < 12) {
+        if (tid < 6) s.nbox[tid] = tid < 3 ? dkey(INFINITY) : dkey(-INFINITY);
+        s.cbox[tid] = (tid % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
+    }
     for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
         const KdJob job = s.small[jb];
         const int base = job.begin, size = job.end - job.begin;
