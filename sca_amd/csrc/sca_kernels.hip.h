@@ -295,6 +295,167 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1, packed form: FOUR AGENTS PER WAVEFRONT, 16 lanes each.  The box arithmetic of an inner node is the same for all
+// 64 lanes in the one-agent-per-wave kernel (36 fp64 operations per node, per wave); here the 16 lanes of a group load
+// the 16 doubles of the node record in one 128-byte read, 12 of them square one box term each, and the ordered sums
+// (kdTree.py:132-145 adds the terms in a fixed order) are gathered on two lanes -- for four agents at once.
+// Sixteen lanes are also exactly what the rest needs: <= 10 leaf members, <= 16 list entries (agent.py:32).
+constexpr int K1P_WAVES = 4;
+constexpr int K1P_G = 16;
+constexpr int K1P_APW = 4;
+
+__device__ __forceinline__ int lo32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) & 0xffffffffull); }
+__device__ __forceinline__ int hi32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
+
+__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
+                                                                 double max_radius) {
+    __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int g = lane >> 4, gl = lane & 15, gbase = g << 4, gshift = g << 4;
+    const int end = d.shard_begin + d.shard_count;
+    const int agent_raw = d.shard_begin + (blockIdx.x * K1P_WAVES + wid) * K1P_APW + g;
+    const bool exists = agent_raw < end;
+    const int agent = exists ? agent_raw : end - 1;                 // clamp: idle groups read a valid record, write nothing
+    const PubRec me = d.rec[agent];
+    int st = 0;
+    bool skip = !exists || (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;    // scaPolicy.py:34: no computeNeighbors on the bootstrap step
+    const V3 pA = v3(me.px, me.py, me.pz);
+    const double rangeSq = P.neighbor_dist * P.neighbor_dist;       // scaPolicy.py:112
+    const int maxn = P.max_neighbors;
+    const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
+    const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
+    // which box term this lane squares: lanes 2..13 hold lmn[3], lmx[3], rmn[3], rmx[3] of the node record
+    const int tk = gl >= 2 ? (gl - 2) % 3 : 0;
+    const bool t_is_mx = gl >= 2 && (((gl - 2) / 3) & 1);
+    const bool t_live = gl >= 2 && gl < 14;
+    const double pk = tk == 0 ? pA.x : (tk == 1 ? pA.y : pA.z);
+    const int side6 = gl == 1 ? 6 : 0;
+    // sorted list: entry gl of the group's agent
+    double Ld = 0.0; int Li = -1; int cnt = 0; bool coll = false; int near_cnt = 0;
+    int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
+    int *stack = stacks[wid][g];
+
+    for (int phase = 0; phase < 2; phase++) {                       // obstacles first (scaPolicy.py:114-116)
+        const bool ob = phase == 0;
+        if (ob && d.m <= 0) continue;
+        const double *wd = (const double *)(ob ? d.owide : d.awide);
+        int node = 0, sp = 0;
+        bool have = !skip;
+        while (__any(have)) {
+            const double w = have ? wd[(size_t)node * 16 + gl] : 0.0;
+            const double h0 = __shfl(w, gbase), h1 = __shfl(w, gbase + 1);
+            const int nb = lo32(h0), ne = hi32(h0), nl = lo32(h1), nr_ = hi32(h1);
+            const bool leaf = have && (ne - nb <= MAX_LEAF);
+            const bool inner = have && !leaf;
+            bool descend = false; int next = 0;
+            if (__any(inner)) {                                      // kdTree.py:132-156
+                double t = t_is_mx ? pk - w : w - pk;
+                t = fmax(0.0, t);
+                const double sq = t_live ? t * t : 0.0;
+                double ssum = __shfl(sq, gbase + 2 + side6);         // mn0
+                ssum = ssum + __shfl(sq, gbase + 5 + side6);         // mx0
+                ssum = ssum + __shfl(sq, gbase + 3 + side6);         // mn1
+                ssum = ssum + __shfl(sq, gbase + 6 + side6);         // mx1
+                ssum = ssum + __shfl(sq, gbase + 4 + side6);         // mn2
+                ssum = ssum + __shfl(sq, gbase + 7 + side6);         // mx2
+                const double dl = __shfl(ssum, gbase), dr = __shfl(ssum, gbase + 1);
+                int first, second; double dfirst, dsecond;
+                if (dl < dr) { first = nl; second = nr_; dfirst = dl; dsecond = dr; }
+                else { first = nr_; second = nl; dfirst = dr; dsecond = dl; }
+                if (inner && dfirst < rangeSq) {
+                    if (dsecond < rangeSq) {
+                        if (sp < KD_STACK) { if (gl == 0) stack[sp] = second; sp++; }
+                        else st |= ST_KD_STACK;
+                    }
+                    next = first; descend = true;
+                }
+            }
+            if (__any(leaf)) {
+                const bool valid = leaf && gl < ne - nb;
+                int o = -1; double dsq = 0.0; bool c = false, r = false, nr = false;
+                if (valid) {
+                    if (ob) {                                        // agent.py:101-124
+                        o = d.operm[nb + gl];
+                        const ObsRec orec = d.obs_sorted[nb + gl];
+                        const V3 pO = v3(orec.px, orec.py, orec.pz);
+                        const double distSq1 = l3normsq(pA, pO);
+                        const double tt = l3norm(pA, pO) - orec.radius;
+                        dsq = tt * tt;
+                        const double rs = me.radius + orec.radius;
+                        r = dsq < rangeSq;
+                        c = r && distSq1 < rs * rs;
+                        const V3 dd = pA - pO;
+                        nr = (dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) < reach_o * reach_o;
+                        o |= NBR_OBSTACLE_BIT;
+                    } else {                                         // agent.py:79-99
+                        o = d.aperm[nb + gl];
+                        if (o != agent) {
+                            dsq = l3normsq(pA, v3(d.kx[nb + gl], d.ky[nb + gl], d.kz[nb + gl]));
+                            r = dsq < rangeSq;
+                            if (r && dsq < rmax2) { const double rs = me.radius + d.rec[o].radius; c = dsq < rs * rs; }
+                            nr = dsq < reach_a * reach_a;
+                        }
+                    }
+                }
+                {
+                    const unsigned nm = (unsigned)((__ballot(nr) >> gshift) & 0xffffull);
+                    if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
+                    near_cnt += __popc(nm);
+                }
+                unsigned todo = (unsigned)((__ballot(r) >> gshift) & 0xffffull);
+                while (__any(todo != 0)) {                           // members in range, in leaf order
+                    const bool act = todo != 0;
+                    const int b = act ? __ffs((int)todo) - 1 : 0;
+                    const bool cb = __shfl((int)c, gbase + b) != 0;
+                    const double db = __shfl(dsq, gbase + b);
+                    const int ib = __shfl(o, gbase + b);
+                    if (act && cb && !coll) { coll = true; cnt = 0; }            // agent.py:83-85
+                    const bool ins = act && (cb || !coll);
+                    int ncnt = cnt;
+                    if (ins && ncnt == maxn) ncnt--;                             // neighbors.pop()
+                    const unsigned bm = (unsigned)((__ballot(ins && gl < ncnt && Ld <= db) >> gshift) & 0xffffull);
+                    const int pos = __popc(bm);
+                    const double up_d = __shfl_up(Ld, 1, 16);
+                    const int up_i = __shfl_up(Li, 1, 16);
+                    if (ins) {
+                        if (gl > pos && gl <= ncnt) { Ld = up_d; Li = up_i; }
+                        if (gl == pos) { Ld = db; Li = ib; }
+                        cnt = ncnt + 1;
+                    }
+                    todo &= todo - 1;
+                }
+            }
+            if (have) {
+                if (descend) node = next;
+                else if (sp > 0) { sp--; node = stack[sp]; }
+                else have = false;
+            }
+        }
+    }
+    if (!exists) return;
+    if (skip) {
+        d.nbr_id[agent * K_MAX + gl] = -1; d.nbr_dsq[agent * K_MAX + gl] = 0.0;
+        if (gl == 0) { d.coll_new[agent] = 0; d.nbr_valid[agent] = 0; d.nbr_n[agent] = 0; d.status[agent] = 0; d.near_n[agent] = -1; }
+        return;
+    }
+    d.nbr_id[agent * K_MAX + gl] = (gl < cnt) ? Li : -1;
+    d.nbr_dsq[agent * K_MAX + gl] = (gl < cnt) ? Ld : 0.0;
+    if (gl == 0) {
+        d.nbr_n[agent] = cnt;
+        d.nbr_valid[agent] = 1;
+        d.coll_new[agent] = coll ? 1u : 0u;
+        d.status[agent] = st;
+        const bool complete = near_cnt <= NEAR_MAX && reach_a * reach_a <= rangeSq && reach_o * reach_o <= rangeSq;
+        d.near_n[agent] = complete ? near_cnt : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2/K3: one wavefront per agent.
 constexpr int SOLVE_WAVES = 4;
 constexpr int SLOT = 16;                  // doubles per neighbour slot in LDS
