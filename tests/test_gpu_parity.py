@@ -404,3 +404,32 @@ def test_unsupported_pref_speed_is_reported_not_hidden(S):
     st = sol.diag()['status']
     assert st[0] & 4 and not (st[1:] & 4).any()
     sol.close()
+
+
+@pytest.mark.parametrize('name', ['F5_rvo_dense80', 'F5_orcalp_packed60', 'F5_srvo_packed60', 'F4_mixed_takeoff16',
+                                  'F9_hetero_mixed60', 'F3_orca_random100', 'F2_sca_circle100'])
+def test_packed_k1_variant_vs_golden(S, name, monkeypatch):
+    """The four-agents-per-wavefront neighbour kernel (normally chosen for shards >= 8192 agents) forced on the small
+    golden scenes: dense clusters (>16 in range, collisions), obstacles, heterogeneous radii."""
+    monkeypatch.setenv('SCA_K1_PACKED', '1')
+    fx = load(name)
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    for t in range(0, T, max(1, T // 25)):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_kd_perm(fx['perm'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_KDTREE)
+        nb = sol.neighbors()
+        valid = fx['nbr_valid'][t].astype(bool)
+        ctx = (name, t)
+        assert np.array_equal(nb['nbr_valid'].astype(bool), valid), ctx
+        assert np.array_equal(nb['nbr_n'][valid], fx['nbr_n'][t][valid]), ctx
+        assert np.array_equal(nb['nbr_id'][valid], fx['nbr_id'][t][valid]), ctx
+        assert np.array_equal(nb['nbr_kind'][valid], fx['nbr_kind'][t][valid]), ctx
+        assert np.allclose(nb['nbr_dsq'][valid], fx['nbr_dsq'][t][valid], rtol=4e-16, atol=0), ctx
+        check_actions(sol.actions(), fx['action'][t], ctx)
+        sol.env_update()
+        assert np.array_equal(sol.get_state()['flags'], fx['flags_after'][t]), ctx
+    sol.close()
