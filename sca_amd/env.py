@@ -13,9 +13,9 @@ Differences that matter:
     batched pass and returns that agent's row;
   * per-agent state lives in structure-of-arrays owned by the env; the Agent attributes the reference exposes
     (pos_global_frame, vel_global_frame, heading_global_frame, is_at_goal, ...) are views / properties over them;
-  * SCAPolicy and RVO3dDubinsPolicy need the reference's Dubins tracker for v_pref (scaPolicy.py:264-338). That
-    tracker is a host-side, per-agent stateful planner outside the kernel boundary (not built yet):
-    pass `v_pref_fn(env) -> [N,3]` to MACAEnv to supply it; without one the straight-line rule of
+  * SCAPolicy and RVO3dDubinsPolicy take v_pref from the reference's Dubins tracker (scaPolicy.py:264-338), a host-side,
+    per-agent stateful planner outside the kernel boundary.  The native restatement is sca_amd.tracker.DubinsTracker:
+    pass it as MACAEnv(v_pref_fn=tracker) (any `v_pref_fn(env) -> [N,3]` works); without one the straight-line rule of
     rvo3dPolicy.py:182-196 is used and `env.dubins_tracker` is False;
   * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
 There is no CPU path: constructing the env without a GPU raises.
