@@ -504,6 +504,19 @@ def main():
         obs9 = [([4.0, 1.0, 31.0], 1.5), ([-5.0, -3.0, 27.0], 0.6), ([0.0, 6.0, 34.0], 2.5)]
         run_env_episode(agent_mod, env_mod, classes, 'F9_hetero_mixed60', pos, goal, pol, obs9, 30, radius=rad,
                         pref_speed=psp, outdir=od)
+    # F10: exp3 "low altitude search" (run_sca.py:118,152-154): 16 drones among the 1491 r=0.2 spheres that
+    # read_map.read_obstacle extracts from visualization/map/map.binvox -- an obstacle kd-tree with real depth,
+    # obstacles filling the neighbour lists.  Only the obstacle list (data) enters the fixture.
+    if want('F10_sca_exp3_map'):
+        np.bool = bool                      # harness shim: read_map.py:19 uses the alias numpy 2 removed (asset loading only)
+        from mamp.read_map import read_obstacle
+        with contextlib.redirect_stdout(io.StringIO()):
+            objs = read_obstacle(center=(35, 30), environ="exp3", obs_path=os.path.join(args.ref, 'visualization', 'map', 'map.binvox'))
+        obs10 = [(list(map(float, o.pos_global_frame)), float(o.radius)) for o in objs]
+        pos, goal = rs.spawn_n_drones(center=(35, 30), rad=10.0, drone_num=16, environment="exp3")
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        run_env_episode(agent_mod, env_mod, classes, 'F10_sca_exp3_map', pos, goal, [POL_SCA] * 16, obs10, 160, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
