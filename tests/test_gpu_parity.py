@@ -433,3 +433,18 @@ def test_packed_k1_variant_vs_golden(S, name, monkeypatch):
         sol.env_update()
         assert np.array_equal(sol.get_state()['flags'], fx['flags_after'][t]), ctx
     sol.close()
+
+
+def test_episode_metrics_of_c1(S):
+    """run_sca.py:199-259 metrics on the finished N=8 episode (RVO3D so that no tracker is needed): all agents arrive."""
+    from sca_amd import env as E, metrics
+    agents = E.build_circle_agents(8, policy=E.RVO3DPolicy, rad=10.0)
+    env = E.MACAEnv()
+    env.set_agents(agents, obstacles=[])
+    for _ in range(400):
+        if env.step({}):
+            break
+    m = metrics.episode_metrics(env, total_policy_time_s=1.0)
+    assert m['SuccessRate'] == 1.0 and m['successful_num'] == 8
+    assert 0.8 < m['AverageSpeed'] <= 1.0 + 1e-9 and m['ExtraDistance'] >= 0.0
+    assert m['all_step_num'] == int(env.step_num.sum())
