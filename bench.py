@@ -7,9 +7,11 @@ flags), with the state resident in HBM when the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workloads (BASELINE.json configs): c4 = circle N=100000 SCA (default at every GPU count: the configuration the metric's
-"N-agent circle at 1/2/4/8 GPUs" clause names; it fits one GPU and keeps the scaling runs strong-scaling), c2 = circle
-N=1024 SCA, c3 = random N=4096 ORCA3D, c5 = take-off/landing N=16384 mixed SCA + S-RVO3D.
+Workloads (BASELINE.json configs): c4 = circle N=100000 SCA (default: the configuration the metric's "N-agent circle at
+1/2/4/8 GPUs" clause names; it fits one GPU), c2 = circle N=1024 SCA, c3 = random N=4096 ORCA3D, c5 = take-off/landing
+N=16384 mixed SCA + S-RVO3D.  With several GPUs the default is WEAK scaling: the workload's agent count per GPU (one
+circle of 100000 x n_gpus agents, sharded by id, one all-gather of the moved 48-byte records per step);
+`--scaling strong` keeps the total at the workload's N.
 SCA's preferred velocity comes from the reference's host-side Dubins tracker (scaPolicy.py:264-338), which is
 outside the kernel boundary; the bench feeds the straight-line rule (rvo3dPolicy.py:182-196)
 computed on the device instead, and says so in `config`.
@@ -67,6 +69,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
     ap.add_argument('--agents', type=int, default=None)
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N>1 GPUs: weak = the workload\'s agent count PER GPU (default), strong = the same total')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins'],
                     help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound)')
@@ -92,6 +96,8 @@ def main():
     w = WORKLOADS[wname]
     n_req = args.agents or w['n']
     if world > 1:
+        if args.scaling == 'weak':
+            n_req *= world                                     # per-GPU work fixed: N grows with the GPU count
         n_req = ((n_req + world - 1) // world) * world
     scene = build_scene(w, n_req)
     n = scene['n']
@@ -164,8 +170,10 @@ def main():
         out = {
             'metric': 'agent_steps_per_sec', 'value': value, 'unit': 'agent-steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': w['desc'], 'agents': n, 'neighbor_search': 'kd-tree replica (host build, device query)',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': w['desc'] + (f' -- weak scaling: {w["n"] if not args.agents else args.agents} agents per GPU'
+                                                if world > 1 and args.scaling == 'weak' else ''),
+                       'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': 'kd-tree replica (host build, device query)',
                        'v_pref': ('straight-line rule on device (the Dubins tracker is host-side, outside the kernel boundary)'
                                   if args.vpref == 'straight' else 'native Dubins tracker on the host every step (end-to-end SCA)'),
                        'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'
