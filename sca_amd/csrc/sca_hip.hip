@@ -288,7 +288,8 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.near_n, N); r |= dalloc(c, &d.near_id, N * NEAR_MAX);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.vpost, 3 * N);
-    r |= dalloc(c, &d.fb_list, N); r |= dalloc(c, &d.fb_count, 1); r |= dalloc(c, &d.diag, N * 8);
+    r |= dalloc(c, &d.fb_list, N); r |= dalloc(c, &d.fb_count, 1);
+    { Prep *pp = nullptr; r |= dalloc(c, &pp, N); d.prep = pp; } r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
     r |= dalloc(c, &c->kd.ml, N); r |= dalloc(c, &c->kd.mr, N);
@@ -330,7 +331,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
-                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.diag, d.status,
+                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps, c->kd.cbox, c->kd.chain};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -527,7 +528,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         c->perm_on_device = true;
     }
-    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd);
+    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd, c->P);
     int levels = 0;
     if (n > KD_WAVE_MAX) {
         int need = 1;
@@ -598,6 +599,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->perm_on_device = false;
         }
         if (int r = build_agent_tree(c)) return r;
+        hipLaunchKernelGGL(k_prep, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d, c->P);
     } else { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     const int cnt = d.shard_count;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];

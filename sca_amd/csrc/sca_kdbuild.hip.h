@@ -74,7 +74,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 
 // Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
-__global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
+__global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Params P) {
     __shared__ double red[4][6];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s) {
     if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
-        const PubRec r = d.rec[d.aperm[p]];
+        const int id = d.aperm[p];
+        const PubRec r = d.rec[id];
         s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
         mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
+        prep_agent(d, P, (Prep *)d.prep, id);                               // every agent appears once in the permutation
     }
     if (d.n > KD_WAVE_MAX) {
 #pragma unroll

@@ -62,6 +62,7 @@ struct DeviceView {
     float *action;           // [n*8] (7 used)
     double *vpref_used;      // [n*3]
     double *vpost;           // [n*3] selected velocity (k_solve -> k_action)
+    void *prep;              // [n] Prep records (per-agent scalar prologue)
     int32_t *fb_list;        // [n] agents without a suitable candidate: finished by k_solve_full
     int32_t *fb_count;       // [1]
     int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
@@ -461,6 +462,44 @@ constexpr int SOLVE_WAVES = 4;
 constexpr int SLOT = 16;                  // doubles per neighbour slot in LDS
 constexpr int NR = 8;                     // candidate rounds: 8 * 64 = 512 table candidates
 
+// Per-agent scalar prologue of find_next_action, computed ONE LANE PER AGENT (inside k_kd_gather, or k_prep when the
+// tree comes from the host) instead of by a whole wavefront in k_solve: preferred velocity, bootstrap test, the second
+// candidate speed, |vA|, and everything about the v_pref candidate that does not depend on the neighbours.
+struct alignas(16) Prep {
+    double vpref[3];
+    double nvA;            // |vA| as float32 norm (util.py:11)
+    double rad1;           // second element of np.arange(0.5, ps + 0.03, ps - 0.5)
+    unsigned vp_key;       // round5 numerator of |v_pref - v_pref| (= 0) << 10, without the index
+    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint
+};
+static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
+
+__device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P, Prep *out, int agent) {
+    const PubRec me = d.rec[agent];
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    const V3 pA = v3(me.px, me.py, me.pz);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const double ps = d.pref_speed[agent];
+    V3 vpref;
+    if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
+    Prep r;
+    r.vpref[0] = vpref.x; r.vpref[1] = vpref.y; r.vpref[2] = vpref.z;
+    r.nvA = (double)normf(vA);
+    unsigned bits = 0;
+    if (l3norm_f32zero(vA, orca) <= 1e-5) bits |= 1u;                                // scaPolicy.py:34 / orca3dPolicy.py:53
+    double rad1;
+    if (!candidate_speeds(ps, rad1)) { bits |= 2u; rad1 = ps; }
+    r.rad1 = rad1;
+    if (posture_ok(P, vA, r.nvA, pA.z, vpref)) bits |= 4u;
+    double kn;
+    l3norm(vpref, vpref, &kn);
+    r.vp_key = pack_key(kn, 0);
+    r.bits = bits;
+    out[agent] = r;
+}
+
 struct SolveLds {
     double slot[SOLVE_WAVES][K_MAX][SLOT];
     Plane planes[SOLVE_WAVES][K_MAX];
@@ -826,12 +865,10 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
-    const double ps = d.pref_speed[agent];
-    int st = 0;
-    V3 vpref;
-    if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
-    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
-    const bool first_step = l3norm_f32zero(vA, orca) <= 1e-5;                        // scaPolicy.py:34 / orca3dPolicy.py:53
+    const Prep pr = ((const Prep *)d.prep)[agent];        // per-agent scalar prologue (prep_agent)
+    int st = (pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0;
+    const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
+    const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
     V3 vpost;
     const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
@@ -879,9 +916,9 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
             T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
             T.vp_idx = 2 * T.num_N;
-            if (!candidate_speeds(ps, T.rad1)) { st |= ST_BAD_PREF_SPEED; T.rad1 = ps; }
+            T.rad1 = pr.rad1;
             const int nround = T.vp_idx >> 6;
-            const double nvA = (double)normf(vA);
+            const double nvA = pr.nvA;
             unsigned short *listA = S.listA[wid];
             unsigned int *pkS = S.pkS[wid];
             // ---- posture filter (util.py:6-20) + compaction.  c >= thr is decided without sqrt / division whenever
@@ -951,9 +988,9 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     vp_hit = !in_orca(pl, vpref);
                 }
             }
-            const bool vp_ok = posture_ok(P, vA, nvA, pA.z, vpref) && (__ballot(vp_hit) == 0);
+            const bool vp_ok = (pr.bits & 4u) && (__ballot(vp_hit) == 0);
             if (vp_ok) {
-                if (lane == 0) { double kn; l3norm(vpref, vpref, &kn); pkS[nS] = pack_key(kn, T.vp_idx); }
+                if (lane == 0) pkS[nS] = pr.vp_key | (unsigned)T.vp_idx;
                 nS++;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1016,6 +1053,11 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
     if (agent < d.shard_begin + d.shard_count) solve_fast(d, P, S, agent, lane, wid);
+}
+
+__global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
+    const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent < d.n) prep_agent(d, P, (Prep *)d.prep, agent);
 }
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
