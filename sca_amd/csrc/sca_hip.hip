@@ -538,7 +538,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
-            c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 2;
+            c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 1;
             c->kd_ev_pending = false;
         }
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);

@@ -127,7 +127,7 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
 }
 
 // ---- level passes over the large nodes, one workgroup per chunk of KD_CHUNK positions ---------------------------------
-constexpr int KD_CHUNK = 4096;
+constexpr int KD_CHUNK = 2048;
 constexpr int KD_LV_T = 512;
 constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
 
