@@ -26,8 +26,6 @@ constexpr int MAX_GRID = 1 << 30;      // one agent per wavefront: measured fast
 double (*volatile p_pow)(double, double) = std::pow;
 double (*volatile p_acos)(double) = std::acos;
 
-struct HostKdNode { int begin, end, left, right; double mn[3], mx[3]; };
-
 // Replica of KDTree.buildAgentTreeRecursive / buildObstacleTreeRecursive (kdTree.py:60-122,162-227),
 // iterative with an explicit work list.  Children live at node+1 and node+2*leftSize.
 void kd_build_host(int n, const double *pos, int32_t *ids, std::vector<KdNode> &tree) {
@@ -299,7 +297,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_MAX_LEVELS + 2);
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MAX + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
-    r |= dalloc(c, &c->kd.chge, (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.ps, N);
+    r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
     if (!r) {   // the root's accumulators start empty (every build's last kernel resets them for the next one)
         unsigned long long h[12];
@@ -333,7 +331,7 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.chge, c->kd.ps, c->kd.cbox, c->kd.chain};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);

@@ -23,9 +23,6 @@
 namespace sca {
 
 constexpr int KD_WAVE_MAX = 2048;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
-constexpr int KD_LEVEL_THREADS = 512;
-constexpr int KD_SMALL_WAVES = 4;
-constexpr int KD_SMALL_STACK = 64;
 constexpr int KD_MAX_LEVELS = 40;
 
 struct KdJob { int begin, end, node, pad; };
@@ -40,7 +37,6 @@ struct KdScratch {
     // multi-workgroup level passes
     unsigned long long *nbox; // [2][job_cap][6] order-preserving keys of the node boxes (per level parity)
     int *nge;                 // [2][job_cap] number of members >= split per node
-    int *chge;                // [chunk_cap] the same per chunk
     int *ps;                  // [n] inclusive count of ">= split" members inside the node up to the position
     int chunk_cap;
     unsigned long long *cbox; // [2][job_cap][2][6] boxes of the two children, accumulated while the parent is partitioned
@@ -332,6 +328,10 @@ struct KbLds {
     int wtot[KB_T / 64];
 };
 
+// Barrier for LDS-only hand-offs inside k_kd_block's level loop: __syncthreads() also waits for the global stores of the
+// node records (s_waitcnt vmcnt(0)), a ~1 us round trip per level that nothing in the loop depends on.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
     static_assert(KB_E == 2, "k_kd_block is written for two consecutive positions per thread");
     __shared__ KbLds S;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                     for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][s0][k], dkey(mn[k])); atomicMax(&S.box[cur][s0][3 + k], dkey(mx[k])); }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- B: split plane of the element's node (kdTree.py:85-96), ">= split" flags, block scan
             int nb_[2] = {0, 0}, ne_[2] = {0, 0};
             bool live[2] = {false, false}, ge[2] = {false, false};
@@ -419,14 +419,14 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
             if (lane == 63) S.wtot[wid] = incl;
-            __syncthreads();
+            lds_barrier();
             {
                 int excl = incl - tsum;
                 for (int w = 0; w < wid; w++) excl += S.wtot[w];
                 if (v0) S.ps[p0] = excl + (ge[0] ? 1 : 0);
                 if (v1) S.ps[p0 + 1] = excl + tsum;
             }
-            __syncthreads();
+            lds_barrier();
             // ---- C: L = #(members < split); the k-th "< split" member of the right part counted from the right
             int L_[2] = {0, 0}, G_[2] = {0, 0};
 #pragma unroll
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                     if (!ge[k] && p >= b + L_[k]) S.mr[b + (L_[k] - ((p - b + 1) - G_[k]))] = p;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- D: the swaps (kdTree.py:108-111); node records and children (kdTree.py:112-122) by the owner of
             //         the node's first position
 #pragma unroll
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                     kd_publish(d.awide, nd, node, S.npar[cur][sl]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- E: positions move to their child's slot (own positions only: no barrier needed before the next A)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
