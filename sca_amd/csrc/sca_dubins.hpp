@@ -10,6 +10,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -44,8 +48,9 @@ static inline double l3norm(const double *a, const double *b) {                 
 struct Maneuver2D { double qi[3]; double r_min, t, p, q, length; char mode[3]; bool ok; };
 
 // dubinsmaneuver2d.py:33-145: one candidate word
-static bool word(int which, double alpha, double beta, double d, double &t, double &p, double &q, char mode[3]) {
-    const double sa = m_sin(alpha), sb = m_sin(beta), ca = m_cos(alpha), cb = m_cos(beta), c_ab = m_cos(alpha - beta);
+// sa..c_ab are the five trig values every planner of the reference recomputes (same arguments, same libm: same bits)
+static bool word(int which, double alpha, double beta, double d, double sa, double sb, double ca, double cb, double c_ab,
+                 double &t, double &p, double &q, char mode[3]) {
     switch (which) {
     case 0: {                                                                                                // LSL :33-51
         mode[0] = 'L'; mode[1] = 'S'; mode[2] = 'L';
@@ -117,9 +122,10 @@ static Maneuver2D plan2d(const double start[3], const double end[3], double c) {
     const double alpha = mod2pi(syaw - theta);
     const double beta = mod2pi(eyaw - theta);
     double bcost = INFINITY;
+    const double sa = m_sin(alpha), sb = m_sin(beta), ca = m_cos(alpha), cb = m_cos(beta), c_ab = m_cos(alpha - beta);
     for (int w = 0; w < 6; w++) {                                     // planners = [LSL, RSR, LSR, RSL, RLR, LRL]
         double t, p, q; char mode[3];
-        if (!word(w, alpha, beta, d, t, p, q, mode)) continue;
+        if (!word(w, alpha, beta, d, sa, sb, ca, cb, c_ab, t, p, q, mode)) continue;
         const double cost = c * (std::fabs(t) + std::fabs(p) + std::fabs(q));
         if (bcost > cost) { m.t = t; m.p = p; m.q = q; std::memcpy(m.mode, mode, 3); bcost = cost; m.ok = true; }
     }
@@ -162,9 +168,19 @@ static void get_coordinates(const Maneuver2D &m, double offset, double q[3]) {
 struct Plan3D {
     Maneuver2D h, v;
     double length = -1.0, sampling_size = 0.1;
+    double qi[5] = {0, 0, 0, 0, 0};
     char mode[7] = {0};
     bool ok = false;
-    std::vector<double> path;            // samples [x, y, z, psi, gamma] in path order
+    long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
+    // sample i of the path, [x, y, z, psi, gamma]: a pure function of i, so the tracker evaluates samples on demand
+    // (the reference materialises all ~1000 of them at every re-plan and then discards most)
+    void sample(long i, double s[5]) const {
+        const double ran = (double)i * sampling_size;
+        double qSZ[3], qXY[3];
+        get_coordinates(v, ran, qSZ);
+        get_coordinates(h, qSZ[0], qXY);
+        s[0] = qXY[0] + qi[0]; s[1] = qXY[1] + qi[1]; s[2] = qSZ[1] + qi[2]; s[3] = qXY[2]; s[4] = qSZ[2];
+    }
 };
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
@@ -210,32 +226,28 @@ static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin, const 
     double ss = 0.1;
     if (P.length > 100) ss = P.length / 1000;
     P.sampling_size = ss;
+    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
     const double stop = P.length + ss;
-    const long cnt = (long)std::ceil(stop / ss);                        // np.arange(0, stop, ss)
-    P.path.reserve((size_t)(cnt > 0 ? cnt : 0) * 5);
-    for (long i = 0; i < cnt; i++) {
-        const double ran = (double)i * ss;
-        double qSZ[3], qXY[3];
-        get_coordinates(P.v, ran, qSZ);
-        get_coordinates(P.h, qSZ[0], qXY);
-        const double s[5] = {qXY[0] + qi[0], qXY[1] + qi[1], qSZ[1] + qi[2], qXY[2], qSZ[2]};
-        P.path.insert(P.path.end(), s, s + 5);
-    }
+    const long cnt = (long)std::ceil(stop / ss);                        // len(np.arange(0, stop, ss))
+    P.count = cnt > 0 ? cnt : 0;
     return P;
 }
 
 // ---- the tracker (scaPolicy.py:243-338) ------------------------------------------------------------------------------
 struct AgentTrack {
     bool is_use_dubins = false;
-    std::vector<double> path;           // remaining samples (x,y,z), stored so that pop() == pop_back()
+    Plan3D plan;                        // agent.dubins_path == samples [next, plan.count) of this plan, popped in path order
+    long next = 0;
     double now_goal[3] = {0, 0, 0};
     double sampling_size = 0.1;
     double v_pref[3] = {0, 0, 0};       // agent.v_pref (not truncated), read by is_parallel on the next call
     int replans = 0;
 };
 
+struct Pool;
 struct Tracker {
     int n = 0;
+    Pool *pool = nullptr;
     std::vector<double> goal, goal_heading, pref_speed;
     std::vector<uint8_t> zaxis;
     double turning_radius = 1.5, pitchlims[2] = {-PI / 4, PI / 4}, neighbor_dist = 10.0;
@@ -245,18 +257,17 @@ struct Tracker {
 static void compute_dubins(const Tracker &T, AgentTrack &a, int i, const double *pos, const double *heading) {     // :92-104
     const double qi[5] = {pos[0], pos[1], pos[2], heading[0], heading[1]};
     const double qf[5] = {T.goal[3 * i], T.goal[3 * i + 1], T.goal[3 * i + 2], T.goal_heading[3 * i], T.goal_heading[3 * i + 1]};
-    Plan3D P = plan3d(qi, qf, T.turning_radius, T.pitchlims);
-    a.sampling_size = P.sampling_size;
-    const size_t cnt = P.path.size() / 5;
-    a.path.clear();
-    for (size_t k = cnt; k-- > 0;) { a.path.push_back(P.path[5 * k]); a.path.push_back(P.path[5 * k + 1]); a.path.push_back(P.path[5 * k + 2]); }
+    a.plan = plan3d(qi, qf, T.turning_radius, T.pitchlims);
+    a.sampling_size = a.plan.sampling_size;
+    a.next = 0;
     a.replans++;
 }
+static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
 static bool path_pop(AgentTrack &a, double out[3]) {
-    if (a.path.empty()) return false;
-    const size_t m = a.path.size();
-    out[0] = a.path[m - 3]; out[1] = a.path[m - 2]; out[2] = a.path[m - 1];
-    a.path.resize(m - 3);
+    if (path_empty(a)) return false;
+    double s5[5];
+    a.plan.sample(a.next++, s5);
+    out[0] = s5[0]; out[1] = s5[1]; out[2] = s5[2];
     return true;
 }
 static void node_pop4(AgentTrack &a) { double t[3]; for (int k = 0; k < 4; k++) path_pop(a, t); }                // :253-261
@@ -306,7 +317,7 @@ static void compute_v_pref(const Tracker &T, AgentTrack &a, int i, const double 
         const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
         if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
             update_dubins(T, a, i, pos);
-            if (!a.path.empty()) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+            if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
             else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
         } else {
             compute_dubins(T, a, i, pos, heading);
@@ -323,20 +334,67 @@ static void compute_v_pref(const Tracker &T, AgentTrack &a, int i, const double 
     for (int q = 0; q < 3; q++) { a.v_pref[q] = v[q]; V_des[q] = trunc5(v[q]); }
 }
 
+// persistent worker threads (spawning 64 threads per step cost more than the tracking itself at N = 1024)
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::function<void(int)> job;
+    int n = 0, gen = 0, pending = 0;
+    bool stop = false;
+    void ensure(int want) {
+        if ((int)th.size() == want) return;
+        shutdown();
+        n = want; stop = false;
+        for (int t = 0; t < want; t++) th.emplace_back([this, t] {
+            int seen = 0;
+            for (;;) {
+                std::function<void(int)> f;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || gen != seen; });
+                    if (stop) return;
+                    seen = gen; f = job;
+                }
+                f(t);
+                { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done_cv.notify_all(); }
+            }
+        });
+    }
+    void run(const std::function<void(int)> &f) {
+        { std::lock_guard<std::mutex> lk(mu); job = f; pending = n; gen++; }
+        cv.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+        th.clear();
+    }
+    ~Pool() { shutdown(); }
+};
+
 static void step_all(Tracker &T, const double *pos, const float *vel, const double *heading, const uint8_t *active,
                      const double *nbr0_dsq, double *vpref_out, int nthreads) {
     auto work = [&](int lo, int hi) {
         for (int i = lo; i < hi; i++)
             if (active[i]) compute_v_pref(T, T.st[i], i, pos + 3 * i, vel + 3 * i, heading + 3 * i, nbr0_dsq[i], vpref_out + 3 * i);
     };
-    if (nthreads <= 1 || T.n < 64) { work(0, T.n); return; }
-    std::vector<std::thread> th;
-    const int chunk = (T.n + nthreads - 1) / nthreads;
-    for (int t = 0; t < nthreads; t++) {
-        const int lo = t * chunk, hi = std::min(T.n, lo + chunk);
-        if (lo < hi) th.emplace_back(work, lo, hi);
-    }
-    for (auto &x : th) x.join();
+    if (nthreads <= 1 || T.n < 32) { work(0, T.n); return; }
+    if (!T.pool) T.pool = new Pool();
+    T.pool->ensure(nthreads);
+    // interleaved blocks of 16 agents: re-plans cluster in id ranges, contiguous chunks would be unbalanced
+    std::atomic<int> next{0};
+    const int blk = 16;
+    T.pool->run([&](int) {
+        for (;;) {
+            const int lo = next.fetch_add(blk);
+            if (lo >= T.n) return;
+            work(lo, std::min(T.n, lo + blk));
+        }
+    });
 }
 
 }  // namespace sca_dubins

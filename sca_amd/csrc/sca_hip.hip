@@ -220,7 +220,10 @@ void *sca_tracker_create(int n, const double *goal, const double *goal_heading, 
     T->st.assign((size_t)n, sca_dubins::AgentTrack());
     return T;
 }
-void sca_tracker_destroy(void *tr) { delete (sca_dubins::Tracker *)tr; }
+void sca_tracker_destroy(void *tr) {
+    auto *T = (sca_dubins::Tracker *)tr;
+    if (T) { delete T->pool; delete T; }
+}
 int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const double *heading, const uint8_t *active,
                       const double *nbr0_dsq, double *vpref_out, int nthreads) {
     if (!tr || !pos || !vel || !heading || !active || !nbr0_dsq || !vpref_out) return SCA_ERR_ARG;
@@ -241,9 +244,9 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
     if (!P.ok) return SCA_ERR_STATE;
     *length = P.length;
     std::memcpy(mode7, P.mode, 7);
-    const int cnt = (int)(P.path.size() / 5);
+    const int cnt = (int)P.count;
     if (n_samples) *n_samples = cnt;
-    if (samples) std::memcpy(samples, P.path.data(), sizeof(double) * 5 * (size_t)std::min(cnt, cap));
+    if (samples) for (int i = 0; i < std::min(cnt, cap); i++) P.sample(i, samples + 5 * (size_t)i);
     return 0;
 }
 

@@ -24,7 +24,7 @@ class DubinsTracker:
                                            float(turning_radius), float(pitchlims[0]), float(pitchlims[1]), float(neighbor_dist))
         if not self.h:
             raise RuntimeError('sca_tracker_create failed')
-        self.nthreads = nthreads or min(os.cpu_count() or 1, 64)
+        self.nthreads = nthreads or min(os.cpu_count() or 1, 256)
         self._nbr0 = np.full(n, -1.0)          # agent.neighbors[0][1] as the last computeNeighbors left it
 
     def close(self):
