@@ -139,6 +139,19 @@ int sca_set_profiling(sca_ctx *ctx, int on);
 /* number of agents that entered find_next_action since the last reset (the metric's "agent-steps") */
 int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 
+/* Trajectory log = Agent.history_info (mamp/agents/agent.py:75-77, filled by to_vector :126-148 at the end of every
+ * update_velocitie, mamp/envs/mampenv.py:105): one 64-byte row per agent per env step, kept in HBM so that resident
+ * runs (sca_run_steps) need no per-step readback.  Row r = the r-th env step after sca_history_enable; every agent logs
+ * every step, done agents included, as in the reference.  The goal and radius columns of ANIMATION_COLUMNS are constants
+ * of sca_set_agents.  Steps beyond capacity_rows are counted as dropped, never overwritten.  With sca_set_shard a rank
+ * logs its own shard only.  capacity_rows == 0 frees the log; sca_set_agents frees it too. */
+int sca_history_enable(sca_ctx *ctx, int capacity_rows);
+int sca_history_rows(sca_ctx *ctx, int *rows_logged, int *rows_dropped);
+/* window [first_row, first_row+nrows) x [agent_begin, agent_begin+agent_count), row-major [row][agent][3]; any output
+ * pointer may be null */
+int sca_get_history(sca_ctx *ctx, int first_row, int nrows, int agent_begin, int agent_count, double *pos /*pos_x..z*/,
+                    double *heading /*alpha, beta, gamma*/, float *vel /*vel_x..z*/);
+
 /* native preferred-velocity tracker for SCAPolicy / RVO3dDubinsPolicy (host side, thread-parallel over agents):
  * replaces compute_v_pref / compute_dubins / update_dubins (mamp/policies/sca/scaPolicy.py:92-104,243-338) and the 3-D
  * Dubins planner (dubinsmaneuver3d.py:34-162, dubinsmaneuver2d.py:33-218,260-297).  Feed its output to sca_set_vpref. */

@@ -55,6 +55,9 @@ SIGNATURES = {
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
     'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    'sca_history_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'sca_history_rows': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'sca_get_history': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, fp]),
     'sca_tracker_create': (C.c_void_p, [C.c_int, dp, dp, dp, bp, C.c_double, C.c_double, C.c_double, C.c_double]),
     'sca_tracker_destroy': (None, [C.c_void_p]),
     'sca_tracker_vpref': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, dp, C.c_int]),

@@ -334,7 +334,7 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, d.hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -376,6 +376,11 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     if (!c) return SCA_ERR_ARG;
     ARG(c, n > 0 && n <= c->max_n);
     ARG(c, radius && pref_speed && goal && policy && max_run_dist);
+    if (c->d.hist) {                                                  // the log's pitch is n: a new agent set starts a new log
+        CHK(c, hipStreamSynchronize(c->stream));
+        CHK(c, hipFree(c->d.hist));
+        c->d.hist = nullptr; c->d.hist_cap = 0; c->d.hist_row = 0;
+    }
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
     c->h_rec.assign(n, PubRec{});
     c->max_radius = 0; c->max_pref_speed = 0;
@@ -628,6 +633,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     else hipLaunchKernelGGL(k_action<false>, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
+    if (fuse_integrate && c->d.hist) c->d.hist_row++;
     return 0;
 }
 
@@ -636,6 +642,7 @@ static int launch_integrate(sca_ctx *c) {
     const int cnt = d.shard_count;
     hipLaunchKernelGGL(k_integrate, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     CHK(c, hipGetLastError());
+    if (c->d.hist) c->d.hist_row++;
     return 0;
 }
 // check_agent_state + is_done; afterwards the moved records become the current ones (buffer swap, no copy)
@@ -746,6 +753,47 @@ int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
     if (reset) {
         CHK(c, hipMemsetAsync(c->d.agent_steps, 0, sizeof(unsigned long long) * parts.size(), c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// ---- trajectory log (Agent.history_info, agent.py:75-77,126-148) kept in HBM --------------------------------------
+int sca_history_enable(sca_ctx *c, int capacity_rows) {
+    if (!c || capacity_rows < 0) return SCA_ERR_ARG;
+    if (c->n <= 0) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (c->d.hist) { CHK(c, hipFree(c->d.hist)); c->d.hist = nullptr; }
+    c->d.hist_cap = 0; c->d.hist_row = 0;
+    if (capacity_rows == 0) return 0;
+    CHK(c, hipMalloc((void **)&c->d.hist, sizeof(HistRow) * (size_t)capacity_rows * (size_t)c->n));
+    c->d.hist_cap = capacity_rows;
+    return 0;
+}
+int sca_history_rows(sca_ctx *c, int *rows_logged, int *rows_dropped) {
+    if (!c) return SCA_ERR_ARG;
+    const int r = c->d.hist ? c->d.hist_row : 0;
+    if (rows_logged) *rows_logged = std::min(r, c->d.hist_cap);
+    if (rows_dropped) *rows_dropped = std::max(0, r - c->d.hist_cap);
+    return 0;
+}
+int sca_get_history(sca_ctx *c, int first_row, int nrows, int agent_begin, int agent_count, double *pos, double *heading, float *vel) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->d.hist) { c->err = "sca_history_enable first"; return SCA_ERR_STATE; }
+    const int have = std::min(c->d.hist_row, c->d.hist_cap);
+    if (first_row < 0 || nrows < 0 || first_row + nrows > have || agent_begin < 0 || agent_count < 0 || agent_begin + agent_count > c->n) {
+        c->err = "history window out of range"; return SCA_ERR_ARG;
+    }
+    if (nrows == 0 || agent_count == 0) return 0;
+    std::vector<HistRow> tmp((size_t)nrows * agent_count);
+    CHK(c, hipMemcpy2DAsync(tmp.data(), sizeof(HistRow) * (size_t)agent_count,
+                            c->d.hist + (size_t)first_row * c->n + agent_begin, sizeof(HistRow) * (size_t)c->n,
+                            sizeof(HistRow) * (size_t)agent_count, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < tmp.size(); i++) {
+        const HistRow &h = tmp[i];
+        if (pos) { pos[3 * i] = h.px; pos[3 * i + 1] = h.py; pos[3 * i + 2] = h.pz; }
+        if (heading) { heading[3 * i] = h.a; heading[3 * i + 1] = h.b; heading[3 * i + 2] = h.g; }
+        if (vel) { vel[3 * i] = h.vx; vel[3 * i + 1] = h.vy; vel[3 * i + 2] = h.vz; }
     }
     return 0;
 }

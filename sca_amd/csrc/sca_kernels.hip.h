@@ -25,6 +25,16 @@ struct alignas(16) KdWide { int begin, end, left, right; double lmn[3], lmx[3], 
 static_assert(sizeof(KdWide) == 128, "KdWide must be 128 bytes");
 struct ObsRec { double px, py, pz, radius; };                          // obstacle.py:5-28 (sphere)
 
+// One row of the trajectory log: what Agent.to_vector (agent.py:126-148) appends to history_info at the end of
+// update_velocitie (mampenv.py:105); the goal and radius columns are per-agent constants and stay on the host.
+struct alignas(16) HistRow {
+    double px, py, pz;       // pos_x, pos_y, pos_z
+    double a, b, g;          // alpha, beta, gamma
+    float vx, vy, vz;        // vel_x, vel_y, vel_z
+    uint32_t flags;          // flags the agent entered the step with (not a reference column)
+};
+static_assert(sizeof(HistRow) == 64, "HistRow must be 64 bytes");
+
 struct DeviceView {
     // public state
     PubRec *rec;             // [n]
@@ -73,6 +83,9 @@ struct DeviceView {
     // (64 adjacent int counters in 2 lines cost 470 us per 100k-agent step; one line each: a few us)
     int32_t *done_count;     // [256*32] count of agents not yet done after the step
     unsigned long long *agent_steps;   // [256*16] running count of agents that entered the policy (mampenv.py:35-40)
+    // trajectory log [hist_cap][n], row = env step since sca_history_enable (null: off)
+    HistRow *hist;
+    int hist_cap, hist_row;
     int n, m, shard_begin, shard_count;
 };
 
@@ -542,6 +555,12 @@ __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Param
     d.heading[agent * 3 + 0] = a; d.heading[agent * 3 + 1] = b; d.heading[agent * 3 + 2] = g;
     if (!(r.flags & FLAG_AT_GOAL)) d.step_num[agent] += 1;
     d.rec_new[agent] = r;
+    if (d.hist && d.hist_row < d.hist_cap) {          // mampenv.py:105 agent.to_vector()
+        HistRow h;
+        h.px = r.px; h.py = r.py; h.pz = r.pz; h.a = a; h.b = b; h.g = g;
+        h.vx = r.vx; h.vy = r.vy; h.vz = r.vz; h.flags = r.flags;
+        d.hist[(size_t)d.hist_row * d.n + agent] = h;
+    }
 }
 
 // generalized pass-on-the-right (scaPolicy.py:119-145) on a list given as per-lane slots.

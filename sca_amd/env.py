@@ -199,7 +199,7 @@ class _KdTreeView:
 
 
 class MACAEnv:
-    def __init__(self, v_pref_fn=None, device=0, neighbor_mode=S.NBR_KDTREE):
+    def __init__(self, v_pref_fn=None, device=0, neighbor_mode=S.NBR_KDTREE, history_capacity=0):
         self.agents = None
         self.obstacles = []
         self.kdTree = None
@@ -208,6 +208,7 @@ class MACAEnv:
         self.dubins_tracker = v_pref_fn is not None
         self.device = device
         self.neighbor_mode = neighbor_mode
+        self.history_capacity = history_capacity      # env steps of Agent.history_info kept on the device (0: no log)
         self._row_cache = None
         self._last_neighbors = None     # neighbour lists of the previous policy pass (read by the v_pref tracker)
 
@@ -237,6 +238,8 @@ class MACAEnv:
         self.solver.set_agents([a.radius for a in agents], [a.pref_speed for a in agents], self.goal, self.policy_ids,
                                S.zaxis_flags(start, goal6), [a.max_run_dist for a in agents])
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
+        if self.history_capacity:
+            self.solver.history_enable(self.history_capacity)
         for a in agents:
             a._env = self
             a.policy._env = self

@@ -172,6 +172,28 @@ class BatchedSolver:
         self._chk(self.L.sca_agent_steps(self.ctx, C.byref(v), 1 if reset else 0), 'sca_agent_steps')
         return int(v.value)
 
+    # ---- trajectory log (Agent.history_info) kept on the device -----------------------------------------
+    def history_enable(self, capacity_rows):
+        self._chk(self.L.sca_history_enable(self.ctx, int(capacity_rows)), 'sca_history_enable')
+
+    def history_rows(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.L.sca_history_rows(self.ctx, C.byref(a), C.byref(b)), 'sca_history_rows')
+        return a.value, b.value
+
+    def history(self, first_row=0, nrows=None, agent_begin=0, agent_count=None):
+        """Rows [first_row, first_row+nrows) of agents [agent_begin, +agent_count): dict of [nrows, agents, 3] arrays."""
+        if nrows is None:
+            nrows = self.history_rows()[0] - first_row
+        if agent_count is None:
+            agent_count = self.n - agent_begin
+        out = dict(pos=np.zeros((nrows, agent_count, 3)), heading=np.zeros((nrows, agent_count, 3)),
+                   vel=np.zeros((nrows, agent_count, 3), np.float32))
+        self._chk(self.L.sca_get_history(self.ctx, int(first_row), int(nrows), int(agent_begin), int(agent_count),
+                                         _lib.ptr(out['pos'], C.c_double), _lib.ptr(out['heading'], C.c_double),
+                                         _lib.ptr(out['vel'], C.c_float)), 'sca_get_history')
+        return out
+
     # ---- multi-GPU --------------------------------------------------------------------------------------
     def set_shard(self, begin, count):
         self._chk(self.L.sca_set_shard(self.ctx, int(begin), int(count)), 'sca_set_shard')
