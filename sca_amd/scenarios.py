@@ -97,3 +97,14 @@ def max_run_dist(start, goal):
     """agent.py:74: 3.0 * l3norm(start, goal) with the rounded l3norm of util.py:104."""
     d = np.sqrt(((np.asarray(start)[:, :3] - np.asarray(goal)[:, :3]) ** 2).sum(1))
     return 3.0 * np.array([round(float(x), 5) for x in d])
+
+
+def spawn_n_drones(n, center=(35.0, 30.0), rad=10.0, environment='exp3'):
+    """run_example/run_sca.py:84-103: ring of n drones facing inward-tangent, goals at the antipodes; exp3 flies at z = 2."""
+    height = 2 if environment == 'exp3' else 10
+    start, goal = [], []
+    for i in range(n):
+        c, s = math.cos(2 * i * np.pi / n), math.sin(2 * i * np.pi / n)
+        start.append([center[0] + rad * c, center[1] + rad * s, height, np.deg2rad(-90 - i * 360 / n), 0, 0])
+        goal.append([center[0] - rad * c, center[1] - rad * s, height, np.deg2rad(90 - i * 360 / n), 0, 0])
+    return dict(start=np.array(start, float), goal=np.array(goal, float), obs_pos=np.zeros((0, 3)), obs_radius=np.zeros(0))

@@ -99,3 +99,36 @@ def test_two_rank_sharded_stepping_matches_single_process(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('OK') == 2, r.stdout[-2000:]
+
+
+def test_binvox_map_to_obstacles_matches_reference():
+    """exp3 map (the reference's visualization/map/map.binvox, kept as a data fixture) -> the 1491 spheres the reference's
+    read_obstacle produced for F10, same order (= obstacle ids), same coordinates bit for bit (mamp/read_map.py:42-85)."""
+    import os
+    from golden_util import GOLDEN, load
+    from sca_amd import read_map, scenarios
+    fx = load('F10_sca_exp3_map')
+    objs = read_map.read_obstacle(center=(35, 30), environ='exp3', obs_path=os.path.join(GOLDEN, 'exp3_map.binvox'))
+    assert len(objs) == 1491 and [o.id for o in objs] == list(range(1491))
+    assert np.array_equal(np.array([o.pos_global_frame for o in objs]), fx['obs_pos'])
+    assert all(o.radius == 0.2 and o.shape == 'sphere' for o in objs)
+    assert read_map.read_obstacle(center=(0, 0), environ='exp1', obs_path='unused') == []
+    with open(os.path.join(GOLDEN, 'exp3_map.binvox'), 'rb') as f:
+        m = read_map.read_as_3d_array(f, fix_coords=False)
+    assert m.axis_order == 'xzy' and list(m.data.shape) == m.dims
+    sc = scenarios.spawn_n_drones(16)
+    assert np.array_equal(sc['start'], fx['start']) and np.array_equal(sc['goal'], fx['goal6'])
+
+
+def test_binvox_rejects_garbage(tmp_path):
+    from sca_amd import read_map
+    p = tmp_path / 'x.binvox'
+    p.write_bytes(b'#notbinvox 1\n')
+    with pytest.raises(IOError):
+        read_map.read_as_3d_array(open(p, 'rb'))
+    p.write_bytes(b'#binvox 1\ndim 2 2 2\ntranslate 0 0 0\nscale 1\ndata\n\x01\x07')
+    with pytest.raises(IOError):
+        read_map.read_as_3d_array(open(p, 'rb'))            # 7 voxels for a 2x2x2 grid
+    p.write_bytes(b'#binvox 1\ndim 2 2 2\ntranslate 0 0 0\nscale 1\ndata\n\x01\x03\x00\x05')
+    m = read_map.read_as_3d_array(open(p, 'rb'))
+    assert m.data.sum() == 3
