@@ -302,6 +302,8 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
+    r |= dalloc(c, &c->kd.chunks[0], (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.chunks[1], (size_t)c->kd.chunk_cap);
+    r |= dalloc(c, &c->kd.nchunks, (size_t)KD_MAX_LEVELS + 1);
     if (!r) {   // the root's accumulators start empty (every build's last kernel resets them for the next one)
         unsigned long long h[12];
         const double pinf = INFINITY, ninf = -INFINITY;
@@ -334,7 +336,7 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.ml, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, d.hist};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], c->kd.nchunks, d.hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -548,7 +550,7 @@ static int build_agent_tree_device(sca_ctx *c) {
             c->kd_ev_pending = false;
         }
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
-        const int grid = c->kd.chunk_cap;
+        const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MAX + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < levels; l++) {
             hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
             hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);

@@ -24,6 +24,7 @@ namespace sca {
 
 constexpr int KD_WAVE_MAX = 2048;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
 constexpr int KD_MAX_LEVELS = 40;
+constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
 struct KdJob { int begin, end, node, pad; };
 
@@ -41,6 +42,8 @@ struct KdScratch {
     int chunk_cap;
     unsigned long long *cbox; // [2][job_cap][2][6] boxes of the two children, accumulated while the parent is partitioned
     unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
+    int2 *chunks[2];          // [chunk_cap] per level parity: workgroup -> (job, first workgroup of the job's node)
+    int *nchunks;             // [KD_MAX_LEVELS + 1] workgroups with work per level
 };
 
 // order-preserving map double -> u64 so that integer atomics give exact min / max
@@ -53,21 +56,9 @@ __device__ __forceinline__ double dunkey(unsigned long long k) {
     return __longlong_as_double((long long)u);
 }
 
-__device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+__device__ __forceinline__ double wave_min_d(double v) { return wave_min_f64(v); }
+__device__ __forceinline__ double wave_max_d(double v) { return wave_max_f64(v); }
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 
 // Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
 __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Params P) {
@@ -79,7 +70,10 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
         if (d.n > KD_WAVE_MAX) { s.jobs[0][0] = j; s.counts[0] = 1; }
         else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
+        for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
+        s.nchunks[0] = d.n > KD_WAVE_MAX ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
+    if (d.n > KD_WAVE_MAX && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) s.chunks[0][p] = make_int2(0, 0);   // the root's workgroups
     if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
@@ -123,27 +117,20 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
 }
 
 // ---- level passes over the large nodes, one workgroup per chunk of KD_CHUNK positions ---------------------------------
-constexpr int KD_CHUNK = 2048;
 constexpr int KD_LV_T = 512;
 constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
 
 struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid; };
 
-// workgroup -> (node, chunk): the node list of a level is short (<= n / KD_WAVE_MAX), every workgroup walks it
-__device__ __forceinline__ KdChunk kd_find_chunk(const KdJob *jobs, int njobs, int blk) {
+// workgroup -> (node, chunk) through the level's chunk table (written by the parent level's swap pass)
+__device__ __forceinline__ KdChunk kd_find_chunk(const KdScratch &s, int level, int blk) {
     KdChunk c; c.valid = 0; c.job = 0; c.begin = c.end = c.node_begin = c.node_end = c.first_chunk = 0;
-    int acc = 0;
-    for (int j = 0; j < njobs; j++) {
-        const int b = jobs[j].begin, e = jobs[j].end;
-        const int nch = (e - b + KD_CHUNK - 1) / KD_CHUNK;
-        if (blk < acc + nch) {
-            c.valid = 1; c.job = j; c.node_begin = b; c.node_end = e; c.first_chunk = acc;
-            c.begin = b + (blk - acc) * KD_CHUNK;
-            c.end = c.begin + KD_CHUNK < e ? c.begin + KD_CHUNK : e;
-            return c;
-        }
-        acc += nch;
-    }
+    if (blk >= s.nchunks[level]) return c;
+    const int2 rec = s.chunks[level & 1][blk];
+    const KdJob job = s.jobs[level & 1][rec.x];
+    c.valid = 1; c.job = rec.x; c.node_begin = job.begin; c.node_end = job.end; c.first_chunk = rec.y;
+    c.begin = job.begin + (blk - rec.y) * KD_CHUNK;
+    c.end = c.begin + KD_CHUNK < job.end ? c.begin + KD_CHUNK : job.end;
     return c;
 }
 
@@ -162,7 +149,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
     __shared__ int carry_sh;
     __shared__ double red[W][12];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const KdChunk c = kd_find_chunk(s.jobs[level & 1], s.counts[level], blockIdx.x);
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
     int axis; double split, bmn[3], bmx[3];
     kd_node_split(s, level, c.job, axis, split, bmn, bmx);
@@ -206,12 +193,14 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
         if (is_min) atomicMin(&cb[tid], dkey(v)); else atomicMax(&cb[tid], dkey(v));
     }
-    // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident)
-    if (tid == 0) {
+    // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident).
+    //      The first wavefront reads 64 predecessors at a time: the words are independent, only their arrival is awaited.
+    if (tid == 0)
         __hip_atomic_store(&s.chain[blockIdx.x], ((unsigned long long)token << 32) | (unsigned)total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    if (wid == 0) {
         int carry = 0;
-        for (int ch = c.first_chunk; ch < (int)blockIdx.x; ch++) {
+        for (int ch = c.first_chunk + lane; ch < (int)blockIdx.x; ch += 64) {
             unsigned long long v = 0;
             int spins = 0;
             for (;;) {
@@ -222,9 +211,12 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
             }
             carry += (int)(unsigned)v;
         }
-        carry_sh = carry;
-        const int nch = (c.node_end - b + KD_CHUNK - 1) / KD_CHUNK;
-        if ((int)blockIdx.x == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
+        carry = wave_sum_i(carry);
+        if (lane == 0) {
+            carry_sh = carry;
+            const int nch = (c.node_end - b + KD_CHUNK - 1) / KD_CHUNK;
+            if ((int)blockIdx.x == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
+        }
     }
     __syncthreads();
     int carry = carry_sh;
@@ -254,7 +246,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
     const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
     KdJob *out = s.jobs[(level + 1) & 1];
-    const KdChunk c = kd_find_chunk(in, s.counts[level], blockIdx.x);
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
     int axis; double split, mn[3], mx[3];
     kd_node_split(s, level, c.job, axis, split, mn, mx);
@@ -297,6 +289,13 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
                         for (int q = 0; q < 6; q++) box[q] = cb[k * 6 + q];          // the child's box is already known
                         unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
                         for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
+                        // the child's workgroups of the next level
+                        const int nch = (ch[k].end - ch[k].begin + KD_CHUNK - 1) / KD_CHUNK;
+                        const int base = atomicAdd(&s.nchunks[level + 1], nch);
+                        if (base + nch <= s.chunk_cap) {
+                            int2 *tab = s.chunks[(level + 1) & 1];
+                            for (int q = 0; q < nch; q++) tab[base + q] = make_int2(at, base);
+                        } else s.counts[KD_MAX_LEVELS + 1] = 1;
                     } else s.counts[KD_MAX_LEVELS + 1] = 1;
                 } else s.counts[KD_MAX_LEVELS + 1] = 1;
             } else {

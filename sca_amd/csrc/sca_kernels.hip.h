@@ -91,6 +91,67 @@ struct DeviceView {
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
+//
+// Full-wave reductions through the DPP cross-lane path of the VALU (no LDS round trip, unlike ds_bpermute behind
+// __shfl_xor): two quad permutes, two row rotations, then row_bcast:15 / row_bcast:31 fold the four 16-lane rows;
+// lane 63 holds the result, which is returned wave-uniform.  All 64 lanes must be active at the call.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+    const int lo = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)v), hi = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+#define SCA_DPP_REDUCE(T, MOV, OP)                                          \
+    v = OP(v, (T)MOV<0xb1, 0xf>(v));  /* quad_perm [1,0,3,2] */            \
+    v = OP(v, (T)MOV<0x4e, 0xf>(v));  /* quad_perm [2,3,0,1] */            \
+    v = OP(v, (T)MOV<0x124, 0xf>(v)); /* row_ror:4 */                      \
+    v = OP(v, (T)MOV<0x128, 0xf>(v)); /* row_ror:8 */                      \
+    v = OP(v, (T)MOV<0x142, 0xa>(v)); /* row_bcast:15 into rows 1, 3 */    \
+    v = OP(v, (T)MOV<0x143, 0xc>(v)); /* row_bcast:31 into rows 2, 3 */
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long dmin_bits(unsigned long long a, unsigned long long b) {
+    return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
+}
+__device__ __forceinline__ unsigned long long dmax_bits(unsigned long long a, unsigned long long b) {
+    return __longlong_as_double((long long)b) > __longlong_as_double((long long)a) ? b : a;
+}
+__device__ __forceinline__ int iadd32(int a, int b) { return a + b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+    int v = (int)x;
+    SCA_DPP_REDUCE(int, dpp_mov, [](int a, int b) { return (int)umin32((unsigned)a, (unsigned)b); })
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned long long bcast63(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    SCA_DPP_REDUCE(unsigned long long, dpp_mov64, umin64)
+    return bcast63(v);
+}
+__device__ __forceinline__ double wave_min_f64(double x) {
+    unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    SCA_DPP_REDUCE(unsigned long long, dpp_mov64, dmin_bits)
+    return __longlong_as_double((long long)bcast63(v));
+}
+__device__ __forceinline__ double wave_max_f64(double x) {
+    unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    SCA_DPP_REDUCE(unsigned long long, dpp_mov64, dmax_bits)
+    return __longlong_as_double((long long)bcast63(v));
+}
+// sums must not count a lane twice: the row_bcast steps add into rows that still hold only their own partial sums
+// (rows 1, 3, then 2, 3), and the rotations inside a row make every lane of the row hold the row total first
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += dpp_mov<0xb1, 0xf>(v);
+    v += dpp_mov<0x4e, 0xf>(v);
+    v += dpp_mov<0x124, 0xf>(v);
+    v += dpp_mov<0x128, 0xf>(v);                       // every lane: total of its 16-lane row
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return r0 + r1 + r2 + r3;
+}
 struct Key3 { double a, b; int idx; };
 __device__ __forceinline__ bool key_less(const Key3 &x, const Key3 &y) {
     if (x.a < y.a) return true;
@@ -858,17 +919,6 @@ struct FastLds {
     unsigned int pkS[SOLVE_WAVES][520];          // survivors: (round5 numerator of |v - v_pref|) << 10 | generation index
     unsigned short listA[SOLVE_WAVES][512];
 };
-
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
-}
 
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
