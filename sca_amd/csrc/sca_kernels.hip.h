@@ -701,6 +701,30 @@ __device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, con
     return alive;
 }
 
+// The same pair test for a short tail of candidates (R <= 32): the wavefront is split into G = 64 / R' neighbour
+// groups (R' = R rounded up to a power of two), lane = g * R' + t tests candidate t against neighbours g, g + G, ...;
+// the caller ORs the groups' verdicts through one ballot.  K / G iterations instead of K.
+template <bool ORCA>
+__device__ __forceinline__ bool sweep_split(const double (*slot)[SLOT], int K, int G, int g, V3 sh, V3 cand) {
+    bool hit = false;
+    for (int j = g; j < K; j += G) {
+        const double *s = slot[j];
+        const double a0 = s[0], a1 = s[1], a2 = s[2], b0 = s[3], b1 = s[4], b2 = s[5], gg = s[6];
+        bool h;
+        if (!ORCA) {
+            const double vx = sh.x - a0, vy = sh.y - a1, vz = sh.z - a2;
+            const double dt = fma(b2, vz, fma(b1, vy, b0 * vx));
+            const double n2 = fma(vz, vz, fma(vy, vy, vx * vx));
+            h = (dt * fabs(dt) > gg * n2) | (n2 == 0.0);
+        } else {
+            const double rx = cand.x - a0, ry = cand.y - a1, rz = cand.z - a2;
+            h = !(fma(rz, b2, fma(ry, b1, rx * b0)) >= 0.0);
+        }
+        hit |= h;
+    }
+    return hit;
+}
+
 __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, SolveLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
@@ -995,54 +1019,86 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             const double thr = P.cos_heading_thr;
             const double tn = thr * nvA;
             const double T2 = tn * tn;
-            const bool filter_ok = thr > 0.0;
+            // Both speeds of a direction share the verdict whenever it is "sure": c = dot / (|vA||v|) does not depend on the
+            // candidate's length beyond rounding (<= 1e-15 relative here, the margin is 1e-13); the z floor is per speed.
             int nA = 0;
-            for (int r = 0; r < nround; r++) {
-                const int idx = r * 64 + lane;
-                const V3 c = cand_from_idx(T, idx, vpref);
-                const double dt = dot(vA64, c);
-                const double n2 = dot(c, c);
+            const bool filter_ok = thr > 1e-6;
+            const int ndir = T.num_N >> 6;
+            for (int r = 0; r < ndir; r++) {
+                const int n0 = r * 64 + lane;
+                const double ux = T.unit[n0], uy = T.unit[T.num_N + n0], uz = T.unit[2 * T.num_N + n0];
+                const V3 u = v3(ux, uy, uz);
+                const double dt = dot(vA64, u);
+                const double n2 = dot(u, u);
                 const double y = T2 * n2;
                 const double lhs = dt * dt;
                 const bool sure_pass = filter_ok & (dt > 0.0) & (lhs > y * (1.0 + 1e-13));
                 const bool sure_fail = filter_ok & ((dt <= 0.0) | (lhs < y * (1.0 - 1e-13)));
-                bool ok = sure_pass;
-                if (__ballot(!(sure_pass | sure_fail)) != 0) {
-                    if (!(sure_pass | sure_fail)) ok = posture_cos(vA, nvA, c) >= thr;
+                const bool unsure = !(sure_pass | sure_fail);
+                const bool any_unsure = __ballot(unsure) != 0;
+#pragma unroll
+                for (int sp = 0; sp < 2; sp++) {
+                    const double rad = sp ? T.rad1 : 0.5;
+                    const V3 c = v3(rad * ux, rad * uy, rad * uz);
+                    bool ok = sure_pass;
+                    if (any_unsure) { if (unsure) ok = posture_cos(vA, nvA, c) >= thr; }
+                    ok = ok & ((pA.z + P.time_step * c.z) >= 0.0);
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) listA[nA + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(sp * T.num_N + n0);
+                    nA += __popcll(m);
                 }
-                ok = ok & ((pA.z + P.time_step * c.z) >= 0.0);
-                const unsigned long long m = __ballot(ok);
-                if (ok) listA[nA + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)idx;
-                nA += __popcll(m);
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- sweep of the compacted candidates, two per lane and chunk; survivors -> (idxS, keyS)
+            // ---- sweep of the compacted candidates; survivors -> packed keys.  Full groups of 128: two candidates per lane;
+            //      then one group of 64; a tail of <= 32 candidates splits the neighbours across lane groups instead.
             int nS = 0;
-            for (int c0 = 0; c0 < nA; c0 += 128) {
+            auto emit = [&](bool a, V3 cdq, int ixq) {
+                const unsigned long long m = __ballot(a);
+                if (a) {
+                    double kn;
+                    l3norm(cdq, vpref, &kn);                                             // scaPolicy.py:219, as integer numerator
+                    pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(kn, ixq);
+                }
+                nS += __popcll(m);
+            };
+            int c0 = 0;
+            for (; nA - c0 >= 128; c0 += 128) {
                 V3 cd[2], sh[2];
                 int ix[2];
-                unsigned valid = 0;
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const int e = c0 + q * 64 + lane;
-                    ix[q] = e < nA ? (int)listA[e] : 0;
-                    if (e < nA) valid |= 1u << q;
+                    ix[q] = (int)listA[c0 + q * 64 + lane];
                     cd[q] = cand_from_idx(T, ix[q], vpref);
                     sh[q] = cd[q] + pA;
                 }
-                unsigned alive;
-                if (nA - c0 > 64) alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, valid) : sweep<2, false, 2, 2>(slot, K, sh, cd, valid);
-                else alive = orca ? sweep<1, true, 2, 2>(slot, K, sh, cd, valid) : sweep<1, false, 2, 2>(slot, K, sh, cd, valid);
+                const unsigned alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, 3u) : sweep<2, false, 2, 2>(slot, K, sh, cd, 3u);
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const bool a = (alive >> q) & 1u;
-                    const unsigned long long m = __ballot(a);
-                    if (a) {
-                        double kn;
-                        l3norm(cd[q], vpref, &kn);                                       // scaPolicy.py:219, as integer numerator
-                        pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(kn, ix[q]);
-                    }
-                    nS += __popcll(m);
+                for (int q = 0; q < 2; q++) emit((alive >> q) & 1u, cd[q], ix[q]);
+            }
+            while (c0 < nA) {
+                const int rem = nA - c0;
+                if (rem > 32) {
+                    const int cnt = rem < 64 ? rem : 64;
+                    V3 cd[1], sh[1];
+                    const int ix = lane < cnt ? (int)listA[c0 + lane] : 0;
+                    cd[0] = cand_from_idx(T, ix, vpref);
+                    sh[0] = cd[0] + pA;
+                    const unsigned valid = lane < cnt ? 1u : 0u;
+                    const unsigned alive = orca ? sweep<1, true, 1, 1>(slot, K, sh, cd, valid) : sweep<1, false, 1, 1>(slot, K, sh, cd, valid);
+                    emit(alive & 1u, cd[0], ix);
+                    c0 += cnt;
+                } else {
+                    int Rp = 1;
+                    while (Rp < rem) Rp <<= 1;                                           // 1 .. 32
+                    const int G = 64 / Rp;
+                    const int t = lane & (Rp - 1), g = lane / Rp;
+                    const int ix = t < rem ? (int)listA[c0 + t] : 0;
+                    const V3 cd = cand_from_idx(T, ix, vpref);
+                    const bool hit = orca ? sweep_split<true>(slot, K, G, g, cd + pA, cd) : sweep_split<false>(slot, K, G, g, cd + pA, cd);
+                    unsigned long long m = __ballot(hit);
+                    for (int w = 32; w >= Rp; w >>= 1) m |= m >> w;                       // OR over the neighbour groups
+                    emit((lane < rem) & !((m >> t) & 1ull), cd, ix);
+                    c0 += rem;
                 }
             }
             // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j
