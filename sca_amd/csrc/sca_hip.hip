@@ -80,8 +80,8 @@ void kd_widen_host(int n, const std::vector<KdNode> &tree, std::vector<KdWide> &
         w.begin = nd.begin; w.end = nd.end; w.left = nd.left; w.right = nd.right;
         if (nd.end - nd.begin > MAX_LEAF) {
             for (int k = 0; k < 3; k++) {
-                w.lmn[k] = tree[nd.left].mn[k]; w.lmx[k] = tree[nd.left].mx[k];
-                w.rmn[k] = tree[nd.right].mn[k]; w.rmx[k] = tree[nd.right].mx[k];
+                w.bx[kdw_idx(0, 0, k)] = tree[nd.left].mn[k]; w.bx[kdw_idx(0, 1, k)] = tree[nd.left].mx[k];
+                w.bx[kdw_idx(1, 0, k)] = tree[nd.right].mn[k]; w.bx[kdw_idx(1, 1, k)] = tree[nd.right].mx[k];
             }
             st.push_back(nd.left); st.push_back(nd.right);
         }

@@ -103,9 +103,8 @@ __device__ __forceinline__ void kd_publish(KdWide *wide, const KdNode &nd, int n
     w->begin = nd.begin; w->end = nd.end; w->left = nd.left; w->right = nd.right;
     if (parent_code >= 0) {
         KdWide *pw = &wide[parent_code >> 1];
-        double *mn = (parent_code & 1) ? pw->rmn : pw->lmn;
-        double *mx = (parent_code & 1) ? pw->rmx : pw->lmx;
-        for (int k = 0; k < 3; k++) { mn[k] = nd.mn[k]; mx[k] = nd.mx[k]; }
+        const int side = parent_code & 1;
+        for (int k = 0; k < 3; k++) { pw->bx[kdw_idx(side, 0, k)] = nd.mn[k]; pw->bx[kdw_idx(side, 1, k)] = nd.mx[k]; }
     }
 }
 

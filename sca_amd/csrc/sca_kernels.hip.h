@@ -21,7 +21,14 @@ namespace sca {
 struct KdNode { int begin, end, left, right; double mn[3], mx[3]; };   // 64 B, kdTree.py:14-21
 // What the query reads: the node header plus BOTH children's boxes, so that a level of the descent costs one
 // (scalar) load instead of two dependent ones.  128 B.
-struct alignas(16) KdWide { int begin, end, left, right; double lmn[3], lmx[3], rmn[3], rmx[3]; double pad[2]; };
+// Query record of a tree node: header + BOTH children's boxes, interleaved so that the packed neighbour kernel can add
+// the six box terms of the left child on lane 2 and of the right child on lane 3 with the same lane shifts:
+// bx = mn0L mn0R mx0L mx0R mn1L mn1R mx1L mx1R mn2L mn2R mx2L mx2R   (index (2*axis + is_max)*2 + side)
+struct alignas(16) KdWide { int begin, end, left, right; double bx[12]; double pad[2]; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int kdw_idx(int side, int is_max, int axis) { return (2 * axis + is_max) * 2 + side; }
 static_assert(sizeof(KdWide) == 128, "KdWide must be 128 bytes");
 struct ObsRec { double px, py, pz, radius; };                          // obstacle.py:5-28 (sphere)
 
@@ -101,6 +108,27 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
     const int lo = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)v), hi = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// inside a 16-lane row: broadcast of lane K (row_newbcast, gfx90a+), shifts towards lower / higher lanes
+template <int K> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false); }
+template <int K> __device__ __forceinline__ double row_bcast_d(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = row_bcast_i<K>((int)(unsigned)v), hi = row_bcast_i<K>((int)(unsigned)(v >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// lane i reads lane i + K of its row (lanes whose source is outside the row keep their own value)
+template <int K> __device__ __forceinline__ double row_shl_d(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, 0x100 + K, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), 0x100 + K, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// lane i reads lane i - 1 of its row (lane 0 keeps its own value)
+__device__ __forceinline__ int row_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ double row_shr1_d(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = row_shr1_i((int)(unsigned)v), hi = row_shr1_i((int)(unsigned)(v >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 #define SCA_DPP_REDUCE(T, MOV, OP)                                          \
     v = OP(v, (T)MOV<0xb1, 0xf>(v));  /* quad_perm [1,0,3,2] */            \
@@ -205,14 +233,14 @@ __device__ __forceinline__ void wave_insert(WaveList &L, int lane, int maxn, int
 
 // Depth-first traversal of kdTree.py:127-156 (nearer child first, ties go right, constant rangeSq) with a
 // wave-uniform explicit stack.  leaf(begin, end) is called for every visited leaf in visit order.
-__device__ __forceinline__ double box_dist_sq(const double mn[3], const double mx[3], V3 p) {   // kdTree.py:132-145
+__device__ __forceinline__ double box_dist_sq(const KdWide &w, int side, V3 p) {   // kdTree.py:132-145
     double t, s;
-    t = fmax(0.0, mn[0] - p.x); s = t * t;
-    t = fmax(0.0, p.x - mx[0]); s = s + t * t;
-    t = fmax(0.0, mn[1] - p.y); s = s + t * t;
-    t = fmax(0.0, p.y - mx[1]); s = s + t * t;
-    t = fmax(0.0, mn[2] - p.z); s = s + t * t;
-    t = fmax(0.0, p.z - mx[2]); s = s + t * t;
+    t = fmax(0.0, w.bx[kdw_idx(side, 0, 0)] - p.x); s = t * t;
+    t = fmax(0.0, p.x - w.bx[kdw_idx(side, 1, 0)]); s = s + t * t;
+    t = fmax(0.0, w.bx[kdw_idx(side, 0, 1)] - p.y); s = s + t * t;
+    t = fmax(0.0, p.y - w.bx[kdw_idx(side, 1, 1)]); s = s + t * t;
+    t = fmax(0.0, w.bx[kdw_idx(side, 0, 2)] - p.z); s = s + t * t;
+    t = fmax(0.0, p.z - w.bx[kdw_idx(side, 1, 2)]); s = s + t * t;
     return s;
 }
 
@@ -228,8 +256,8 @@ __device__ __forceinline__ int kd_traverse(const KdWide *tree, V3 p, double rang
         if (nd.end - nd.begin <= MAX_LEAF) {
             leaf(nd.begin, nd.end);
         } else {
-            const double dl = box_dist_sq(nd.lmn, nd.lmx, p);
-            const double dr = box_dist_sq(nd.rmn, nd.rmx, p);
+            const double dl = box_dist_sq(nd, 0, p);
+            const double dr = box_dist_sq(nd, 1, p);
             int first, second;
             double dfirst, dsecond;
             if (dl < dr) { first = nd.left; second = nd.right; dfirst = dl; dsecond = dr; }
@@ -404,12 +432,11 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     const int maxn = P.max_neighbors;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
-    // which box term this lane squares: lanes 2..13 hold lmn[3], lmx[3], rmn[3], rmx[3] of the node record
-    const int tk = gl >= 2 ? (gl - 2) % 3 : 0;
-    const bool t_is_mx = gl >= 2 && (((gl - 2) / 3) & 1);
+    // which box term this lane squares: lanes 2..13 hold bx[0..11] of the node record (axis, min/max, side interleaved)
+    const int tk = gl >= 2 ? (gl - 2) >> 2 : 0;
+    const bool t_is_mx = gl >= 2 && (((gl - 2) >> 1) & 1);
     const bool t_live = gl >= 2 && gl < 14;
     const double pk = tk == 0 ? pA.x : (tk == 1 ? pA.y : pA.z);
-    const int side6 = gl == 1 ? 6 : 0;
     // sorted list: entry gl of the group's agent
     double Ld = 0.0; int Li = -1; int cnt = 0; bool coll = false; int near_cnt = 0;
     int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
         bool have = !skip;
         while (__any(have)) {
             const double w = have ? wd[(size_t)node * 16 + gl] : 0.0;
-            const double h0 = __shfl(w, gbase), h1 = __shfl(w, gbase + 1);
+            const double h0 = row_bcast_d<0>(w), h1 = row_bcast_d<1>(w);
             const int nb = lo32(h0), ne = hi32(h0), nl = lo32(h1), nr_ = hi32(h1);
             const bool leaf = have && (ne - nb <= MAX_LEAF);
             const bool inner = have && !leaf;
@@ -432,13 +459,14 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                 double t = t_is_mx ? pk - w : w - pk;
                 t = fmax(0.0, t);
                 const double sq = t_live ? t * t : 0.0;
-                double ssum = __shfl(sq, gbase + 2 + side6);         // mn0
-                ssum = ssum + __shfl(sq, gbase + 5 + side6);         // mx0
-                ssum = ssum + __shfl(sq, gbase + 3 + side6);         // mn1
-                ssum = ssum + __shfl(sq, gbase + 6 + side6);         // mx1
-                ssum = ssum + __shfl(sq, gbase + 4 + side6);         // mn2
-                ssum = ssum + __shfl(sq, gbase + 7 + side6);         // mx2
-                const double dl = __shfl(ssum, gbase), dr = __shfl(ssum, gbase + 1);
+                // lane 2 adds the left child's terms mn0 mx0 mn1 mx1 mn2 mx2 in that order, lane 3 the right child's
+                double ssum = sq;
+                ssum = ssum + row_shl_d<2>(sq);
+                ssum = ssum + row_shl_d<4>(sq);
+                ssum = ssum + row_shl_d<6>(sq);
+                ssum = ssum + row_shl_d<8>(sq);
+                ssum = ssum + row_shl_d<10>(sq);
+                const double dl = row_bcast_d<2>(ssum), dr = row_bcast_d<3>(ssum);
                 int first, second; double dfirst, dsecond;
                 if (dl < dr) { first = nl; second = nr_; dfirst = dl; dsecond = dr; }
                 else { first = nr_; second = nl; dfirst = dr; dsecond = dl; }
@@ -495,8 +523,8 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                     if (ins && ncnt == maxn) ncnt--;                             // neighbors.pop()
                     const unsigned bm = (unsigned)((__ballot(ins && gl < ncnt && Ld <= db) >> gshift) & 0xffffull);
                     const int pos = __popc(bm);
-                    const double up_d = __shfl_up(Ld, 1, 16);
-                    const int up_i = __shfl_up(Li, 1, 16);
+                    const double up_d = row_shr1_d(Ld);
+                    const int up_i = row_shr1_i(Li);
                     if (ins) {
                         if (gl > pos && gl <= ncnt) { Ld = up_d; Li = up_i; }
                         if (gl == pos) { Ld = db; Li = ib; }
