@@ -510,13 +510,9 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                     if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
                     near_cnt += __popc(nm);
                 }
-                unsigned todo = (unsigned)((__ballot(r) >> gshift) & 0xffffull);
-                while (__any(todo != 0)) {                           // members in range, in leaf order
-                    const bool act = todo != 0;
-                    const int b = act ? __ffs((int)todo) - 1 : 0;
-                    const bool cb = __shfl((int)c, gbase + b) != 0;
-                    const double db = __shfl(dsq, gbase + b);
-                    const int ib = __shfl(o, gbase + b);
+                const unsigned todo = (unsigned)((__ballot(r) >> gshift) & 0xffffull);
+                // members in range, in leaf order: member k of every group's leaf is broadcast inside the group's row
+                auto member = [&](bool act, bool cb, double db, int ib) {
                     if (act && cb && !coll) { coll = true; cnt = 0; }            // agent.py:83-85
                     const bool ins = act && (cb || !coll);
                     int ncnt = cnt;
@@ -530,8 +526,14 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                         if (gl == pos) { Ld = db; Li = ib; }
                         cnt = ncnt + 1;
                     }
-                    todo &= todo - 1;
-                }
+                };
+                const int ci = c ? 1 : 0;
+#define SCA_K1_MEMBER(KK)                                                                                   \
+                if (__any((todo >> KK) & 1u)) member(((todo >> KK) & 1u) != 0, row_bcast_i<KK>(ci) != 0, row_bcast_d<KK>(dsq), row_bcast_i<KK>(o));
+                SCA_K1_MEMBER(0) SCA_K1_MEMBER(1) SCA_K1_MEMBER(2) SCA_K1_MEMBER(3) SCA_K1_MEMBER(4)
+                SCA_K1_MEMBER(5) SCA_K1_MEMBER(6) SCA_K1_MEMBER(7) SCA_K1_MEMBER(8) SCA_K1_MEMBER(9)
+#undef SCA_K1_MEMBER
+                static_assert(MAX_LEAF == 10, "the member sequence above is written for leaves of <= 10");
             }
             if (have) {
                 if (descend) node = next;
