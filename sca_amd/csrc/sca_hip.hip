@@ -481,9 +481,33 @@ int sca_get_kd_tree(sca_ctx *c, double *tree_out) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, tree_out && c->agents_set);
     const int n = c->n;
-    std::vector<KdNode> t((size_t)2 * n);
-    CHK(c, hipMemcpyAsync(t.data(), c->d.atree, sizeof(KdNode) * (2 * n - 1), hipMemcpyDeviceToHost, c->stream));
-    CHK(c, hipStreamSynchronize(c->stream));
+    std::vector<KdNode> t((size_t)2 * n, KdNode{});
+    if (!c->perm_on_device) {
+        // host-built tree: the node array itself was uploaded
+        CHK(c, hipMemcpyAsync(t.data(), c->d.atree, sizeof(KdNode) * (2 * n - 1), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        // device-built tree: the build only writes the query records (header + both children's boxes) and the root's
+        // node; the node array of kdTree.py:14-21 is put together here
+        std::vector<KdWide> w((size_t)2 * n);
+        CHK(c, hipMemcpyAsync(w.data(), c->d.awide, sizeof(KdWide) * (2 * n - 1), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipMemcpyAsync(t.data(), c->d.atree, sizeof(KdNode), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipStreamSynchronize(c->stream));
+        std::vector<int> st{0};
+        while (!st.empty()) {
+            const int i = st.back();
+            st.pop_back();
+            t[i].begin = w[i].begin; t[i].end = w[i].end; t[i].left = w[i].left; t[i].right = w[i].right;
+            if (w[i].end - w[i].begin > MAX_LEAF) {
+                const int ch[2] = {w[i].left, w[i].right};
+                for (int sd = 0; sd < 2; sd++) {
+                    if (ch[sd] <= i || ch[sd] >= 2 * n - 1) { c->err = "corrupt kd tree"; return SCA_ERR_STATE; }
+                    for (int k = 0; k < 3; k++) { t[ch[sd]].mn[k] = w[i].bx[kdw_idx(sd, 0, k)]; t[ch[sd]].mx[k] = w[i].bx[kdw_idx(sd, 1, k)]; }
+                    st.push_back(ch[sd]);
+                }
+            } else { t[i].left = 0; t[i].right = 0; }
+        }
+    }
     for (int i = 0; i < 2 * n - 1; i++) {
         double *o = tree_out + 10 * (size_t)i;
         o[0] = t[i].begin; o[1] = t[i].end; o[2] = t[i].left; o[3] = t[i].right;
@@ -758,6 +782,14 @@ int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
     }
     return 0;
 }
+
+#ifdef SCA_KB_TIMING
+int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds only: k_kd_block's per-phase ticks
+    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipMemcpy(out, c->kd.ps, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 // ---- trajectory log (Agent.history_info, agent.py:75-77,126-148) kept in HBM --------------------------------------
 int sca_history_enable(sca_ctx *c, int capacity_rows) {

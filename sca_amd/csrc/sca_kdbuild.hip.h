@@ -271,7 +271,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
         KdNode nd;
         nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
         for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
-        d.atree[job.node] = nd;
+        if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
         kd_publish(d.awide, nd, job.node, job.pad);
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
         if (L == 0) s.counts[KD_MAX_LEVELS + 1] = 1;         // children boxes by side do not apply: report (never seen)
@@ -313,10 +313,16 @@ constexpr int KB_T = 1024;
 constexpr int KB_E = KB_MAX / KB_T;     // 8 consecutive positions per thread
 constexpr int KB_NODES = 384;           // live nodes per level: <= 2 * KB_MAX / 11
 
+// x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KB_MAX / 8 + 8)
+// + (p >> 3), so that both patterns touch all LDS banks evenly (rows of 256 + 8: four rows of doubles tile the 64 banks)
+constexpr int KB_SWROW = KB_MAX / 8 + 8;
+constexpr int KB_SWN = 8 * KB_SWROW;
+#define KB_SW(p) ((((p) & 7) * KB_SWROW) + ((p) >> 3))
+
 struct KbLds {
-    double x[KB_MAX], y[KB_MAX], z[KB_MAX];
+    double x[KB_SWN], y[KB_SWN], z[KB_SWN];        // swizzled: index KB_SW(position)
     int id[KB_MAX];
-    int slot[KB_MAX];                   // live-node slot of the position, -1 once its leaf is written
+    int slot[KB_SWN];                   // live-node slot of the position, -1 once its leaf is written
     int mr[KB_MAX];                     // position of the k-th misplaced member of the right part
     int ps[KB_MAX];                     // inclusive prefix count of the ">= split" flags over all positions
     int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES], npar[2][KB_NODES];
@@ -329,6 +335,48 @@ struct KbLds {
 // Barrier for LDS-only hand-offs inside k_kd_block's level loop: __syncthreads() also waits for the global stores of the
 // node records (s_waitcnt vmcnt(0)), a ~1 us round trip per level that nothing in the loop depends on.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// minimum of a 64-bit key over the 16-lane row (every lane of the row gets it) or over the wavefront (uniform result):
+// two chains of 32-bit DPP minima, high words first, then the low words of the lanes that hold the minimal high word
+template <bool WAVE>
+__device__ __forceinline__ unsigned long long kb_key_min(unsigned long long key) {
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    auto red = [](unsigned v) {
+        v = umin32(v, (unsigned)dpp_mov<0xb1, 0xf>((int)v));
+        v = umin32(v, (unsigned)dpp_mov<0x4e, 0xf>((int)v));
+        v = umin32(v, (unsigned)dpp_mov<0x124, 0xf>((int)v));
+        v = umin32(v, (unsigned)dpp_mov<0x128, 0xf>((int)v));
+        if (WAVE) {
+            v = umin32(v, (unsigned)dpp_mov<0x142, 0xa>((int)v));
+            v = umin32(v, (unsigned)dpp_mov<0x143, 0xc>((int)v));
+            v = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+        }
+        return v;
+    };
+    const unsigned h = red(hi);
+    const unsigned l = red(hi == h ? lo : 0xffffffffu);
+    return ((unsigned long long)h << 32) | l;
+}
+// inclusive prefix sum over the wavefront: shifts inside the rows, then the row totals carried across
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    const int lane = (int)(threadIdx.x & 63);
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v += t;      // row_shr:1 (lanes without a source add 0)
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v += t;      // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v += t;      // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v += t;      // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
+
+#ifdef SCA_KB_TIMING   // per-phase wall-clock ticks of workgroup 0's first job into s.ps (debug builds only)
+#define KB_MARK_INIT() int dbg_i = 0; long long dbg_t = wall_clock64()
+#define KB_MARK() do { if (jb == 0 && blockIdx.x == 0 && tid == 0 && dbg_i < 200) { const long long t_ = wall_clock64(); s.ps[dbg_i++] = (int)(t_ - dbg_t); dbg_t = t_; } } while (0)
+#else
+#define KB_MARK_INIT() do { } while (0)
+#define KB_MARK() do { } while (0)
+#endif
 
 __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
     static_assert(KB_E == 2, "k_kd_block is written for two consecutive positions per thread");
@@ -348,8 +396,8 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
         if (size > KB_MAX) { if (tid == 0) s.counts[KD_MAX_LEVELS + 1] = 1; continue; }
         __syncthreads();
         for (int i = tid; i < size; i += KB_T) {
-            S.x[i] = s.kx[base + i]; S.y[i] = s.ky[base + i]; S.z[i] = s.kz[base + i]; S.id[i] = d.aperm[base + i];
-            S.slot[i] = 0;
+            S.x[KB_SW(i)] = s.kx[base + i]; S.y[KB_SW(i)] = s.ky[base + i]; S.z[KB_SW(i)] = s.kz[base + i]; S.id[i] = d.aperm[base + i];
+            S.slot[KB_SW(i)] = 0;
         }
         if (tid == 0) {
             S.nb[0][0] = 0; S.ne[0][0] = size; S.nnode[0][0] = job.node; S.npar[0][0] = job.pad; S.count[0] = 1; S.count[1] = 0;
@@ -357,41 +405,86 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
         }
         __syncthreads();
         int cur = 0;
+        bool first = true;
         const int p0 = tid * KB_E;
+        KB_MARK_INIT();
         for (;;) {
             const int nc = S.count[cur];
             if (nc == 0) break;
             const int nxt = cur ^ 1;
+            // ---- A: positions move to their child's slot (the previous level's result), then the boxes of the level's
+            //         nodes (kdTree.py:63-83).  Two consecutive positions per lane.  All six extremes are carried as
+            //         order-preserving 64-bit keys (maxima inverted, so every one is a minimum) and reduced as two 32-bit
+            //         DPP min chains (high words, then the low words of the lanes that hold the minimum high word):
+            //         over the whole wavefront when its 128 positions sit in one node, else over each 16-lane row whose
+            //         32 positions do; only what is left goes through LDS atomics.
             const bool v0 = p0 < size, v1 = p0 + 1 < size;
-            const int s0 = v0 ? S.slot[p0] : -1, s1 = v1 ? S.slot[p0 + 1] : -1;
-            // ---- A: boxes (kdTree.py:63-83).  A wave whose 128 positions sit in one node reduces first, then 6 atomics.
-            {
-                const int ref = __shfl(s0, 0);
-                const bool uni = __all(s0 == ref && s1 == ref) && ref >= 0;
-                double mn[3], mx[3];
-                if (s0 >= 0) { mn[0] = mx[0] = S.x[p0]; mn[1] = mx[1] = S.y[p0]; mn[2] = mx[2] = S.z[p0]; }
+            int s0 = v0 ? S.slot[KB_SW(p0)] : -1, s1 = v1 ? S.slot[KB_SW(p0 + 1)] : -1;
+            if (!first) {
+                int onew = -1, othr = 0;
+                if (s0 >= 0) {
+                    const int ob = S.nb[nxt][s0], oe = S.ne[nxt][s0];               // the parent level's node
+                    if (oe - ob > MAX_LEAF) { onew = S.child[s0]; othr = ob + S.lfix[s0]; }
+                }
+                int n1 = -1;
                 if (s1 >= 0) {
-                    const double x = S.x[p0 + 1], y = S.y[p0 + 1], z = S.z[p0 + 1];
-                    if (s0 == s1) {
-                        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
-                        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
-                        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
-                    } else {
-                        atomicMin(&S.box[cur][s1][0], dkey(x)); atomicMax(&S.box[cur][s1][3], dkey(x));
-                        atomicMin(&S.box[cur][s1][1], dkey(y)); atomicMax(&S.box[cur][s1][4], dkey(y));
-                        atomicMin(&S.box[cur][s1][2], dkey(z)); atomicMax(&S.box[cur][s1][5], dkey(z));
+                    if (s1 == s0) n1 = onew < 0 ? -1 : onew + (p0 + 1 >= othr ? 1 : 0);
+                    else {
+                        const int ob = S.nb[nxt][s1], oe = S.ne[nxt][s1];
+                        if (oe - ob > MAX_LEAF) n1 = S.child[s1] + (p0 + 1 >= ob + S.lfix[s1] ? 1 : 0);
                     }
                 }
-                if (uni) {
+                s0 = (s0 >= 0 && onew >= 0) ? onew + (p0 >= othr ? 1 : 0) : -1;
+                s1 = n1;
+                if (v0) S.slot[KB_SW(p0)] = s0;
+                if (v1) S.slot[KB_SW(p0 + 1)] = s1;
+            }
+            {
+                const double x0 = S.x[KB_SW(p0)], y0 = S.y[KB_SW(p0)], z0 = S.z[KB_SW(p0)];
+                const int p1 = v1 ? p0 + 1 : p0;
+                const double x1 = S.x[KB_SW(p1)], y1 = S.y[KB_SW(p1)], z1 = S.z[KB_SW(p1)];
+                const bool pair = s0 >= 0 && s1 == s0;
+                unsigned long long key[6];                       // 0..2 minima, 3..5 inverted maxima of the lane's first segment
+                {
+                    const double a0 = pair && x1 < x0 ? x1 : x0, a1 = pair && y1 < y0 ? y1 : y0, a2 = pair && z1 < z0 ? z1 : z0;
+                    const double b0 = pair && x1 > x0 ? x1 : x0, b1 = pair && y1 > y0 ? y1 : y0, b2 = pair && z1 > z0 ? z1 : z0;
+                    key[0] = dkey(a0); key[1] = dkey(a1); key[2] = dkey(a2);
+                    key[3] = ~dkey(b0); key[4] = ~dkey(b1); key[5] = ~dkey(b2);
+                }
+                // the second position on its own when it starts another node
+                if (s1 >= 0 && s1 != s0) {
+                    atomicMin(&S.box[cur][s1][0], dkey(x1)); atomicMax(&S.box[cur][s1][3], dkey(x1));
+                    atomicMin(&S.box[cur][s1][1], dkey(y1)); atomicMax(&S.box[cur][s1][4], dkey(y1));
+                    atomicMin(&S.box[cur][s1][2], dkey(z1)); atomicMax(&S.box[cur][s1][5], dkey(z1));
+                }
+                const int rs = row_bcast_i<0>(s0);
+                const unsigned long long um = __ballot(s0 == rs && (s1 == rs || !v1));
+                const bool row_uni = ((um >> (lane & 48)) & 0xffffull) == 0xffffull;
+                const int ref = __builtin_amdgcn_readfirstlane(s0);
+                const bool wave_uni = um == ~0ull && __all(rs == ref);
+                if (wave_uni) {
+                    if (ref >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
-                    if (lane == 0)
-                        for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][ref][k], dkey(mn[k])); atomicMax(&S.box[cur][ref][3 + k], dkey(mx[k])); }
-                } else if (s0 >= 0) {
-                    for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][s0][k], dkey(mn[k])); atomicMax(&S.box[cur][s0][3 + k], dkey(mx[k])); }
+                        for (int k = 0; k < 6; k++) key[k] = kb_key_min<true>(key[k]);
+                        if (lane == 0)
+                            for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][ref][k], key[k]); atomicMax(&S.box[cur][ref][3 + k], ~key[3 + k]); }
+                    }
+                } else {
+                    unsigned long long rk[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) rk[k] = kb_key_min<false>(key[k]);
+                    const bool mine = row_uni ? ((lane & 15) == 0 && rs >= 0) : (s0 >= 0);
+                    if (mine) {
+                        const int sl = row_uni ? rs : s0;
+                        for (int k = 0; k < 3; k++) {
+                            atomicMin(&S.box[cur][sl][k], row_uni ? rk[k] : key[k]);
+                            atomicMax(&S.box[cur][sl][3 + k], ~(row_uni ? rk[3 + k] : key[3 + k]));
+                        }
+                    }
                 }
             }
             lds_barrier();
+            KB_MARK();
             // ---- B: split plane of the element's node (kdTree.py:85-96), ">= split" flags, block scan
             int nb_[2] = {0, 0}, ne_[2] = {0, 0};
             bool live[2] = {false, false}, ge[2] = {false, false};
@@ -407,24 +500,27 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                         int axis; double split;
                         kd_split(mn, mx, axis, split);
                         const int p = p0 + k;
-                        const double c = axis == 0 ? S.x[p] : (axis == 1 ? S.y[p] : S.z[p]);
+                        const double c = axis == 0 ? S.x[KB_SW(p)] : (axis == 1 ? S.y[KB_SW(p)] : S.z[KB_SW(p)]);
                         ge[k] = !(c < split);
                     }
                 }
             }
             const int tsum = (ge[0] ? 1 : 0) + (ge[1] ? 1 : 0);
-            int incl = tsum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            const int incl = wave_incl_scan_i32(tsum);
             if (lane == 63) S.wtot[wid] = incl;
             lds_barrier();
+            KB_MARK();
             {
-                int excl = incl - tsum;
-                for (int w = 0; w < wid; w++) excl += S.wtot[w];
+                // exclusive prefix of the wavefront totals: the 16 totals sit in one row, scanned with row shifts
+                const int wv = lane < KB_T / 64 ? S.wtot[lane] : 0;
+                const int wscan = wave_incl_scan_i32(wv);
+                const int wbase = wid > 0 ? __builtin_amdgcn_readlane(wscan, wid - 1) : 0;
+                const int excl = wbase + incl - tsum;
                 if (v0) S.ps[p0] = excl + (ge[0] ? 1 : 0);
                 if (v1) S.ps[p0 + 1] = excl + tsum;
             }
             lds_barrier();
+            KB_MARK();
             // ---- C: L = #(members < split); the k-th "< split" member of the right part counted from the right
             int L_[2] = {0, 0}, G_[2] = {0, 0};
 #pragma unroll
@@ -438,56 +534,56 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 }
             }
             lds_barrier();
-            // ---- D: the swaps (kdTree.py:108-111); node records and children (kdTree.py:112-122) by the owner of
-            //         the node's first position
+            KB_MARK();
+            // ---- D: the swaps (kdTree.py:108-111) by position ...
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const int sl = k == 0 ? s0 : s1;
                 const int p = p0 + k;
                 if (live[k] && ge[k] && p < nb_[k] + L_[k]) {
                     const int q = S.mr[nb_[k] + G_[k] - 1];
                     const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
                     double t;
-                    t = S.x[p]; S.x[p] = S.x[q]; S.x[q] = t;
-                    t = S.y[p]; S.y[p] = S.y[q]; S.y[q] = t;
-                    t = S.z[p]; S.z[p] = S.z[q]; S.z[q] = t;
-                }
-                if (sl >= 0 && p == nb_[k]) {
-                    KdNode nd;
-                    nd.begin = base + nb_[k]; nd.end = base + ne_[k]; nd.left = 0; nd.right = 0;
-                    for (int q = 0; q < 3; q++) { nd.mn[q] = dunkey(S.box[cur][sl][q]); nd.mx[q] = dunkey(S.box[cur][sl][3 + q]); }
-                    const int node = S.nnode[cur][sl];
-                    if (live[k]) {
-                        const int lf = L_[k] == 0 ? 1 : L_[k];
-                        nd.left = node + 1; nd.right = node + 2 * lf;
-                        const int c0 = atomicAdd(&S.count[nxt], 2);
-                        S.child[sl] = c0; S.lfix[sl] = lf;
-                        S.nb[nxt][c0] = nb_[k]; S.ne[nxt][c0] = nb_[k] + lf; S.nnode[nxt][c0] = nd.left; S.npar[nxt][c0] = 2 * node;
-                        S.nb[nxt][c0 + 1] = nb_[k] + lf; S.ne[nxt][c0 + 1] = ne_[k]; S.nnode[nxt][c0 + 1] = nd.right;
-                        S.npar[nxt][c0 + 1] = 2 * node + 1;
-                        for (int q = 0; q < 3; q++) {
-                            S.box[nxt][c0][q] = dkey(INFINITY); S.box[nxt][c0][3 + q] = dkey(-INFINITY);
-                            S.box[nxt][c0 + 1][q] = dkey(INFINITY); S.box[nxt][c0 + 1][3 + q] = dkey(-INFINITY);
-                        }
-                    }
-                    d.atree[node] = nd;
-                    kd_publish(d.awide, nd, node, S.npar[cur][sl]);
+                    t = S.x[KB_SW(p)]; S.x[KB_SW(p)] = S.x[KB_SW(q)]; S.x[KB_SW(q)] = t;
+                    t = S.y[KB_SW(p)]; S.y[KB_SW(p)] = S.y[KB_SW(q)]; S.y[KB_SW(q)] = t;
+                    t = S.z[KB_SW(p)]; S.z[KB_SW(p)] = S.z[KB_SW(q)]; S.z[KB_SW(q)] = t;
                 }
             }
-            lds_barrier();
-            // ---- E: positions move to their child's slot (own positions only: no barrier needed before the next A)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int sl = k == 0 ? s0 : s1;
-                if (sl >= 0) S.slot[p0 + k] = live[k] ? S.child[sl] + (p0 + k >= nb_[k] + S.lfix[sl] ? 1 : 0) : -1;
+            //         ... and the node records and children (kdTree.py:112-122), one lane per node of the level
+            if (tid < nc) {
+                const int sl = tid;
+                const int b = S.nb[cur][sl], e = S.ne[cur][sl];
+                const int node = S.nnode[cur][sl], par = S.npar[cur][sl];
+                KdNode nd;
+                nd.begin = base + b; nd.end = base + e; nd.left = 0; nd.right = 0;
+                for (int q = 0; q < 3; q++) { nd.mn[q] = dunkey(S.box[cur][sl][q]); nd.mx[q] = dunkey(S.box[cur][sl][3 + q]); }
+                if (e - b > MAX_LEAF) {
+                    const int pb = b > 0 ? S.ps[b - 1] : 0;
+                    const int L = (e - b) - (S.ps[e - 1] - pb);
+                    const int lf = L == 0 ? 1 : L;
+                    nd.left = node + 1; nd.right = node + 2 * lf;
+                    const int c0 = atomicAdd(&S.count[nxt], 2);
+                    S.child[sl] = c0; S.lfix[sl] = lf;
+                    S.nb[nxt][c0] = b; S.ne[nxt][c0] = b + lf; S.nnode[nxt][c0] = nd.left; S.npar[nxt][c0] = 2 * node;
+                    S.nb[nxt][c0 + 1] = b + lf; S.ne[nxt][c0 + 1] = e; S.nnode[nxt][c0 + 1] = nd.right;
+                    S.npar[nxt][c0 + 1] = 2 * node + 1;
+                    for (int q = 0; q < 3; q++) {
+                        S.box[nxt][c0][q] = dkey(INFINITY); S.box[nxt][c0][3 + q] = dkey(-INFINITY);
+                        S.box[nxt][c0 + 1][q] = dkey(INFINITY); S.box[nxt][c0 + 1][3 + q] = dkey(-INFINITY);
+                    }
+                }
+                if (node == 0) d.atree[0] = nd;              // the root's box has no parent record to live in
+                kd_publish(d.awide, nd, node, par);
             }
             if (tid == 0) S.count[cur] = 0;
+            lds_barrier();
+            KB_MARK();
             cur = nxt;
+            first = false;
         }
         __syncthreads();
         for (int i = tid; i < size; i += KB_T) {
             d.aperm[base + i] = S.id[i];
-            s.kx[base + i] = S.x[i]; s.ky[base + i] = S.y[i]; s.kz[base + i] = S.z[i];     // final position order: K1 reads leaves from here
+            s.kx[base + i] = S.x[KB_SW(i)]; s.ky[base + i] = S.y[KB_SW(i)]; s.kz[base + i] = S.z[KB_SW(i)];     // final position order: K1 reads leaves from here
         }
     }
 }
