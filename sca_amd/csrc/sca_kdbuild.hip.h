@@ -311,6 +311,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
 constexpr int KB_MAX = KD_WAVE_MAX;
 constexpr int KB_T = 1024;
 constexpr int KB_E = KB_MAX / KB_T;     // 8 consecutive positions per thread
+constexpr int KB_SMALL = 32;            // nodes this small: box by one lane walking the members
 constexpr int KB_NODES = 384;           // live nodes per level: <= 2 * KB_MAX / 11
 
 // x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KB_MAX / 8 + 8)
@@ -439,11 +440,19 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 if (v0) S.slot[KB_SW(p0)] = s0;
                 if (v1) S.slot[KB_SW(p0 + 1)] = s1;
             }
+            // extents of the positions' nodes; nodes of <= KB_SMALL members get their box from one lane each (below)
+            int nb_[2] = {0, 0}, ne_[2] = {0, 0};
+            if (s0 >= 0) { nb_[0] = S.nb[cur][s0]; ne_[0] = S.ne[cur][s0]; }
+            if (s1 >= 0) {
+                if (s1 == s0) { nb_[1] = nb_[0]; ne_[1] = ne_[0]; }
+                else { nb_[1] = S.nb[cur][s1]; ne_[1] = S.ne[cur][s1]; }
+            }
+            const bool big0 = s0 >= 0 && ne_[0] - nb_[0] > KB_SMALL, big1 = s1 >= 0 && ne_[1] - nb_[1] > KB_SMALL;
             {
                 const double x0 = S.x[KB_SW(p0)], y0 = S.y[KB_SW(p0)], z0 = S.z[KB_SW(p0)];
                 const int p1 = v1 ? p0 + 1 : p0;
                 const double x1 = S.x[KB_SW(p1)], y1 = S.y[KB_SW(p1)], z1 = S.z[KB_SW(p1)];
-                const bool pair = s0 >= 0 && s1 == s0;
+                const bool pair = big0 && s1 == s0;
                 unsigned long long key[6];                       // 0..2 minima, 3..5 inverted maxima of the lane's first segment
                 {
                     const double a0 = pair && x1 < x0 ? x1 : x0, a1 = pair && y1 < y0 ? y1 : y0, a2 = pair && z1 < z0 ? z1 : z0;
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                     key[3] = ~dkey(b0); key[4] = ~dkey(b1); key[5] = ~dkey(b2);
                 }
                 // the second position on its own when it starts another node
-                if (s1 >= 0 && s1 != s0) {
+                if (big1 && s1 != s0) {
                     atomicMin(&S.box[cur][s1][0], dkey(x1)); atomicMax(&S.box[cur][s1][3], dkey(x1));
                     atomicMin(&S.box[cur][s1][1], dkey(y1)); atomicMax(&S.box[cur][s1][4], dkey(y1));
                     atomicMin(&S.box[cur][s1][2], dkey(z1)); atomicMax(&S.box[cur][s1][5], dkey(z1));
@@ -463,36 +472,51 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 const int ref = __builtin_amdgcn_readfirstlane(s0);
                 const bool wave_uni = um == ~0ull && __all(rs == ref);
                 if (wave_uni) {
-                    if (ref >= 0) {
+                    if (ref >= 0) {                              // 128 positions: never a small node
 #pragma unroll
                         for (int k = 0; k < 6; k++) key[k] = kb_key_min<true>(key[k]);
                         if (lane == 0)
                             for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][ref][k], key[k]); atomicMax(&S.box[cur][ref][3 + k], ~key[3 + k]); }
                     }
                 } else {
+                    const bool row_red = row_uni && big0;
                     unsigned long long rk[6];
+                    for (int k = 0; k < 6; k++) rk[k] = key[k];
+                    if (__any(row_red)) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) rk[k] = kb_key_min<false>(key[k]);
-                    const bool mine = row_uni ? ((lane & 15) == 0 && rs >= 0) : (s0 >= 0);
+                        for (int k = 0; k < 6; k++) rk[k] = kb_key_min<false>(key[k]);
+                    }
+                    const bool mine = row_uni ? (row_red && (lane & 15) == 0) : big0;
                     if (mine) {
-                        const int sl = row_uni ? rs : s0;
                         for (int k = 0; k < 3; k++) {
-                            atomicMin(&S.box[cur][sl][k], row_uni ? rk[k] : key[k]);
-                            atomicMax(&S.box[cur][sl][3 + k], ~(row_uni ? rk[3 + k] : key[3 + k]));
+                            atomicMin(&S.box[cur][s0][k], row_red ? rk[k] : key[k]);
+                            atomicMax(&S.box[cur][s0][3 + k], ~(row_red ? rk[3 + k] : key[3 + k]));
                         }
                     }
+                }
+            }
+            // small nodes: one lane per node walks its members (no atomics; bottom levels are all of this kind)
+            if (tid < nc) {
+                const int b = S.nb[cur][tid], e = S.ne[cur][tid];
+                if (e - b <= KB_SMALL) {
+                    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (int p = b; p < e; p++) {
+                        const double x = S.x[KB_SW(p)], y = S.y[KB_SW(p)], z = S.z[KB_SW(p)];
+                        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
+                        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
+                        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+                    }
+                    for (int k = 0; k < 3; k++) { S.box[cur][tid][k] = dkey(mn[k]); S.box[cur][tid][3 + k] = dkey(mx[k]); }
                 }
             }
             lds_barrier();
             KB_MARK();
             // ---- B: split plane of the element's node (kdTree.py:85-96), ">= split" flags, block scan
-            int nb_[2] = {0, 0}, ne_[2] = {0, 0};
             bool live[2] = {false, false}, ge[2] = {false, false};
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int sl = k == 0 ? s0 : s1;
                 if (sl >= 0) {
-                    nb_[k] = S.nb[cur][sl]; ne_[k] = S.ne[cur][sl];
                     if (ne_[k] - nb_[k] > MAX_LEAF) {
                         live[k] = true;
                         double mn[3], mx[3];
