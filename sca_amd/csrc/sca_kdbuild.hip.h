@@ -27,6 +27,9 @@ constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
 struct KdJob { int begin, end, node, pad; };
+// workgroup -> node of a level pass: job index, first workgroup of the node, the node's extent and its split plane
+// (axis < 0: not known when the record was written -- the root -- take it from the node's box)
+struct alignas(16) KdChunkRec { int job, first, nb, ne, axis, pad; double split; };
 
 struct KdScratch {
     double *kx, *ky, *kz;     // [n] coordinates in position order
@@ -42,7 +45,7 @@ struct KdScratch {
     int chunk_cap;
     unsigned long long *cbox; // [2][job_cap][2][6] boxes of the two children, accumulated while the parent is partitioned
     unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
-    int2 *chunks[2];          // [chunk_cap] per level parity: workgroup -> (job, first workgroup of the job's node)
+    KdChunkRec *chunks[2];    // [chunk_cap] per level parity: everything a workgroup of a level pass needs, in one 32-byte read
     int *nchunks;             // [KD_MAX_LEVELS + 1] workgroups with work per level
 };
 
@@ -73,7 +76,10 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
         s.nchunks[0] = d.n > KD_WAVE_MAX ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
-    if (d.n > KD_WAVE_MAX && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) s.chunks[0][p] = make_int2(0, 0);   // the root's workgroups
+    if (d.n > KD_WAVE_MAX && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
+        KdChunkRec r; r.job = 0; r.first = 0; r.nb = 0; r.ne = d.n; r.axis = -1; r.pad = 0; r.split = 0.0;
+        s.chunks[0][p] = r;
+    }
     if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
@@ -119,17 +125,24 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
 constexpr int KD_LV_T = 512;
 constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
 
-struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid; };
 
-// workgroup -> (node, chunk) through the level's chunk table (written by the parent level's swap pass)
+// workgroup -> (node, chunk, split plane) through the level's chunk table (written by the parent level's swap pass)
+struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid, axis; double split; };
 __device__ __forceinline__ KdChunk kd_find_chunk(const KdScratch &s, int level, int blk) {
-    KdChunk c; c.valid = 0; c.job = 0; c.begin = c.end = c.node_begin = c.node_end = c.first_chunk = 0;
-    if (blk >= s.nchunks[level]) return c;
-    const int2 rec = s.chunks[level & 1][blk];
-    const KdJob job = s.jobs[level & 1][rec.x];
-    c.valid = 1; c.job = rec.x; c.node_begin = job.begin; c.node_end = job.end; c.first_chunk = rec.y;
-    c.begin = job.begin + (blk - rec.y) * KD_CHUNK;
-    c.end = c.begin + KD_CHUNK < job.end ? c.begin + KD_CHUNK : job.end;
+    KdChunk c; c.valid = 0; c.job = 0; c.begin = c.end = c.node_begin = c.node_end = c.first_chunk = 0; c.axis = 0; c.split = 0.0;
+    const int nch = s.nchunks[level];
+    const KdChunkRec rec = s.chunks[level & 1][blk];             // blk < chunk_cap always: read before the bound is known
+    if (blk >= nch) return c;
+    c.valid = 1; c.job = rec.job; c.node_begin = rec.nb; c.node_end = rec.ne; c.first_chunk = rec.first;
+    c.begin = rec.nb + (blk - rec.first) * KD_CHUNK;
+    c.end = c.begin + KD_CHUNK < rec.ne ? c.begin + KD_CHUNK : rec.ne;
+    c.axis = rec.axis; c.split = rec.split;
+    if (rec.axis < 0) {
+        const unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + rec.job) * 6;
+        double mn[3], mx[3];
+        for (int k = 0; k < 3; k++) { mn[k] = dunkey(box[k]); mx[k] = dunkey(box[3 + k]); }
+        kd_split(mn, mx, c.axis, c.split);
+    }
     return c;
 }
 
@@ -150,9 +163,8 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
-    int axis; double split, bmn[3], bmx[3];
-    kd_node_split(s, level, c.job, axis, split, bmn, bmx);
-    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
+    const int axis = c.axis;
+    const double split = c.split;
     const int b = c.node_begin;
     // ---- flags of this thread's positions (tile t covers [begin + t*T, begin + (t+1)*T)), chunk total
     unsigned flags = 0;
@@ -247,8 +259,8 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
     KdJob *out = s.jobs[(level + 1) & 1];
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
-    int axis; double split, mn[3], mx[3];
-    kd_node_split(s, level, c.job, axis, split, mn, mx);
+    const int axis = c.axis;
+    const double split = c.split;
     const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
     const int b = c.node_begin, e = c.node_end;
     const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
@@ -267,6 +279,8 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
     }
     if (tid == 0 && c.begin == b) {
         const KdJob job = in[c.job];
+        double mn[3], mx[3];
+        { int ax_; double sp_; kd_node_split(s, level, c.job, ax_, sp_, mn, mx); }
         const int leftSize = L == 0 ? 1 : L;                 // degenerate: every member on the split plane
         KdNode nd;
         nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
@@ -292,8 +306,12 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
                         const int nch = (ch[k].end - ch[k].begin + KD_CHUNK - 1) / KD_CHUNK;
                         const int base = atomicAdd(&s.nchunks[level + 1], nch);
                         if (base + nch <= s.chunk_cap) {
-                            int2 *tab = s.chunks[(level + 1) & 1];
-                            for (int q = 0; q < nch; q++) tab[base + q] = make_int2(at, base);
+                            KdChunkRec r; r.job = at; r.first = base; r.nb = ch[k].begin; r.ne = ch[k].end; r.pad = 0;
+                            double cmn[3], cmx[3];
+                            for (int q = 0; q < 3; q++) { cmn[q] = dunkey(cb[k * 6 + q]); cmx[q] = dunkey(cb[k * 6 + 3 + q]); }
+                            kd_split(cmn, cmx, r.axis, r.split);
+                            KdChunkRec *tab = s.chunks[(level + 1) & 1];
+                            for (int q = 0; q < nch; q++) tab[base + q] = r;
                         } else s.counts[KD_MAX_LEVELS + 1] = 1;
                     } else s.counts[KD_MAX_LEVELS + 1] = 1;
                 } else s.counts[KD_MAX_LEVELS + 1] = 1;
