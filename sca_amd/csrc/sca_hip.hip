@@ -680,7 +680,7 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     if (!c->near_valid) CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));   // no policy pass before
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     c->near_valid = false;
-    hipLaunchKernelGGL(k_collide_finish, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
+    hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K4_WAVES * K4_APW - 1) / (K4_WAVES * K4_APW)), dim3(K4_WAVES * 64), 0,
                        c->stream, d, c->P, agent_reach, obs_reach);
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));

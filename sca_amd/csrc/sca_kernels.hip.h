@@ -1248,75 +1248,100 @@ __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     integrate_agent(d, P, agent, d.rec[agent], act);
 }
 
-// check_agent_state (mampenv.py:61-80) + is_done (mampenv.py:51-59), one wave per agent, candidates from the
-// kd-tree of the step's OLD positions: any pair that touches after the move was within
-// r_a + r_b + 2 * max_step of each other before it.  The flags are committed into the moved record; the
-// host swaps the two record buffers afterwards.
-__device__ __forceinline__ void collide_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
-                                            int *stack, int agent, int lane) {
-    const PubRec me = d.rec_new[agent];
-    const PubRec me_old = d.rec[agent];
-    const V3 p = v3(me.px, me.py, me.pz);
-    const V3 p_old = v3(me_old.px, me_old.py, me_old.pz);
-    const bool me_goal = (me.flags & FLAG_AT_GOAL) != 0;
+// check_agent_state (mampenv.py:61-80) + is_done (mampenv.py:51-59).  Candidates come from the kd-tree of the step's OLD
+// positions: any pair that touches after the move was within r_a + r_b + 2 * max_step of each other before it.  K1 leaves
+// the <= NEAR_MAX such objects of every agent it visits, so the usual case is EIGHT AGENTS PER WAVEFRONT, eight lanes each,
+// one candidate per lane.  Agents without a list (K1 skipped them: bootstrap step; or the list overflowed) are traversed
+// afterwards by the whole wavefront, one at a time.  The flags are committed into the moved record; the host swaps the
+// two record buffers afterwards.
+struct CollideCtx {
+    PubRec me; V3 p, p_old; bool me_goal; int agent;
+};
+__device__ __forceinline__ bool collide_obstacle(const DeviceView &d, const CollideCtx &c, int o) {
+    const ObsRec r = d.obs[o];
+    return l3norm(c.p, v3(r.px, r.py, r.pz)) <= c.me.radius + r.radius;                    // mampenv.py:63-66
+}
+__device__ __forceinline__ bool collide_agent(const DeviceView &d, const CollideCtx &c, int j) {
+    const PubRec rn = d.rec_new[j];
+    const PubRec ro = d.rec[j];
+    const double rs = c.me.radius + rn.radius;
+    const V3 pn = v3(rn.px, rn.py, rn.pz);
+    // new-new is seen by whichever of the two is checked second; the mixed pair by the first one
+    bool hit = l3norm(c.p, pn) <= rs;
+    if (j > c.agent) hit = hit || (l3norm(c.p, v3(ro.px, ro.py, ro.pz)) <= rs);            // agent moved, j not yet
+    else hit = hit || (l3norm(pn, c.p_old) <= rs);                                         // j moved, agent not yet
+    return hit && !c.me_goal;                                                              // mampenv.py:72-75
+}
+__device__ __forceinline__ CollideCtx collide_ctx(const DeviceView &d, int agent, PubRec &me_old) {
+    CollideCtx c;
+    c.agent = agent;
+    c.me = d.rec_new[agent];
+    me_old = d.rec[agent];
+    c.p = v3(c.me.px, c.me.py, c.me.pz);
+    c.p_old = v3(me_old.px, me_old.py, me_old.pz);
+    c.me_goal = (c.me.flags & FLAG_AT_GOAL) != 0;
+    return c;
+}
+// whole wavefront, one agent: range queries in both trees (wave-uniform agent)
+__device__ __forceinline__ bool collide_traverse(const DeviceView &d, double agent_reach, double obs_reach, int *stack, int agent, int lane) {
+    PubRec me_old;
+    const CollideCtx c = collide_ctx(d, agent, me_old);
     bool hit = false;
-    // the pair tests of mampenv.py:63-75 against object j (id as stored in the neighbour lists)
-    auto test_obstacle = [&](int o) {
-        const ObsRec r = d.obs[o];
-        if (l3norm(p, v3(r.px, r.py, r.pz)) <= me.radius + r.radius) hit = true;           // mampenv.py:63-66
-    };
-    auto test_agent = [&](int j) {
-        const PubRec rn = d.rec_new[j];
-        const PubRec ro = d.rec[j];
-        const double rs = me.radius + rn.radius;
-        const V3 pn = v3(rn.px, rn.py, rn.pz);
-        // new-new is seen by whichever of the two is checked second; the mixed pair by the first one
-        bool c = l3norm(p, pn) <= rs;
-        if (j > agent) c = c || (l3norm(p, v3(ro.px, ro.py, ro.pz)) <= rs);                // agent moved, j not yet
-        else c = c || (l3norm(pn, p_old) <= rs);                                           // j moved, agent not yet
-        if (c && !me_goal) hit = true;                                                     // mampenv.py:72-75
-    };
+    if (d.m > 0) {
+        const double rq = c.me.radius + obs_reach;
+        kd_traverse(d.owide, c.p, rq * rq, stack, lane, [&](int begin, int end) {
+            if (lane < end - begin) hit = hit || collide_obstacle(d, c, d.operm[begin + lane]);
+        });
+    }
+    const double rq = c.me.radius + agent_reach;
+    kd_traverse(d.awide, c.p_old, rq * rq, stack, lane, [&](int begin, int end) {
+        if (lane < end - begin) { const int j = d.aperm[begin + lane]; if (j != agent) hit = hit || collide_agent(d, c, j); }
+    });
+    return __ballot(hit) != 0;
+}
+
+constexpr int K4_WAVES = 4;
+constexpr int K4_APW = 64 / NEAR_MAX;      // agents per wavefront
+static_assert(NEAR_MAX == 8, "k_collide_finish packs 8 lanes per agent");
+
+__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
+    __shared__ int stacks[K4_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane & (NEAR_MAX - 1), grp = lane / NEAR_MAX;
+    const int end = d.shard_begin + d.shard_count;
+    const int agent_raw = d.shard_begin + (blockIdx.x * K4_WAVES + wid) * K4_APW + grp;
+    const bool exists = agent_raw < end;
+    const int agent = exists ? agent_raw : end - 1;
+    PubRec me_old;
+    const CollideCtx c = collide_ctx(d, agent, me_old);
     const int near_n = d.near_n[agent];
     // an agent that had arrived or collided before this step did not move and cannot gain a flag (mampenv.py:72-75
     // never flags an agent at its goal; a collided one is flagged already)
     const bool settled = (me_old.flags & (FLAG_AT_GOAL | FLAG_COLLISION)) != 0;
-    if (settled) {
-    } else if (near_n >= 0) {
-        if (lane < near_n) {
-            const int id = d.near_id[(size_t)agent * NEAR_MAX + lane];
-            if (id & NBR_OBSTACLE_BIT) test_obstacle(id & ~NBR_OBSTACLE_BIT);
-            else test_agent(id);
-        }
-    } else {
-        if (d.m > 0) {
-            const double rq = me.radius + obs_reach;
-            kd_traverse(d.owide, p, rq * rq, stack, lane, [&](int begin, int end) {
-                if (lane < end - begin) test_obstacle(d.operm[begin + lane]);
-            });
-        }
-        const double rq = me.radius + agent_reach;
-        kd_traverse(d.awide, p_old, rq * rq, stack, lane, [&](int begin, int end) {
-            if (lane < end - begin) { const int j = d.aperm[begin + lane]; if (j != agent) test_agent(j); }
-        });
+    bool hit = false;
+    if (exists && !settled && sub < near_n) {
+        const int id = d.near_id[(size_t)agent * NEAR_MAX + sub];
+        hit = (id & NBR_OBSTACLE_BIT) ? collide_obstacle(d, c, id & ~NBR_OBSTACLE_BIT) : collide_agent(d, c, id);
     }
-    const bool any = __ballot(hit) != 0;
-    if (lane == 0) {
-        uint32_t f = me.flags;
+    bool any = ((__ballot(hit) >> (grp * NEAR_MAX)) & ((1ull << NEAR_MAX) - 1ull)) != 0;
+    unsigned long long todo = __ballot(exists && !settled && near_n < 0 && sub == 0);
+    while (todo) {
+        const int l0 = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ag = __builtin_amdgcn_readlane(agent, l0);
+        const bool r = collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane);
+        if (lane / NEAR_MAX == l0 / NEAR_MAX) any = r;
+    }
+    if (exists && sub == 0) {
+        uint32_t f = c.me.flags;
         if (any) f |= FLAG_COLLISION;
         if (d.total_dist[agent] > d.max_run_dist[agent]) f |= FLAG_TIMEOUT;               // mampenv.py:77-79
         const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
-        if (l3norm(p, g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;                     // mampenv.py:53-54
+        if (l3norm(c.p, g) <= P.near_goal_threshold) f |= FLAG_AT_GOAL;                   // mampenv.py:53-54
         d.rec_new[agent].flags = f;
         if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[(agent & 255) * 32], 1);
     }
-}
-
-__global__ __launch_bounds__(K1_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
-    __shared__ int stacks[K1_WAVES][KD_STACK];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) collide_one(d, P, agent_reach, obs_reach, stacks[wid], agent, lane);
 }
 
 // the near lists belong to the policy pass of the same step; without one, k_collide_finish must traverse
