@@ -574,7 +574,7 @@ struct alignas(16) Prep {
     double nvA;            // |vA| as float32 norm (util.py:11)
     double rad1;           // second element of np.arange(0.5, ps + 0.03, ps - 0.5)
     unsigned vp_key;       // round5 numerator of |v_pref - v_pref| (= 0) << 10, without the index
-    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint
+    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint; bits 8..: get_phi numerator of v_pref
 };
 static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
 
@@ -600,6 +600,7 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P,
     double kn;
     l3norm(vpref, vpref, &kn);
     r.vp_key = pack_key(kn, 0);
+    bits |= (unsigned)get_phi_num(vpref.x, vpref.y) << 8;                            // util.py:145 of the v_pref candidate, <= 628318
     r.bits = bits;
     out[agent] = r;
 }
@@ -1164,13 +1165,21 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             best = wave_min_u32(best);
             int chosen = (int)(best & 1023u);
             if (shunted && nS > 1) {                                                     // scaPolicy.py:119-145
+                // |l3norm(v0, vA) - l3norm(vi, vA)| < thr on the rounded values: both are k / 1e5 with integer k, so the
+                // verdict is the integer comparison |k0 - ki| vs thr * 1e5 except when they are equal (then the doubles decide)
                 const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
-                const double s0 = l3norm(cand_from_idx(T, chosen, vpref), vA64);
+                const double kthr = pol == POL_SCA ? 3000.0 : 10000.0;
+                double k0;
+                l3norm(cand_from_idx(T, chosen, vpref), vA64, &k0);
                 unsigned fail = 0xffffffffu;                                             // first list element that breaks the prefix
                 for (int e = lane; e < nS; e += 64) {
                     const unsigned k = pkS[e];
-                    const double sv = l3norm(cand_from_idx(T, (int)(k & 1023u), vpref), vA64);
-                    if (!(fabs(s0 - sv) < sthr)) fail = k < fail ? k : fail;
+                    double kv;
+                    l3norm(cand_from_idx(T, (int)(k & 1023u), vpref), vA64, &kv);
+                    const double dk = fabs(k0 - kv);
+                    bool pass = dk < kthr;
+                    if (dk == kthr) pass = fabs(k0 / EPS5 - kv / EPS5) < sthr;          // round5_py returns k / 1e5
+                    if (!pass) fail = k < fail ? k : fail;
                 }
                 fail = wave_min_u32(fail);
                 // first minimal / first maximal get_phi inside the prefix: (phi numerator, list position) as one 64-bit key
@@ -1178,7 +1187,9 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 for (int e = lane; e < nS; e += 64) {
                     const unsigned k = pkS[e];
                     if (k < fail) {
-                        const unsigned long long ph = (unsigned long long)phi_from_idx(T, (int)(k & 1023u), vpref);   // <= 628318
+                        const int ci = (int)(k & 1023u);
+                        const unsigned long long ph = ci >= T.vp_idx ? (unsigned long long)(pr.bits >> 8)
+                                                                     : (unsigned long long)T.phi[ci >= T.num_N ? ci - T.num_N : ci];   // <= 628318
                         const unsigned long long a = (ph << 32) | k, b = ((0xfffffull - ph) << 32) | k;
                         kmin = a < kmin ? a : kmin;
                         kmax = b < kmax ? b : kmax;
