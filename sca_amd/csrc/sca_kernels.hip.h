@@ -967,6 +967,28 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_full(DeviceView d, P
 // ~85 % of the 512 directions before any cone is looked at, so the candidates that pass it are COMPACTED across the
 // wavefront (ballot + prefix into an LDS list) and only those are swept, two per lane at a time.  The survivors go to
 // a second LDS list with their sort key; the selection passes run over that list.
+// Integer numerator of l3norm(a, b) = round(sqrt(|a - b|^2), 5) (util.py:104) without the correctly rounded square root:
+// rsq + one residual step gives sqrt to ~2^-46, i.e. the product with 1e5 to ~1e-9; unless that lands within 1e-6 of a
+// rounding tie (checked for the whole wavefront) its nearest integer IS the reference's numerator.  Otherwise (about one
+// wavefront in 4000) everybody takes the exact path.
+__device__ __forceinline__ double l3norm_num(V3 a, V3 b) {
+    const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    double s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    const double h = __builtin_amdgcn_rsq(s);
+    const double q0 = s * h;
+    const double q1 = fma(0.5 * fma(-q0, q0, s), h, q0);
+    const double y = q1 * EPS5;
+    double r = rint(y);
+    const bool unsure = !(fabs(fabs(y - r) - 0.5) > 1e-6) || !(s > 1e-200);        // near a tie, zero, or not finite
+    if (__any(unsure)) {
+        double k;
+        round5_py(sqrt(s), &k);
+        r = k;
+    }
+    return r;
+}
+
 struct FastLds {
     double slot[SOLVE_WAVES][K_MAX][SLOT];
     Plane planes[SOLVE_WAVES][K_MAX];
@@ -1086,9 +1108,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             auto emit = [&](bool a, V3 cdq, int ixq) {
                 const unsigned long long m = __ballot(a);
                 if (a) {
-                    double kn;
-                    l3norm(cdq, vpref, &kn);                                             // scaPolicy.py:219, as integer numerator
-                    pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(kn, ixq);
+                    pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(l3norm_num(cdq, vpref), ixq);   // scaPolicy.py:219
                 }
                 nS += __popcll(m);
             };
@@ -1169,13 +1189,11 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 // verdict is the integer comparison |k0 - ki| vs thr * 1e5 except when they are equal (then the doubles decide)
                 const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
                 const double kthr = pol == POL_SCA ? 3000.0 : 10000.0;
-                double k0;
-                l3norm(cand_from_idx(T, chosen, vpref), vA64, &k0);
+                const double k0 = l3norm_num(cand_from_idx(T, chosen, vpref), vA64);
                 unsigned fail = 0xffffffffu;                                             // first list element that breaks the prefix
                 for (int e = lane; e < nS; e += 64) {
                     const unsigned k = pkS[e];
-                    double kv;
-                    l3norm(cand_from_idx(T, (int)(k & 1023u), vpref), vA64, &kv);
+                    const double kv = l3norm_num(cand_from_idx(T, (int)(k & 1023u), vpref), vA64);
                     const double dk = fabs(k0 - kv);
                     bool pass = dk < kthr;
                     if (dk == kthr) pass = fabs(k0 / EPS5 - kv / EPS5) < sthr;          // round5_py returns k / 1e5
