@@ -139,6 +139,10 @@ int sca_set_profiling(sca_ctx *ctx, int on);
 /* number of agents that entered find_next_action since the last reset (the metric's "agent-steps") */
 int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 
+/* device self-test: numerators of l3norm(a_i, b_i) = round(|a_i - b_i|, 5) (mamp/util.py:104) as the solver's fast path
+ * computes them (fast[]) and as the literal restatement does (exact[]); they must be identical */
+int sca_selftest_l3norm(sca_ctx *ctx, int n, const double *a /*n*3*/, const double *b /*n*3*/, double *fast /*n*/, double *exact /*n*/);
+
 /* Trajectory log = Agent.history_info (mamp/agents/agent.py:75-77, filled by to_vector :126-148 at the end of every
  * update_velocitie, mamp/envs/mampenv.py:105): one 64-byte row per agent per env step, kept in HBM so that resident
  * runs (sca_run_steps) need no per-step readback.  Row r = the r-th env step after sca_history_enable; every agent logs

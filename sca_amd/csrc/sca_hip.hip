@@ -791,6 +791,22 @@ int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds on
 }
 #endif
 
+int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, double *fast, double *exact) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, n > 0 && a && b && fast && exact);
+    double *da = nullptr, *db = nullptr, *df = nullptr, *de = nullptr;
+    CHK(c, hipMalloc((void **)&da, sizeof(double) * 3 * n)); CHK(c, hipMalloc((void **)&db, sizeof(double) * 3 * n));
+    CHK(c, hipMalloc((void **)&df, sizeof(double) * n)); CHK(c, hipMalloc((void **)&de, sizeof(double) * n));
+    CHK(c, hipMemcpyAsync(da, a, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(db, b, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_selftest_l3norm, dim3((n + 63) / 64), dim3(64), 0, c->stream, da, db, n, df, de);
+    CHK(c, hipMemcpyAsync(fast, df, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipMemcpyAsync(exact, de, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(df); (void)hipFree(de);
+    return 0;
+}
+
 // ---- trajectory log (Agent.history_info, agent.py:75-77,126-148) kept in HBM --------------------------------------
 int sca_history_enable(sca_ctx *c, int capacity_rows) {
     if (!c || capacity_rows < 0) return SCA_ERR_ARG;

@@ -989,6 +989,17 @@ __device__ __forceinline__ double l3norm_num(V3 a, V3 b) {
     return r;
 }
 
+// self-test of l3norm_num against the exact path (tests/test_gpu_parity.py feeds random and near-tie inputs)
+__global__ __launch_bounds__(64) void k_selftest_l3norm(const double *a, const double *b, int n, double *fast, double *exact) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = i < n ? i : n - 1;
+    const V3 va = v3(a[3 * j], a[3 * j + 1], a[3 * j + 2]), vb = v3(b[3 * j], b[3 * j + 1], b[3 * j + 2]);
+    const double f = l3norm_num(va, vb);
+    double k;
+    l3norm(va, vb, &k);
+    if (i < n) { fast[i] = f; exact[i] = k; }
+}
+
 struct FastLds {
     double slot[SOLVE_WAVES][K_MAX][SLOT];
     Plane planes[SOLVE_WAVES][K_MAX];

@@ -448,3 +448,35 @@ def test_episode_metrics_of_c1(S):
     assert m['SuccessRate'] == 1.0 and m['successful_num'] == 8
     assert 0.8 < m['AverageSpeed'] <= 1.0 + 1e-9 and m['ExtraDistance'] >= 0.0
     assert m['all_step_num'] == int(env.step_num.sum())
+
+
+def test_l3norm_numerator_fast_path_is_exact(S):
+    """k_solve takes round(|a-b|, 5) * 1e5 from rsq + one residual step, guarded by a distance-to-tie check.  On random
+    inputs and on inputs built to sit at / next to rounding ties it must equal the literal restatement, which itself must
+    equal Python's round(math.sqrt(...), 5) (util.py:104)."""
+    import ctypes as C
+    import math
+    from sca_amd import _lib
+    rng = np.random.default_rng(7)
+    n = 1 << 16
+    a = rng.uniform(-3, 3, (n, 3))
+    b = rng.uniform(-3, 3, (n, 3))
+    # ties and near-ties: |a - b| = (k + 0.5) / 1e5 * (1 + eps), eps in {0, +-1 ulp, +-1e-9, +-1e-7}
+    m = n // 2
+    k = rng.integers(0, 400000, m).astype(np.float64)
+    eps = rng.choice([0.0, 2.2e-16, -2.2e-16, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7], m)
+    d = (k + 0.5) / 1e5 * (1.0 + eps)
+    a[:m] = 0.0; b[:m] = 0.0
+    a[:m, 0] = d
+    a[m - 1] = b[m - 1]                                       # zero distance
+    sol = S.BatchedSolver(max_agents=1, max_obstacles=1)
+    fast = np.zeros(n); exact = np.zeros(n)
+    rc = sol.L.sca_selftest_l3norm(sol.ctx, n, _lib.ptr(a, C.c_double), _lib.ptr(b, C.c_double), _lib.ptr(fast, C.c_double), _lib.ptr(exact, C.c_double))
+    assert rc == 0
+    assert np.array_equal(fast, exact)
+    idx = np.concatenate([np.arange(0, 2000), np.arange(m, m + 2000)])
+    for i in idx:
+        dd = a[i] - b[i]
+        ref = round(math.sqrt((dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]), 5)
+        assert exact[i] == round(ref * 1e5), i
+    sol.close()
