@@ -171,9 +171,10 @@ def main():
             'metric': 'agent_steps_per_sec', 'value': value, 'unit': 'agent-steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': w['desc'] + (f' -- weak scaling: {w["n"] if not args.agents else args.agents} agents per GPU'
-                                                if world > 1 and args.scaling == 'weak' else ''),
-                       'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': 'kd-tree replica (host build, device query)',
+            'config': {'workload': w['desc'] + (f' [--agents {args.agents}]' if args.agents else '')
+                       + (f' -- weak scaling: {w["n"] if not args.agents else args.agents} agents per GPU'
+                          if world > 1 and args.scaling == 'weak' else ''),
+                       'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': 'kd-tree of kdTree.py rebuilt on the device every step (replicated per rank), device query',
                        'v_pref': ('straight-line rule on device (the Dubins tracker is host-side, outside the kernel boundary)'
                                   if args.vpref == 'straight' else 'native Dubins tracker on the host every step (end-to-end SCA)'),
                        'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'

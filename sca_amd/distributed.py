@@ -11,17 +11,18 @@ returning (full tensor, this rank's slice) -- tests drive the same class on CPU 
 
 
 class ShardedStepper:
-    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0, staged=False):
+    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0, staged=False, force_exchange=False):
         """staged=True exchanges through host memory (for backends without GPU collectives, e.g. gloo when several
         ranks share one GPU in tests); the default hands the device buffers to the collective directly (RCCL)."""
         self.staged = staged
+        self.exchange = int(world) > 1 or force_exchange      # force_exchange: the begin / all-gather / end path even alone
         self.sol = solver
         self.rank, self.world = int(rank), int(world)
         self.torch = torch_mod
         self.dist = dist_mod
         self.mode = mode
         n = solver.n
-        if self.world > 1:
+        if self.exchange:
             if n % self.world:
                 raise ValueError(f'{n} agents do not split evenly over {self.world} ranks')
             self.count = n // self.world
@@ -54,7 +55,7 @@ class ShardedStepper:
         return full, full[self.rank * self._per:(self.rank + 1) * self._per]
 
     def run(self, steps):
-        if self.world == 1:
+        if not self.exchange:
             self.sol.run_steps(steps, self.mode)
             return
         for _ in range(int(steps)):

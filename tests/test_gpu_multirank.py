@@ -58,3 +58,49 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count('OK') == 2, r.stdout[-3000:]
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sca_amd import scenarios, solver as S
+from sca_amd.distributed import ShardedStepper
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))          # backend "nccl" is RCCL on ROCm
+n, steps = 4096, 10
+sc = scenarios.circle(n)
+
+def make():
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1, device=0)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], np.zeros(n, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
+                   scenarios.max_run_dist(sc['start'], sc['goal']))
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    return sol
+
+sol = make()
+st = ShardedStepper(sol, 0, 1, torch_mod=torch, dist_mod=dist, force_exchange=True)   # device buffers straight into the collective
+st.run(steps); st.sync()
+dist.barrier(); torch.cuda.synchronize()
+got = sol.get_state()
+ref_sol = make()
+ref_sol.run_steps(steps); ref_sol.synchronize()
+ref = ref_sol.get_state()
+ok = all(np.array_equal(got[k], ref[k]) for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'))
+print('RCCL', 'OK' if ok else 'MISMATCH', flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_rccl_in_place_all_gather_path_single_rank(tmp_path):
+    """The exchange exactly as bench.py --gpus N runs it (bound device record buffers, in-place all_gather_into_tensor on
+    the RCCL backend, library kernels on torch's current stream), with the one rank a 1-GPU box offers."""
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29543', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'RCCL OK' in r.stdout, r.stdout[-3000:]
