@@ -563,7 +563,8 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
 // ------------------------------------------------------------------------------------------------
 // K2/K3: one wavefront per agent.
 constexpr int SOLVE_WAVES = 4;
-constexpr int SLOT = 16;                  // doubles per neighbour slot in LDS
+constexpr int SLOT = 16;                  // doubles per neighbour slot in LDS (k_solve_full: cone + R, absSq for time-to-collision)
+constexpr int SLOTF = 8;                  // k_solve: apex / point (3), pAB / normal (3), g
 constexpr int NR = 8;                     // candidate rounds: 8 * 64 = 512 table candidates
 
 // Per-agent scalar prologue of find_next_action, computed ONE LANE PER AGENT (inside k_kd_gather, or k_prep when the
@@ -705,8 +706,8 @@ __device__ __forceinline__ int select_from_list(bool shunted, double thr, int co
 
 // The hot loop: K neighbours x NROUND candidates per lane, branch-free.  Per pair (cone): 3 sub, 2x(mul+2 fma), 2 mul,
 // 2 compares -- all fp64, no transcendental (the asin/acos comparison of util.py:30-41 in algebraic form).
-template <int NROUND, bool ORCA, int NA, int NB>
-__device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, const V3 (&sh)[NA], const V3 (&cand)[NB],
+template <int NROUND, bool ORCA, int NA, int NB, int SL>
+__device__ __forceinline__ unsigned sweep(const double (*slot)[SL], int K, const V3 (&sh)[NA], const V3 (&cand)[NB],
                                           unsigned alive) {
     for (int j = 0; j < K; j++) {
         const double *s = slot[j];
@@ -735,8 +736,8 @@ __device__ __forceinline__ unsigned sweep(const double (*slot)[SLOT], int K, con
 // The same pair test for a short tail of candidates (R <= 32): the wavefront is split into G = 64 / R' neighbour
 // groups (R' = R rounded up to a power of two), lane = g * R' + t tests candidate t against neighbours g, g + G, ...;
 // the caller ORs the groups' verdicts through one ballot.  K / G iterations instead of K.
-template <bool ORCA>
-__device__ __forceinline__ bool sweep_split(const double (*slot)[SLOT], int K, int G, int g, V3 sh, V3 cand) {
+template <bool ORCA, int SL>
+__device__ __forceinline__ bool sweep_split(const double (*slot)[SL], int K, int G, int g, V3 sh, V3 cand) {
     bool hit = false;
     for (int j = g; j < K; j += G) {
         const double *s = slot[j];
@@ -852,8 +853,8 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
             const bool vp_post = posture_ok(P, vA, nvA, pA.z, vpref);
             // table candidates: neighbours outer (constants broadcast from LDS), candidates in registers
             unsigned alive;
-            if (nround == NR) alive = orca ? sweep<NR, true, NR, NR + 1>(slot, K, sh, cand, okp) : sweep<NR, false, NR, NR + 1>(slot, K, sh, cand, okp);
-            else alive = orca ? sweep<NR / 2, true, NR, NR + 1>(slot, K, sh, cand, okp) : sweep<NR / 2, false, NR, NR + 1>(slot, K, sh, cand, okp);
+            if (nround == NR) alive = orca ? sweep<NR, true, NR, NR + 1, SLOT>(slot, K, sh, cand, okp) : sweep<NR, false, NR, NR + 1, SLOT>(slot, K, sh, cand, okp);
+            else alive = orca ? sweep<NR / 2, true, NR, NR + 1, SLOT>(slot, K, sh, cand, okp) : sweep<NR / 2, false, NR, NR + 1, SLOT>(slot, K, sh, cand, okp);
             // v_pref candidate: lane j tests neighbour j
             bool vp_hit = false;
             if (lane < K) {
@@ -1001,11 +1002,12 @@ __global__ __launch_bounds__(64) void k_selftest_l3norm(const double *a, const d
 }
 
 struct FastLds {
-    double slot[SOLVE_WAVES][K_MAX][SLOT];
-    Plane planes[SOLVE_WAVES][K_MAX];
-    Plane proj[SOLVE_WAVES][K_MAX];
-    unsigned int pkS[SOLVE_WAVES][520];          // survivors: (round5 numerator of |v - v_pref|) << 10 | generation index
-    unsigned short listA[SOLVE_WAVES][512];
+    double slot[SOLVE_WAVES][K_MAX][SLOTF];
+    union PerWave {                                // the LP policy never builds candidate lists
+        struct { Plane planes[K_MAX]; Plane proj[K_MAX]; } lp;
+        struct { unsigned int pkS[520];            // survivors: (round5 numerator of |v - v_pref|) << 10 | generation index
+                 unsigned short listA[512]; } cl;
+    } u[SOLVE_WAVES];
 };
 
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
-        double (*slot)[SLOT] = S.slot[wid];
+        double (*slot)[SLOTF] = S.slot[wid];
         if (lane < K) {                                   // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
             const int nid = d.nbr_id[agent * K_MAX + lane];
             V3 pB; F3 vB; double rB; bool stat; const bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
@@ -1052,7 +1054,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 const OrcaOb o = make_orca(P, pA, vA, rA, pB, vB, rB, isob);
                 sl[0] = o.pl.p.x; sl[1] = o.pl.p.y; sl[2] = o.pl.p.z; sl[3] = o.pl.n.x; sl[4] = o.pl.n.y; sl[5] = o.pl.n.z; sl[6] = 0.0;
                 Plane pl; pl.p = o.pl.p; pl.n = o.pl.n;
-                S.planes[wid][lane] = pl;
+                S.u[wid].lp.planes[lane] = pl;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1061,8 +1063,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             V3 nv = v3(0, 0, 0);
             int pf = 0, l4 = 0;
             if (lane == 0) {
-                pf = lp3(S.planes[wid], K, P.max_speed, vpref, false, nv);
-                if (pf < K) { lp4(S.planes[wid], K, pf, P.max_speed, nv, S.proj[wid]); l4 = 1; }
+                pf = lp3(S.u[wid].lp.planes, K, P.max_speed, vpref, false, nv);
+                if (pf < K) { lp4(S.u[wid].lp.planes, K, pf, P.max_speed, nv, S.u[wid].lp.proj); l4 = 1; }
             }
             vpost = v3(__shfl(nv.x, 0), __shfl(nv.y, 0), __shfl(nv.z, 0));
             dg_pfail = __shfl(pf, 0);
@@ -1076,8 +1078,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             T.rad1 = pr.rad1;
             const int nround = T.vp_idx >> 6;
             const double nvA = pr.nvA;
-            unsigned short *listA = S.listA[wid];
-            unsigned int *pkS = S.pkS[wid];
+            unsigned short *listA = S.u[wid].cl.listA;
+            unsigned int *pkS = S.u[wid].cl.pkS;
             // ---- posture filter (util.py:6-20) + compaction.  c >= thr is decided without sqrt / division whenever
             //      dot^2 and (thr*|vA|)^2 |v|^2 are more than 1e-13 apart (relative); otherwise the exact expression runs.
             const double thr = P.cos_heading_thr;
@@ -1133,7 +1135,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     cd[q] = cand_from_idx(T, ix[q], vpref);
                     sh[q] = cd[q] + pA;
                 }
-                const unsigned alive = orca ? sweep<2, true, 2, 2>(slot, K, sh, cd, 3u) : sweep<2, false, 2, 2>(slot, K, sh, cd, 3u);
+                const unsigned alive = orca ? sweep<2, true, 2, 2, SLOTF>(slot, K, sh, cd, 3u) : sweep<2, false, 2, 2, SLOTF>(slot, K, sh, cd, 3u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) emit((alive >> q) & 1u, cd[q], ix[q]);
             }
@@ -1146,7 +1148,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     cd[0] = cand_from_idx(T, ix, vpref);
                     sh[0] = cd[0] + pA;
                     const unsigned valid = lane < cnt ? 1u : 0u;
-                    const unsigned alive = orca ? sweep<1, true, 1, 1>(slot, K, sh, cd, valid) : sweep<1, false, 1, 1>(slot, K, sh, cd, valid);
+                    const unsigned alive = orca ? sweep<1, true, 1, 1, SLOTF>(slot, K, sh, cd, valid) : sweep<1, false, 1, 1, SLOTF>(slot, K, sh, cd, valid);
                     emit(alive & 1u, cd[0], ix);
                     c0 += cnt;
                 } else {
@@ -1156,7 +1158,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     const int t = lane & (Rp - 1), g = lane / Rp;
                     const int ix = t < rem ? (int)listA[c0 + t] : 0;
                     const V3 cd = cand_from_idx(T, ix, vpref);
-                    const bool hit = orca ? sweep_split<true>(slot, K, G, g, cd + pA, cd) : sweep_split<false>(slot, K, G, g, cd + pA, cd);
+                    const bool hit = orca ? sweep_split<true, SLOTF>(slot, K, G, g, cd + pA, cd) : sweep_split<false, SLOTF>(slot, K, G, g, cd + pA, cd);
                     unsigned long long m = __ballot(hit);
                     for (int w = 32; w >= Rp; w >>= 1) m |= m >> w;                       // OR over the neighbour groups
                     emit((lane < rem) & !((m >> t) & 1ull), cd, ix);
@@ -1241,7 +1243,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     }
 }
 
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(DeviceView d, Params P) {
+__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Params P) {
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
