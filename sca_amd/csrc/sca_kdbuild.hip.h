@@ -22,7 +22,7 @@
 
 namespace sca {
 
-constexpr int KD_WAVE_MAX = 2048;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
+constexpr int KD_WAVE_MAX = 1024;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
 constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
 // One workgroup finishes one subtree of <= KB_MAX members in LDS.  Every level is one element-parallel pass over all
 // of the subtree's positions: each thread owns KB_E consecutive positions.
 constexpr int KB_MAX = KD_WAVE_MAX;
-constexpr int KB_T = 1024;
+constexpr int KB_T = 512;
 constexpr int KB_E = KB_MAX / KB_T;     // 8 consecutive positions per thread
 constexpr int KB_SMALL = 32;            // nodes this small: box by one lane walking the members
-constexpr int KB_NODES = 384;           // live nodes per level: <= 2 * KB_MAX / 11
+constexpr int KB_NODES = 192;           // live nodes per level: <= 2 * KB_MAX / 11
 
 // x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KB_MAX / 8 + 8)
 // + (p >> 3), so that both patterns touch all LDS banks evenly (rows of 256 + 8: four rows of doubles tile the 64 banks)
