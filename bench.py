@@ -212,7 +212,8 @@ def cpu_baseline(scene, sol, S):
     n = scene['n']
     sc = scene['sc']
     st = sol.get_state()
-    cores = min(os.cpu_count() or 1, 64)
+    from sca_amd import hostinfo
+    cores = min(hostinfo.usable_cores(), 64)            # affinity AND cgroup quota: threads beyond it only oversubscribe
     perm = sol.get_kd_perm()
     vmode = np.zeros(n, np.uint8)
     args = (st['pos'], st['vel'], st['heading'], scene['radius'], scene['pref_speed'], st['flags'], sc['goal'][:, :3],

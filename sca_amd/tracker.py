@@ -5,6 +5,8 @@ import ctypes as C
 import math
 import os
 
+from . import hostinfo
+
 import numpy as np
 
 from . import _lib
@@ -24,7 +26,7 @@ class DubinsTracker:
                                            float(turning_radius), float(pitchlims[0]), float(pitchlims[1]), float(neighbor_dist))
         if not self.h:
             raise RuntimeError('sca_tracker_create failed')
-        self.nthreads = nthreads or min(os.cpu_count() or 1, 256)
+        self.nthreads = nthreads or min(hostinfo.usable_cores(), 256)
         self._nbr0 = np.full(n, -1.0)          # agent.neighbors[0][1] as the last computeNeighbors left it
 
     def close(self):

@@ -132,3 +132,9 @@ def test_binvox_rejects_garbage(tmp_path):
     p.write_bytes(b'#binvox 1\ndim 2 2 2\ntranslate 0 0 0\nscale 1\ndata\n\x01\x03\x00\x05')
     m = read_map.read_as_3d_array(open(p, 'rb'))
     assert m.data.sum() == 3
+
+
+def test_usable_cores_respects_quota(monkeypatch, tmp_path):
+    from sca_amd import hostinfo
+    n = hostinfo.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
