@@ -108,3 +108,21 @@ def spawn_n_drones(n, center=(35.0, 30.0), rad=10.0, environment='exp3'):
         start.append([center[0] + rad * c, center[1] + rad * s, height, np.deg2rad(-90 - i * 360 / n), 0, 0])
         goal.append([center[0] - rad * c, center[1] - rad * s, height, np.deg2rad(90 - i * 360 / n), 0, 0])
     return dict(start=np.array(start, float), goal=np.array(goal, float), obs_pos=np.zeros((0, 3)), obs_radius=np.zeros(0))
+
+
+def sphere(n, rad=25.0, z_value=30.0):
+    """run_example/run_orca.py:36-54 set_sphere (also run_rvo.py, run_srvo.py): n starts on a Fibonacci sphere of radius 25
+    lifted by 30 m, goals at the antipodes, all headings 0."""
+    phi = (math.sqrt(5.0) - 1.0) / 2.0
+    start, goal = [], []
+    for k in range(1, n + 1):
+        zn = (2 * k - 1) / n - 1
+        xn = math.sqrt(1 - zn ** 2) * math.cos(2 * math.pi * k * phi)
+        yn = math.sqrt(1 - zn ** 2) * math.sin(2 * math.pi * k * phi)
+        p = np.array([rad * xn, rad * yn, rad * zn, 0.0, 0.0, 0.0])
+        g = -p
+        p[2] += z_value
+        g[2] += z_value
+        start.append(p)
+        goal.append(g)
+    return dict(start=np.array(start, float), goal=np.array(goal, float), obs_pos=np.zeros((0, 3)), obs_radius=np.zeros(0))

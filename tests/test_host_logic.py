@@ -138,3 +138,20 @@ def test_usable_cores_respects_quota(monkeypatch, tmp_path):
     from sca_amd import hostinfo
     n = hostinfo.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_scenario_generators_match_reference_fixtures():
+    """sphere / circle / take-off generators against the start and goal states the reference's own generator functions
+    produced for the golden fixtures (run_orca.py:17-54, run_sca.py:17-30,53-81)."""
+    from golden_util import load
+    from sca_amd import scenarios
+    fx = load('F3_srvo_sphere100')
+    sc = scenarios.sphere(100)
+    assert np.array_equal(sc['start'], fx['start']) and np.array_equal(sc['goal'], fx['goal6'])
+    fx = load('F1_sca_circle8')
+    sc = scenarios.circle(8, rad=10.0)
+    assert np.array_equal(sc['start'], fx['start']) and np.array_equal(sc['goal'], fx['goal6'])
+    fx = load('F4_sca_takeoff16')
+    sc = scenarios.takeoff_landing(16)
+    assert np.array_equal(sc['start'], fx['start']) and np.array_equal(sc['goal'], fx['goal6'])
+    assert np.array_equal(sc['obs_pos'], fx['obs_pos'])
