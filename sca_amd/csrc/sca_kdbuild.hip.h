@@ -11,12 +11,14 @@
 //     every other element stays where it is.
 // That form is data-parallel: one prefix count per element.
 //
-//   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced
+//   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced;
+//                 root box; the per-agent prologue of the solver for the rank's shard
 //   k_kd_lv_*   : two launches per tree level for the nodes with more than KD_WAVE_MAX members; a node is cut into
 //                 chunks of KD_CHUNK positions, one workgroup per chunk: (flags + chained scan + ranks + children's
-//                 boxes) -> (swaps + node record + children)
+//                 boxes) -> (swaps + query record + children and their chunk records)
 //   k_kd_block  : every subtree of <= KD_WAVE_MAX members is finished by ONE WORKGROUP entirely in LDS, level by level,
-//                 all nodes of a level at once (element-parallel; boxes by LDS atomics on order-preserving keys)
+//                 all nodes of a level at once (element-parallel; boxes as DPP minima of order-preserving keys, LDS
+//                 atomics for what is left, one lane per node for the records)
 #pragma once
 #include "sca_kernels.hip.h"
 
@@ -33,7 +35,7 @@ struct alignas(16) KdChunkRec { int job, first, nb, ne, axis, pad; double split;
 
 struct KdScratch {
     double *kx, *ky, *kz;     // [n] coordinates in position order
-    int *ml, *mr;             // [n] positions of the k-th misplaced element on the left / right side
+    int *mr;                  // [n] mr[b + j - 1] = position of the j-th "< split" member of the node that starts at b
     KdJob *jobs[2];           // ping-pong lists of nodes with > KD_WAVE_MAX members
     KdJob *small;             // [n] subtrees handed to k_kd_block
     int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
 // of the subtree's positions: each thread owns KB_E consecutive positions.
 constexpr int KB_MAX = KD_WAVE_MAX;
 constexpr int KB_T = 512;
-constexpr int KB_E = KB_MAX / KB_T;     // 8 consecutive positions per thread
+constexpr int KB_E = KB_MAX / KB_T;     // consecutive positions per thread (2)
 constexpr int KB_SMALL = 32;            // nodes this small: box by one lane walking the members
 constexpr int KB_NODES = 192;           // live nodes per level: <= 2 * KB_MAX / 11
 

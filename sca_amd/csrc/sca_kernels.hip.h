@@ -1,12 +1,15 @@
 // sca_kernels.hip.h -- gfx950 kernels of the batched SCA / RVO3D / S-RVO3D / ORCA3D velocity solver.
 //
-//   k_neighbors_kd : replica of KDTree.query*TreeRecursive + Agent.insert*Neighbor  (kdTree.py:127-262,
-//                    agent.py:79-124), one lane per agent, explicit stack + bounded sorted list in LDS.
-//   k_solve        : cone / half-space construction + 513-candidate sweep + selection (or LP1-4),
-//                    ONE WAVEFRONT (64 lanes) PER AGENT, neighbour constants staged in LDS and read as
-//                    wave-uniform broadcasts, selection by wave-level tuple reductions / ballots.
-//   k_integrate / k_collide_finish : MACAEnv second loop (mampenv.py:42-59); integrate is fused into k_solve
-//                    when the state stays resident (sca_run_steps).
+//   k_neighbors_kd / k_neighbors_kd4 : replica of KDTree.query*TreeRecursive + Agent.insert*Neighbor (kdTree.py:127-262,
+//                    agent.py:79-124): one wavefront per agent, or four agents per wavefront (16 lanes = one DPP row
+//                    each) once the shard fills the chip; bounded sorted list one entry per lane.
+//   k_solve        : cone / half-space construction + posture filter + compacted candidate sweep + selection (or
+//                    LP1-4), ONE WAVEFRONT (64 lanes) PER AGENT, neighbour constants staged in LDS and read as
+//                    wave-uniform broadcasts, selection by packed integer keys and DPP wave minima.
+//                    k_solve_full finishes the rare agents without a suitable candidate (compute_without_suitV).
+//   k_action       : cartesian2spherical + float32 action row, one lane per agent; also update_velocitie
+//                    (mampenv.py:83-105) and the trajectory log when the state stays resident (sca_run_steps).
+//   k_collide_finish : check_agent_state + is_done (mampenv.py:51-80), eight agents per wavefront.
 //
 // HBM layout: one 48-byte PubRec per agent (pos f64x3, vel f32x3, flags, radius) -- the only thing other
 // agents / other GPUs read; private per-agent arrays are SoA.  No MFMA: there is no contraction here.
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const int g = lane >> 4, gl = lane & 15, gbase = g << 4, gshift = g << 4;
+    const int g = lane >> 4, gl = lane & 15, gshift = g << 4;
     const int end = d.shard_begin + d.shard_count;
     const int agent_raw = d.shard_begin + (blockIdx.x * K1P_WAVES + wid) * K1P_APW + g;
     const bool exists = agent_raw < end;
@@ -1076,7 +1079,6 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
             T.vp_idx = 2 * T.num_N;
             T.rad1 = pr.rad1;
-            const int nround = T.vp_idx >> 6;
             const double nvA = pr.nvA;
             unsigned short *listA = S.u[wid].cl.listA;
             unsigned int *pkS = S.u[wid].cl.pkS;
