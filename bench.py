@@ -185,7 +185,7 @@ def main():
                          'bytes_per_agent_step': BYTES_PER_AGENT_STEP,
                          'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU leg is a single-GPU (rank 0, N = 1) measurement
             out['cpu_baseline'] = cpu_baseline(scene, sol, S)
         print(json.dumps(out), flush=True)
     sol.close()
