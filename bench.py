@@ -81,11 +81,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch
     dist = None
+    # test hook: all ranks on GPU 0 with a host-staged gloo exchange, to exercise this script's N > 1 path on a 1-GPU box
+    share_gpu = bool(os.environ.get('SCA_BENCH_SHARE_GPU'))
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: libsca_hip has no CPU path')
 
@@ -108,7 +115,7 @@ def main():
     sol.set_agents(scene['radius'], scene['pref_speed'], sc['goal'][:, :3], scene['policy'], scene['zaxis'],
                    scene['max_run_dist'])
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
-    stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist)
+    stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu)
 
     if args.vpref == 'dubins':
         if world > 1:
@@ -153,10 +160,11 @@ def main():
     my_steps = sol.agent_steps(reset=True)
     kms = sol.kernel_ms()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        red_dev = 'cpu' if share_gpu else 'cuda'
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([my_steps], dtype=torch.int64, device='cuda')
+        c = torch.tensor([my_steps], dtype=torch.int64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_steps = int(c.item())
     else:

@@ -104,3 +104,20 @@ def test_rccl_in_place_all_gather_path_single_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'RCCL OK' in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_script_two_rank_path():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), with the ranks sharing
+    GPU 0 through the script's test hook: one JSON line from rank 0, whole-job agent-steps summed over the ranks."""
+    import json
+    env = dict(os.environ, SCA_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
+                        '--warmup', '3', '--agents', '6000'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['agents'] == 12000
+    assert out['config']['agent_steps_timed'] == 12000 * 6
+    assert out['value'] > 0 and 'roofline' in out and 'cpu_baseline' not in out
