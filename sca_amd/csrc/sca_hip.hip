@@ -289,7 +289,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.coll_new, N); r |= dalloc(c, &d.nbr_valid, N);
     r |= dalloc(c, &d.near_n, N); r |= dalloc(c, &d.near_id, N * NEAR_MAX);
     r |= dalloc(c, &d.action, N * 8); r |= dalloc(c, &d.vpref_used, 3 * N); r |= dalloc(c, &d.vpost, 3 * N);
-    r |= dalloc(c, &d.fb_list, N); r |= dalloc(c, &d.fb_count, 1);
+    r |= dalloc(c, &d.fb_list, N); r |= dalloc(c, &d.fb_count, 1); r |= dalloc(c, &d.is_fb, N);
     { Prep *pp = nullptr; r |= dalloc(c, &pp, N); d.prep = pp; } r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
@@ -334,7 +334,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
-                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.prep, d.diag, d.status,
+                    d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], c->kd.nchunks, d.hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -653,10 +653,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-    // agents without any suitable candidate (rare): the complete sweep incl. compute_without_suitV
-    hipLaunchKernelGGL(k_solve_full, dim3(std::max(1, std::min(4096, (cnt + SOLVE_WAVES - 1) / SOLVE_WAVES))), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-    if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
-    else hipLaunchKernelGGL(k_action<false>, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    // epilogue (one lane per agent) + the agents without any suitable candidate (rare; one wavefront each), one launch
+    const int ablocks = (cnt + 255) / 256;
+    if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
+    else hipLaunchKernelGGL(k_action<false>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
     if (fuse_integrate && c->d.hist) c->d.hist_row++;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         s.chunks[0][p] = r;
     }
     if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
+    if (p == 0) *d.fb_count = 0;                                             // ... and an empty fallback list
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
         const int id = d.aperm[p];

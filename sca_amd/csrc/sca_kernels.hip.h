@@ -85,6 +85,7 @@ struct DeviceView {
     void *prep;              // [n] Prep records (per-agent scalar prologue)
     int32_t *fb_list;        // [n] agents without a suitable candidate: finished by k_solve_full
     int32_t *fb_count;       // [1]
+    uint8_t *is_fb;          // [n] 1: k_solve handed the agent to the fallback list (the epilogue kernel finishes it)
     int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
@@ -953,19 +954,6 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     if (lane != 0 && st) atomicOr(&d.status[agent], st);
 }
 
-// The complete sweep (all 513 candidates per agent in registers, incl. compute_without_suitV).  It runs only for the
-// agents k_solve could not finish (no suitable candidate: scaPolicy.py:224-238), taken from the fallback list.
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_full(DeviceView d, Params P) {
-    __shared__ SolveLds S;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = *d.fb_count;
-    for (int i = blockIdx.x * SOLVE_WAVES + wid; i < n; i += gridDim.x * SOLVE_WAVES) {
-        solve_one(d, P, S, d.fb_list[i], lane, wid);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2 fast path.  The posture constraint (util.py:6-20: within max_heading_change of the current velocity) removes
 // ~85 % of the 512 directions before any cone is looked at, so the candidates that pass it are COMPACTED across the
@@ -1016,6 +1004,7 @@ struct FastLds {
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
+    if (lane == 0) d.is_fb[agent] = 0;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
         if (lane < 8) diag[lane] = -1;
         if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
@@ -1188,7 +1177,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             dg_nsuit = nS;
             if (nS == 0) {
                 // no suitable candidate: compute_without_suitV needs all 513 candidates -> k_solve_full finishes this agent
-                if (lane == 0) { const int at = atomicAdd(d.fb_count, 1); d.fb_list[at] = agent; }
+                if (lane == 0) { const int at = atomicAdd(d.fb_count, 1); d.fb_list[at] = agent; d.is_fb[agent] = 1; }
                 return;
             }
             dg_fallback = 0;
@@ -1256,16 +1245,14 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Par
 
 __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
     const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent == 0) *d.fb_count = 0;                                       // start of a pass: empty fallback list
     if (agent < d.n) prep_agent(d, P, (Prep *)d.prep, agent);
 }
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
 template <bool FUSE_INTEGRATE>
-__global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d.fb_count = 0;            // k_solve_full has run: ready for the next pass
-    if (agent >= d.shard_begin + d.shard_count) return;
+__device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent) {
     PubRec me = d.rec[agent];
     float actf[7] = {0, 0, 0, 0, 0, 0, 0};
     if (!(me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) {                // mampenv.py:35: else the row stays zero
@@ -1282,6 +1269,33 @@ __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
     for (int k = 0; k < 7; k++) out[k] = actf[k];
     out[7] = 0.0f;
     if (FUSE_INTEGRATE) integrate_agent(d, P, agent, me, actf);
+}
+
+// K2 epilogue and fallback in ONE launch.  Blocks [0, action_blocks): one LANE per agent (see above), skipping the agents
+// k_solve could not finish.  The remaining blocks: one wavefront per entry of the fallback list runs the complete sweep
+// (all 513 candidates in registers, incl. compute_without_suitV, scaPolicy.py:224-238) and then the same epilogue for that
+// agent.  The two halves never touch the same agent, so they need no order.
+constexpr int FB_BLOCKS = 1024;
+template <bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action(DeviceView d, Params P, int action_blocks) {
+    __shared__ SolveLds S;
+    if ((int)blockIdx.x < action_blocks) {
+        const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+        if (agent >= d.shard_begin + d.shard_count) return;
+        if (d.is_fb[agent]) return;
+        action_one<FUSE_INTEGRATE>(d, P, agent);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *d.fb_count;
+    for (int i = ((int)blockIdx.x - action_blocks) * SOLVE_WAVES + wid; i < n; i += FB_BLOCKS * SOLVE_WAVES) {
+        const int agent = d.fb_list[i];
+        solve_one(d, P, S, agent, lane, wid);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) action_one<FUSE_INTEGRATE>(d, P, agent);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
