@@ -208,7 +208,7 @@ def test_resident_steps_match_stepwise_oracle(S, oracle):
     sol.close()
 
 
-@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 200, 257, 300, 1000, 5000, 40000])
+@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 200, 257, 300, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 5000, 40000])
 def test_device_kd_build_matches_host_replica(S, n):
     """K0: the kd-tree built on the device (nodes, boxes, permutation) against the sequential host replica of
     kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent)."""
