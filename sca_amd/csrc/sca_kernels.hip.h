@@ -710,9 +710,12 @@ __device__ __forceinline__ int select_from_list(bool shunted, double thr, int co
 
 // The hot loop: K neighbours x NROUND candidates per lane, branch-free.  Per pair (cone): 3 sub, 2x(mul+2 fma), 2 mul,
 // 2 compares -- all fp64, no transcendental (the asin/acos comparison of util.py:30-41 in algebraic form).
-template <int NROUND, bool ORCA, int NA, int NB, int SL>
+// EARLY: leave the loop once every candidate of the wavefront is dead (worth it for the 8-round form of the complete
+// sweep; in k_solve's short groups the test costs more scalar work per trip than the rare early exit saves).
+template <int NROUND, bool ORCA, int NA, int NB, int SL, bool EARLY = true>
 __device__ __forceinline__ unsigned sweep(const double (*slot)[SL], int K, const V3 (&sh)[NA], const V3 (&cand)[NB],
                                           unsigned alive) {
+#pragma unroll 1
     for (int j = 0; j < K; j++) {
         const double *s = slot[j];
         const double a0 = s[0], a1 = s[1], a2 = s[2], b0 = s[3], b1 = s[4], b2 = s[5], g = s[6];
@@ -732,7 +735,7 @@ __device__ __forceinline__ unsigned sweep(const double (*slot)[SL], int K, const
             hits |= (h ? 1u : 0u) << r;
         }
         alive &= ~hits;
-        if (__ballot(alive != 0) == 0) break;
+        if (EARLY) { if (__ballot(alive != 0) == 0) break; }
     }
     return alive;
 }
@@ -1126,7 +1129,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     cd[q] = cand_from_idx(T, ix[q], vpref);
                     sh[q] = cd[q] + pA;
                 }
-                const unsigned alive = orca ? sweep<2, true, 2, 2, SLOTF>(slot, K, sh, cd, 3u) : sweep<2, false, 2, 2, SLOTF>(slot, K, sh, cd, 3u);
+                const unsigned alive = orca ? sweep<2, true, 2, 2, SLOTF, false>(slot, K, sh, cd, 3u) : sweep<2, false, 2, 2, SLOTF, false>(slot, K, sh, cd, 3u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) emit((alive >> q) & 1u, cd[q], ix[q]);
             }
@@ -1139,7 +1142,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     cd[0] = cand_from_idx(T, ix, vpref);
                     sh[0] = cd[0] + pA;
                     const unsigned valid = lane < cnt ? 1u : 0u;
-                    const unsigned alive = orca ? sweep<1, true, 1, 1, SLOTF>(slot, K, sh, cd, valid) : sweep<1, false, 1, 1, SLOTF>(slot, K, sh, cd, valid);
+                    const unsigned alive = orca ? sweep<1, true, 1, 1, SLOTF, false>(slot, K, sh, cd, valid) : sweep<1, false, 1, 1, SLOTF, false>(slot, K, sh, cd, valid);
                     emit(alive & 1u, cd[0], ix);
                     c0 += cnt;
                 } else {
