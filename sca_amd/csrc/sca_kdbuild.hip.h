@@ -470,7 +470,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 else { nb_[1] = S.nb[cur][s1]; ne_[1] = S.ne[cur][s1]; }
             }
             const bool big0 = s0 >= 0 && ne_[0] - nb_[0] > KB_SMALL, big1 = s1 >= 0 && ne_[1] - nb_[1] > KB_SMALL;
-            {
+            if (__any(big0 || big1)) {                           // the bottom levels have only small nodes: nothing to do here
                 const double x0 = S.x[KB_SW(p0)], y0 = S.y[KB_SW(p0)], z0 = S.z[KB_SW(p0)];
                 const int p1 = v1 ? p0 + 1 : p0;
                 const double x1 = S.x[KB_SW(p1)], y1 = S.y[KB_SW(p1)], z1 = S.z[KB_SW(p1)];
@@ -522,11 +522,20 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 const int b = S.nb[cur][tid], e = S.ne[cur][tid];
                 if (e - b <= KB_SMALL) {
                     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    for (int p = b; p < e; p++) {
-                        const double x = S.x[KB_SW(p)], y = S.y[KB_SW(p)], z = S.z[KB_SW(p)];
-                        mn[0] = x < mn[0] ? x : mn[0]; mx[0] = x > mx[0] ? x : mx[0];
-                        mn[1] = y < mn[1] ? y : mn[1]; mx[1] = y > mx[1] ? y : mx[1];
-                        mn[2] = z < mn[2] ? z : mn[2]; mx[2] = z > mx[2] ? z : mx[2];
+                    // four members per trip: the twelve LDS reads are issued together (the last trip repeats member e-1)
+                    for (int p = b; p < e; p += 4) {
+                        double x[4], y[4], z[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int pp = p + q < e ? p + q : e - 1;
+                            x[q] = S.x[KB_SW(pp)]; y[q] = S.y[KB_SW(pp)]; z[q] = S.z[KB_SW(pp)];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            mn[0] = x[q] < mn[0] ? x[q] : mn[0]; mx[0] = x[q] > mx[0] ? x[q] : mx[0];
+                            mn[1] = y[q] < mn[1] ? y[q] : mn[1]; mx[1] = y[q] > mx[1] ? y[q] : mx[1];
+                            mn[2] = z[q] < mn[2] ? z[q] : mn[2]; mx[2] = z[q] > mx[2] ? z[q] : mx[2];
+                        }
                     }
                     for (int k = 0; k < 3; k++) { S.box[cur][tid][k] = dkey(mn[k]); S.box[cur][tid][3 + k] = dkey(mx[k]); }
                 }
