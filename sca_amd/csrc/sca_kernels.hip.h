@@ -107,28 +107,35 @@ struct DeviceView {
 // __shfl_xor): two quad permutes, two row rotations, then row_bcast:15 / row_bcast:31 fold the four 16-lane rows;
 // lane 63 holds the result, which is returned wave-uniform.  All 64 lanes must be active at the call.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int dpp_mov(int v) {
+    // with every row enabled and a pattern that gives every lane a source the old value is never used: the plain DPP move
+    // needs no tied copy of the register first (one VALU instruction instead of two)
+    if (ROW_MASK == 0xf && (CTRL < 0x100 || (CTRL >= 0x121 && CTRL <= 0x12f) || (CTRL >= 0x150 && CTRL <= 0x15f)))
+        return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
     const int lo = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)v), hi = dpp_mov<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 // inside a 16-lane row: broadcast of lane K (row_newbcast, gfx90a+), shifts towards lower / higher lanes
-template <int K> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false); }
+template <int K> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true); }
 template <int K> __device__ __forceinline__ double row_bcast_d(double x) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(x);
     const int lo = row_bcast_i<K>((int)(unsigned)v), hi = row_bcast_i<K>((int)(unsigned)(v >> 32));
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
-// lane i reads lane i + K of its row (lanes whose source is outside the row keep their own value)
+// lane i reads lane i + K of its row
 template <int K> __device__ __forceinline__ double row_shl_d(double x) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, 0x100 + K, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), 0x100 + K, 0xf, 0xf, false);
+    // lanes without a source read 0 (bound_ctrl): the callers only use lanes that have one
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)v, 0x100 + K, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), 0x100 + K, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
-// lane i reads lane i - 1 of its row (lane 0 keeps its own value)
-__device__ __forceinline__ int row_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
+// lane i reads lane i - 1 of its row (lane 0 reads 0)
+__device__ __forceinline__ int row_shr1_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true); }
 __device__ __forceinline__ double row_shr1_d(double x) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(x);
     const int lo = row_shr1_i((int)(unsigned)v), hi = row_shr1_i((int)(unsigned)(v >> 32));
