@@ -85,7 +85,8 @@ struct DeviceView {
     void *prep;              // [n] Prep records (per-agent scalar prologue)
     int32_t *fb_list;        // [n] agents without a suitable candidate: finished by k_solve_full
     int32_t *fb_count;       // [1]
-    uint8_t *is_fb;          // [n] 1: k_solve handed the agent to the fallback list (the epilogue kernel finishes it)
+    uint8_t *is_fb;          // [n] 0: vpost holds the new velocity; 1: k_solve handed the agent to the fallback list (the epilogue
+                             //     kernel's second half finishes it); 2: the epilogue derives vpost from the chosen candidate index
     int32_t *diag;           // [n*8]: n_suit, fallback, chosen, plane_fail, lp4
     int32_t *status;         // [n]
     // candidate tables (SoA [3][N]) and phi numerators
@@ -1031,7 +1032,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
-    V3 vpost;
+    V3 vpost = v3(0, 0, 0);
+    bool defer = false;
     const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
@@ -1214,30 +1216,32 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     if (!pass) fail = k < fail ? k : fail;
                 }
                 fail = wave_min_u32(fail);
-                // first minimal / first maximal get_phi inside the prefix: (phi numerator, list position) as one 64-bit key
-                unsigned long long kmin = ~0ull, kmax = ~0ull;
+                // first minimal / first maximal get_phi inside the prefix, "first" in list order (= order of the packed keys):
+                // per lane the best (phi, key) pair, then two 32-bit wave minima each (phi, then the key among the lanes that hold it)
+                unsigned pmin = 0xffffffffu, kpmin = 0xffffffffu, pmax = 0xffffffffu, kpmax = 0xffffffffu;   // pmax holds 0xfffff - phi
                 for (int e = lane; e < nS; e += 64) {
                     const unsigned k = pkS[e];
                     if (k < fail) {
                         const int ci = (int)(k & 1023u);
-                        const unsigned long long ph = ci >= T.vp_idx ? (unsigned long long)(pr.bits >> 8)
-                                                                     : (unsigned long long)T.phi[ci >= T.num_N ? ci - T.num_N : ci];   // <= 628318
-                        const unsigned long long a = (ph << 32) | k, b = ((0xfffffull - ph) << 32) | k;
-                        kmin = a < kmin ? a : kmin;
-                        kmax = b < kmax ? b : kmax;
+                        const unsigned ph = ci >= T.vp_idx ? (pr.bits >> 8) : (unsigned)T.phi[ci >= T.num_N ? ci - T.num_N : ci];   // <= 628318
+                        const unsigned ih = 0xfffffu - ph;
+                        if (ph < pmin || (ph == pmin && k < kpmin)) { pmin = ph; kpmin = k; }
+                        if (ih < pmax || (ih == pmax && k < kpmax)) { pmax = ih; kpmax = k; }
                     }
                 }
-                kmin = wave_min_u64(kmin);
-                kmax = wave_min_u64(kmax);
-                const double phi_min = (double)(kmin >> 32) / EPS5, phi_max = (double)(0xfffffull - (kmax >> 32)) / EPS5;
+                const unsigned wpmin = wave_min_u32(pmin), wpmax = wave_min_u32(pmax);
+                const unsigned kmin = wave_min_u32(pmin == wpmin ? kpmin : 0xffffffffu);
+                const unsigned kmax = wave_min_u32(pmax == wpmax ? kpmax : 0xffffffffu);
+                const double phi_min = (double)wpmin / EPS5, phi_max = (double)(0xfffffu - wpmax) / EPS5;
                 chosen = (fabs(phi_max - phi_min) <= PI) ? (int)(kmin & 1023u) : (int)(kmax & 1023u);
             }
             dg_chosen = chosen;
-            vpost = trunc5(cand_from_idx(T, chosen, vpref));                             // scaPolicy.py:239
+            defer = true;                         // vA_post = trunc5(candidate `chosen`) (scaPolicy.py:239): the epilogue derives it
         }
     }
     if (lane == 0) {
-        d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z;
+        if (defer) d.is_fb[agent] = 2;
+        else { d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z; }
         diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = dg_pfail; diag[4] = dg_lp4;
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         if (st) atomicOr(&d.status[agent], st);
@@ -1262,12 +1266,24 @@ __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
 template <bool FUSE_INTEGRATE>
-__device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent) {
+__device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent, bool derive) {
     PubRec me = d.rec[agent];
     float actf[7] = {0, 0, 0, 0, 0, 0, 0};
     if (!(me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) {                // mampenv.py:35: else the row stays zero
         double act[7];
-        const V3 v = v3(d.vpost[agent * 3], d.vpost[agent * 3 + 1], d.vpost[agent * 3 + 2]);
+        V3 v;
+        if (derive) {                              // k_solve left the index of the chosen candidate: scaPolicy.py:239 here, 64 agents per wavefront
+            const Prep pr = ((const Prep *)d.prep)[agent];
+            const int pol = d.policy[agent];
+            CandTab T;
+            T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;
+            T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
+            T.phi = nullptr;
+            T.vp_idx = 2 * T.num_N;
+            T.rad1 = pr.rad1;
+            v = trunc5(cand_from_idx(T, d.diag[(size_t)agent * 8 + 2], v3(pr.vpref[0], pr.vpref[1], pr.vpref[2])));
+            d.vpost[agent * 3] = v.x; d.vpost[agent * 3 + 1] = v.y; d.vpost[agent * 3 + 2] = v.z;
+        } else v = v3(d.vpost[agent * 3], d.vpost[agent * 3 + 1], d.vpost[agent * 3 + 2]);
         cartesian2spherical(d.heading[agent * 3 + 0], d.heading[agent * 3 + 1], v, d.policy[agent] == POL_ORCA_LP, act);
 #pragma unroll
         for (int k = 0; k < 7; k++) actf[k] = (float)act[k];
@@ -1292,8 +1308,9 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action(DeviceView d, Param
     if ((int)blockIdx.x < action_blocks) {
         const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
         if (agent >= d.shard_begin + d.shard_count) return;
-        if (d.is_fb[agent]) return;
-        action_one<FUSE_INTEGRATE>(d, P, agent);
+        const int kind = d.is_fb[agent];
+        if (kind == 1) return;
+        action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -1303,7 +1320,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action(DeviceView d, Param
         const int agent = d.fb_list[i];
         solve_one(d, P, S, agent, lane, wid);
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) action_one<FUSE_INTEGRATE>(d, P, agent);
+        if (lane == 0) action_one<FUSE_INTEGRATE>(d, P, agent, false);
         __builtin_amdgcn_wave_barrier();
     }
 }
