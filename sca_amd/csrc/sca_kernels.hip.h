@@ -163,6 +163,12 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
     SCA_DPP_REDUCE(int, dpp_mov, [](int a, int b) { return (int)umin32((unsigned)a, (unsigned)b); })
     return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ double readlane_f64(double x, int lane_uniform) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane_uniform);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane_uniform);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ unsigned long long bcast63(unsigned long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
     return ((unsigned long long)hi << 32) | lo;
@@ -1205,15 +1211,32 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 // verdict is the integer comparison |k0 - ki| vs thr * 1e5 except when they are equal (then the doubles decide)
                 const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
                 const double kthr = pol == POL_SCA ? 3000.0 : 10000.0;
-                const double k0 = l3norm_num(cand_from_idx(T, chosen, vpref), vA64);
-                unsigned fail = 0xffffffffu;                                             // first list element that breaks the prefix
-                for (int e = lane; e < nS; e += 64) {
-                    const unsigned k = pkS[e];
-                    const double kv = l3norm_num(cand_from_idx(T, (int)(k & 1023u), vpref), vA64);
+                // numerators of l3norm(v_i, vA) for the list (entries lane and lane + 64 in registers; longer lists loop);
+                // the best entry's numerator k0 is picked up from the lane that holds it instead of being computed again
+                const unsigned kA = lane < nS ? pkS[lane] : 0xffffffffu;
+                const unsigned kB = lane + 64 < nS ? pkS[lane + 64] : 0xffffffffu;
+                double nA_ = 0.0, nB_ = 0.0;
+                if (lane < nS) nA_ = l3norm_num(cand_from_idx(T, (int)(kA & 1023u), vpref), vA64);
+                if (nS > 64) { if (lane + 64 < nS) nB_ = l3norm_num(cand_from_idx(T, (int)(kB & 1023u), vpref), vA64); }
+                double k0;
+                {
+                    const unsigned long long mA = __ballot(kA == best), mB = __ballot(kB == best);
+                    if (mA != 0) k0 = readlane_f64(nA_, __ffsll((long long)mA) - 1);
+                    else if (mB != 0) k0 = readlane_f64(nB_, __ffsll((long long)mB) - 1);
+                    else k0 = l3norm_num(cand_from_idx(T, chosen, vpref), vA64);         // best sits beyond entry 127
+                }
+                auto passes = [&](double kv) {
                     const double dk = fabs(k0 - kv);
                     bool pass = dk < kthr;
                     if (dk == kthr) pass = fabs(k0 / EPS5 - kv / EPS5) < sthr;          // round5_py returns k / 1e5
-                    if (!pass) fail = k < fail ? k : fail;
+                    return pass;
+                };
+                unsigned fail = 0xffffffffu;                                             // first list element that breaks the prefix
+                if (lane < nS && !passes(nA_)) fail = kA;
+                if (lane + 64 < nS && !passes(nB_)) fail = kB < fail ? kB : fail;
+                for (int e = lane + 128; e < nS; e += 64) {
+                    const unsigned k = pkS[e];
+                    if (!passes(l3norm_num(cand_from_idx(T, (int)(k & 1023u), vpref), vA64))) fail = k < fail ? k : fail;
                 }
                 fail = wave_min_u32(fail);
                 // first minimal / first maximal get_phi inside the prefix, "first" in list order (= order of the packed keys):
