@@ -320,6 +320,15 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     std::vector<double> tab(768 + 384 + 256 + 128);
     candidate_table_host(256, tab.data(), tab.data() + 768 + 384);
     candidate_table_host(128, tab.data() + 768, tab.data() + 768 + 384 + 256);
+    // k_solve's posture pre-filter treats the table directions as unit vectors (|u|^2 = 1 inside its 1e-13 margin): make sure
+    for (int set = 0; set < 2; set++) {
+        const int nn = set ? 128 : 256;
+        const double *u = tab.data() + (set ? 768 : 0);
+        for (int i = 0; i < nn; i++) {
+            const double n2 = u[i] * u[i] + u[nn + i] * u[nn + i] + u[2 * nn + i] * u[2 * nn + i];
+            if (std::fabs(n2 - 1.0) > 1e-14) { c->err = "candidate table is not unit length"; return SCA_ERR_STATE; }
+        }
+    }
     if (dalloc(c, &c->tab, tab.size())) return SCA_ERR_HIP;
     CHK(c, hipMemcpyAsync(c->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));

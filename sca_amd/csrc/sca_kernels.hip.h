@@ -1104,8 +1104,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 const double ux = T.unit[n0], uy = T.unit[T.num_N + n0], uz = T.unit[2 * T.num_N + n0];
                 const V3 u = v3(ux, uy, uz);
                 const double dt = dot(vA64, u);
-                const double n2 = dot(u, u);
-                const double y = T2 * n2;
+                const double y = T2;                       // T2 * |u|^2 with |u|^2 = 1 +- 4e-16 (table of unit vectors): inside the margin
                 const double lhs = dt * dt;
                 const bool sure_pass = filter_ok & (dt > 0.0) & (lhs > y * (1.0 + 1e-13));
                 const bool sure_fail = filter_ok & ((dt <= 0.0) | (lhs < y * (1.0 - 1e-13)));
@@ -1242,16 +1241,18 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 // first minimal / first maximal get_phi inside the prefix, "first" in list order (= order of the packed keys):
                 // per lane the best (phi, key) pair, then two 32-bit wave minima each (phi, then the key among the lanes that hold it)
                 unsigned pmin = 0xffffffffu, kpmin = 0xffffffffu, pmax = 0xffffffffu, kpmax = 0xffffffffu;   // pmax holds 0xfffff - phi
-                for (int e = lane; e < nS; e += 64) {
-                    const unsigned k = pkS[e];
-                    if (k < fail) {
+                auto consider = [&](unsigned k) {
+                    if (k < fail) {                                                      // 0xffffffff (no entry) never is
                         const int ci = (int)(k & 1023u);
                         const unsigned ph = ci >= T.vp_idx ? (pr.bits >> 8) : (unsigned)T.phi[ci >= T.num_N ? ci - T.num_N : ci];   // <= 628318
                         const unsigned ih = 0xfffffu - ph;
                         if (ph < pmin || (ph == pmin && k < kpmin)) { pmin = ph; kpmin = k; }
                         if (ih < pmax || (ih == pmax && k < kpmax)) { pmax = ih; kpmax = k; }
                     }
-                }
+                };
+                consider(kA);
+                if (nS > 64) consider(kB);
+                for (int e = lane + 128; e < nS; e += 64) consider(pkS[e]);
                 const unsigned wpmin = wave_min_u32(pmin), wpmax = wave_min_u32(pmax);
                 const unsigned kmin = wave_min_u32(pmin == wpmin ? kpmin : 0xffffffffu);
                 const unsigned kmax = wave_min_u32(pmax == wpmax ? kpmax : 0xffffffffu);
