@@ -1099,6 +1099,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             int nA = 0;
             const bool filter_ok = thr > 1e-6;
             const int ndir = T.num_N >> 6;
+            // util.py:16 `pos.z + dt * v.z >= 0` holds for every candidate once the agent is higher than the fastest one can sink
+            const bool z_safe = pA.z > P.time_step * (T.rad1 > 0.5 ? T.rad1 : 0.5) * 1.000001;
             for (int r = 0; r < ndir; r++) {
                 const int n0 = r * 64 + lane;
                 const double ux = T.unit[n0], uy = T.unit[T.num_N + n0], uz = T.unit[2 * T.num_N + n0];
@@ -1116,7 +1118,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     const V3 c = v3(rad * ux, rad * uy, rad * uz);
                     bool ok = sure_pass;
                     if (any_unsure) { if (unsure) ok = posture_cos(vA, nvA, c) >= thr; }
-                    ok = ok & ((pA.z + P.time_step * c.z) >= 0.0);
+                    if (!z_safe) ok = ok & ((pA.z + P.time_step * c.z) >= 0.0);
                     const unsigned long long m = __ballot(ok);
                     if (ok) listA[nA + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(sp * T.num_N + n0);
                     nA += __popcll(m);
