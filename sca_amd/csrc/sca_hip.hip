@@ -144,6 +144,7 @@ struct sca_ctx {
     hipEvent_t kd_ev = nullptr;
     bool kd_ev_pending = false;
     int kd_levels_hint = 0;
+    int kd_single_hint = 0;             // first level from which one launch per level suffices (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
     int k1_force = -1;                  // K1 variant: -1 choose by shard size, 0 one agent per wavefront, 1 four (k_neighbors_kd4)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
@@ -272,7 +273,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->stream = c->stream_own;
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
     CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
-    CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (KD_MAX_LEVELS + 2)));
+    CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3)));   // counts | nchunks
     const size_t N = (size_t)max_agents, M = (size_t)max_obstacles;
     DeviceView &d = c->d;
     int r = 0;
@@ -580,13 +581,23 @@ static int build_agent_tree_device(sca_ctx *c) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
             c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 1;
+            // levels whose nodes all fit one chunk (as many chunks as nodes) need one launch; one level of slack, because
+            // a node that outgrows its chunk at such a level makes the build report failure
+            const int *nch = c->kd_host_counts + KD_MAX_LEVELS + 2;
+            int single = depth;
+            while (single > 0 && nch[single - 1] == c->kd_host_counts[single - 1]) single--;
+            c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : single + 2;      // 1-based: level >= hint - 1 is fused
             c->kd_ev_pending = false;
         }
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MAX + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < levels; l++) {
-            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
-            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
+            if (c->kd_levels_hint > 0 && c->kd_single_hint > 0 && l >= c->kd_single_hint - 1)
+                hipLaunchKernelGGL(k_kd_level_single, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l, ++c->kd_token);
+            else {
+                hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
+                hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
+            }
         }
     }
     const int sgrid = std::max(1, std::min(1024, 4 * n / KB_MAX + 2));
@@ -594,6 +605,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     CHK(c, hipGetLastError());
     if (n > KD_WAVE_MAX && !c->kd_ev_pending) {
         CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (KD_MAX_LEVELS + 2), hipMemcpyDeviceToHost, c->stream));
+        CHK(c, hipMemcpyAsync(c->kd_host_counts + KD_MAX_LEVELS + 2, c->kd.nchunks, sizeof(int) * (KD_MAX_LEVELS + 1), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipEventRecord(c->kd_ev, c->stream));
         c->kd_ev_pending = true;
     }
@@ -605,6 +617,7 @@ static int check_kd_overflow(sca_ctx *c) {
     CHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
         c->kd_levels_hint = 0;
+        c->kd_single_hint = 0;
         c->err = "device kd-tree build overflow (tree deeper than the level budget): results of this pass are invalid; "
                  "use SCA_NBR_KDTREE_HOSTBUILD for this scene";
         return SCA_ERR_STATE;

@@ -159,14 +159,13 @@ __device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int
 // Level pass A: one workgroup per chunk.  The node's box is complete (accumulated by the parent's pass), so the chunk
 // can flag its members against the split plane, scan the flags (chained across the chunks of the node through one
 // 64-bit word per chunk: launch token | count), write the in-node ranks, and accumulate the boxes of the two children.
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
+struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; double red[KD_LV_T / 64][12]; };
+__device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsigned token, const KdChunk c, KdRankLds &SH) {
     constexpr int W = KD_LV_T / 64;
-    __shared__ int wtot[W];
-    __shared__ int carry_sh;
-    __shared__ double red[W][12];
+    int (&wtot)[W] = SH.wtot;
+    int &carry_sh = SH.carry_sh;
+    double (&red)[W][12] = SH.red;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
-    if (!c.valid) return;
     const int axis = c.axis;
     const double split = c.split;
     const int b = c.node_begin;
@@ -256,13 +255,18 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
     }
 }
 
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
+    __shared__ KdRankLds SH;
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
+    if (!c.valid) return;
+    kd_rank_part(s, level, token, c, SH);
+}
+
 // Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+__device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch s, int level, const KdChunk c) {
     const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
     KdJob *out = s.jobs[(level + 1) & 1];
-    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
-    if (!c.valid) return;
     const int axis = c.axis;
     const double split = c.split;
     const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
@@ -325,6 +329,25 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
             }
         }
     }
+}
+
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
+    if (!c.valid) return;
+    kd_swap_part(d, s, level, c);
+}
+
+// Both passes in one launch for the levels whose nodes all fit ONE chunk (the deepest level passes: nodes of 1025..2048
+// members): the node's only workgroup ranks, synchronises with itself and swaps.  A node with more chunks at such a level
+// (the host's hint from earlier builds was wrong) is reported, never half-processed.
+__global__ __launch_bounds__(KD_LV_T) void k_kd_level_single(DeviceView d, KdScratch s, int level, unsigned token) {
+    __shared__ KdRankLds SH;
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
+    if (!c.valid) return;
+    if (c.node_end - c.node_begin > KD_CHUNK) { if (threadIdx.x == 0) s.counts[KD_MAX_LEVELS + 1] = 1; return; }
+    kd_rank_part(s, level, token, c, SH);
+    __syncthreads();                                   // the workgroup's ranks, node total and children boxes are complete
+    kd_swap_part(d, s, level, c);
 }
 
 // ------------------------------------------------------------------------------------------------
