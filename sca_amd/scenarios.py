@@ -26,11 +26,15 @@ def circle(n, rad=None, center=(0.0, 0.0), z=10.0):
     return dict(start=start, goal=goal, obs_pos=np.zeros((0, 3)), obs_radius=np.zeros(0))
 
 
-def random_cube(n, seed=0, min_sep=1.5, z_offset=30.0):
+def random_cube(n, seed=0, min_sep=1.5, z_offset=None):
     """run_sca.set_random_pos (run_sca.py:33-50) at constant density: cube half-side 25 * (n/100)^(1/3),
-    seeded numpy Generator, rejection sampling for a minimum pairwise start distance."""
+    seeded numpy Generator, rejection sampling for a minimum pairwise start distance.  The cube is lifted by its half-side
+    + 5 m, as the reference's is (half-side 25, offset 30): everything stays above the ground plane that the posture
+    constraint enforces (util.py:16, `pos.z + dt * v.z >= 0`); an agent below it has no admissible candidate at all."""
     rng = np.random.default_rng(seed)
     r = 25.0 * (n / 100.0) ** (1.0 / 3.0)
+    if z_offset is None:
+        z_offset = r + 5.0
     cell = max(min_sep, 1e-9)
     grid = {}
     pts = []

@@ -141,6 +141,8 @@ CASES = [
     ('circle1024_sca', 'circle', 1024, 0),          # BASELINE config 2
     ('random4096_orca', 'random', 4096, 3),         # BASELINE config 3
     ('random4096_orcalp', 'random', 4096, 4),
+    ('random4096_underground_orca', 'random_low', 4096, 3),   # a third of the agents below z = 0: no admissible candidate, fallback path
+    ('random4096_underground_sca', 'random_low', 4096, 0),
     ('takeoff1024_mixed', 'takeoff', 1024, -1),     # BASELINE config 5 (scaled), SCA even ids / S-RVO3D odd ids
     ('circle2048_rvo', 'circle', 2048, 1),
 ]
@@ -150,6 +152,7 @@ CASES = [
 def test_policy_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
     from sca_amd import scenarios
     sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=0),
+          'random_low': lambda: scenarios.random_cube(n, seed=0, z_offset=30.0),
           'takeoff': lambda: scenarios.takeoff_landing(n)}[kind]()
     policy = np.where(np.arange(n) % 2 == 0, 0, 2) if pol < 0 else pol
     s = _scenario_state(S, sc, policy)

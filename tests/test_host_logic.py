@@ -43,6 +43,8 @@ def test_random_generator_is_seeded_and_separated():
     p = a['start'][:, :3]
     d = np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1)) + np.eye(300) * 1e9
     assert d.min() >= 1.5
+    assert a['start'][:, 2].min() >= 5.0 and a['goal'][:, 2].min() >= 5.0        # above the ground plane of util.py:16, like the reference's cube
+    assert scenarios.random_cube(4096, seed=0)['start'][:, 2].min() >= 5.0
 
 
 def test_drop_in_api_surface():
