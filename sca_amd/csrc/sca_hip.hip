@@ -143,6 +143,8 @@ struct sca_ctx {
     int *kd_host_counts = nullptr;      // pinned
     hipEvent_t kd_ev = nullptr;
     bool kd_ev_pending = false;
+    unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
+    unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     int kd_levels_hint = 0;
     int kd_single_hint = 0;             // first level from which one launch per level suffices (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
@@ -298,13 +300,13 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     d.kx = c->kd.kx; d.ky = c->kd.ky; d.kz = c->kd.kz;
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
-    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_MAX_LEVELS + 2);
+    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 3);   // counts | nchunks: one readback
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MAX + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
     r |= dalloc(c, &c->kd.chunks[0], (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.chunks[1], (size_t)c->kd.chunk_cap);
-    r |= dalloc(c, &c->kd.nchunks, (size_t)KD_MAX_LEVELS + 1);
+    c->kd.nchunks = c->kd.counts ? c->kd.counts + KD_MAX_LEVELS + 2 : nullptr;
     if (!r) {   // the root's accumulators start empty (every build's last kernel resets them for the next one)
         unsigned long long h[12];
         const double pinf = INFINITY, ninf = -INFINITY;
@@ -346,7 +348,7 @@ void sca_destroy(sca_ctx *c) {
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], c->kd.nchunks, d.hist};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -433,6 +435,7 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
         r.flags = flags[i];
     }
     c->h_pos.assign(pos, pos + 3 * (size_t)n);
+    c->kd_levels_hint = 0; c->kd_single_hint = 0; c->kd_gen++;       // a new state: the previous trees' depth profile says nothing
     c->h_pos_valid = true;
     c->near_valid = false;
     CHK(c, hipMemcpyAsync(c->d.rec, c->h_rec.data(), sizeof(PubRec) * n, hipMemcpyHostToDevice, c->stream));
@@ -577,6 +580,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         while ((KD_WAVE_MAX << need) < n) need++;                    // balanced depth down to KD_WAVE_MAX
         levels = std::min(need + 6, KD_MAX_LEVELS - 1);               // slack for uneven midpoint splits
         // the tree changes slowly from step to step: use the depth seen by an earlier build (+2) when it has arrived
+        if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess && c->kd_ev_gen != c->kd_gen) c->kd_ev_pending = false;   // stale
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
@@ -603,11 +607,14 @@ static int build_agent_tree_device(sca_ctx *c) {
     const int sgrid = std::max(1, std::min(1024, 4 * n / KB_MAX + 2));
     hipLaunchKernelGGL(k_kd_block, dim3(sgrid), dim3(KB_T), 0, c->stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
-    if (n > KD_WAVE_MAX && !c->kd_ev_pending) {
-        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (KD_MAX_LEVELS + 2), hipMemcpyDeviceToHost, c->stream));
-        CHK(c, hipMemcpyAsync(c->kd_host_counts + KD_MAX_LEVELS + 2, c->kd.nchunks, sizeof(int) * (KD_MAX_LEVELS + 1), hipMemcpyDeviceToHost, c->stream));
+    // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
+    // 8th build, every build while no hint exists yet
+    c->kd_builds++;
+    if (n > KD_WAVE_MAX && !c->kd_ev_pending && (c->kd_levels_hint == 0 || (c->kd_builds & 7u) == 0)) {
+        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipEventRecord(c->kd_ev, c->stream));
         c->kd_ev_pending = true;
+        c->kd_ev_gen = c->kd_gen;
     }
     return 0;
 }
