@@ -299,10 +299,69 @@ __device__ __forceinline__ int kd_traverse(const KdWide *tree, V3 p, double rang
     return st;
 }
 
+__device__ __forceinline__ int lo32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) & 0xffffffffull); }
+__device__ __forceinline__ int hi32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
+
+// The same traversal for the one-agent-per-wavefront neighbour kernel, which is pure node-fetch latency at small N:
+// the 16 lanes of row 0 hold the current node's 128-byte record (one double each, as in the packed kernel), and when both
+// children will be visited ONE load instruction brings both records: row 0 takes the child visited first, row 1 the other
+// one, which goes onto a stack of RECORDS in LDS -- popping it later costs an LDS read instead of another trip to the L2.
+constexpr int KD_RSTACK = 48;
+template <class LeafFn>
+__device__ __forceinline__ int kd_traverse_rec(const KdWide *tree, V3 p, double rangeSq, double (*rstack)[16], int lane, LeafFn leaf) {
+    const double *wd = (const double *)tree;
+    const int gl = lane & 15, row = lane >> 4;
+    const int tk = gl >= 2 ? (gl - 2) >> 2 : 0;                       // which box term this lane squares (see k_neighbors_kd4)
+    const bool t_is_mx = gl >= 2 && (((gl - 2) >> 1) & 1);
+    const bool t_live = gl >= 2 && gl < 14;
+    const double pk = tk == 0 ? p.x : (tk == 1 ? p.y : p.z);
+    int sp = 0, st = 0;
+    double w = lane < 16 ? wd[lane] : 0.0;                            // the root's record
+    bool have = true;
+    while (have) {
+        const double h0 = readlane_f64(w, 0), h1 = readlane_f64(w, 1);
+        const int nb = lo32(h0), ne = hi32(h0), nl = lo32(h1), nr = hi32(h1);
+        bool descend = false, push = false;
+        int first = 0, second = 0;
+        if (ne - nb <= MAX_LEAF) {
+            leaf(nb, ne);
+        } else {                                                      // kdTree.py:132-156
+            double t = t_is_mx ? pk - w : w - pk;
+            t = fmax(0.0, t);
+            const double sq = t_live ? t * t : 0.0;
+            double ssum = sq;                                         // lane 2: left child's terms in order, lane 3: right child's
+            ssum = ssum + row_shl_d<2>(sq);
+            ssum = ssum + row_shl_d<4>(sq);
+            ssum = ssum + row_shl_d<6>(sq);
+            ssum = ssum + row_shl_d<8>(sq);
+            ssum = ssum + row_shl_d<10>(sq);
+            const double dl = readlane_f64(ssum, 2), dr = readlane_f64(ssum, 3);
+            double dfirst, dsecond;
+            if (dl < dr) { first = nl; second = nr; dfirst = dl; dsecond = dr; }
+            else { first = nr; second = nl; dfirst = dr; dsecond = dl; }
+            if (dfirst < rangeSq) { descend = true; push = dsecond < rangeSq; }
+        }
+        if (descend) {
+            const bool ld = row == 0 || (row == 1 && push);
+            const double nw = ld ? wd[(size_t)(row == 0 ? first : second) * 16 + gl] : 0.0;
+            if (push) {
+                if (sp < KD_RSTACK) { if (row == 1) rstack[sp][gl] = nw; sp++; }
+                else st |= ST_KD_STACK;
+            }
+            w = nw;
+        } else if (sp > 0) {
+            sp--;
+            __builtin_amdgcn_wave_barrier();
+            w = lane < 16 ? rstack[sp][lane] : 0.0;
+        } else have = false;
+    }
+    return st;
+}
+
 // agent_reach / obs_reach: see k_collide_finish.  Every object that can touch this agent after the move is visited
 // here anyway (it is within neighborDist), so the few that are close enough are written down for K4.
 __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
-                                              double max_radius, int *stack, int agent, int lane) {
+                                              double max_radius, double (*rstack)[16], int agent, int lane) {
     const PubRec me = d.rec[agent];
     int st = 0;
     bool skip = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
@@ -326,7 +385,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     bool coll = false;
     // obstacles first (scaPolicy.py:114-116), agent.py:101-124
     if (d.m > 0) {
-        st |= kd_traverse(d.owide, pA, rangeSq, stack, lane, [&](int begin, int end) {
+        st |= kd_traverse_rec(d.owide, pA, rangeSq, rstack, lane, [&](int begin, int end) {
             const bool valid = lane < end - begin;
             int o = 0; double distSq = 0.0; bool c = false, r = false, nr = false;
             if (valid) {
@@ -363,7 +422,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     // leaf members are contiguous in position order: ids and coordinates come in one coalesced round trip; the other
     // agent's radius is only fetched when the pair is close enough for the collision test to matter
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
-    st |= kd_traverse(d.awide, pA, rangeSq, stack, lane, [&](int begin, int end) {
+    st |= kd_traverse_rec(d.awide, pA, rangeSq, rstack, lane, [&](int begin, int end) {
         const bool valid = lane < end - begin;
         int o = -1; double distSq = 0.0; bool c = false, r = false, nr = false;
         if (valid) {
@@ -408,11 +467,11 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
 
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                 double max_radius) {
-    __shared__ int stacks[K1_WAVES][KD_STACK];
+    __shared__ double rstacks[K1_WAVES][KD_RSTACK][16];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, max_radius, stacks[wid], agent, lane);
+    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], agent, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,8 +484,6 @@ constexpr int K1P_WAVES = 4;
 constexpr int K1P_G = 16;
 constexpr int K1P_APW = 4;
 
-__device__ __forceinline__ int lo32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) & 0xffffffffull); }
-__device__ __forceinline__ int hi32(double v) { return (int)(unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
 
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                  double max_radius) {
