@@ -669,9 +669,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
-    // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 3.2x at 100k and 16k agents);
-    // below that the one-agent-per-wave form has the shorter critical path (1024..4096 agents: 10-15 % faster)
-    const bool packed = c->k1_force < 0 ? cnt >= 8192 : c->k1_force != 0;
+    // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
+    // below that the one-agent-per-wave form with its record stack has the shorter critical path (4096 random: 30 % faster)
+    const bool packed = c->k1_force < 0 ? cnt >= 6144 : c->k1_force != 0;
     if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
         hipLaunchKernelGGL(k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, c->stream, d, c->P,
