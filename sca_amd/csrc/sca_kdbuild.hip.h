@@ -513,7 +513,6 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 }
                 const int rs = row_bcast_i<0>(s0);
                 const unsigned long long um = __ballot(s0 == rs && (s1 == rs || !v1));
-                const bool row_uni = ((um >> (lane & 48)) & 0xffffull) == 0xffffull;
                 const int ref = __builtin_amdgcn_readfirstlane(s0);
                 const bool wave_uni = um == ~0ull && __all(rs == ref);
                 if (wave_uni) {
@@ -524,19 +523,29 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                             for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][ref][k], key[k]); atomicMax(&S.box[cur][ref][3 + k], ~key[3 + k]); }
                     }
                 } else {
-                    const bool row_red = row_uni && big0;
+                    // segmented minimum scan along the row: a node's positions are consecutive, so equal slots at distance D
+                    // mean one node in between; the last lane of every run holds the run's extremes and alone goes to LDS
                     unsigned long long rk[6];
                     for (int k = 0; k < 6; k++) rk[k] = key[k];
-                    if (__any(row_red)) {
-#pragma unroll
-                        for (int k = 0; k < 6; k++) rk[k] = kb_key_min<false>(key[k]);
+                    const int gl16 = lane & 15;
+#define KB_SEG_STEP(D)                                                                                            \
+                    {                                                                                             \
+                        /* the DPP read runs for EVERY lane (a source lane masked off by a short-circuit && would read 0) */ \
+                        const int ps_ = __builtin_amdgcn_mov_dpp(s0, 0x110 + D, 0xf, 0xf, true);                  \
+                        const bool take = (gl16 >= D) & (ps_ == s0);                                              \
+                        _Pragma("unroll") for (int k = 0; k < 6; k++) {                                           \
+                            const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)rk[k], 0x110 + D, 0xf, 0xf, true);            \
+                            const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(rk[k] >> 32), 0x110 + D, 0xf, 0xf, true);    \
+                            const unsigned long long o = ((unsigned long long)hi << 32) | lo;                     \
+                            if (take && o < rk[k]) rk[k] = o;                                                     \
+                        }                                                                                         \
                     }
-                    const bool mine = row_uni ? (row_red && (lane & 15) == 0) : big0;
-                    if (mine) {
-                        for (int k = 0; k < 3; k++) {
-                            atomicMin(&S.box[cur][s0][k], row_red ? rk[k] : key[k]);
-                            atomicMax(&S.box[cur][s0][3 + k], ~(row_red ? rk[3 + k] : key[3 + k]));
-                        }
+                    KB_SEG_STEP(1) KB_SEG_STEP(2) KB_SEG_STEP(4) KB_SEG_STEP(8)
+#undef KB_SEG_STEP
+                    const int nxt_slot = __builtin_amdgcn_mov_dpp(s0, 0x101, 0xf, 0xf, true);      // row_shl:1
+                    const bool run_end = gl16 == 15 || nxt_slot != s0;
+                    if (big0 && run_end) {
+                        for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][s0][k], rk[k]); atomicMax(&S.box[cur][s0][3 + k], ~rk[3 + k]); }
                     }
                 }
             }
