@@ -356,7 +356,6 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_level_single(DeviceView d, KdScr
 constexpr int KB_MAX = KD_WAVE_MAX;
 constexpr int KB_T = 512;
 constexpr int KB_E = KB_MAX / KB_T;     // consecutive positions per thread (2)
-constexpr int KB_SMALL = 32;            // nodes this small: box by one lane walking the members
 constexpr int KB_NODES = 192;           // live nodes per level: <= 2 * KB_MAX / 11
 
 // x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KB_MAX / 8 + 8)
@@ -485,15 +484,15 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 if (v0) S.slot[KB_SW(p0)] = s0;
                 if (v1) S.slot[KB_SW(p0 + 1)] = s1;
             }
-            // extents of the positions' nodes; nodes of <= KB_SMALL members get their box from one lane each (below)
+            // extents of the positions' nodes
             int nb_[2] = {0, 0}, ne_[2] = {0, 0};
             if (s0 >= 0) { nb_[0] = S.nb[cur][s0]; ne_[0] = S.ne[cur][s0]; }
             if (s1 >= 0) {
                 if (s1 == s0) { nb_[1] = nb_[0]; ne_[1] = ne_[0]; }
                 else { nb_[1] = S.nb[cur][s1]; ne_[1] = S.ne[cur][s1]; }
             }
-            const bool big0 = s0 >= 0 && ne_[0] - nb_[0] > KB_SMALL, big1 = s1 >= 0 && ne_[1] - nb_[1] > KB_SMALL;
-            if (__any(big0 || big1)) {                           // the bottom levels have only small nodes: nothing to do here
+            const bool big0 = s0 >= 0, big1 = s1 >= 0;
+            if (__any(big0 || big1)) {
                 const double x0 = S.x[KB_SW(p0)], y0 = S.y[KB_SW(p0)], z0 = S.z[KB_SW(p0)];
                 const int p1 = v1 ? p0 + 1 : p0;
                 const double x1 = S.x[KB_SW(p1)], y1 = S.y[KB_SW(p1)], z1 = S.z[KB_SW(p1)];
@@ -516,7 +515,7 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                 const int ref = __builtin_amdgcn_readfirstlane(s0);
                 const bool wave_uni = um == ~0ull && __all(rs == ref);
                 if (wave_uni) {
-                    if (ref >= 0) {                              // 128 positions: never a small node
+                    if (ref >= 0) {
 #pragma unroll
                         for (int k = 0; k < 6; k++) key[k] = kb_key_min<true>(key[k]);
                         if (lane == 0)
@@ -547,29 +546,6 @@ __global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, in
                     if (big0 && run_end) {
                         for (int k = 0; k < 3; k++) { atomicMin(&S.box[cur][s0][k], rk[k]); atomicMax(&S.box[cur][s0][3 + k], ~rk[3 + k]); }
                     }
-                }
-            }
-            // small nodes: one lane per node walks its members (no atomics; bottom levels are all of this kind)
-            if (tid < nc) {
-                const int b = S.nb[cur][tid], e = S.ne[cur][tid];
-                if (e - b <= KB_SMALL) {
-                    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    // four members per trip: the twelve LDS reads are issued together (the last trip repeats member e-1)
-                    for (int p = b; p < e; p += 4) {
-                        double x[4], y[4], z[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int pp = p + q < e ? p + q : e - 1;
-                            x[q] = S.x[KB_SW(pp)]; y[q] = S.y[KB_SW(pp)]; z[q] = S.z[KB_SW(pp)];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            mn[0] = x[q] < mn[0] ? x[q] : mn[0]; mx[0] = x[q] > mx[0] ? x[q] : mx[0];
-                            mn[1] = y[q] < mn[1] ? y[q] : mn[1]; mx[1] = y[q] > mx[1] ? y[q] : mx[1];
-                            mn[2] = z[q] < mn[2] ? z[q] : mn[2]; mx[2] = z[q] > mx[2] ? z[q] : mx[2];
-                        }
-                    }
-                    for (int k = 0; k < 3; k++) { S.box[cur][tid][k] = dkey(mn[k]); S.box[cur][tid][3 + k] = dkey(mx[k]); }
                 }
             }
             lds_barrier();
