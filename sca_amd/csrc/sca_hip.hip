@@ -301,7 +301,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
     r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 3);   // counts | nchunks: one readback
-    c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MAX + 8);
+    c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MIN + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
@@ -573,11 +573,20 @@ static int build_agent_tree_device(sca_ctx *c) {
         CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         c->perm_on_device = true;
     }
+    // size of the subtrees handed to k_kd_block: 1.25 x the average node size of the first level that fits (n / 2^k), so that
+    // the nodes of that level -- all within a few per cent of the average -- are on one side of it
+    int wave_max = n <= 1024 ? 1024 : KD_WAVE_CAP;          // a tree that fits one workgroup: the smaller one if it can
+    if (n > KD_WAVE_CAP) {
+        double sz = (double)n;
+        while (sz > KD_WAVE_CAP / 1.25) sz *= 0.5;
+        wave_max = std::min(KD_WAVE_CAP, std::max(KD_WAVE_MIN + 1, (int)std::ceil(1.25 * sz)));
+    }
+    c->kd.wave_max = wave_max;
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd, c->P);
     int levels = 0;
-    if (n > KD_WAVE_MAX) {
+    if (n > wave_max) {
         int need = 1;
-        while ((KD_WAVE_MAX << need) < n) need++;                    // balanced depth down to KD_WAVE_MAX
+        while (((long long)wave_max << need) < n) need++;             // balanced depth down to wave_max
         levels = std::min(need + 6, KD_MAX_LEVELS - 1);               // slack for uneven midpoint splits
         // the tree changes slowly from step to step: use the depth seen by an earlier build (+2) when it has arrived
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess && c->kd_ev_gen != c->kd_gen) c->kd_ev_pending = false;   // stale
@@ -594,7 +603,7 @@ static int build_agent_tree_device(sca_ctx *c) {
             c->kd_ev_pending = false;
         }
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
-        const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MAX + 8);   // >= chunks of any level of n agents
+        const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < levels; l++) {
             if (c->kd_levels_hint > 0 && c->kd_single_hint > 0 && l >= c->kd_single_hint - 1)
                 hipLaunchKernelGGL(k_kd_level_single, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l, ++c->kd_token);
@@ -604,13 +613,14 @@ static int build_agent_tree_device(sca_ctx *c) {
             }
         }
     }
-    const int sgrid = std::max(1, std::min(1024, 4 * n / KB_MAX + 2));
-    hipLaunchKernelGGL(k_kd_block, dim3(sgrid), dim3(KB_T), 0, c->stream, d, c->kd, levels);
+    const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
+    if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->stream, d, c->kd, levels);
+    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
-    if (n > KD_WAVE_MAX && !c->kd_ev_pending && (c->kd_levels_hint == 0 || (c->kd_builds & 7u) == 0)) {
+    if (n > wave_max && !c->kd_ev_pending && (c->kd_levels_hint == 0 || (c->kd_builds & 7u) == 0)) {
         CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipEventRecord(c->kd_ev, c->stream));
         c->kd_ev_pending = true;

@@ -13,10 +13,10 @@
 //
 //   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced;
 //                 root box; the per-agent prologue of the solver for the rank's shard
-//   k_kd_lv_*   : two launches per tree level for the nodes with more than KD_WAVE_MAX members; a node is cut into
+//   k_kd_lv_*   : two launches per tree level for the nodes with more than wave_max members; a node is cut into
 //                 chunks of KD_CHUNK positions, one workgroup per chunk: (flags + chained scan + ranks + children's
 //                 boxes) -> (swaps + query record + children and their chunk records)
-//   k_kd_block  : every subtree of <= KD_WAVE_MAX members is finished by ONE WORKGROUP entirely in LDS, level by level,
+//   k_kd_block  : every subtree of <= wave_max members is finished by ONE WORKGROUP entirely in LDS, level by level,
 //                 all nodes of a level at once (element-parallel; boxes as DPP minima of order-preserving keys, LDS
 //                 atomics for what is left, one lane per node for the records)
 #pragma once
@@ -24,7 +24,11 @@
 
 namespace sca {
 
-constexpr int KD_WAVE_MAX = 1024;      // a node this small is finished (whole subtree) by ONE WORKGROUP in LDS (k_kd_block)
+// A node of <= wave_max members (KdScratch::wave_max, chosen per build) is finished, whole subtree, by ONE WORKGROUP in LDS
+// (k_kd_block).  The host picks it between these bounds so that the node sizes of a level (n / 2^k, within a few per cent)
+// do not straddle it: with a fixed 1024 the 4096- and 16384-agent trees needed a whole level pass for the half of their
+// ~1024-member nodes that were a little larger.
+constexpr int KD_WAVE_MIN = 768, KD_WAVE_CAP = 1536;
 constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
@@ -36,10 +40,11 @@ struct alignas(16) KdChunkRec { int job, first, nb, ne, axis, pad; double split;
 struct KdScratch {
     double *kx, *ky, *kz;     // [n] coordinates in position order
     int *mr;                  // [n] mr[b + j - 1] = position of the j-th "< split" member of the node that starts at b
-    KdJob *jobs[2];           // ping-pong lists of nodes with > KD_WAVE_MAX members
+    KdJob *jobs[2];           // ping-pong lists of nodes with > wave_max members
     KdJob *small;             // [n] subtrees handed to k_kd_block
     int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag
     int job_cap;
+    int wave_max;             // nodes up to this size go to k_kd_block (KD_WAVE_MIN < wave_max <= KD_WAVE_CAP)
     // multi-workgroup level passes
     unsigned long long *nbox; // [2][job_cap][6] order-preserving keys of the node boxes (per level parity)
     int *nge;                 // [2][job_cap] number of members >= split per node
@@ -73,12 +78,12 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
     if (p == 0) {
         for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
         KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
-        if (d.n > KD_WAVE_MAX) { s.jobs[0][0] = j; s.counts[0] = 1; }
+        if (d.n > s.wave_max) { s.jobs[0][0] = j; s.counts[0] = 1; }
         else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
         for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
-        s.nchunks[0] = d.n > KD_WAVE_MAX ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
+        s.nchunks[0] = d.n > s.wave_max ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
-    if (d.n > KD_WAVE_MAX && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
+    if (d.n > s.wave_max && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
         KdChunkRec r; r.job = 0; r.first = 0; r.nb = 0; r.ne = d.n; r.axis = -1; r.pad = 0; r.split = 0.0;
         s.chunks[0][p] = r;
     }
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
         if (id >= d.shard_begin && id < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, id);
     }
-    if (d.n > KD_WAVE_MAX) {
+    if (d.n > s.wave_max) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { mn[k] = wave_min_d(mn[k]); mx[k] = wave_max_d(mx[k]); }
         if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
@@ -301,7 +306,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
         ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
         ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
         for (int k = 0; k < 2; k++) {
-            if (ch[k].end - ch[k].begin > KD_WAVE_MAX) {
+            if (ch[k].end - ch[k].begin > s.wave_max) {
                 if (level + 1 < KD_MAX_LEVELS) {
                     const int at = atomicAdd(&s.counts[level + 1], 1);
                     if (at < s.job_cap) {
@@ -351,30 +356,27 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_level_single(DeviceView d, KdScr
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup finishes one subtree of <= KB_MAX members in LDS.  Every level is one element-parallel pass over all
-// of the subtree's positions: each thread owns KB_E consecutive positions.
-constexpr int KB_MAX = KD_WAVE_MAX;
-constexpr int KB_T = 512;
-constexpr int KB_E = KB_MAX / KB_T;     // consecutive positions per thread (2)
-constexpr int KB_NODES = 192;           // live nodes per level: <= 2 * KB_MAX / 11
-
-// x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KB_MAX / 8 + 8)
-// + (p >> 3), so that both patterns touch all LDS banks evenly (rows of 256 + 8: four rows of doubles tile the 64 banks)
-constexpr int KB_SWROW = KB_MAX / 8 + 8;
-constexpr int KB_SWN = 8 * KB_SWROW;
+// One workgroup finishes one subtree of <= KBM members in LDS.  Every level is one element-parallel pass over all of the
+// subtree's positions: each thread owns two consecutive positions.  Two instantiations: 1024 members / 512 threads (69 KB
+// of LDS: two workgroups per CU) and 1536 / 768 (one per CU), picked by the build's wave_max.
+//
+// x, y, z and slot are read both as 2 and as 8 consecutive positions per lane; position p lives at (p & 7) * (KBM / 8 + 8)
+// + (p >> 3), so that both patterns touch all LDS banks evenly (rows of KBM / 8 + 8: four rows of doubles tile the 64 banks)
 #define KB_SW(p) ((((p) & 7) * KB_SWROW) + ((p) >> 3))
 
+template <int KBM, int KBT>
 struct KbLds {
-    double x[KB_SWN], y[KB_SWN], z[KB_SWN];        // swizzled: index KB_SW(position)
-    int id[KB_MAX];
-    int slot[KB_SWN];                   // live-node slot of the position, -1 once its leaf is written
-    int mr[KB_MAX];                     // position of the k-th misplaced member of the right part
-    int ps[KB_MAX];                     // inclusive prefix count of the ">= split" flags over all positions
-    int nb[2][KB_NODES], ne[2][KB_NODES], nnode[2][KB_NODES], npar[2][KB_NODES];
-    unsigned long long box[2][KB_NODES][6];
-    int child[KB_NODES], lfix[KB_NODES];
+    static constexpr int SWROW = KBM / 8 + 8, SWN = 8 * SWROW, NODES = (2 * KBM) / 11 + 8;   // live nodes per level <= 2 * KBM / 11
+    double x[SWN], y[SWN], z[SWN];          // swizzled: index KB_SW(position)
+    int id[KBM];
+    int slot[SWN];                          // live-node slot of the position, -1 once its leaf is written
+    int mr[KBM];                            // position of the k-th misplaced member of the right part
+    int ps[KBM];                            // inclusive prefix count of the ">= split" flags over all positions
+    int nb[2][NODES], ne[2][NODES], nnode[2][NODES], npar[2][NODES];
+    unsigned long long box[2][NODES][6];
+    int child[NODES], lfix[NODES];
     int count[2];
-    int wtot[KB_T / 64];
+    int wtot[KBT / 64];
 };
 
 // Barrier for LDS-only hand-offs inside k_kd_block's level loop: __syncthreads() also waits for the global stores of the
@@ -423,9 +425,11 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 #define KB_MARK() do { } while (0)
 #endif
 
-__global__ __launch_bounds__(KB_T) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
-    static_assert(KB_E == 2, "k_kd_block is written for two consecutive positions per thread");
-    __shared__ KbLds S;
+template <int KBM, int KBT>
+__global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+    static_assert(KBM == 2 * KBT, "k_kd_block is written for two consecutive positions per thread");
+    constexpr int KB_SWROW = KbLds<KBM, KBT>::SWROW, KB_MAX = KBM, KB_T = KBT, KB_E = 2;
+    __shared__ KbLds<KBM, KBT> S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int njobs = s.counts[KD_MAX_LEVELS];
     // nodes still larger than KB_MAX after the last level launch were never split: report, never guess
