@@ -594,12 +594,13 @@ static int build_agent_tree_device(sca_ctx *c) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
             c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 1;
-            // levels whose nodes all fit one chunk (as many chunks as nodes) need one launch; one level of slack, because
-            // a node that outgrows its chunk at such a level makes the build report failure
+            // levels whose nodes all fit one chunk (as many chunks as nodes) need one launch: from one level below the first
+            // such level (children of one-chunk nodes are one-chunk nodes for certain), and the spare level(s) below the
+            // observed depth (a node there is the child of a node of about one chunk; anything larger is reported)
             const int *nch = c->kd_host_counts + KD_MAX_LEVELS + 2;
             int single = depth;
             while (single > 0 && nch[single - 1] == c->kd_host_counts[single - 1]) single--;
-            c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : single + 2;      // 1-based: level >= hint - 1 is fused
+            c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : std::min(single + 1, depth) + 1;   // 1-based: level >= hint - 1 is fused
             c->kd_ev_pending = false;
         }
         if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
