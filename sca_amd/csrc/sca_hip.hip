@@ -693,11 +693,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));         // [e1, e2] = k_solve alone (what rocprofv3 reports for it)
     // epilogue (one lane per agent) + the agents without any suitable candidate (rare; one wavefront each), one launch
     const int ablocks = (cnt + 255) / 256;
     if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
     else hipLaunchKernelGGL(k_action<false>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
-    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     CHK(c, hipGetLastError());
     if (fuse_integrate && c->d.hist) c->d.hist_row++;
     return 0;
