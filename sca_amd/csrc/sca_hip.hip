@@ -145,8 +145,8 @@ struct sca_ctx {
     bool kd_ev_pending = false;
     unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
-    int kd_levels_hint = 0;
-    int kd_single_hint = 0;             // first level from which one launch per level suffices (0: unknown)
+    bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
+    int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
     int k1_force = -1;                  // K1 variant: -1 choose by shard size, 0 one agent per wavefront, 1 four (k_neighbors_kd4)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
@@ -267,6 +267,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0;
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
+    if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     int ndev = 0;
     CHK(c, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { c->err = "no HIP device: libsca_hip has no CPU path"; return SCA_ERR_HIP; }
@@ -435,7 +436,7 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
         r.flags = flags[i];
     }
     c->h_pos.assign(pos, pos + 3 * (size_t)n);
-    c->kd_levels_hint = 0; c->kd_single_hint = 0; c->kd_gen++;       // a new state: the previous trees' depth profile says nothing
+    c->kd_single_hint = 0; c->kd_gen++;   // a new state: the previous trees' depth profile says nothing
     c->h_pos_valid = true;
     c->near_valid = false;
     CHK(c, hipMemcpyAsync(c->d.rec, c->h_rec.data(), sizeof(PubRec) * n, hipMemcpyHostToDevice, c->stream));
@@ -585,34 +586,33 @@ static int build_agent_tree_device(sca_ctx *c) {
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd, c->P);
     int levels = 0;
     if (n > wave_max) {
-        int need = 1;
-        while (((long long)wave_max << need) < n) need++;             // balanced depth down to wave_max
-        levels = std::min(need + 6, KD_MAX_LEVELS - 1);               // slack for uneven midpoint splits
-        // the tree changes slowly from step to step: use the depth seen by an earlier build (+2) when it has arrived
+        // Level passes: two launches per level (rank | swap) while the nodes span several chunks, then ONE launch
+        // (k_kd_level_tail) in which every remaining node's workgroup finishes its whole subtree down to wave_max.  Where the
+        // switch happens only sets the speed -- the tail handles any node size and any depth -- so it is taken from the
+        // statistics of an earlier build when they have arrived (the first level whose nodes all fit one chunk), otherwise
+        // from the balanced tree.
+        int first_single = 1;
+        while (((long long)KD_CHUNK << first_single) < n) first_single++;       // n / 2^l <= KD_CHUNK
+        first_single += 1;                                                      // uneven midpoint splits
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess && c->kd_ev_gen != c->kd_gen) c->kd_ev_pending = false;   // stale
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
-            c->kd_levels_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : depth + 1;
-            // levels whose nodes all fit one chunk (as many chunks as nodes) need one launch: from one level below the first
-            // such level (children of one-chunk nodes are one-chunk nodes for certain), and the spare level(s) below the
-            // observed depth (a node there is the child of a node of about one chunk; anything larger is reported)
             const int *nch = c->kd_host_counts + KD_MAX_LEVELS + 2;
             int single = depth;
             while (single > 0 && nch[single - 1] == c->kd_host_counts[single - 1]) single--;
-            c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : std::min(single + 1, depth) + 1;   // 1-based: level >= hint - 1 is fused
+            c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : single + 1;        // 1-based
             c->kd_ev_pending = false;
         }
-        if (c->kd_levels_hint > 0) levels = std::min(levels, c->kd_levels_hint);
+        if (c->kd_single_hint > 0 && !c->kd_nohint) first_single = c->kd_single_hint - 1;
+        first_single = std::min(first_single, KD_MAX_LEVELS - 2);
+        levels = first_single + 1;
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
-        for (int l = 0; l < levels; l++) {
-            if (c->kd_levels_hint > 0 && c->kd_single_hint > 0 && l >= c->kd_single_hint - 1)
-                hipLaunchKernelGGL(k_kd_level_single, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l, ++c->kd_token);
-            else {
-                hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
-                hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
-            }
+        for (int l = 0; l < first_single; l++) {
+            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
         }
+        hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, first_single, ++c->kd_token);
     }
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
     if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->stream, d, c->kd, levels);
@@ -621,7 +621,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
-    if (n > wave_max && !c->kd_ev_pending && (c->kd_levels_hint == 0 || (c->kd_builds & 7u) == 0)) {
+    if (n > wave_max && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
         CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipEventRecord(c->kd_ev, c->stream));
         c->kd_ev_pending = true;
@@ -634,10 +634,9 @@ static int check_kd_overflow(sca_ctx *c) {
     CHK(c, hipMemcpyAsync(&flag, c->kd.counts + KD_MAX_LEVELS + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
-        c->kd_levels_hint = 0;
         c->kd_single_hint = 0;
         c->err = "device kd-tree build overflow (tree deeper than the level budget): results of this pass are invalid; "
-                 "use SCA_NBR_KDTREE_HOSTBUILD for this scene";
+                 "use SCA_NBR_KDTREE_HOSTBUILD for this scene [code " + std::to_string(flag) + "]";
         return SCA_ERR_STATE;
     }
     return 0;

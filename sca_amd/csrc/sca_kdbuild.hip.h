@@ -32,6 +32,8 @@ constexpr int KD_WAVE_MIN = 768, KD_WAVE_CAP = 1536;
 constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
+// why a build reported failure (bits of counts[KD_MAX_LEVELS + 1])
+enum { KD_ERR_SPIN = 1, KD_ERR_DEGENERATE = 2, KD_ERR_CHUNKS = 4, KD_ERR_JOBS = 8, KD_ERR_LEVELS = 16, KD_ERR_BLOCK = 128 };
 struct KdJob { int begin, end, node, pad; };
 // workgroup -> node of a level pass: job index, first workgroup of the node, the node's extent and its split plane
 // (axis < 0: not known when the record was written -- the root -- take it from the node's box)
@@ -165,7 +167,7 @@ __device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int
 // can flag its members against the split plane, scan the flags (chained across the chunks of the node through one
 // 64-bit word per chunk: launch token | count), write the in-node ranks, and accumulate the boxes of the two children.
 struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; double red[KD_LV_T / 64][12]; };
-__device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsigned token, const KdChunk c, KdRankLds &SH) {
+__device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsigned token, const KdChunk c, KdRankLds &SH, int blk) {
     constexpr int W = KD_LV_T / 64;
     int (&wtot)[W] = SH.wtot;
     int &carry_sh = SH.carry_sh;
@@ -215,17 +217,17 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
     // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident).
     //      The first wavefront reads 64 predecessors at a time: the words are independent, only their arrival is awaited.
     if (tid == 0)
-        __hip_atomic_store(&s.chain[blockIdx.x], ((unsigned long long)token << 32) | (unsigned)total, __ATOMIC_RELAXED,
+        __hip_atomic_store(&s.chain[blk], ((unsigned long long)token << 32) | (unsigned)total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (wid == 0) {
         int carry = 0;
-        for (int ch = c.first_chunk + lane; ch < (int)blockIdx.x; ch += 64) {
+        for (int ch = c.first_chunk + lane; ch < blk; ch += 64) {
             unsigned long long v = 0;
             int spins = 0;
             for (;;) {
                 v = __hip_atomic_load(&s.chain[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(v >> 32) == token) break;
-                if (++spins > (1 << 24)) { s.counts[KD_MAX_LEVELS + 1] = 1; break; }     // never hang the GPU: report
+                if (++spins > (1 << 24)) { atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_SPIN); break; }     // never hang the GPU: report
                 __builtin_amdgcn_s_sleep(2);
             }
             carry += (int)(unsigned)v;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
         if (lane == 0) {
             carry_sh = carry;
             const int nch = (c.node_end - b + KD_CHUNK - 1) / KD_CHUNK;
-            if ((int)blockIdx.x == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
+            if (blk == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
         }
     }
     __syncthreads();
@@ -264,11 +266,13 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
     __shared__ KdRankLds SH;
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
-    kd_rank_part(s, level, token, c, SH);
+    kd_rank_part(s, level, token, c, SH, (int)blockIdx.x);
 }
 
 // Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
-__device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch s, int level, const KdChunk c) {
+// the children that need another level pass, as the chunk records written for them (for k_kd_level_tail)
+struct KdTailOut { int n; KdChunkRec r[2]; };
+__device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch s, int level, const KdChunk c, KdTailOut *tail = nullptr) {
     const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
     KdJob *out = s.jobs[(level + 1) & 1];
@@ -291,6 +295,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
         }
     }
     if (tid == 0 && c.begin == b) {
+        if (tail) tail->n = 0;
         const KdJob job = in[c.job];
         double mn[3], mx[3];
         { int ax_; double sp_; kd_node_split(s, level, c.job, ax_, sp_, mn, mx); }
@@ -301,7 +306,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
         if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
         kd_publish(d.awide, nd, job.node, job.pad);
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
-        if (L == 0) s.counts[KD_MAX_LEVELS + 1] = 1;         // children boxes by side do not apply: report (never seen)
+        if (L == 0) atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_DEGENERATE);   // children boxes by side do not apply: report (never seen)
         KdJob ch[2];
         ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
         ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
@@ -325,9 +330,10 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
                             kd_split(cmn, cmx, r.axis, r.split);
                             KdChunkRec *tab = s.chunks[(level + 1) & 1];
                             for (int q = 0; q < nch; q++) tab[base + q] = r;
-                        } else s.counts[KD_MAX_LEVELS + 1] = 1;
-                    } else s.counts[KD_MAX_LEVELS + 1] = 1;
-                } else s.counts[KD_MAX_LEVELS + 1] = 1;
+                            if (tail) tail->r[tail->n++] = r;
+                        } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_CHUNKS);
+                    } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
+                } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
             } else {
                 const int at = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
                 s.small[at] = ch[k];
@@ -342,17 +348,60 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch 
     kd_swap_part(d, s, level, c);
 }
 
-// Both passes in one launch for the levels whose nodes all fit ONE chunk (the deepest level passes: nodes of 1025..2048
-// members): the node's only workgroup ranks, synchronises with itself and swaps.  A node with more chunks at such a level
-// (the host's hint from earlier builds was wrong) is reported, never half-processed.
-__global__ __launch_bounds__(KD_LV_T) void k_kd_level_single(DeviceView d, KdScratch s, int level, unsigned token) {
+// The LAST level launch of a build: one workgroup per node of that level finishes everything that is left below it -- both
+// passes of the node (its chunks one after the other: ranks, `__syncthreads`, swaps), then the same for every child that
+// still has more than wave_max members, depth first from a small stack.  At the level the host picks (from the previous
+// builds' statistics: the first one whose nodes are about one chunk) that is one short pass per workgroup; if the tree has
+// changed since -- a node with many chunks, more levels -- it is slower, never wrong: the statistics only set the speed.
+constexpr int KD_TAIL_STACK = 2 * KD_MAX_LEVELS;
+__global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScratch s, int level, unsigned token) {
     __shared__ KdRankLds SH;
-    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
-    if (!c.valid) return;
-    if (c.node_end - c.node_begin > KD_CHUNK) { if (threadIdx.x == 0) s.counts[KD_MAX_LEVELS + 1] = 1; return; }
-    kd_rank_part(s, level, token, c, SH);
-    __syncthreads();                                   // the workgroup's ranks, node total and children boxes are complete
-    kd_swap_part(d, s, level, c);
+    __shared__ KdTailOut out;
+    __shared__ KdChunkRec stack[KD_TAIL_STACK];
+    __shared__ int stack_lv[KD_TAIL_STACK];
+    __shared__ int sp_sh;
+    __shared__ KdChunkRec cur_rec;
+    __shared__ int cur_lv;
+    const int blk = (int)blockIdx.x;
+    if (blk >= s.nchunks[level]) return;
+    const KdChunk c0 = kd_find_chunk(s, level, blk);
+    if (c0.first_chunk != blk) return;                              // one workgroup per node: the one of its first chunk
+    if (threadIdx.x == 0) {
+        KdChunkRec r; r.job = c0.job; r.first = c0.first_chunk; r.nb = c0.node_begin; r.ne = c0.node_end; r.axis = c0.axis; r.pad = 0; r.split = c0.split;
+        stack[0] = r; stack_lv[0] = level; sp_sh = 1;
+    }
+    const int chain0 = c0.first_chunk;                              // this workgroup's own range of chain words
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (sp_sh > 0) { sp_sh--; cur_rec = stack[sp_sh]; cur_lv = stack_lv[sp_sh]; }
+            else cur_lv = -1;
+        }
+        __syncthreads();
+        const int lv = cur_lv;
+        if (lv < 0) break;
+        const KdChunkRec r = cur_rec;
+        const int nch = (r.ne - r.nb + KD_CHUNK - 1) / KD_CHUNK;
+        KdChunk c; c.valid = 1; c.job = r.job; c.node_begin = r.nb; c.node_end = r.ne; c.first_chunk = chain0; c.axis = r.axis; c.split = r.split;
+        for (int t = 0; t < nch; t++) {
+            c.begin = r.nb + t * KD_CHUNK;
+            c.end = c.begin + KD_CHUNK < r.ne ? c.begin + KD_CHUNK : r.ne;
+            kd_rank_part(s, lv, token, c, SH, chain0 + t);
+            __syncthreads();
+        }
+        for (int t = 0; t < nch; t++) {
+            c.begin = r.nb + t * KD_CHUNK;
+            c.end = c.begin + KD_CHUNK < r.ne ? c.begin + KD_CHUNK : r.ne;
+            kd_swap_part(d, s, lv, c, &out);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < out.n; k++) {
+                if (sp_sh < KD_TAIL_STACK) { stack[sp_sh] = out.r[k]; stack_lv[sp_sh] = lv + 1; sp_sh++; }
+                else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,8 +481,7 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
     __shared__ KbLds<KBM, KBT> S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int njobs = s.counts[KD_MAX_LEVELS];
-    // nodes still larger than KB_MAX after the last level launch were never split: report, never guess
-    if (blockIdx.x == 0 && tid == 0 && s.counts[levels_run] > 0) s.counts[KD_MAX_LEVELS + 1] = 1;
+    (void)levels_run;                      // k_kd_level_tail leaves no node larger than wave_max behind
     // the level passes are over: reset the root's accumulators (box, children boxes) for the next build
     if (blockIdx.x == 0 && tid < 12) {
         if (tid < 6) s.nbox[tid] = tid < 3 ? dkey(INFINITY) : dkey(-INFINITY);
@@ -442,7 +490,7 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
     for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
         const KdJob job = s.small[jb];
         const int base = job.begin, size = job.end - job.begin;
-        if (size > KB_MAX) { if (tid == 0) s.counts[KD_MAX_LEVELS + 1] = 1; continue; }
+        if (size > KB_MAX) { if (tid == 0) atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_BLOCK); continue; }
         __syncthreads();
         for (int i = tid; i < size; i += KB_T) {
             S.x[KB_SW(i)] = s.kx[base + i]; S.y[KB_SW(i)] = s.ky[base + i]; S.z[KB_SW(i)] = s.kz[base + i]; S.id[i] = d.aperm[base + i];

@@ -483,3 +483,31 @@ def test_l3norm_numerator_fast_path_is_exact(S):
         ref = round(math.sqrt((dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]), 5)
         assert exact[i] == round(ref * 1e5), i
     sol.close()
+
+
+def test_converging_swarm_device_build_matches_host_build(S):
+    """Everybody flies to (almost) the same point: a dense core in a sparse halo, very uneven midpoint splits, a tree whose
+    depth and node sizes keep changing -- the case in which the level statistics of earlier builds are always out of date.
+    The device build (level passes + k_kd_level_tail + k_kd_block) must never report failure and must stay identical to the
+    host-built tree's run, permutation included."""
+    rng = np.random.default_rng(1)
+    n = 8000
+    start = rng.uniform(-45, 45, (n, 3)) + np.array([0, 0, 100.0])
+    goal = np.tile(np.array([[0.0, 0.0, 100.0]]), (n, 1)) + rng.normal(0, 0.5, (n, 3))
+    outs = []
+    for mode in (S.NBR_KDTREE, S.NBR_KDTREE_HOSTBUILD):
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), goal, np.full(n, 1, np.uint8), np.zeros(n, np.uint8), np.full(n, 1e9))
+        sol.set_state(start, np.zeros((n, 3), np.float32), np.zeros((n, 3)), np.zeros(n, np.uint8))
+        snaps = []
+        for _ in range(5):
+            sol.run_steps(80, mode)
+            sol.synchronize()                                  # raises if the build reported an overflow
+            st = sol.get_state()
+            snaps.append((st['pos'].copy(), st['flags'].copy(), sol.get_kd_perm().copy()))
+        outs.append(snaps)
+        sol.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert ((outs[0][-1][1] & 3) != 0).mean() > 0.3            # the core has formed (arrived or collided)
