@@ -635,7 +635,8 @@ static int check_kd_overflow(sca_ctx *c) {
     CHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
         c->kd_single_hint = 0;
-        c->err = "device kd-tree build overflow (tree deeper than the level budget): results of this pass are invalid; "
+        CHK(c, hipMemsetAsync(c->kd.counts + KD_MAX_LEVELS + 1, 0, sizeof(int), c->stream));      // reported: start afresh
+        c->err = "device kd-tree build overflow (a build since the last check ran out of levels or table space): results are invalid; "
                  "use SCA_NBR_KDTREE_HOSTBUILD for this scene [code " + std::to_string(flag) + "]";
         return SCA_ERR_STATE;
     }

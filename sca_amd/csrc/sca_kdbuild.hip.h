@@ -32,8 +32,8 @@ constexpr int KD_WAVE_MIN = 768, KD_WAVE_CAP = 1536;
 constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 
-// why a build reported failure (bits of counts[KD_MAX_LEVELS + 1])
-enum { KD_ERR_SPIN = 1, KD_ERR_DEGENERATE = 2, KD_ERR_CHUNKS = 4, KD_ERR_JOBS = 8, KD_ERR_LEVELS = 16, KD_ERR_BLOCK = 128 };
+// why a build reported failure (bits of counts[KD_MAX_LEVELS + 1]; sticky across builds until sca_synchronize reports them)
+enum { KD_ERR_SPIN = 1, KD_ERR_CHUNKS = 4, KD_ERR_JOBS = 8, KD_ERR_LEVELS = 16, KD_ERR_BLOCK = 128 };
 struct KdJob { int begin, end, node, pad; };
 // workgroup -> node of a level pass: job index, first workgroup of the node, the node's extent and its split plane
 // (axis < 0: not known when the record was written -- the root -- take it from the node's box)
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (p == 0) {
-        for (int i = 0; i < KD_MAX_LEVELS + 2; i++) s.counts[i] = 0;
+        for (int i = 0; i < KD_MAX_LEVELS + 1; i++) s.counts[i] = 0;      // not the error word: it stays until the host has read it
         KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
         if (d.n > s.wave_max) { s.jobs[0][0] = j; s.counts[0] = 1; }
         else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
@@ -306,7 +306,11 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
         if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
         kd_publish(d.awide, nd, job.node, job.pad);
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
-        if (L == 0) atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_DEGENERATE);   // children boxes by side do not apply: report (never seen)
+        if (L == 0) {
+            // nobody below the midpoint: the box has no extent, every member sits on one point (kdTree.py:113-116 then puts
+            // one of them left, the rest right) -- both children have the parent's box
+            for (int q = 0; q < 3; q++) { cb[q] = cb[6 + q] = dkey(mn[q]); cb[3 + q] = cb[9 + q] = dkey(mx[q]); }
+        }
         KdJob ch[2];
         ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
         ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
