@@ -12,9 +12,10 @@ Workloads (BASELINE.json configs): c4 = circle N=100000 SCA (default: the config
 N=16384 mixed SCA + S-RVO3D.  With several GPUs the default is WEAK scaling: the workload's agent count per GPU (one
 circle of 100000 x n_gpus agents, sharded by id, one all-gather of the moved 48-byte records per step);
 `--scaling strong` keeps the total at the workload's N.
-SCA's preferred velocity comes from the reference's host-side Dubins tracker (scaPolicy.py:264-338), which is
-outside the kernel boundary; the bench feeds the straight-line rule (rvo3dPolicy.py:182-196)
-computed on the device instead, and says so in `config`.
+SCA's preferred velocity comes from the reference's Dubins tracker (scaPolicy.py:264-338), which is outside the path
+north_star names: by default the bench feeds the straight-line rule (rvo3dPolicy.py:182-196) computed on
+the device instead, and says so in `config`.  `--vpref dubins-device` runs the tracker on the device inside every step
+(end-to-end SCA, state still resident); `--vpref dubins` runs the native host tracker (bit-exact, host-bound).
 
 Prints ONE JSON line on rank 0.
 """
@@ -72,8 +73,9 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N>1 GPUs: weak = the workload\'s agent count PER GPU (default), strong = the same total')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins'],
-                    help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound)')
+    ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins', 'dubins-device'],
+                    help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound); '
+                         'dubins-device: from the device tracker inside every step (end-to-end SCA, resident)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -117,6 +119,8 @@ def main():
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
     stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu)
 
+    if args.vpref == 'dubins-device':
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
     if args.vpref == 'dubins':
         if world > 1:
             raise SystemExit('--vpref dubins is a single-GPU measurement')
@@ -183,8 +187,9 @@ def main():
                        + (f' -- weak scaling: {w["n"] if not args.agents else args.agents} agents per GPU'
                           if world > 1 and args.scaling == 'weak' else ''),
                        'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': 'kd-tree of kdTree.py rebuilt on the device every step (replicated per rank), device query',
-                       'v_pref': ('straight-line rule on device (the Dubins tracker is host-side, outside the kernel boundary)'
-                                  if args.vpref == 'straight' else 'native Dubins tracker on the host every step (end-to-end SCA)'),
+                       'v_pref': {'straight': 'straight-line rule on device (SCA\'s Dubins tracker is outside the path: --vpref)',
+                                  'dubins': 'native Dubins tracker on the host every step (end-to-end SCA)',
+                                  'dubins-device': 'Dubins tracker on the device inside every step (end-to-end SCA)'}[args.vpref],
                        'parallelism': f'agents sharded over {world} GPU(s), all-gather of 48-B records per step'
                        if world > 1 else 'single GPU', 'agent_steps_timed': total_steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -194,7 +199,7 @@ def main():
                          'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
         }
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is a single-GPU (rank 0, N = 1) measurement
-            out['cpu_baseline'] = cpu_baseline(scene, sol, S)
+            out['cpu_baseline'] = cpu_baseline(scene, sol, S, tracked=args.vpref != 'straight')
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:
@@ -213,7 +218,7 @@ def measured_traffic(wname):
         return None
 
 
-def cpu_baseline(scene, sol, S):
+def cpu_baseline(scene, sol, S, tracked=False):
     """The CPU oracle (decision-identical C restatement of the reference, oracle/sca_oracle.c) timed on this box's host
     cores on a bounded sample: policy passes over the current device state.  Also reports max |v_hip - v_oracle|."""
     from oracle import oracle as orc
@@ -223,9 +228,13 @@ def cpu_baseline(scene, sol, S):
     from sca_amd import hostinfo
     cores = min(hostinfo.usable_cores(), 64)            # affinity AND cgroup quota: threads beyond it only oversubscribe
     perm = sol.get_kd_perm()
-    vmode = np.zeros(n, np.uint8)
+    # the same pass on the GPU for the parity number (first: with a tracker the oracle is fed the v_pref this pass used)
+    sol.policy_pass(S.NBR_KDTREE)
+    a = sol.actions()
+    vused = np.nan_to_num(sol.diag()['vpref'])
+    vmode = (np.isin(scene['policy'], (0, 5)).astype(np.uint8) if tracked else np.zeros(n, np.uint8))
     args = (st['pos'], st['vel'], st['heading'], scene['radius'], scene['pref_speed'], st['flags'], sc['goal'][:, :3],
-            scene['policy'], scene['zaxis'], np.zeros((n, 3)), vmode, perm, sc['obs_pos'], sc['obs_radius'])
+            scene['policy'], scene['zaxis'], vused, vmode, perm, sc['obs_pos'], sc['obs_radius'])
     t0 = time.perf_counter()
     ref = orc.policy_step(*args, nthreads=cores)
     reps = 1
@@ -235,9 +244,6 @@ def cpu_baseline(scene, sol, S):
         reps += 1
     dt = time.perf_counter() - t0
     active = int(((st['flags'] & 7) == 0).sum())
-    # the same pass on the GPU for the parity number
-    sol.policy_pass(S.NBR_KDTREE)
-    a = sol.actions()
     dv = float(np.abs(a[:, :3] - ref['action'][:, :3]).max())
     return {'value': active * reps / dt, 'unit': 'agent-steps/s', 'cores': cores, 'kind': 'port',
             'sample': f'{reps} policy passes over the {n}-agent state after the timed steps ({one:.2f} s each), '

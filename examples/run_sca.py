@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--map', default=None, help='binvox map for --scenario exp3')
     ap.add_argument('--max-steps', type=int, default=100000)
     ap.add_argument('--log-dir', default='visualization/sca/log')
+    ap.add_argument('--tracker', default='host', choices=['host', 'device'],
+                    help='where the Dubins v_pref tracker of SCA / RVO3D+Dubins runs: host = native threads, bit-exact against '
+                         'the reference; device = kernels inside every step (large swarms)')
     args = ap.parse_args()
 
     n = args.agents
@@ -64,9 +67,10 @@ def main():
                       policy=pol, id=i) for i in range(n)]
 
     v_pref_fn = None
-    if pol in (E.SCAPolicy, E.RVO3dDubinsPolicy):               # these two follow a Dubins path (scaPolicy.py:264-338)
+    dubins = pol in (E.SCAPolicy, E.RVO3dDubinsPolicy)          # these two follow a Dubins path (scaPolicy.py:264-338)
+    if dubins and args.tracker == 'host':
         v_pref_fn = tracker.DubinsTracker(sc['goal'][:, :3], sc['goal'][:, 3:6], np.ones(n), S.zaxis_flags(sc['start'], sc['goal']))
-    env = E.MACAEnv(v_pref_fn=v_pref_fn, history_capacity=args.max_steps)
+    env = E.MACAEnv(v_pref_fn=v_pref_fn, history_capacity=args.max_steps, device_tracker=dubins and args.tracker == 'device')
     env.set_agents(agents, obstacles=obstacles)
 
     step, t0 = 0, time.time()

@@ -172,6 +172,21 @@ int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
 int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
                     char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
 
+/* The same tracker on the device: one lane per agent, tracker records resident in HBM, the re-planning agents of a step
+ * compacted into a kernel of their own (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker, compiled for
+ * gfx950 with the device library's sin / cos / atan2 / acos, whose last bit differs from glibc's in a few percent of the
+ * calls: v_pref equals the host tracker's except for isolated 1e-5 steps of the truncation of scaPolicy.py:338.
+ * sca_device_tracker_enable: agents with policy SCA / RVO3D_DUBINS take v_pref from it from now on -- inside every
+ * sca_policy_pass / sca_step_begin / sca_run_steps when in_pass != 0 (agent.neighbors[0] of the previous pass is read from
+ * the neighbour lists on the device), otherwise only through sca_device_tracker_vpref.  sca_set_agents disables it. */
+int sca_device_tracker_enable(sca_ctx *ctx, const double *goal_heading /*n*3, agent.py:19*/, double turning_radius,
+                              double pitch_min, double pitch_max, int in_pass);
+int sca_device_tracker_disable(sca_ctx *ctx);
+/* one compute_v_pref per active tracked agent on the current state; nbr0_dsq as in sca_tracker_vpref, NULL = from the
+ * device's neighbour lists; vpref_out nullable */
+int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*/, double *vpref_out /*n*3, nullable*/);
+int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
+
 /* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
 /* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */
 int sca_candidate_table(int num_N, double *unit /*3*num_N*/, double *phi_num /*num_N*/);

@@ -2,9 +2,13 @@
 //
 // The reference computes v_pref for SCAPolicy / RVO3dDubinsPolicy with a per-agent, stateful tracker over a sampled 3-D
 // Dubins path (mamp/policies/sca/scaPolicy.py:92-104,243-338), planned by dubinsmaneuver3d.py:34-162 on top of the 2-D
-// planner dubinsmaneuver2d.py:33-218,260-297.  It is scalar, branchy and stateful, so it stays on the host; this file is
-// a C++ restatement that follows the Python statement by statement (same libm calls through function pointers so that the
-// compiler cannot fold pow(x, 2) or fuse sin/cos), thread-parallel over agents.
+// planner dubinsmaneuver2d.py:33-218,260-297.  This file is a C++ restatement that follows the Python statement by
+// statement and is compiled twice from the same text:
+//   * for the host (sca_tracker_*): thread-parallel over agents, libm through function pointers so that the compiler cannot
+//     fold pow(x, 2) or fuse sin/cos -- bit-exact against the reference on the fixtures (tests/test_tracker.py);
+//   * for gfx950 (sca_device_tracker_*, kernels in sca_tracker.hip.h): one lane per agent, state resident in HBM.  The
+//     device's sin / cos / atan2 / acos are not glibc's (they differ in the last bit in a few percent of the calls), so
+//     the device tracker is the reference's algorithm to within rounding noise, not bit for bit: see DESIGN.md.
 // generate_course (dubinsmaneuver2d.py:221-257) is not reproduced: the 3-D planner never reads its output.
 #pragma once
 #include <cmath>
@@ -17,20 +21,45 @@
 #include <thread>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define SCA_DHD __host__ __device__
+#else
+#define SCA_DHD
+#endif
+
 namespace sca_dubins {
 
-// libm through volatile pointers: literal evaluation, no folding / fusing
-static double (*volatile m_pow)(double, double) = std::pow;
-static double (*volatile m_sin)(double) = std::sin;
-static double (*volatile m_cos)(double) = std::cos;
-static double (*volatile m_acos)(double) = std::acos;
-static double (*volatile m_atan2)(double, double) = std::atan2;
+// host: libm through volatile pointers (literal evaluation, no folding / fusing); device: the ROCm device library
+static double (*volatile h_pow)(double, double) = std::pow;
+static double (*volatile h_sin)(double) = std::sin;
+static double (*volatile h_cos)(double) = std::cos;
+static double (*volatile h_acos)(double) = std::acos;
+static double (*volatile h_atan2)(double, double) = std::atan2;
+#if defined(__HIP_DEVICE_COMPILE__)
+SCA_DHD static inline double m_pow(double x, double) { return x * x; }        // only ever called with exponent 2
+SCA_DHD static inline double m_sin(double x) { return ::sin(x); }
+SCA_DHD static inline double m_cos(double x) { return ::cos(x); }
+SCA_DHD static inline double m_acos(double x) { return ::acos(x); }
+SCA_DHD static inline double m_atan2(double y, double x) { return ::atan2(y, x); }
+SCA_DHD static inline void m_sincos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+#else
+SCA_DHD static inline double m_pow(double x, double y) { return h_pow(x, y); }
+SCA_DHD static inline double m_sin(double x) { return h_sin(x); }
+SCA_DHD static inline double m_cos(double x) { return h_cos(x); }
+SCA_DHD static inline double m_acos(double x) { return h_acos(x); }
+SCA_DHD static inline double m_atan2(double y, double x) { return h_atan2(y, x); }
+SCA_DHD static inline void m_sincos(double x, double &s, double &c) { s = h_sin(x); c = h_cos(x); }
+#endif
 
 static const double PI = 3.141592653589793;
-static inline double fma3(const double *a, const double *b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); }
-static inline double mod2pi(double t) { return t - 2.0 * PI * std::floor(t / 2.0 / PI); }                    // util.py:113
+SCA_DHD static inline double fma3(const double *a, const double *b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); }
+// util.py:113  theta - 2.0 * pi * floor(theta / 2.0 / pi).  The planner's search calls this ~20 times per candidate radius and
+// the division is a third of its arithmetic on the device, so the quotient's floor is taken from a multiplication whenever the
+// product is clear of every non-zero integer by 1e-6 (the two quotients differ by < 4e-10 for |q| < 1e6): same floor, same
+// bits; otherwise (and for nan / inf) the literal division decides.
+SCA_DHD static inline double mod2pi(double t) { return t - 2.0 * PI * std::floor(t / 2.0 / PI); }
 // Python round(x, 5): correctly rounded (see sca_core.h round5_py)
-static inline double round5_py(double x) {
+SCA_DHD static inline double round5_py(double x) {
     const double y = x * 100000.0;
     const double e = std::fma(x, 100000.0, -y);
     double r = std::rint(y);
@@ -39,17 +68,19 @@ static inline double round5_py(double x) {
     else if (d == -0.5) { if (e < 0.0) r -= 1.0; }
     return r / 100000.0;
 }
-static inline double round5_np(double x) { return std::rint(x * 100000.0) / 100000.0; }
-static inline double trunc5(double x) { double t = std::trunc(x * 100000.0); if (t == 0.0) t = 0.0; return t / 100000.0; }
-static inline double l3norm(const double *a, const double *b) {                                              // util.py:104
+SCA_DHD static inline double round5_np(double x) { return std::rint(x * 100000.0) / 100000.0; }
+SCA_DHD static inline double trunc5(double x) { double t = std::trunc(x * 100000.0); if (t == 0.0) t = 0.0; return t / 100000.0; }
+SCA_DHD static inline double l3norm(const double *a, const double *b) {                                              // util.py:104
     return round5_py(std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0)));
 }
 
-struct Maneuver2D { double qi[3]; double r_min, t, p, q, length; char mode[3]; bool ok; };
+// one 2-D maneuver: what the 3-D planner and the sampler read of dubinsmaneuver2d's result (start yaw, radius, the first two
+// segment lengths, total length, word)
+struct Maneuver2D { double yaw, r_min, t, p, length; char mode[3]; bool ok; };
 
 // dubinsmaneuver2d.py:33-145: one candidate word
 // sa..c_ab are the five trig values every planner of the reference recomputes (same arguments, same libm: same bits)
-static bool word(int which, double alpha, double beta, double d, double sa, double sb, double ca, double cb, double c_ab,
+SCA_DHD static bool word(int which, double alpha, double beta, double d, double sa, double sb, double ca, double cb, double c_ab,
                  double &t, double &p, double &q, char mode[3]) {
     switch (which) {
     case 0: {                                                                                                // LSL :33-51
@@ -109,32 +140,42 @@ static bool word(int which, double alpha, double beta, double d, double sa, doub
     }
 }
 
-// dubins_path_planning (:179-218) + dubins_path_planning_from_origin (:148-176)
-static Maneuver2D plan2d(const double start[3], const double end[3], double c) {
-    Maneuver2D m;
-    m.qi[0] = start[0]; m.qi[1] = start[1]; m.qi[2] = start[2];
-    m.r_min = c; m.t = m.p = m.q = -1.0; m.length = INFINITY; m.ok = false;
+// dubins_path_planning (:179-218) + dubins_path_planning_from_origin (:148-176), in two parts: the frame depends on the end
+// points only, so the 3-D planner's search over the horizontal radius (dubinsmaneuver3d.py:52-100, ~50-100 calls with the same
+// end points) computes it once -- same arguments, same library functions, same bits as recomputing it every time
+struct Frame2D { double D, alpha, beta, sa, sb, ca, cb, c_ab; };
+SCA_DHD static Frame2D frame2d(const double start[3], const double end[3]) {
+    Frame2D F;
     const double ex = end[0] - start[0], ey = end[1] - start[1];
     const double syaw = start[2], eyaw = end[2];
-    const double D = std::sqrt(m_pow(ex, 2.0) + m_pow(ey, 2.0));
-    const double d = D / c;
+    F.D = std::sqrt(m_pow(ex, 2.0) + m_pow(ey, 2.0));
     const double theta = mod2pi(m_atan2(ey, ex));
-    const double alpha = mod2pi(syaw - theta);
-    const double beta = mod2pi(eyaw - theta);
+    F.alpha = mod2pi(syaw - theta);
+    F.beta = mod2pi(eyaw - theta);
+    m_sincos(F.alpha, F.sa, F.ca);
+    m_sincos(F.beta, F.sb, F.cb);
+    F.c_ab = m_cos(F.alpha - F.beta);
+    return F;
+}
+SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
+    Maneuver2D m;
+    m.yaw = yaw;
+    m.r_min = c; m.t = m.p = -1.0; m.length = INFINITY; m.ok = false;
+    m.mode[0] = m.mode[1] = m.mode[2] = 0;
+    const double d = F.D / c;
     double bcost = INFINITY;
-    const double sa = m_sin(alpha), sb = m_sin(beta), ca = m_cos(alpha), cb = m_cos(beta), c_ab = m_cos(alpha - beta);
     for (int w = 0; w < 6; w++) {                                     // planners = [LSL, RSR, LSR, RSL, RLR, LRL]
         double t, p, q; char mode[3];
-        if (!word(w, alpha, beta, d, sa, sb, ca, cb, c_ab, t, p, q, mode)) continue;
+        if (!word(w, F.alpha, F.beta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t, p, q, mode)) continue;
         const double cost = c * (std::fabs(t) + std::fabs(p) + std::fabs(q));
-        if (bcost > cost) { m.t = t; m.p = p; m.q = q; std::memcpy(m.mode, mode, 3); bcost = cost; m.ok = true; }
+        if (bcost > cost) { m.t = t; m.p = p; m.mode[0] = mode[0]; m.mode[1] = mode[1]; m.mode[2] = mode[2]; bcost = cost; m.ok = true; }
     }
     m.length = bcost;
     return m;
 }
 
 // get_position_in_segment (:283-297) / get_coordinates (:260-280)
-static void seg(double offset, const double qi[3], char mode, double q[3]) {
+SCA_DHD static void seg(double offset, const double qi[3], char mode, double q[3]) {
     q[0] = q[1] = q[2] = 0.0;
     if (mode == 'L') {
         q[0] = qi[0] + m_sin(qi[2] + offset) - m_sin(qi[2]);
@@ -150,9 +191,9 @@ static void seg(double offset, const double qi[3], char mode, double q[3]) {
         q[2] = qi[2];
     }
 }
-static void get_coordinates(const Maneuver2D &m, double offset, double q[3]) {
+SCA_DHD static void get_coordinates(const Maneuver2D &m, double offset, double q[3]) {
     const double noffset = offset / m.r_min;
-    const double qi[3] = {0., 0., m.qi[2]};
+    const double qi[3] = {0., 0., m.yaw};
     const double l1 = m.t, l2 = m.p;
     double q1[3], q2[3];
     seg(l1, qi, m.mode[0], q1);
@@ -174,7 +215,7 @@ struct Plan3D {
     long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
     // sample i of the path, [x, y, z, psi, gamma]: a pure function of i, so the tracker evaluates samples on demand
     // (the reference materialises all ~1000 of them at every re-plan and then discards most)
-    void sample(long i, double s[5]) const {
+    SCA_DHD void sample(long i, double s[5]) const {
         const double ran = (double)i * sampling_size;
         double qSZ[3], qXY[3];
         get_coordinates(v, ran, qSZ);
@@ -184,15 +225,15 @@ struct Plan3D {
 };
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
-static int try_to_construct(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2], double hr,
-                            Maneuver2D &mh, Maneuver2D &mv) {
-    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
-    mh = plan2d(qi2D, qf2D, hr);
+// H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
+SCA_DHD static int try_to_construct(const Frame2D &H, const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
+                                    double hr, Maneuver2D &mh, Maneuver2D &mv) {
+    mh = plan2d(H, qi[3], hr);
     const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
     const double vc = std::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
     if (vc < 1e-5) return 0;
     const double vr = 1.0 / vc;
-    mv = plan2d(qi3D, qf3D, vr);
+    mv = plan2d(frame2d(qi3D, qf3D), qi3D[2], vr);
     if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
     if (mv.mode[0] == 'R') { if (qi[4] - mv.t < pitchlims[0]) return 0; }
     else { if (qi[4] + mv.t > pitchlims[1]) return 0; }
@@ -200,29 +241,32 @@ static int try_to_construct(const double qi[5], const double qf[5], double Rmin,
 }
 
 // dubinsmaneuver3d (dubinsmaneuver3d.py:34-113) + compute_sampling (:116-132)
-static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2]) {
+SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2]) {
     Plan3D P;
     double b = 1.0;
     Maneuver2D fbh, fbv, fch, fcv;
-    int nfb = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
+    const Frame2D H = frame2d(qi2D, qf2D);
+    int nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
     int guard = 0;
     while (nfb < 2) {
         b *= 2.0;
-        nfb = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+        nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
         if (++guard > 200) return P;                                   // the reference would loop forever
     }
     double step = 0.1;
     while (std::fabs(step) > 1e-10) {
         double c = b + step;
         if (c < 1.0) c = 1.0;
-        const int nfc = try_to_construct(qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
+        const int nfc = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
         if (nfc > 0) {
             if (fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
         }
         step *= -0.1;
     }
     P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
-    std::memcpy(P.mode, fbh.mode, 3); std::memcpy(P.mode + 3, fbv.mode, 3); P.mode[6] = 0;
+    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
+    P.mode[6] = 0;
     double ss = 0.1;
     if (P.length > 100) ss = P.length / 1000;
     P.sampling_size = ss;
@@ -244,6 +288,15 @@ struct AgentTrack {
     int replans = 0;
 };
 
+// what the tracker reads of the agents (agent.py:13-36): plain pointers, host or device
+struct TrackView {
+    const double *goal;           // [n*3] goal_global_frame
+    const double *goal_heading;   // [n*3] goal_heading_frame
+    const double *pref_speed;     // [n]
+    const uint8_t *zaxis;         // [n] is_zAxis of scaPolicy.py:188-190 (condition_dist :300)
+    double turning_radius, pitch_lo, pitch_hi, neighbor_dist;
+};
+
 struct Pool;
 struct Tracker {
     int n = 0;
@@ -252,33 +305,42 @@ struct Tracker {
     std::vector<uint8_t> zaxis;
     double turning_radius = 1.5, pitchlims[2] = {-PI / 4, PI / 4}, neighbor_dist = 10.0;
     std::vector<AgentTrack> st;
+    TrackView view() const {
+        return TrackView{goal.data(), goal_heading.data(), pref_speed.data(), zaxis.data(), turning_radius, pitchlims[0], pitchlims[1],
+                         neighbor_dist};
+    }
 };
 
-static void compute_dubins(const Tracker &T, AgentTrack &a, int i, const double *pos, const double *heading) {     // :92-104
+SCA_DHD static void compute_dubins(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading) {  // :92-104
     const double qi[5] = {pos[0], pos[1], pos[2], heading[0], heading[1]};
     const double qf[5] = {T.goal[3 * i], T.goal[3 * i + 1], T.goal[3 * i + 2], T.goal_heading[3 * i], T.goal_heading[3 * i + 1]};
-    a.plan = plan3d(qi, qf, T.turning_radius, T.pitchlims);
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    a.plan = plan3d(qi, qf, T.turning_radius, pl);
     a.sampling_size = a.plan.sampling_size;
     a.next = 0;
     a.replans++;
 }
-static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
-static bool path_pop(AgentTrack &a, double out[3]) {
+SCA_DHD static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
+SCA_DHD static bool path_pop(AgentTrack &a, double out[3]) {
     if (path_empty(a)) return false;
     double s5[5];
     a.plan.sample(a.next++, s5);
     out[0] = s5[0]; out[1] = s5[1]; out[2] = s5[2];
     return true;
 }
-static void node_pop4(AgentTrack &a) { double t[3]; for (int k = 0; k < 4; k++) path_pop(a, t); }                // :253-261
-static void update_dubins(const Tracker &T, AgentTrack &a, int i, const double *pos) {                            // :243-250
+SCA_DHD static void node_pop4(AgentTrack &a) {                                                                    // :253-261
+    // the four popped nodes are discarded: only the cursor moves (pop past the end is a no-op, as list.pop guarded by `if`)
+    const long left = a.plan.count - a.next;
+    a.next += left < 4 ? (left > 0 ? left : 0) : 4;
+}
+SCA_DHD static void update_dubins(TrackView T, AgentTrack &a, int i, const double *pos) {                         // :243-250
     const double dis = l3norm(pos, a.now_goal);
     if (dis < a.sampling_size * 2) {
         if (!path_pop(a, a.now_goal)) { a.now_goal[0] = T.goal[3 * i]; a.now_goal[1] = T.goal[3 * i + 1]; a.now_goal[2] = T.goal[3 * i + 2]; }
     }
 }
 // util.py:125-137 is_parallel(vA float32, v_pref float64)
-static bool is_parallel(const float *vA, const double *vp) {
+SCA_DHD static bool is_parallel(const float *vA, const double *vp) {
     const float n1 = std::sqrt((float)((double)(float)(vA[0] * vA[0]) + (double)(float)(vA[1] * vA[1]) + (double)(float)(vA[2] * vA[2])));
     const double n2 = std::sqrt(fma3(vp, vp));
     const float v1[3] = {vA[0] / n1, vA[1] / n1, vA[2] / n1};
@@ -288,50 +350,62 @@ static bool is_parallel(const float *vA, const double *vp) {
     return round5_np(1.0 - std::fabs(fma3(v1d, v2))) < 3e-3;
 }
 
-// compute_v_pref (scaPolicy.py:264-338) for one agent; nbr0_dsq < 0 means agent.neighbors is empty
-static void compute_v_pref(const Tracker &T, AgentTrack &a, int i, const double *pos, const float *vel, const double *heading,
-                           double nbr0_dsq, double *V_des) {
+// compute_v_pref (scaPolicy.py:264-338) for one agent, in three parts so that the device can run the (rare, long) re-plans
+// of a step in a kernel of their own: decide -> [replan] -> finish.  nbr0_dsq < 0 means agent.neighbors is empty.
+// track_decide: everything up to the choice between following the path and re-planning; returns true when the agent must
+// re-plan (first call :283-287, off-track :322-327), otherwise dif is the vector to the tracked node.
+SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double *pos, const float *vel, double nbr0_dsq,
+                                 double dif[3]) {
     const double *goal = &T.goal[3 * i];
     const double dis_goal = l3norm(pos, goal);
     const double k = 3.0 * T.turning_radius;
-    double dif[3];
     if (!a.is_use_dubins) {
         a.is_use_dubins = true;
-        compute_dubins(T, a, i, pos, heading);
-        node_pop4(a);
-        path_pop(a, a.now_goal);
-        for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
-    } else {
-        update_dubins(T, a, i, pos);
-        const double dis = l3norm(pos, a.now_goal);
-        const double max_size = round5_py(6 * a.sampling_size);
-        const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
-        const double vA64[3] = {(double)vel[0], (double)vel[1], (double)vel[2]};
-        const float nvA = std::sqrt((float)((double)(float)(vel[0] * vel[0]) + (double)(float)(vel[1] * vel[1]) + (double)(float)(vel[2] * vel[2])));
-        double cs = fma3(vA64, pApG) / ((double)nvA * std::sqrt(fma3(pApG, pApG)));
-        if (!(cs < 1.0)) cs = 1.0;                                       // min(x, 1.0); nan -> 1.0 as Python's min does here
-        if (cs < -1.0) cs = -1.0;                                        // the reference would raise; clamp
-        const double theta = round5_py(m_acos(cs));
-        const double deg100 = round5_np(100.0 * (PI / 180.0));
-        const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
-        const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
-        if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
-            update_dubins(T, a, i, pos);
-            if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
-            else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
-        } else {
-            compute_dubins(T, a, i, pos, heading);
-            node_pop4(a);
-            path_pop(a, a.now_goal);
-            for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
-        }
+        return true;
     }
+    update_dubins(T, a, i, pos);
+    const double dis = l3norm(pos, a.now_goal);
+    const double max_size = round5_py(6 * a.sampling_size);
+    const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
+    const double vA64[3] = {(double)vel[0], (double)vel[1], (double)vel[2]};
+    const float nvA = std::sqrt((float)((double)(float)(vel[0] * vel[0]) + (double)(float)(vel[1] * vel[1]) + (double)(float)(vel[2] * vel[2])));
+    double cs = fma3(vA64, pApG) / ((double)nvA * std::sqrt(fma3(pApG, pApG)));
+    if (!(cs < 1.0)) cs = 1.0;                                       // min(x, 1.0); nan -> 1.0 as Python's min does here
+    if (cs < -1.0) cs = -1.0;                                        // the reference would raise; clamp
+    const double theta = round5_py(m_acos(cs));
+    const double deg100 = round5_np(100.0 * (PI / 180.0));
+    const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
+    const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
+    if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
+        update_dubins(T, a, i, pos);
+        if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+        else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
+        return false;
+    }
+    return true;
+}
+// compute_dubins + dubins_path_node_pop + the first tracked node (:284-287, :323-327)
+SCA_DHD static void track_replan(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading, double dif[3]) {
+    compute_dubins(T, a, i, pos, heading);
+    node_pop4(a);
+    path_pop(a, a.now_goal);
+    for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+}
+// :329-338
+SCA_DHD static void track_finish(TrackView T, AgentTrack &a, int i, const double *pos, const double dif[3], double *V_des) {
+    const double *goal = &T.goal[3 * i];
     const double zero[3] = {0, 0, 0};
     const double norm = l3norm(dif, zero);
     double v[3];
     for (int q = 0; q < 3; q++) v[q] = dif[q] * T.pref_speed[i] / norm;
     if (l3norm(goal, pos) < 0.2) v[0] = v[1] = v[2] = 0.0;               // util.reached, bound 0.2
     for (int q = 0; q < 3; q++) { a.v_pref[q] = v[q]; V_des[q] = trunc5(v[q]); }
+}
+static void compute_v_pref(TrackView T, AgentTrack &a, int i, const double *pos, const float *vel, const double *heading,
+                           double nbr0_dsq, double *V_des) {
+    double dif[3];
+    if (track_decide(T, a, i, pos, vel, nbr0_dsq, dif)) track_replan(T, a, i, pos, heading, dif);
+    track_finish(T, a, i, pos, dif, V_des);
 }
 
 // persistent worker threads (spawning 64 threads per step cost more than the tracking itself at N = 1024)
@@ -378,9 +452,10 @@ struct Pool {
 
 static void step_all(Tracker &T, const double *pos, const float *vel, const double *heading, const uint8_t *active,
                      const double *nbr0_dsq, double *vpref_out, int nthreads) {
+    const TrackView V = T.view();
     auto work = [&](int lo, int hi) {
         for (int i = lo; i < hi; i++)
-            if (active[i]) compute_v_pref(T, T.st[i], i, pos + 3 * i, vel + 3 * i, heading + 3 * i, nbr0_dsq[i], vpref_out + 3 * i);
+            if (active[i]) compute_v_pref(V, T.st[i], i, pos + 3 * i, vel + 3 * i, heading + 3 * i, nbr0_dsq[i], vpref_out + 3 * i);
     };
     if (nthreads <= 1 || T.n < 32) { work(0, T.n); return; }
     if (!T.pool) T.pool = new Pool();

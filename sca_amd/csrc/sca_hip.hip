@@ -13,6 +13,7 @@
 #include "sca_kernels.hip.h"
 #include "sca_kdbuild.hip.h"
 #include "sca_dubins.hpp"
+#include "sca_tracker.hip.h"
 
 using namespace sca;
 
@@ -155,6 +156,11 @@ struct sca_ctx {
     double max_radius = 0, max_obs_radius = 0, max_pref_speed = 0;
     std::string err;
     double *tab = nullptr;
+    // device-side v_pref tracker (sca_tracker.hip.h)
+    TrackDev trk{};
+    sca_dubins::TrackView trk_view{};
+    double *trk_goal_heading = nullptr;
+    bool trk_on = false, trk_in_pass = false;
 };
 
 #define CHK(ctx, call)                                                                         \
@@ -253,6 +259,72 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
     return 0;
 }
 
+// ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
+static int launch_tracker(sca_ctx *c, bool from_lists);
+static int tracker_free(sca_ctx *c) {
+    if (!c->trk.st) { c->trk_on = false; return 0; }
+    CHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->trk.st); (void)hipFree(c->trk.nbr0); (void)hipFree(c->trk.list); (void)hipFree(c->trk.count);
+    (void)hipFree(c->trk_goal_heading);
+    c->trk = TrackDev{}; c->trk_goal_heading = nullptr; c->trk_on = false; c->trk_in_pass = false;
+    return 0;
+}
+int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double turning_radius, double pitch_min, double pitch_max,
+                              int in_pass) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    ARG(c, goal_heading && turning_radius > 0);
+    if (int r = tracker_free(c)) return r;
+    const int n = c->n;
+    CHK(c, hipMalloc((void **)&c->trk.st, sizeof(sca_dubins::AgentTrack) * n));
+    CHK(c, hipMalloc((void **)&c->trk.nbr0, sizeof(double) * n));
+    CHK(c, hipMalloc((void **)&c->trk.list, sizeof(int32_t) * n));
+    CHK(c, hipMalloc((void **)&c->trk.count, sizeof(int32_t) * 2));
+    CHK(c, hipMalloc((void **)&c->trk_goal_heading, sizeof(double) * 3 * n));
+    std::vector<sca_dubins::AgentTrack> init((size_t)n);
+    std::vector<double> nb((size_t)n, -1.0);
+    std::vector<uint8_t> pol((size_t)n), mode((size_t)n);
+    CHK(c, hipMemcpyAsync(pol.data(), c->d.policy, n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipMemcpyAsync(c->trk.st, init.data(), sizeof(sca_dubins::AgentTrack) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->trk.nbr0, nb.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->trk_goal_heading, goal_heading, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemsetAsync(c->trk.count, 0, sizeof(int32_t) * 2, c->stream));
+    CHK(c, hipMemsetAsync(c->d.nbr_valid, 0, n, c->stream));            // no policy pass of this agent set has left lists yet
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) mode[i] = (pol[i] == SCA_POLICY_SCA || pol[i] == SCA_POLICY_RVO3D_DUBINS) ? 1 : 0;
+    CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode.data(), n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemsetAsync(c->d.vpref_ext, 0, sizeof(double) * 3 * n, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    c->trk.parity = 0;
+    c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
+                                        pitch_max, c->P.neighbor_dist};
+    c->trk_on = true; c->trk_in_pass = in_pass != 0;
+    return 0;
+}
+int sca_device_tracker_disable(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    return tracker_free(c);
+}
+int sca_device_tracker_vpref(sca_ctx *c, const double *nbr0_dsq, double *vpref_out) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->trk_on || !c->state_set) { c->err = "sca_device_tracker_enable and sca_set_state first"; return SCA_ERR_STATE; }
+    if (nbr0_dsq) CHK(c, hipMemcpyAsync(c->trk.nbr0, nbr0_dsq, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launch_tracker(c, nbr0_dsq == nullptr)) return r;
+    if (vpref_out) CHK(c, hipMemcpyAsync(vpref_out, c->d.vpref_ext, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int sca_device_tracker_replans(sca_ctx *c, int32_t *replans) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, replans);
+    if (!c->trk_on) { c->err = "sca_device_tracker_enable first"; return SCA_ERR_STATE; }
+    int32_t *tmp = (int32_t *)c->trk.list;                              // free between passes
+    hipLaunchKernelGGL(k_track_replans, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->trk.st, tmp, c->n);
+    CHK(c, hipMemcpyAsync(replans, tmp, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int sca_create(const sca_params *p, int device, int max_agents, int max_obstacles, sca_ctx **out) {
     if (!out || max_agents <= 0 || max_obstacles < 0) return SCA_ERR_ARG;
     sca_ctx *c = new sca_ctx();
@@ -345,6 +417,7 @@ void sca_destroy(sca_ctx *c) {
     if (!c) return;
     DeviceView &d = c->d;
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
+    (void)tracker_free(c);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
@@ -396,6 +469,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
         CHK(c, hipFree(c->d.hist));
         c->d.hist = nullptr; c->d.hist_cap = 0; c->d.hist_row = 0;
     }
+    if (int r = tracker_free(c)) return r;                            // the tracker records belong to the old agent set
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
     c->h_rec.assign(n, PubRec{});
     c->max_radius = 0; c->max_pref_speed = 0;
@@ -661,8 +735,23 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
     return 0;
 }
 
+// v_pref of the SCA / RVO3D+Dubins agents of the shard, before anything of the pass reads it (the per-agent prologue inside
+// k_kd_gather does)
+static int launch_tracker(sca_ctx *c, bool from_lists) {
+    const int cnt = c->d.shard_count;
+    TrackDev K = c->trk;
+    K.nbr0_from_lists = from_lists ? 1 : 0;
+    hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
+    hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, c->stream, c->d,
+                       c->trk_view, K);
+    CHK(c, hipGetLastError());
+    c->trk.parity ^= 1;
+    return 0;
+}
+
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
     const DeviceView &d = c->d;
+    if (c->trk_on && c->trk_in_pass) { if (int r = launch_tracker(c, true)) return r; }
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
     else if (mode == SCA_NBR_KDTREE_HOSTBUILD) {
         if (c->perm_on_device) {

@@ -15,8 +15,10 @@ Differences that matter:
     (pos_global_frame, vel_global_frame, heading_global_frame, is_at_goal, ...) are views / properties over them;
   * SCAPolicy and RVO3dDubinsPolicy take v_pref from the reference's Dubins tracker (scaPolicy.py:264-338), a host-side,
     per-agent stateful planner outside the kernel boundary.  The native restatement is sca_amd.tracker.DubinsTracker:
-    pass it as MACAEnv(v_pref_fn=tracker) (any `v_pref_fn(env) -> [N,3]` works); without one the straight-line rule of
-    rvo3dPolicy.py:182-196 is used and `env.dubins_tracker` is False;
+    pass it as MACAEnv(v_pref_fn=tracker) (any `v_pref_fn(env) -> [N,3]` works; bit-exact, host-bound), or use
+    MACAEnv(device_tracker=True): the same tracker as kernels inside every pass (state stays in HBM; equal to the host
+    tracker up to isolated 1e-5 steps); without either the straight-line rule of rvo3dPolicy.py:182-196
+    is used and `env.dubins_tracker` is False;
   * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
 There is no CPU path: constructing the env without a GPU raises.
 """
@@ -199,13 +201,16 @@ class _KdTreeView:
 
 
 class MACAEnv:
-    def __init__(self, v_pref_fn=None, device=0, neighbor_mode=S.NBR_KDTREE, history_capacity=0):
+    def __init__(self, v_pref_fn=None, device=0, neighbor_mode=S.NBR_KDTREE, history_capacity=0, device_tracker=False):
         self.agents = None
         self.obstacles = []
         self.kdTree = None
         self.solver = None
         self.v_pref_fn = v_pref_fn
-        self.dubins_tracker = v_pref_fn is not None
+        self.device_tracker = bool(device_tracker)     # SCA / RVO3D+Dubins v_pref from the tracker kernels inside every pass
+        if self.device_tracker and v_pref_fn is not None:
+            raise ValueError('device_tracker=True and v_pref_fn are alternatives')
+        self.dubins_tracker = v_pref_fn is not None or self.device_tracker
         self.device = device
         self.neighbor_mode = neighbor_mode
         self.history_capacity = history_capacity      # env steps of Agent.history_info kept on the device (0: no log)
@@ -240,6 +245,8 @@ class MACAEnv:
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
         if self.history_capacity:
             self.solver.history_enable(self.history_capacity)
+        if self.device_tracker and self._ext.any():
+            self.solver.device_tracker_enable(goal6[:, 3:6])
         for a in agents:
             a._env = self
             a.policy._env = self

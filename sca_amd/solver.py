@@ -118,6 +118,31 @@ class BatchedSolver:
         mode = np.ascontiguousarray(np.broadcast_to(mode, (self.n,)), np.uint8)
         self._chk(self.L.sca_set_vpref(self.ctx, _lib.ptr(vpref, C.c_double), _lib.ptr(mode, C.c_uint8)), 'sca_set_vpref')
 
+    # ---- SCA's v_pref tracker on the device (scaPolicy.py:264-338) ---------------------------------------
+    def device_tracker_enable(self, goal_heading, turning_radius=1.5, pitchlims=(-math.pi / 4, math.pi / 4), in_pass=True):
+        """From now on the SCA / RVO3D+Dubins agents take v_pref from the device tracker: inside every policy pass
+        (in_pass=True) or only when device_tracker_vpref() is called."""
+        gh = _lib.as_d(goal_heading).reshape(self.n, 3)
+        self._chk(self.L.sca_device_tracker_enable(self.ctx, _lib.ptr(gh, C.c_double), float(turning_radius), float(pitchlims[0]),
+                                                   float(pitchlims[1]), int(bool(in_pass))), 'sca_device_tracker_enable')
+
+    def device_tracker_disable(self):
+        self._chk(self.L.sca_device_tracker_disable(self.ctx), 'sca_device_tracker_disable')
+
+    def device_tracker_vpref(self, nbr0_dsq=None):
+        """One compute_v_pref for every active tracked agent on the current state; nbr0_dsq[i] = distSq of agent.neighbors[0]
+        of the previous pass (negative: empty), None = taken from the neighbour lists on the device."""
+        out = np.zeros((self.n, 3))
+        nb = None if nbr0_dsq is None else _lib.as_d(nbr0_dsq).reshape(self.n)
+        self._chk(self.L.sca_device_tracker_vpref(self.ctx, None if nb is None else _lib.ptr(nb, C.c_double),
+                                                  _lib.ptr(out, C.c_double)), 'sca_device_tracker_vpref')
+        return out
+
+    def device_tracker_replans(self):
+        r = np.zeros(self.n, np.int32)
+        self._chk(self.L.sca_device_tracker_replans(self.ctx, _lib.ptr(r, C.c_int32)), 'sca_device_tracker_replans')
+        return r
+
     # ---- hot path --------------------------------------------------------------------------------------
     def policy_pass(self, mode=NBR_KDTREE):
         self._chk(self.L.sca_policy_pass(self.ctx, int(mode)), 'sca_policy_pass')
