@@ -161,6 +161,10 @@ struct sca_ctx {
     sca_dubins::TrackView trk_view{};
     double *trk_goal_heading = nullptr;
     bool trk_on = false, trk_in_pass = false;
+    // the re-plans run on a stream of their own, next to the kd build and the neighbour query of the same pass
+    hipStream_t trk_stream = nullptr;
+    hipEvent_t trk_fork = nullptr, trk_join = nullptr;
+    bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
 };
 
 #define CHK(ctx, call)                                                                         \
@@ -260,12 +264,16 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
 }
 
 // ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
-static int launch_tracker(sca_ctx *c, bool from_lists);
+static int launch_tracker(sca_ctx *c, bool from_lists, bool side);
 static int tracker_free(sca_ctx *c) {
     if (!c->trk.st) { c->trk_on = false; return 0; }
     CHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->trk.st); (void)hipFree(c->trk.nbr0); (void)hipFree(c->trk.list); (void)hipFree(c->trk.count);
     (void)hipFree(c->trk_goal_heading);
+    if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
+    if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
+    if (c->trk_join) { (void)hipEventDestroy(c->trk_join); c->trk_join = nullptr; }
+    c->kd.skip_prep = 0;
     c->trk = TrackDev{}; c->trk_goal_heading = nullptr; c->trk_on = false; c->trk_in_pass = false;
     return 0;
 }
@@ -281,6 +289,9 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipMalloc((void **)&c->trk.list, sizeof(int32_t) * n));
     CHK(c, hipMalloc((void **)&c->trk.count, sizeof(int32_t) * 2));
     CHK(c, hipMalloc((void **)&c->trk_goal_heading, sizeof(double) * 3 * n));
+    CHK(c, hipStreamCreateWithFlags(&c->trk_stream, hipStreamNonBlocking));
+    CHK(c, hipEventCreateWithFlags(&c->trk_fork, hipEventDisableTiming));
+    CHK(c, hipEventCreateWithFlags(&c->trk_join, hipEventDisableTiming));
     std::vector<sca_dubins::AgentTrack> init((size_t)n);
     std::vector<double> nb((size_t)n, -1.0);
     std::vector<uint8_t> pol((size_t)n), mode((size_t)n);
@@ -299,6 +310,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
                                         pitch_max, c->P.neighbor_dist};
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
+    c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -309,7 +321,7 @@ int sca_device_tracker_vpref(sca_ctx *c, const double *nbr0_dsq, double *vpref_o
     if (!c) return SCA_ERR_ARG;
     if (!c->trk_on || !c->state_set) { c->err = "sca_device_tracker_enable and sca_set_state first"; return SCA_ERR_STATE; }
     if (nbr0_dsq) CHK(c, hipMemcpyAsync(c->trk.nbr0, nbr0_dsq, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
-    if (int r = launch_tracker(c, nbr0_dsq == nullptr)) return r;
+    if (int r = launch_tracker(c, nbr0_dsq == nullptr, false)) return r;
     if (vpref_out) CHK(c, hipMemcpyAsync(vpref_out, c->d.vpref_ext, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -737,13 +749,21 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
 
 // v_pref of the SCA / RVO3D+Dubins agents of the shard, before anything of the pass reads it (the per-agent prologue inside
 // k_kd_gather does)
-static int launch_tracker(sca_ctx *c, bool from_lists) {
+// side = true: k_replan goes to the tracker's own stream; the caller waits for trk_join before anything reads v_pref
+static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
     K.nbr0_from_lists = from_lists ? 1 : 0;
     hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
-    hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, c->stream, c->d,
+    hipStream_t rs = c->stream;
+    if (side) {
+        CHK(c, hipEventRecord(c->trk_fork, c->stream));
+        CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
+        rs = c->trk_stream;
+    }
+    hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                        c->trk_view, K);
+    if (side) CHK(c, hipEventRecord(c->trk_join, c->trk_stream));
     CHK(c, hipGetLastError());
     c->trk.parity ^= 1;
     return 0;
@@ -751,7 +771,12 @@ static int launch_tracker(sca_ctx *c, bool from_lists) {
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
     const DeviceView &d = c->d;
-    if (c->trk_on && c->trk_in_pass) { if (int r = launch_tracker(c, true)) return r; }
+    // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
+    // v_pref) then moves from k_kd_gather to k_prep_shard behind the join
+    const bool tracked = c->trk_on && c->trk_in_pass;
+    const bool overlap = tracked && mode == SCA_NBR_KDTREE && !c->trk_serial;
+    c->kd.skip_prep = overlap ? 1 : 0;
+    if (tracked) { if (int r = launch_tracker(c, true, overlap)) return r; }
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
     else if (mode == SCA_NBR_KDTREE_HOSTBUILD) {
         if (c->perm_on_device) {
@@ -780,6 +805,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
                            c->stream, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
+    if (overlap) {
+        CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));
+        hipLaunchKernelGGL(k_prep_shard, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    }
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));         // [e1, e2] = k_solve alone (what rocprofv3 reports for it)

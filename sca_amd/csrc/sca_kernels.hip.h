@@ -1346,6 +1346,12 @@ __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
     if (agent < d.n) prep_agent(d, P, (Prep *)d.prep, agent);
 }
 
+// the prologue of the rank's own shard only, after the tracker's v_pref has arrived (k_kd_gather skipped it)
+__global__ __launch_bounds__(256) void k_prep_shard(DeviceView d, Params P) {
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, agent);
+}
+
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
 template <bool FUSE_INTEGRATE>
