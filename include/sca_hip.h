@@ -187,6 +187,11 @@ int sca_device_tracker_disable(sca_ctx *ctx);
 int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*/, double *vpref_out /*n*3, nullable*/);
 int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
 
+/* host self-test (no GPU needed): the device planner's four-lane form evaluates the four CSC Dubins words
+ * (dubinsmaneuver2d.py:33-109) as one sign-parametrised instruction stream; this compares it with the literal words on the
+ * given frames (alpha, beta in [0, 2 pi), d >= 0) and counts results that are not bit-identical (must be 0) */
+int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, const double *d, int64_t *mismatches);
+
 /* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
 /* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */
 int sca_candidate_table(int num_N, double *unit /*3*num_N*/, double *phi_num /*num_N*/);

@@ -140,6 +140,39 @@ SCA_DHD static bool word(int which, double alpha, double beta, double d, double 
     }
 }
 
+// The four CSC words (LSL, RSR, LSR, RSL = word 0..3 above) as ONE instruction stream with per-word signs, for the device's
+// four-lanes-per-plan kernel (sca_tracker.hip.h: a lane evaluates the word of its index).  Only exact transformations of the
+// literal statements are used -- negation commutes with rounding, a - b == a + (-b), a + b == b + a, x - (+0) == x -- so the
+// result equals word(w, ...) bit for bit on any IEEE machine (checked on the host: sca_selftest_dubins_words).
+//   S = (+-sa) + (+-sb) is the bracket of p2 and of atan2's x;  y = (+-ca) + (+-cb);  the second atan2 (LSR / RSL only)
+//   becomes atan2(0, p) = +0 for LSL / RSR.
+// Returns false (word not feasible) exactly when word() does; t, p, q are computed unconditionally (nan when infeasible), so
+// that lanes of one plan never diverge.
+SCA_DHD static bool csc_word_uniform(int w, double alpha, double beta, double mbeta /* mod2pi(beta) */, double d, double sa,
+                                     double sb, double ca, double cb, double c_ab, double &t, double &p, double &q) {
+    const bool cross = w >= 2;                         // LSR, RSL
+    const bool rfirst = (w & 1) != 0;                  // RSR, RSL start with a right turn
+    const double u = rfirst ? -sa : sa;                // LSL(+,-) RSR(-,+) LSR(+,+) RSL(-,-)
+    const double v = (w == 0 || w == 3) ? -sb : sb;
+    const double S = u + v;
+    const double k2 = cross ? -2.0 : 2.0;
+    const double cab2 = 2 * c_ab;
+    const double p2 = ((k2 + (d * d)) + (cross ? cab2 : -cab2)) + ((2 * d) * S);
+    const double x = (d + u) + v;
+    const double ya = (w == 0 || w == 2) ? -ca : ca;   // LSL(-,+) RSR(+,-) LSR(-,-) RSL(+,+)
+    const double yb = (w == 1 || w == 2) ? -cb : cb;
+    const double y = ya + yb;
+    p = std::sqrt(p2);
+    const double A1 = m_atan2(y, x);
+    const double A2 = m_atan2(cross ? (w == 2 ? -2.0 : 2.0) : 0.0, p);
+    const double tmp = A1 - A2;
+    const double ta = tmp - alpha;
+    t = mod2pi(rfirst ? -ta : ta);
+    const double qa = (w == 2 ? mbeta : beta) - tmp;
+    q = mod2pi((w == 1 || w == 2) ? -qa : qa);
+    return !(p2 < 0);
+}
+
 // dubins_path_planning (:179-218) + dubins_path_planning_from_origin (:148-176), in two parts: the frame depends on the end
 // points only, so the 3-D planner's search over the horizontal radius (dubinsmaneuver3d.py:52-100, ~50-100 calls with the same
 // end points) computes it once -- same arguments, same library functions, same bits as recomputing it every time
@@ -311,14 +344,23 @@ struct Tracker {
     }
 };
 
-SCA_DHD static void compute_dubins(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading) {  // :92-104
-    const double qi[5] = {pos[0], pos[1], pos[2], heading[0], heading[1]};
-    const double qf[5] = {T.goal[3 * i], T.goal[3 * i + 1], T.goal[3 * i + 2], T.goal_heading[3 * i], T.goal_heading[3 * i + 1]};
-    const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    a.plan = plan3d(qi, qf, T.turning_radius, pl);
+// the end points of compute_dubins (scaPolicy.py:92-104): qi = pose now, qf = goal pose
+SCA_DHD static void dubins_endpoints(TrackView T, int i, const double *pos, const double *heading, double qi[5], double qf[5]) {
+    qi[0] = pos[0]; qi[1] = pos[1]; qi[2] = pos[2]; qi[3] = heading[0]; qi[4] = heading[1];
+    qf[0] = T.goal[3 * i]; qf[1] = T.goal[3 * i + 1]; qf[2] = T.goal[3 * i + 2];
+    qf[3] = T.goal_heading[3 * i]; qf[4] = T.goal_heading[3 * i + 1];
+}
+SCA_DHD static void adopt_plan(AgentTrack &a, const Plan3D &P) {
+    a.plan = P;
     a.sampling_size = a.plan.sampling_size;
     a.next = 0;
     a.replans++;
+}
+SCA_DHD static void compute_dubins(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading) {  // :92-104
+    double qi[5], qf[5];
+    dubins_endpoints(T, i, pos, heading, qi, qf);
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    adopt_plan(a, plan3d(qi, qf, T.turning_radius, pl));
 }
 SCA_DHD static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
 SCA_DHD static bool path_pop(AgentTrack &a, double out[3]) {
@@ -387,6 +429,13 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
 // compute_dubins + dubins_path_node_pop + the first tracked node (:284-287, :323-327)
 SCA_DHD static void track_replan(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading, double dif[3]) {
     compute_dubins(T, a, i, pos, heading);
+    node_pop4(a);
+    path_pop(a, a.now_goal);
+    for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
+}
+// the same with a plan computed elsewhere (the device's four-lane planner)
+SCA_DHD static void track_adopt(AgentTrack &a, const Plan3D &P, const double *pos, double dif[3]) {
+    adopt_plan(a, P);
     node_pop4(a);
     path_pop(a, a.now_goal);
     for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];

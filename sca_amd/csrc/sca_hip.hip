@@ -165,6 +165,7 @@ struct sca_ctx {
     hipStream_t trk_stream = nullptr;
     hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
+    bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
 };
 
 #define CHK(ctx, call)                                                                         \
@@ -263,6 +264,29 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
     return 0;
 }
 
+// host self-test: the sign-parametrised CSC word of the device's four-lane planner against the literal word(), bit for bit
+int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, const double *d, int64_t *mismatches) {
+    if (n < 0 || !alpha || !beta || !d || !mismatches) return SCA_ERR_ARG;
+    int64_t bad = 0;
+    auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0 || (a != a && b != b); };
+    for (int i = 0; i < n; i++) {
+        double sa, sb, ca, cb;
+        sca_dubins::m_sincos(alpha[i], sa, ca);
+        sca_dubins::m_sincos(beta[i], sb, cb);
+        const double c_ab = sca_dubins::m_cos(alpha[i] - beta[i]);
+        const double mb = sca_dubins::mod2pi(beta[i]);
+        for (int w = 0; w < 4; w++) {
+            double t0 = 0, p0 = 0, q0 = 0, t1 = 0, p1 = 0, q1 = 0;
+            char mode[3];
+            const bool ok0 = sca_dubins::word(w, alpha[i], beta[i], d[i], sa, sb, ca, cb, c_ab, t0, p0, q0, mode);
+            const bool ok1 = sca_dubins::csc_word_uniform(w, alpha[i], beta[i], mb, d[i], sa, sb, ca, cb, c_ab, t1, p1, q1);
+            if (ok0 != ok1 || (ok0 && !(same(t0, t1) && same(p0, p1) && same(q0, q1)))) bad++;
+        }
+    }
+    *mismatches = bad;
+    return 0;
+}
+
 // ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
 static int launch_tracker(sca_ctx *c, bool from_lists, bool side);
 static int tracker_free(sca_ctx *c) {
@@ -311,6 +335,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
                                         pitch_max, c->P.neighbor_dist};
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
+    c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -761,8 +786,13 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
         CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
         rs = c->trk_stream;
     }
-    hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
-                       c->trk_view, K);
+    K.quad = c->trk_quad ? 1 : 0;
+    // both forms are launched; the device-side count of this pass decides which of them does the work
+    if (c->trk_quad)
+        hipLaunchKernelGGL(k_replan4, dim3((std::min(cnt, TRK_QUAD_MAX) * 4 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
+    if (!c->trk_quad || cnt > TRK_QUAD_MAX)
+        hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
+                           c->trk_view, K);
     if (side) CHK(c, hipEventRecord(c->trk_join, c->trk_stream));
     CHK(c, hipGetLastError());
     c->trk.parity ^= 1;

@@ -26,8 +26,10 @@ struct TrackDev {
     int32_t *count;               // [2] list length, double-buffered by pass parity (k_track zeroes the other one)
     int parity;
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
+    int quad;                     // 1: k_replan4 (four lanes per plan) takes the passes with <= TRK_QUAD_MAX re-plans
 };
 
+constexpr int TRK_QUAD_MAX = 16384;       // re-plans per pass up to which the four-lanes-per-plan kernel is used
 constexpr int TRK_REPLAN_LANES = 64;      // one wavefront per workgroup: re-plans spread over as many CUs as possible
 
 __device__ __forceinline__ bool track_active(const DeviceView &d, int agent) {
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= K.count[K.parity]) return;
+    const int count = K.count[K.parity];
+    if (idx >= count || (K.quad && count <= TRK_QUAD_MAX)) return;          // few re-plans: k_replan4's pass
     const int agent = K.list[idx];
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -85,6 +88,168 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
     sca_dubins::track_replan(T, a, agent, pos, heading, dif);
+    sca_dubins::track_finish(T, a, agent, pos, dif, V);
+    track_store(d, agent, V);
+}
+
+// ---- four lanes per plan ---------------------------------------------------------------------------------------------------
+// One re-plan is a strictly sequential search (every candidate radius depends on the verdict on the previous one), ~65 and up
+// to ~115 candidates of two 2-D plans each; a lane working alone needs 0.6-0.8 ms for it, whatever the size of the swarm.
+// Inside one candidate, though, the four CSC words of a 2-D plan are independent, and so are the three sin/cos pairs of its
+// frame: a DPP quad evaluates them side by side (csc_word_uniform: one instruction stream, per-lane signs), the winner is
+// picked with the reference's first-minimum rule from quad broadcasts, and everything else is computed redundantly by the
+// four lanes, which therefore never diverge.  ~3x shorter critical path; 4x the lanes, so ~1.3x the total work: used while
+// the re-plans of a pass leave SIMDs idle anyway (count <= TRK_QUAD_MAX), the lane-per-plan kernel takes over above that.
+
+template <int K> __device__ __forceinline__ double quad_bcast_d(double x) {
+    constexpr int CTRL = K | (K << 2) | (K << 4) | (K << 6);               // quad_perm:[K,K,K,K]
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double lane_fetch_d(double x, int src_lane) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = __shfl((int)(unsigned)v, src_lane), hi = __shfl((int)(unsigned)(v >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+struct QuadFrame { sca_dubins::Frame2D F; double mbeta; };
+
+// frame2d with the three sincos arguments (alpha, beta, alpha - beta) on lanes 0, 1, 2 of the quad
+__device__ __forceinline__ QuadFrame frame2d_quad(const double start[3], const double end[3], int sub) {
+    using namespace sca_dubins;
+    QuadFrame Q;
+    const double ex = end[0] - start[0], ey = end[1] - start[1];
+    Q.F.D = ::sqrt(m_pow(ex, 2.0) + m_pow(ey, 2.0));
+    const double theta = mod2pi(m_atan2(ey, ex));
+    Q.F.alpha = mod2pi(start[2] - theta);
+    Q.F.beta = mod2pi(end[2] - theta);
+    const double arg = sub == 0 ? Q.F.alpha : (sub == 1 ? Q.F.beta : Q.F.alpha - Q.F.beta);
+    double sn, cs;
+    m_sincos(arg, sn, cs);
+    Q.F.sa = quad_bcast_d<0>(sn);
+    Q.F.ca = quad_bcast_d<0>(cs);
+    Q.F.sb = quad_bcast_d<1>(sn);
+    Q.F.cb = quad_bcast_d<1>(cs);
+    Q.F.c_ab = quad_bcast_d<2>(cs);
+    Q.mbeta = mod2pi(Q.F.beta);
+    return Q;
+}
+
+// plan2d: lane `sub` of the quad evaluates CSC word `sub`; RLR / LRL (feasible only for end points closer than four radii) by
+// all four lanes alike
+__device__ __forceinline__ sca_dubins::Maneuver2D plan2d_quad(const QuadFrame &Q, double yaw, double c, int sub, int lane) {
+    using namespace sca_dubins;
+    const Frame2D &F = Q.F;
+    Maneuver2D m;
+    m.yaw = yaw; m.r_min = c; m.t = m.p = -1.0; m.length = INFINITY; m.ok = false;
+    m.mode[0] = m.mode[1] = m.mode[2] = 0;
+    const double d = F.D / c;
+    double t, p, q;
+    const bool ok = csc_word_uniform(sub, F.alpha, F.beta, Q.mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t, p, q);
+    const double cost = ok ? c * (::fabs(t) + ::fabs(p) + ::fabs(q)) : INFINITY;     // an infeasible word is skipped (:200-203)
+    const double c0 = quad_bcast_d<0>(cost);
+    const double c1 = quad_bcast_d<1>(cost);
+    const double c2 = quad_bcast_d<2>(cost);
+    const double c3 = quad_bcast_d<3>(cost);
+    int w = -1;
+    double bcost = INFINITY;                                                         // `if bcost > cost` in planner order
+    if (bcost > c0) { w = 0; bcost = c0; }
+    if (bcost > c1) { w = 1; bcost = c1; }
+    if (bcost > c2) { w = 2; bcost = c2; }
+    if (bcost > c3) { w = 3; bcost = c3; }
+    const int src = (lane & ~3) | (w & 3);
+    double bt = lane_fetch_d(t, src);
+    double bp = lane_fetch_d(p, src);
+    for (int k = 4; k < 6; k++) {
+        double t2, p2, q2; char md[3];
+        if (!word(k, F.alpha, F.beta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t2, p2, q2, md)) continue;
+        const double cost2 = c * (::fabs(t2) + ::fabs(p2) + ::fabs(q2));
+        if (bcost > cost2) { w = k; bcost = cost2; bt = t2; bp = p2; }
+    }
+    if (w >= 0) {
+        m.ok = true; m.t = bt; m.p = bp;
+        m.mode[0] = (w == 0 || w == 2 || w == 5) ? 'L' : 'R';
+        m.mode[1] = w < 4 ? 'S' : (w == 4 ? 'L' : 'R');
+        m.mode[2] = (w == 0 || w == 3 || w == 5) ? 'L' : 'R';
+    }
+    m.length = bcost;
+    return m;
+}
+
+__device__ __forceinline__ int try_to_construct_quad(const QuadFrame &H, const double qi[5], const double qf[5], double Rmin,
+                                                     const double pitchlims[2], double hr, sca_dubins::Maneuver2D &mh,
+                                                     sca_dubins::Maneuver2D &mv, int sub, int lane) {
+    using namespace sca_dubins;
+    mh = plan2d_quad(H, qi[3], hr, sub, lane);
+    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
+    const double vc = ::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
+    if (vc < 1e-5) return 0;
+    const double vr = 1.0 / vc;
+    const QuadFrame V = frame2d_quad(qi3D, qf3D, sub);
+    mv = plan2d_quad(V, qi3D[2], vr, sub, lane);
+    if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
+    if (mv.mode[0] == 'R') { if (qi[4] - mv.t < pitchlims[0]) return 0; }
+    else { if (qi[4] + mv.t > pitchlims[1]) return 0; }
+    return 2;
+}
+
+// plan3d (sca_dubins.hpp) with the quad planner; the reference's three stages (first try, doubling, local search) are
+// phases 0, 1, 2 of one loop so that the planner is inlined once
+__device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
+                                                          int sub, int lane) {
+    using namespace sca_dubins;
+    Plan3D P;
+    double b = 1.0, step = 0.1;
+    Maneuver2D fbh, fbv, fch, fcv;
+    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
+    const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
+    int phase = 0, guard = 0;
+    while (phase < 2 || ::fabs(step) > 1e-10) {
+        double c;
+        if (phase == 0) c = b;
+        else if (phase == 1) { b *= 2.0; c = b; }
+        else { c = b + step; if (c < 1.0) c = 1.0; }
+        const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv, sub, lane);
+        if (phase < 2) {
+            if (phase == 1 && ++guard > 200) return P;
+            if (nf >= 2) { fbh = fch; fbv = fcv; phase = 2; }
+            else phase = 1;
+        } else if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
+        else step *= -0.1;
+    }
+    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
+    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
+    P.mode[6] = 0;
+    double ss = 0.1;
+    if (P.length > 100) ss = P.length / 1000;
+    P.sampling_size = ss;
+    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
+    const double stop = P.length + ss;
+    const long cnt = (long)::ceil(stop / ss);
+    P.count = cnt > 0 ? cnt : 0;
+    return P;
+}
+
+__global__ __launch_bounds__(64) void k_replan4(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    const int count = K.count[K.parity];
+    if (count > TRK_QUAD_MAX) return;                                    // k_replan's pass
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gid >> 2, sub = gid & 3, lane = threadIdx.x & 63;
+    if (idx >= count) return;                                            // whole quads leave together
+    const int agent = K.list[idx];
+    const PubRec r = d.rec[agent];
+    const double pos[3] = {r.px, r.py, r.pz};
+    const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
+    double qi[5], qf[5];
+    sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    const sca_dubins::Plan3D P = plan3d_quad(qi, qf, T.turning_radius, pl, sub, lane);
+    if (sub != 0) return;
+    sca_dubins::AgentTrack &a = K.st[agent];
+    double dif[3], V[3];
+    sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
     track_store(d, agent, V);
 }

@@ -44,3 +44,30 @@ def test_tracker_reproduces_reference_v_pref(name):
         tr.note_neighbors(fx['nbr_valid'][t], fx['nbr_n'][t], fx['nbr_dsq'][t])
     assert tr.replans()[ext].min() >= 1
     tr.close()
+
+
+def test_uniform_csc_word_equals_literal_words():
+    """The device's four-lanes-per-plan planner evaluates LSL / RSR / LSR / RSL as one sign-parametrised instruction stream
+    (sca_dubins.hpp csc_word_uniform); on the host, with glibc on both sides, it must equal the literal words of
+    dubinsmaneuver2d.py:33-109 bit for bit -- random frames plus the symmetric ones (alpha = beta, zeros, d = 0)."""
+    import ctypes as C
+    from sca_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    n = 300000
+    al = rng.uniform(0, 2 * np.pi, n)
+    be = rng.uniform(0, 2 * np.pi, n)
+    d = 10 ** rng.uniform(-3, 4, n)
+    al[:1000] = 0
+    be[1000:2000] = 0
+    al[2000:3000] = be[2000:3000]
+    d[3000:4000] = 0
+    al[4000:5000] = np.pi
+    be[5000:6000] = np.pi / 2
+    al[6000:7000] = np.round(al[6000:7000], 2)
+    be[6000:7000] = 0.0
+    d[7000:8000] = rng.uniform(0, 4, 1000)                     # close end points: every word feasible or nearly so
+    bad = C.c_int64(-1)
+    assert L.sca_selftest_dubins_words(n, _lib.ptr(al, C.c_double), _lib.ptr(be, C.c_double), _lib.ptr(d, C.c_double),
+                                       C.byref(bad)) == 0
+    assert bad.value == 0
