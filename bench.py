@@ -73,6 +73,8 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N>1 GPUs: weak = the workload\'s agent count PER GPU (default), strong = the same total')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-end-to-end', action='store_true',
+                    help='skip the second timed leg (SCA workloads: the same steps with the Dubins v_pref tracker on the device)')
     ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins', 'dubins-device'],
                     help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound); '
                          'dubins-device: from the device tracker inside every step (end-to-end SCA, resident)')
@@ -174,6 +176,33 @@ def main():
     else:
         total_steps = my_steps
 
+    # second leg, SCA workloads only: the same step with SCA's own v_pref -- the Dubins tracker of scaPolicy.py:264-338 as
+    # kernels inside every step (SURVEY.md 8d asks for both the solver and the end-to-end throughput)
+    e2e = None
+    if args.vpref == 'straight' and not args.no_end_to_end and w['policy'] in ('sca', 'mixed'):
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+        stepper.run(max(3, args.warmup // 2))
+        stepper.sync()
+        sol.agent_steps(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        stepper.run(args.steps)
+        stepper.sync()
+        barrier()
+        dt2 = time.perf_counter() - t0
+        steps2 = sol.agent_steps(reset=True)
+        replans = int(sol.device_tracker_replans()[stepper.begin:stepper.begin + stepper.count].sum())
+        if dist is not None:
+            t = torch.tensor([dt2], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+            c = torch.tensor([steps2, replans], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            steps2, replans = int(c[0].item()), int(c[1].item())
+        e2e = {'value': steps2 / dt2, 'unit': 'agent-steps/s', 'ms_per_step': dt2 / args.steps * 1e3,
+               'v_pref': 'Dubins tracker + 3-D Dubins planner on the device inside every step (k_track, k_replan / k_replan4)',
+               'plans_since_enable': replans, 'agent_steps_timed': steps2}
+
     if rank == 0:
         value = total_steps / dt
         per_launch_agents = my_steps / max(args.steps, 1)
@@ -198,8 +227,10 @@ def main():
                          'bytes_per_agent_step': BYTES_PER_AGENT_STEP,
                          'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
         }
+        if e2e is not None:
+            out['end_to_end_sca'] = e2e
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is a single-GPU (rank 0, N = 1) measurement
-            out['cpu_baseline'] = cpu_baseline(scene, sol, S, tracked=args.vpref != 'straight')
+            out['cpu_baseline'] = cpu_baseline(scene, sol, S, tracked=args.vpref != 'straight' or e2e is not None)
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:

@@ -29,6 +29,8 @@ def make():
     sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
                    scenarios.max_run_dist(sc['start'], sc['goal']))
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    if os.environ.get('SCA_TEST_TRACK'):
+        sol.device_tracker_enable(sc['goal'][:, 3:6])          # the SCA third of the agents follows Dubins paths, per shard
     return sol
 
 sol = make()
@@ -49,10 +51,15 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def test_two_ranks_one_gpu_match_single_rank(tmp_path):
+@pytest.mark.parametrize('track', [False, True])
+def test_two_ranks_one_gpu_match_single_rank(tmp_path, track):
+    """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
+    on a side stream next to the replicated kd build)."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    if track:
+        env['SCA_TEST_TRACK'] = '1'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                         '--master-addr', '127.0.0.1', '--master-port', '29541', str(script), ROOT],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -77,6 +84,8 @@ def make():
     sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], np.zeros(n, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
                    scenarios.max_run_dist(sc['start'], sc['goal']))
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    if os.environ.get('SCA_TEST_TRACK'):
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
     return sol
 
 sol = make()
@@ -94,13 +103,17 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def test_rccl_in_place_all_gather_path_single_rank(tmp_path):
+@pytest.mark.parametrize('track', [False, True])
+def test_rccl_in_place_all_gather_path_single_rank(tmp_path, track):
     """The exchange exactly as bench.py --gpus N runs it (bound device record buffers, in-place all_gather_into_tensor on
-    the RCCL backend, library kernels on torch's current stream), with the one rank a 1-GPU box offers."""
+    the RCCL backend, library kernels on torch's current stream), with the one rank a 1-GPU box offers.  track=True adds the
+    device-side v_pref tracker (its side stream forks from and joins torch's stream)."""
     script = tmp_path / 'rccl_worker.py'
     script.write_text(RCCL_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29543', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if track:
+        env['SCA_TEST_TRACK'] = '1'
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'RCCL OK' in r.stdout, r.stdout[-3000:]
