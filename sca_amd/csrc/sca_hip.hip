@@ -410,7 +410,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     d.kx = c->kd.kx; d.ky = c->kd.ky; d.kz = c->kd.kz;
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
-    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 3);   // counts | nchunks: one readback
+    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 4);   // counts | nchunks (one readback) | tail slot counter
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MIN + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
@@ -725,6 +725,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         }
         hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, first_single, ++c->kd_token);
     }
+
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
     if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->stream, d, c->kd, levels);
     else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->stream, d, c->kd, levels);

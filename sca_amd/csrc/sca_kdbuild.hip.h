@@ -44,7 +44,8 @@ struct KdScratch {
     int *mr;                  // [n] mr[b + j - 1] = position of the j-th "< split" member of the node that starts at b
     KdJob *jobs[2];           // ping-pong lists of nodes with > wave_max members
     KdJob *small;             // [n] subtrees handed to k_kd_block
-    int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag
+    int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag;
+                              // behind nchunks, [2 * KD_MAX_LEVELS + 3] = table slots handed out by the tail launch
     int job_cap;
     int wave_max;             // nodes up to this size go to k_kd_block (KD_WAVE_MIN < wave_max <= KD_WAVE_CAP)
     // multi-workgroup level passes
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         if (d.n > s.wave_max) { s.jobs[0][0] = j; s.counts[0] = 1; }
         else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
         for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
+        s.counts[2 * KD_MAX_LEVELS + 3] = 0;                                 // table slots handed out by the tail launch
         s.nchunks[0] = d.n > s.wave_max ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
     if (d.n > s.wave_max && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, 
 
 // Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
 // the children that need another level pass, as the chunk records written for them (for k_kd_level_tail)
-struct KdTailOut { int n; KdChunkRec r[2]; };
+struct KdTailOut { int n; int slot_base; KdChunkRec r[2]; };   // slot_base: first free table slot of the tail launch
 __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch s, int level, const KdChunk c, KdTailOut *tail = nullptr) {
     const int tid = threadIdx.x;
     const KdJob *in = s.jobs[level & 1];
@@ -319,7 +321,15 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
         for (int k = 0; k < 2; k++) {
             if (ch[k].end - ch[k].begin > s.wave_max) {
                 if (level + 1 < KD_MAX_LEVELS) {
-                    const int at = atomicAdd(&s.counts[level + 1], 1);
+                    const int nch = (ch[k].end - ch[k].begin + KD_CHUNK - 1) / KD_CHUNK;
+                    // table slot of the child.  A level launch owns the level's slots: index = arrival order.  In the tail
+                    // launch workgroups are at DIFFERENT levels at the same time, so slots (and chunk records) indexed per
+                    // level parity would collide: there the index comes from one counter that starts behind the tail
+                    // level's own nodes (unique over both parities), the chunk records stay in the workgroup's stack, and
+                    // the per-level counters are only statistics for the host.
+                    const int arrival = atomicAdd(&s.counts[level + 1], 1);
+                    const int base = atomicAdd(&s.nchunks[level + 1], nch);
+                    const int at = tail ? tail->slot_base + atomicAdd(&s.counts[2 * KD_MAX_LEVELS + 3], 1) : arrival;
                     if (at < s.job_cap) {
                         out[at] = ch[k];
                         unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
@@ -327,16 +337,16 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
                         unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
                         for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
                         // the child's workgroups of the next level
-                        const int nch = (ch[k].end - ch[k].begin + KD_CHUNK - 1) / KD_CHUNK;
-                        const int base = atomicAdd(&s.nchunks[level + 1], nch);
-                        if (base + nch <= s.chunk_cap) {
+                        if (tail || base + nch <= s.chunk_cap) {
                             KdChunkRec r; r.job = at; r.first = base; r.nb = ch[k].begin; r.ne = ch[k].end; r.pad = 0;
                             double cmn[3], cmx[3];
                             for (int q = 0; q < 3; q++) { cmn[q] = dunkey(cb[k * 6 + q]); cmx[q] = dunkey(cb[k * 6 + 3 + q]); }
                             kd_split(cmn, cmx, r.axis, r.split);
-                            KdChunkRec *tab = s.chunks[(level + 1) & 1];
-                            for (int q = 0; q < nch; q++) tab[base + q] = r;
                             if (tail) tail->r[tail->n++] = r;
+                            else {
+                                KdChunkRec *tab = s.chunks[(level + 1) & 1];
+                                for (int q = 0; q < nch; q++) tab[base + q] = r;
+                            }
                         } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_CHUNKS);
                     } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
                 } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScrat
     if (threadIdx.x == 0) {
         KdChunkRec r; r.job = c0.job; r.first = c0.first_chunk; r.nb = c0.node_begin; r.ne = c0.node_end; r.axis = c0.axis; r.pad = 0; r.split = c0.split;
         stack[0] = r; stack_lv[0] = level; sp_sh = 1;
+        out.slot_base = s.counts[level];                           // behind the nodes this launch starts from
     }
     const int chain0 = c0.first_chunk;                              // this workgroup's own range of chain words
     for (;;) {

@@ -161,3 +161,42 @@ def test_env_episode_with_device_tracker_matches_host_tracker_outcome():
     assert (f_dev & 1).all() and not (f_dev & 6).any()
     assert abs(s_dev - s_host) <= max(3, 0.03 * s_host), (s_dev, s_host)
     assert float(np.abs(p_dev - p_host).max()) <= 1e-4                    # the first 30 steps stay together
+
+
+def test_kd_tail_launch_with_desynchronised_workgroups():
+    """Regression: the last level launch of the kd build (k_kd_level_tail) lets every workgroup run depth-first through its
+    own subtree, so workgroups are at different levels at the same time; table slots indexed per level parity then collide
+    (a workgroup two levels down overwrote the chunk records later-starting workgroups had not read yet).  It only showed
+    once the tracker's re-plans ran beside the build and delayed some of its workgroups: a converging 20 000-agent swarm
+    failed around step 530.  Now: no failure, and the run equals the one with everything on one stream and the host-built
+    tree, permutation included."""
+    from sca_amd import scenarios, solver as S
+    n = 20000
+    rng = np.random.default_rng(5)
+    sc = scenarios.random_cube(n, seed=1)
+    c = sc['start'][:, :3].mean(0)
+    goal = c + rng.normal(0, 3.0, (n, 3))
+    goal[:, 2] = np.maximum(goal[:, 2], 5.0)
+    outs = []
+    for mode in (S.NBR_KDTREE, S.NBR_KDTREE_HOSTBUILD):
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=4)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), goal, np.zeros(n, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
+                       np.full(n, 1e9))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+        if mode == S.NBR_KDTREE:
+            sol.run_steps(500, mode)
+            sol.synchronize()                                  # raises if a build reported failure
+        else:
+            for _ in range(500):                               # the host build reads positions back: step by step
+                sol.run_steps(1, mode)
+            sol.synchronize()
+        st = sol.get_state()
+        outs.append((st['pos'].copy(), st['flags'].copy(), sol.get_kd_perm().copy(), sol.device_tracker_replans().copy()))
+        if mode == S.NBR_KDTREE:
+            sol.run_steps(200, mode)
+            sol.synchronize()
+        sol.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
