@@ -8,7 +8,10 @@
 //             followers, v_pref.  Agents that must re-plan are appended to a list (wave-aggregated atomic).
 //   k_replan  one lane per listed agent: the 3-D Dubins planner (dubinsmaneuver3d.py:34-162 -- a scalar search of ~50-100
 //             2-D plans, ~10^5 fp64 instructions), the first tracked node, v_pref.  Compacting the re-planning agents into
-//             dense wavefronts keeps the (rare, long) plans from stalling the 63 followers that would share their wave.
+//             dense wavefronts keeps the long plans from stalling the followers that would share their wave.
+//   k_replan4 the same with four lanes (one DPP quad) per plan, for passes with few re-plans (see below).
+// Both re-plan kernels are launched every pass -- on a stream of their own, beside the kd build and the neighbour query,
+// joined before k_solve -- and the device-side count of the pass decides which of them does the work.
 //
 // The arithmetic is sca_dubins.hpp compiled for gfx950: same statements as the host tracker, the device library's
 // sin / cos / atan2 / acos instead of glibc's.  State: one AgentTrack record per agent, resident in HBM.
