@@ -145,6 +145,8 @@ CASES = [
     ('random4096_underground_sca', 'random_low', 4096, 0),
     ('takeoff1024_mixed', 'takeoff', 1024, -1),     # BASELINE config 5 (scaled), SCA even ids / S-RVO3D odd ids
     ('circle2048_rvo', 'circle', 2048, 1),
+    ('circle100000_sca', 'circle', 100000, 0),      # BASELINE config 4 at its full size (the oracle needs ~0.3 s for one pass)
+    ('takeoff16384_mixed', 'takeoff', 16384, -1),   # BASELINE config 5 at its full size
 ]
 
 
