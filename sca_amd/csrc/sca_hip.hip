@@ -789,8 +789,11 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     }
     K.quad = c->trk_quad ? 1 : 0;
     // both forms are launched; the device-side count of this pass decides which of them does the work
-    if (c->trk_quad)
-        hipLaunchKernelGGL(k_replan4, dim3((std::min(cnt, TRK_QUAD_MAX) * 4 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
+    if (c->trk_quad) {
+        hipLaunchKernelGGL(k_replan16, dim3((std::min(cnt, TRK_SPEC_MAX) * 16 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
+        if (cnt > TRK_SPEC_MAX)
+            hipLaunchKernelGGL(k_replan4, dim3((std::min(cnt, TRK_QUAD_MAX) * 4 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
+    }
     if (!c->trk_quad || cnt > TRK_QUAD_MAX)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);

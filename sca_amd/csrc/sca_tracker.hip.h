@@ -235,9 +235,117 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
     return P;
 }
 
+// ---- sixteen lanes per plan: the search two candidates at a time ------------------------------------------------------------
+// The local search (dubinsmaneuver3d.py:86-100) is a chain: the next candidate radius is b + 2 step after a success, b - 0.1 step
+// after a failure.  Both are known before the verdict on the current one, so three quads of a 16-lane DPP row evaluate the
+// current candidate and its two possible successors side by side; the verdicts are then applied in order, exactly as the
+// sequential loop would (same expressions for the candidates, same comparisons, the speculated result that is not needed is
+// dropped), and every round advances the chain by two.  1.5x the work of the four-lane form, half its critical path: used
+// while a pass has so few re-plans (<= TRK_SPEC_MAX) that most SIMDs would idle anyway.
+constexpr int TRK_SPEC_MAX = 4096;
+
+__device__ __forceinline__ void fetch_maneuver(sca_dubins::Maneuver2D &dst, const sca_dubins::Maneuver2D &mine, int src) {
+    const double r = lane_fetch_d(mine.r_min, src);
+    const double t = lane_fetch_d(mine.t, src);
+    const double p = lane_fetch_d(mine.p, src);
+    const double l = lane_fetch_d(mine.length, src);
+    const int packed = (int)(unsigned char)mine.mode[0] | ((int)(unsigned char)mine.mode[1] << 8) | ((int)(unsigned char)mine.mode[2] << 16) |
+                       ((int)mine.ok << 24);
+    const int m = __shfl(packed, src);
+    dst.yaw = mine.yaw;                                                    // the same start yaw for every candidate
+    dst.r_min = r; dst.t = t; dst.p = p; dst.length = l;
+    dst.mode[0] = (char)(m & 255); dst.mode[1] = (char)((m >> 8) & 255); dst.mode[2] = (char)((m >> 16) & 255);
+    dst.ok = ((m >> 24) & 1) != 0;
+}
+
+__device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
+                                                          int sub, int lane) {
+    using namespace sca_dubins;
+    Plan3D P;
+    const int quad = (lane >> 2) & 3, row = lane & ~15;
+    Maneuver2D fbh, fbv, fch, fcv;
+    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
+    const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
+    // first try and doubling (:74-78): rare beyond the first candidate, all quads evaluate the same radius
+    double b = 1.0;
+    int nfb = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);
+    int guard = 0;
+    while (nfb < 2) {
+        b *= 2.0;
+        nfb = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);
+        if (++guard > 200) return P;
+    }
+    double step = 0.1;
+    while (::fabs(step) > 1e-10) {
+        double c0 = b + step;
+        if (c0 < 1.0) c0 = 1.0;
+        const double stepS = step * 2., stepF = step * -0.1;               // `step *= 2.` / `step *= -0.1`
+        double cS = c0 + stepS;                                            // next candidate if c0 is accepted (b = c0)
+        if (cS < 1.0) cS = 1.0;
+        double cF = b + stepF;                                             // ... if it is not
+        if (cF < 1.0) cF = 1.0;
+        const double myc = quad == 1 ? cS : (quad == 2 ? cF : c0);
+        const int nfc = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * myc, fch, fcv, sub, lane);
+        // verdict on c0 (quad 0)
+        const int nf0 = __shfl(nfc, row);
+        const double len0 = lane_fetch_d(fcv.length, row);
+        const bool acc0 = nf0 > 0 && len0 < fbv.length;
+        Maneuver2D h0, v0;
+        fetch_maneuver(h0, fch, row);
+        fetch_maneuver(v0, fcv, row);
+        if (acc0) { b = c0; fbh = h0; fbv = v0; step = stepS; }
+        else step = stepF;
+        if (!(::fabs(step) > 1e-10)) break;
+        // verdict on the successor the sequential loop would have tried next (quad 1 after a success, quad 2 after a failure)
+        const int src = row + (acc0 ? 4 : 8);
+        const double c1 = acc0 ? cS : cF;
+        const int nf1 = __shfl(nfc, src);
+        const double len1 = lane_fetch_d(fcv.length, src);
+        const bool acc1 = nf1 > 0 && len1 < fbv.length;
+        Maneuver2D h1, v1;
+        fetch_maneuver(h1, fch, src);
+        fetch_maneuver(v1, fcv, src);
+        if (acc1) { b = c1; fbh = h1; fbv = v1; step *= 2.; }
+        else step *= -0.1;
+    }
+    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
+    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
+    P.mode[6] = 0;
+    double ss = 0.1;
+    if (P.length > 100) ss = P.length / 1000;
+    P.sampling_size = ss;
+    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
+    const double stop = P.length + ss;
+    const long cnt = (long)::ceil(stop / ss);
+    P.count = cnt > 0 ? cnt : 0;
+    return P;
+}
+
+__global__ __launch_bounds__(64) void k_replan16(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    const int count = K.count[K.parity];
+    if (count > TRK_SPEC_MAX) return;                                    // k_replan4's or k_replan's pass
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gid >> 4, sub = gid & 3, lane = threadIdx.x & 63;
+    if (idx >= count) return;                                            // whole rows leave together
+    const int agent = K.list[idx];
+    const PubRec r = d.rec[agent];
+    const double pos[3] = {r.px, r.py, r.pz};
+    const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
+    double qi[5], qf[5];
+    sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    const sca_dubins::Plan3D P = plan3d_spec(qi, qf, T.turning_radius, pl, sub, lane);
+    if ((gid & 15) != 0) return;
+    sca_dubins::AgentTrack &a = K.st[agent];
+    double dif[3], V[3];
+    sca_dubins::track_adopt(a, P, pos, dif);
+    sca_dubins::track_finish(T, a, agent, pos, dif, V);
+    track_store(d, agent, V);
+}
+
 __global__ __launch_bounds__(64) void k_replan4(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
-    if (count > TRK_QUAD_MAX) return;                                    // k_replan's pass
+    if (count > TRK_QUAD_MAX || count <= TRK_SPEC_MAX) return;           // k_replan's or k_replan16's pass
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid >> 2, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole quads leave together
