@@ -235,14 +235,17 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
     return P;
 }
 
-// ---- sixteen lanes per plan: the search two candidates at a time ------------------------------------------------------------
+// ---- 16 / 32 / 64 lanes per plan: the search several candidates at a time --------------------------------------------------------
 // The local search (dubinsmaneuver3d.py:86-100) is a chain: the next candidate radius is b + 2 step after a success, b - 0.1 step
-// after a failure.  Both are known before the verdict on the current one, so three quads of a 16-lane DPP row evaluate the
-// current candidate and its two possible successors side by side; the verdicts are then applied in order, exactly as the
-// sequential loop would (same expressions for the candidates, same comparisons, the speculated result that is not needed is
-// dropped), and every round advances the chain by two.  1.5x the work of the four-lane form, half its critical path: used
-// while a pass has so few re-plans (<= TRK_SPEC_MAX) that most SIMDs would idle anyway.
-constexpr int TRK_SPEC_MAX = 4096;
+// after a failure.  Both are known before the verdict on the current one, and so are their successors: the quads of a 16- or
+// 32- (64-)lane group evaluate the current candidate and the 2 (6, 14) candidates that can follow it within two (three, four) steps, as a binary
+// tree in heap order (node k: success -> 2k, failure -> 2k + 1).  The verdicts are then applied in the sequential loop's order
+// along the path that loop would have taken -- same expressions for the candidates, same comparisons, results off the path are
+// dropped -- so every round advances the chain by D steps.  3/2 (7/3, 15/4) of the four-lane form's work, 1/2 (1/3, 1/4) of its critical
+// path: used while a pass has so few re-plans that most SIMDs would idle anyway.
+constexpr int TRK_SPEC2_MAX = 4096;        // <= this many re-plans in the pass: two steps per round, 16 lanes per plan
+constexpr int TRK_SPEC3_MAX = 2048;        // <= this many: three steps per round, 32 lanes per plan
+constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: four steps per round, a whole wavefront per plan
 
 __device__ __forceinline__ void fetch_maneuver(sca_dubins::Maneuver2D &dst, const sca_dubins::Maneuver2D &mine, int src) {
     const double r = lane_fetch_d(mine.r_min, src);
@@ -258,11 +261,13 @@ __device__ __forceinline__ void fetch_maneuver(sca_dubins::Maneuver2D &dst, cons
     dst.ok = ((m >> 24) & 1) != 0;
 }
 
+template <int D>
 __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
                                                           int sub, int lane) {
     using namespace sca_dubins;
+    constexpr int NODES = (1 << D) - 1, LANES = 4 << D;
     Plan3D P;
-    const int quad = (lane >> 2) & 3, row = lane & ~15;
+    const int quad = (lane & (LANES - 1)) >> 2, base = lane & ~(LANES - 1);
     Maneuver2D fbh, fbv, fch, fcv;
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
@@ -277,36 +282,40 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     }
     double step = 0.1;
     while (::fabs(step) > 1e-10) {
-        double c0 = b + step;
-        if (c0 < 1.0) c0 = 1.0;
-        const double stepS = step * 2., stepF = step * -0.1;               // `step *= 2.` / `step *= -0.1`
-        double cS = c0 + stepS;                                            // next candidate if c0 is accepted (b = c0)
-        if (cS < 1.0) cS = 1.0;
-        double cF = b + stepF;                                             // ... if it is not
-        if (cF < 1.0) cF = 1.0;
-        const double myc = quad == 1 ? cS : (quad == 2 ? cF : c0);
+        // candidates of the tree, heap order; nb / ns = the (b, step) the sequential loop holds when it reaches the node
+        double nb[NODES + 1], ns[NODES + 1], nc[NODES + 1];
+        nb[1] = b; ns[1] = step;
+#pragma unroll
+        for (int k = 1; k <= NODES; k++) {
+            double c = nb[k] + ns[k];
+            if (c < 1.0) c = 1.0;
+            nc[k] = c;
+            if (2 * k + 1 <= NODES) {
+                nb[2 * k] = c; ns[2 * k] = ns[k] * 2.;                     // success: b = c, step *= 2.
+                nb[2 * k + 1] = nb[k]; ns[2 * k + 1] = ns[k] * -0.1;       // failure: step *= -0.1
+            }
+        }
+        double myc = nc[1];
+#pragma unroll
+        for (int k = 2; k <= NODES; k++) myc = quad == k - 1 ? nc[k] : myc;
         const int nfc = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * myc, fch, fcv, sub, lane);
-        // verdict on c0 (quad 0)
-        const int nf0 = __shfl(nfc, row);
-        const double len0 = lane_fetch_d(fcv.length, row);
-        const bool acc0 = nf0 > 0 && len0 < fbv.length;
-        Maneuver2D h0, v0;
-        fetch_maneuver(h0, fch, row);
-        fetch_maneuver(v0, fcv, row);
-        if (acc0) { b = c0; fbh = h0; fbv = v0; step = stepS; }
-        else step = stepF;
-        if (!(::fabs(step) > 1e-10)) break;
-        // verdict on the successor the sequential loop would have tried next (quad 1 after a success, quad 2 after a failure)
-        const int src = row + (acc0 ? 4 : 8);
-        const double c1 = acc0 ? cS : cF;
-        const int nf1 = __shfl(nfc, src);
-        const double len1 = lane_fetch_d(fcv.length, src);
-        const bool acc1 = nf1 > 0 && len1 < fbv.length;
-        Maneuver2D h1, v1;
-        fetch_maneuver(h1, fch, src);
-        fetch_maneuver(v1, fcv, src);
-        if (acc1) { b = c1; fbh = h1; fbv = v1; step *= 2.; }
-        else step *= -0.1;
+        int node = 1;
+#pragma unroll
+        for (int depth = 0; depth < D; depth++) {
+            const int src = base + 4 * (node - 1);
+            const int nf = __shfl(nfc, src);
+            const double len = lane_fetch_d(fcv.length, src);
+            Maneuver2D hh, vv;
+            fetch_maneuver(hh, fch, src);
+            fetch_maneuver(vv, fcv, src);
+            double cn = nc[1];
+#pragma unroll
+            for (int k = 2; k <= NODES; k++) cn = node == k ? nc[k] : cn;
+            const bool acc = nf > 0 && len < fbv.length;
+            if (acc) { b = cn; fbh = hh; fbv = vv; step *= 2.; node = 2 * node; }
+            else { step *= -0.1; node = 2 * node + 1; }
+            if (!(::fabs(step) > 1e-10)) break;
+        }
     }
     P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
     for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
@@ -321,12 +330,17 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     return P;
 }
 
-__global__ __launch_bounds__(64) void k_replan16(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+// D = 2: passes with (TRK_SPEC3_MAX, TRK_SPEC2_MAX] re-plans; D = 3: (TRK_SPEC4_MAX, TRK_SPEC3_MAX]; D = 4: <= TRK_SPEC4_MAX
+template <int D>
+__global__ __launch_bounds__(64) void k_replan_spec(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    constexpr int LANES = 4 << D;
     const int count = K.count[K.parity];
-    if (count > TRK_SPEC_MAX) return;                                    // k_replan4's or k_replan's pass
+    constexpr int HI = D == 4 ? TRK_SPEC4_MAX : (D == 3 ? TRK_SPEC3_MAX : TRK_SPEC2_MAX);
+    constexpr int LO = D == 4 ? -1 : (D == 3 ? TRK_SPEC4_MAX : TRK_SPEC3_MAX);
+    if (count > HI || count <= LO) return;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int idx = gid >> 4, sub = gid & 3, lane = threadIdx.x & 63;
-    if (idx >= count) return;                                            // whole rows leave together
+    const int idx = gid / LANES, sub = gid & 3, lane = threadIdx.x & 63;
+    if (idx >= count) return;                                            // whole groups leave together
     const int agent = K.list[idx];
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -334,8 +348,8 @@ __global__ __launch_bounds__(64) void k_replan16(DeviceView d, sca_dubins::Track
     double qi[5], qf[5];
     sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
     const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    const sca_dubins::Plan3D P = plan3d_spec(qi, qf, T.turning_radius, pl, sub, lane);
-    if ((gid & 15) != 0) return;
+    const sca_dubins::Plan3D P = plan3d_spec<D>(qi, qf, T.turning_radius, pl, sub, lane);
+    if ((gid & (LANES - 1)) != 0) return;
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
     sca_dubins::track_adopt(a, P, pos, dif);
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(64) void k_replan16(DeviceView d, sca_dubins::Track
 
 __global__ __launch_bounds__(64) void k_replan4(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
-    if (count > TRK_QUAD_MAX || count <= TRK_SPEC_MAX) return;           // k_replan's or k_replan16's pass
+    if (count > TRK_QUAD_MAX || count <= TRK_SPEC2_MAX) return;          // k_replan's or k_replan_spec's pass
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid >> 2, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole quads leave together
