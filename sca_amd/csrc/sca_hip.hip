@@ -789,15 +789,8 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     }
     K.quad = c->trk_quad ? 1 : 0;
     // both forms are launched; the device-side count of this pass decides which of them does the work
-    if (c->trk_quad) {                   // only the forms this shard size can need (each idle launch is a few us on the tracker's path)
-        hipLaunchKernelGGL(k_replan_spec<4>, dim3(std::min(cnt, TRK_SPEC4_MAX)), dim3(64), 0, rs, c->d, c->trk_view, K);
-        if (cnt > TRK_SPEC4_MAX)
-            hipLaunchKernelGGL(k_replan_spec<3>, dim3((std::min(cnt, TRK_SPEC3_MAX) * 32 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
-        if (cnt > TRK_SPEC3_MAX)
-            hipLaunchKernelGGL(k_replan_spec<2>, dim3((std::min(cnt, TRK_SPEC2_MAX) * 16 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
-        if (cnt > TRK_SPEC2_MAX)
-            hipLaunchKernelGGL(k_replan4, dim3((std::min(cnt, TRK_QUAD_MAX) * 4 + 63) / 64), dim3(64), 0, rs, c->d, c->trk_view, K);
-    }
+    if (c->trk_quad)
+        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, TRK_FEW_BLOCKS)), dim3(64), 0, rs, c->d, c->trk_view, K);
     if (!c->trk_quad || cnt > TRK_QUAD_MAX)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);

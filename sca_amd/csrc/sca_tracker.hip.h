@@ -9,9 +9,10 @@
 //   k_replan  one lane per listed agent: the 3-D Dubins planner (dubinsmaneuver3d.py:34-162 -- a scalar search of ~50-100
 //             2-D plans, ~10^5 fp64 instructions), the first tracked node, v_pref.  Compacting the re-planning agents into
 //             dense wavefronts keeps the long plans from stalling the followers that would share their wave.
-//   k_replan4 the same with four lanes (one DPP quad) per plan, for passes with few re-plans (see below).
-// Both re-plan kernels are launched every pass -- on a stream of their own, beside the kd build and the neighbour query,
-// joined before k_solve -- and the device-side count of the pass decides which of them does the work.
+//   k_replan_few  the same with 4, 16, 32 or 64 lanes per plan, for passes with few re-plans (see below).
+// Both re-plan kernels are launched every pass (k_replan only when the shard is large enough to need it) -- on a stream of
+// their own, beside the kd build and the neighbour query, joined before k_solve -- and the device-side count of the pass
+// decides which of them, and which form, does the work.
 //
 // The arithmetic is sca_dubins.hpp compiled for gfx950: same statements as the host tracker, the device library's
 // sin / cos / atan2 / acos instead of glibc's.  State: one AgentTrack record per agent, resident in HBM.
@@ -29,7 +30,7 @@ struct TrackDev {
     int32_t *count;               // [2] list length, double-buffered by pass parity (k_track zeroes the other one)
     int parity;
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
-    int quad;                     // 1: k_replan4 (four lanes per plan) takes the passes with <= TRK_QUAD_MAX re-plans
+    int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= TRK_QUAD_MAX re-plans
 };
 
 constexpr int TRK_QUAD_MAX = 16384;       // re-plans per pass up to which the four-lanes-per-plan kernel is used
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = K.count[K.parity];
-    if (idx >= count || (K.quad && count <= TRK_QUAD_MAX)) return;          // few re-plans: k_replan4's pass
+    if (idx >= count || (K.quad && count <= TRK_QUAD_MAX)) return;          // few re-plans: k_replan_few's pass
     const int agent = K.list[idx];
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -330,14 +331,9 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     return P;
 }
 
-// D = 2: passes with (TRK_SPEC3_MAX, TRK_SPEC2_MAX] re-plans; D = 3: (TRK_SPEC4_MAX, TRK_SPEC3_MAX]; D = 4: <= TRK_SPEC4_MAX
-template <int D>
-__global__ __launch_bounds__(64) void k_replan_spec(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
-    constexpr int LANES = 4 << D;
-    const int count = K.count[K.parity];
-    constexpr int HI = D == 4 ? TRK_SPEC4_MAX : (D == 3 ? TRK_SPEC3_MAX : TRK_SPEC2_MAX);
-    constexpr int LO = D == 4 ? -1 : (D == 3 ? TRK_SPEC4_MAX : TRK_SPEC3_MAX);
-    if (count > HI || count <= LO) return;
+// one group of LANES lanes per plan: 4 = the quad planner, 16 / 32 / 64 = speculative search of depth 2 / 3 / 4
+template <int LANES>
+__device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubins::TrackView T, const TrackDev K, int count) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid / LANES, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole groups leave together
@@ -348,7 +344,11 @@ __global__ __launch_bounds__(64) void k_replan_spec(DeviceView d, sca_dubins::Tr
     double qi[5], qf[5];
     sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
     const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    const sca_dubins::Plan3D P = plan3d_spec<D>(qi, qf, T.turning_radius, pl, sub, lane);
+    sca_dubins::Plan3D P;
+    if constexpr (LANES == 4) P = plan3d_quad(qi, qf, T.turning_radius, pl, sub, lane);
+    else if constexpr (LANES == 16) P = plan3d_spec<2>(qi, qf, T.turning_radius, pl, sub, lane);
+    else if constexpr (LANES == 32) P = plan3d_spec<3>(qi, qf, T.turning_radius, pl, sub, lane);
+    else P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane);
     if ((gid & (LANES - 1)) != 0) return;
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
@@ -357,26 +357,17 @@ __global__ __launch_bounds__(64) void k_replan_spec(DeviceView d, sca_dubins::Tr
     track_store(d, agent, V);
 }
 
-__global__ __launch_bounds__(64) void k_replan4(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+// All the many-lanes-per-plan forms in ONE launch: the device-side count of the pass picks the widest form that still leaves
+// no SIMD with more than one wavefront (every form needs <= 1024 workgroups).  Passes with more re-plans than TRK_QUAD_MAX
+// belong to k_replan.
+constexpr int TRK_FEW_BLOCKS = 1024;
+__global__ __launch_bounds__(64) void k_replan_few(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
-    if (count > TRK_QUAD_MAX || count <= TRK_SPEC2_MAX) return;          // k_replan's or k_replan_spec's pass
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int idx = gid >> 2, sub = gid & 3, lane = threadIdx.x & 63;
-    if (idx >= count) return;                                            // whole quads leave together
-    const int agent = K.list[idx];
-    const PubRec r = d.rec[agent];
-    const double pos[3] = {r.px, r.py, r.pz};
-    const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
-    double qi[5], qf[5];
-    sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
-    const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    const sca_dubins::Plan3D P = plan3d_quad(qi, qf, T.turning_radius, pl, sub, lane);
-    if (sub != 0) return;
-    sca_dubins::AgentTrack &a = K.st[agent];
-    double dif[3], V[3];
-    sca_dubins::track_adopt(a, P, pos, dif);
-    sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V);
+    if (count > TRK_QUAD_MAX) return;
+    if (count <= TRK_SPEC4_MAX) replan_group<64>(d, T, K, count);
+    else if (count <= TRK_SPEC3_MAX) replan_group<32>(d, T, K, count);
+    else if (count <= TRK_SPEC2_MAX) replan_group<16>(d, T, K, count);
+    else replan_group<4>(d, T, K, count);
 }
 
 __global__ __launch_bounds__(256) void k_track_replans(const sca_dubins::AgentTrack *st, int32_t *out, int n) {
