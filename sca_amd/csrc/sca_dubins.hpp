@@ -210,17 +210,24 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
 // get_position_in_segment (:283-297) / get_coordinates (:260-280)
 SCA_DHD static void seg(double offset, const double qi[3], char mode, double q[3]) {
     q[0] = q[1] = q[2] = 0.0;
+    // sin and cos of the same angle in one call (the host's m_sincos is the two separate libm calls of the reference)
+    double s0, c0;
+    m_sincos(qi[2], s0, c0);
     if (mode == 'L') {
-        q[0] = qi[0] + m_sin(qi[2] + offset) - m_sin(qi[2]);
-        q[1] = qi[1] - m_cos(qi[2] + offset) + m_cos(qi[2]);
+        double s1, c1;
+        m_sincos(qi[2] + offset, s1, c1);
+        q[0] = qi[0] + s1 - s0;
+        q[1] = qi[1] - c1 + c0;
         q[2] = qi[2] + offset;
     } else if (mode == 'R') {
-        q[0] = qi[0] - m_sin(qi[2] - offset) + m_sin(qi[2]);
-        q[1] = qi[1] + m_cos(qi[2] - offset) - m_cos(qi[2]);
+        double s1, c1;
+        m_sincos(qi[2] - offset, s1, c1);
+        q[0] = qi[0] - s1 + s0;
+        q[1] = qi[1] + c1 - c0;
         q[2] = qi[2] - offset;
     } else if (mode == 'S') {
-        q[0] = qi[0] + m_cos(qi[2]) * offset;
-        q[1] = qi[1] + m_sin(qi[2]) * offset;
+        q[0] = qi[0] + c0 * offset;
+        q[1] = qi[1] + s0 * offset;
         q[2] = qi[2];
     }
 }
