@@ -306,15 +306,16 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             const int src = base + 4 * (node - 1);
             const int nf = __shfl(nfc, src);
             const double len = lane_fetch_d(fcv.length, src);
-            Maneuver2D hh, vv;
-            fetch_maneuver(hh, fch, src);
-            fetch_maneuver(vv, fcv, src);
             double cn = nc[1];
 #pragma unroll
             for (int k = 2; k <= NODES; k++) cn = node == k ? nc[k] : cn;
-            const bool acc = nf > 0 && len < fbv.length;
-            if (acc) { b = cn; fbh = hh; fbv = vv; step *= 2.; node = 2 * node; }
-            else { step *= -0.1; node = 2 * node + 1; }
+            const bool acc = nf > 0 && len < fbv.length;                   // the same in every lane of the group
+            if (acc) {
+                b = cn;
+                fetch_maneuver(fbh, fch, src);                             // whole groups take this branch together
+                fetch_maneuver(fbv, fcv, src);
+                step *= 2.; node = 2 * node;
+            } else { step *= -0.1; node = 2 * node + 1; }
             if (!(::fabs(step) > 1e-10)) break;
         }
     }
