@@ -206,7 +206,7 @@ def main():
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             steps2, replans = int(c[0].item()), int(c[1].item())
         e2e = {'value': steps2 / dt2, 'unit': 'agent-steps/s', 'ms_per_step': dt2 / args.steps * 1e3,
-               'v_pref': 'Dubins tracker + 3-D Dubins planner on the device inside every step (k_track, k_replan / k_replan4)',
+               'v_pref': 'Dubins tracker + 3-D Dubins planner on the device inside every step (k_track, k_replan / k_replan_few)',
                'plans_since_enable': replans, 'agent_steps_timed': steps2}
 
     if rank == 0:
