@@ -113,6 +113,9 @@ int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/)
 /* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising */
 int sca_run_steps(sca_ctx *ctx, int steps, int neighbor_mode);
 int sca_synchronize(sca_ctx *ctx);
+/* number of this rank's agents that are not done (at goal, collided or timed out) after the last env update; 0 == the
+ * `all(agent.is_run_done)` of MACAEnv.is_done (mampenv.py:51-59).  Synchronises; reports a failed device kd build. */
+int sca_active_count(sca_ctx *ctx, int *active);
 
 /* multi-GPU / interop ------------------------------------------------------------------------------ */
 /* This rank solves agents [begin, begin+count); all agents' public records must be present. */

@@ -911,6 +911,20 @@ int sca_env_update(sca_ctx *c, int *all_done) {
     return 0;
 }
 
+int sca_active_count(sca_ctx *c, int *active) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, active);
+    if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    std::vector<int32_t> parts(256 * 32);
+    CHK(c, hipMemcpyAsync(parts.data(), c->d.done_count, sizeof(int32_t) * parts.size(), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
+    int n = 0;
+    for (int v : parts) n += v;
+    *active = n;
+    return 0;
+}
+
 int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }

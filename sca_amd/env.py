@@ -226,12 +226,11 @@ class MACAEnv:
         self.agents = agents
         self.obstacles = obstacles
         n, m = len(agents), len(obstacles)
-        self.pos = np.array([a._pos for a in agents], dtype=np.float64).reshape(n, 3)
-        self.vel = np.array([a._vel for a in agents], dtype=np.float32).reshape(n, 3)
-        self.heading = np.array([a._heading for a in agents], dtype=np.float64).reshape(n, 3)
-        self.flags = np.zeros(n, np.uint8)
-        self.total_dist = np.zeros(n)
-        self.step_num = np.zeros(n, np.int32)
+        self._mirror = dict(pos=np.array([a._pos for a in agents], dtype=np.float64).reshape(n, 3),
+                            vel=np.array([a._vel for a in agents], dtype=np.float32).reshape(n, 3),
+                            heading=np.array([a._heading for a in agents], dtype=np.float64).reshape(n, 3),
+                            flags=np.zeros(n, np.uint8), total_dist=np.zeros(n), step_num=np.zeros(n, np.int32))
+        self._stale = False
         self.goal = np.array([a.goal_global_frame for a in agents], dtype=np.float64).reshape(n, 3)
         self.policy_ids = np.array([a.policy.policy_id for a in agents], np.uint8)
         self._ext = np.array([a.policy.needs_external_vpref for a in agents], bool)
@@ -254,6 +253,22 @@ class MACAEnv:
         self._row_cache = None
         self._nbr_cache = None
 
+    # ---- host mirrors of the device state, refreshed on first use after a step (the reference's per-agent attributes) -------
+    def _state(self, name):
+        if self._stale:
+            st = self.solver.get_state()
+            for k in self._mirror:
+                self._mirror[k][...] = st[k]
+            self._stale = False
+        return self._mirror[name]
+
+    pos = property(lambda self: self._state('pos'))
+    vel = property(lambda self: self._state('vel'))
+    heading = property(lambda self: self._state('heading'))
+    flags = property(lambda self: self._state('flags'))
+    total_dist = property(lambda self: self._state('total_dist'))
+    step_num = property(lambda self: self._state('step_num'))
+
     # ---- one step = MACAEnv.step (mampenv.py:22-25) ---------------------------------------------------------------------
     def _policy_pass(self):
         if self._row_cache is None:
@@ -265,7 +280,7 @@ class MACAEnv:
             self._nbr_cache = None
             if self.v_pref_fn is not None:
                 self._nbr_cache = self._last_neighbors = self.solver.neighbors()
-            self.flags[:] = self.solver.get_state()['flags']      # is_collision set inside insert*Neighbor (agent.py:84)
+            self._stale = True                                    # is_collision set inside insert*Neighbor (agent.py:84)
         return self._row_cache
 
     def _policy_row(self, i):
@@ -283,16 +298,17 @@ class MACAEnv:
         return out
 
     def step(self, actions=None):
-        """`actions` is ignored, as in the reference (mampenv.py:22)."""
-        self._policy_pass()
-        done = self.solver.env_update()
-        st = self.solver.get_state()
-        self.pos[:] = st['pos']
-        self.vel[:] = st['vel']
-        self.heading[:] = st['heading']
-        self.flags[:] = st['flags']
-        self.total_dist[:] = st['total_dist']
-        self.step_num[:] = st['step_num']
+        """`actions` is ignored, as in the reference (mampenv.py:22).  Without a host-side v_pref_fn the whole step (both loops
+        of _take_action, mampenv.py:27-49) is one resident library call and nothing but the done count comes back: the
+        per-agent attributes are read from the device the next time somebody looks at them."""
+        if self._row_cache is None and self.v_pref_fn is None:
+            self.solver.run_steps(1, self.neighbor_mode)
+            done = self.solver.active_count() == 0
+            self._nbr_cache = None
+        else:
+            self._policy_pass()
+            done = self.solver.env_update()
+        self._stale = True
         self._row_cache = None
         return done
 

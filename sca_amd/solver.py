@@ -158,6 +158,12 @@ class BatchedSolver:
     def synchronize(self):
         self._chk(self.L.sca_synchronize(self.ctx), 'sca_synchronize')
 
+    def active_count(self):
+        """Agents of this rank not yet done after the last env update (0 == MACAEnv.is_done); synchronises."""
+        v = C.c_int(0)
+        self._chk(self.L.sca_active_count(self.ctx, C.byref(v)), 'sca_active_count')
+        return int(v.value)
+
     def actions(self):
         a = np.zeros((self.n, 7), np.float32)
         self._chk(self.L.sca_get_actions(self.ctx, _lib.ptr(a, C.c_float)), 'sca_get_actions')

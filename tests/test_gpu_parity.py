@@ -513,3 +513,32 @@ def test_converging_swarm_device_build_matches_host_build(S):
     for a, b in zip(*outs):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert ((outs[0][-1][1] & 3) != 0).mean() > 0.3            # the core has formed (arrived or collided)
+
+
+def test_env_step_one_call_path_equals_per_agent_api_path(S):
+    """MACAEnv.step without a host v_pref_fn is one resident library call and the per-agent attributes are read back lazily;
+    asking a policy for its action first (the reference's per-agent find_next_action, mampenv.py:40) takes the two-call path
+    (policy pass, env update) for that step.  Both must walk through the same states, and the mirrors must be fresh whenever
+    they are looked at."""
+    from sca_amd import env as E
+    runs = []
+    for per_agent_every in (0, 3):
+        agents = E.build_circle_agents(200, policy=E.ORCA3DPolicy)
+        env = E.MACAEnv()
+        env.set_agents(agents, obstacles=[])
+        snaps = []
+        for t in range(40):
+            if per_agent_every and t % per_agent_every == 0:
+                row = agents[5].policy.find_next_action({}, agents[5], env.kdTree)
+                assert len(row) == 7
+            env.step({})
+            if t % 7 == 0:
+                snaps.append((env.pos.copy(), env.vel.copy(), env.flags.copy(), agents[7].pos_global_frame.copy(), agents[7].step_num))
+        snaps.append((env.pos.copy(), env.vel.copy(), env.flags.copy(), agents[7].pos_global_frame.copy(), agents[7].step_num))
+        st = env.solver.get_state()
+        assert np.array_equal(st['pos'], env.pos) and np.array_equal(st['step_num'], env.step_num)
+        runs.append(snaps)
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert runs[0][-1][4] == 40
