@@ -207,12 +207,11 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     return m;
 }
 
-// get_position_in_segment (:283-297) / get_coordinates (:260-280)
-SCA_DHD static void seg(double offset, const double qi[3], char mode, double q[3]) {
+// get_position_in_segment (:283-297) / get_coordinates (:260-280).  The reference recomputes the two segment boundaries of
+// the maneuver (and the sin / cos of every segment's start angle) for every sample; they are functions of the maneuver only,
+// so they are computed once per plan (PathFrame) -- same arguments, same library functions, same bits.
+SCA_DHD static void seg(double offset, const double qi[3], double s0, double c0, char mode, double q[3]) {   // s0, c0 = sin, cos of qi[2]
     q[0] = q[1] = q[2] = 0.0;
-    // sin and cos of the same angle in one call (the host's m_sincos is the two separate libm calls of the reference)
-    double s0, c0;
-    m_sincos(qi[2], s0, c0);
     if (mode == 'L') {
         double s1, c1;
         m_sincos(qi[2] + offset, s1, c1);
@@ -231,16 +230,24 @@ SCA_DHD static void seg(double offset, const double qi[3], char mode, double q[3
         q[2] = qi[2];
     }
 }
-SCA_DHD static void get_coordinates(const Maneuver2D &m, double offset, double q[3]) {
+struct PathFrame { double s0, c0, q1[3], s1, c1, q2[3], s2, c2; };   // start of segment 1 / 2 / 3: state and sin / cos of its angle
+SCA_DHD static PathFrame path_frame(const Maneuver2D &m) {
+    PathFrame F;
+    const double qi[3] = {0., 0., m.yaw};
+    m_sincos(qi[2], F.s0, F.c0);
+    seg(m.t, qi, F.s0, F.c0, m.mode[0], F.q1);
+    m_sincos(F.q1[2], F.s1, F.c1);
+    seg(m.p, F.q1, F.s1, F.c1, m.mode[1], F.q2);
+    m_sincos(F.q2[2], F.s2, F.c2);
+    return F;
+}
+SCA_DHD static void get_coordinates(const Maneuver2D &m, const PathFrame &F, double offset, double q[3]) {
     const double noffset = offset / m.r_min;
     const double qi[3] = {0., 0., m.yaw};
     const double l1 = m.t, l2 = m.p;
-    double q1[3], q2[3];
-    seg(l1, qi, m.mode[0], q1);
-    seg(l2, q1, m.mode[1], q2);
-    if (noffset < l1) seg(noffset, qi, m.mode[0], q);
-    else if (noffset < (l1 + l2)) seg(noffset - l1, q1, m.mode[1], q);
-    else seg(noffset - l1 - l2, q2, m.mode[2], q);
+    if (noffset < l1) seg(noffset, qi, F.s0, F.c0, m.mode[0], q);
+    else if (noffset < (l1 + l2)) seg(noffset - l1, F.q1, F.s1, F.c1, m.mode[1], q);
+    else seg(noffset - l1 - l2, F.q2, F.s2, F.c2, m.mode[2], q);
     q[0] = q[0] * m.r_min + qi[0];
     q[1] = q[1] * m.r_min + qi[1];
     q[2] = mod2pi(q[2]);
@@ -248,6 +255,7 @@ SCA_DHD static void get_coordinates(const Maneuver2D &m, double offset, double q
 
 struct Plan3D {
     Maneuver2D h, v;
+    PathFrame fh, fv;
     double length = -1.0, sampling_size = 0.1;
     double qi[5] = {0, 0, 0, 0, 0};
     char mode[7] = {0};
@@ -258,11 +266,25 @@ struct Plan3D {
     SCA_DHD void sample(long i, double s[5]) const {
         const double ran = (double)i * sampling_size;
         double qSZ[3], qXY[3];
-        get_coordinates(v, ran, qSZ);
-        get_coordinates(h, qSZ[0], qXY);
+        get_coordinates(v, fv, ran, qSZ);
+        get_coordinates(h, fh, qSZ[0], qXY);
         s[0] = qXY[0] + qi[0]; s[1] = qXY[1] + qi[1]; s[2] = qSZ[1] + qi[2]; s[3] = qXY[2]; s[4] = qSZ[2];
     }
 };
+// the tail of dubinsmaneuver3d (:102-113) + compute_sampling's grid (:116-132) for the winning pair of maneuvers
+SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver2D &fbv, const double qi[5]) {
+    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
+    P.fh = path_frame(fbh); P.fv = path_frame(fbv);
+    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
+    P.mode[6] = 0;
+    double ss = 0.1;
+    if (P.length > 100) ss = P.length / 1000;
+    P.sampling_size = ss;
+    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
+    const double stop = P.length + ss;
+    const long cnt = (long)std::ceil(stop / ss);                        // len(np.arange(0, stop, ss))
+    P.count = cnt > 0 ? cnt : 0;
+}
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
 // H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
@@ -304,16 +326,7 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
         }
         step *= -0.1;
     }
-    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
-    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
-    P.mode[6] = 0;
-    double ss = 0.1;
-    if (P.length > 100) ss = P.length / 1000;
-    P.sampling_size = ss;
-    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
-    const double stop = P.length + ss;
-    const long cnt = (long)std::ceil(stop / ss);                        // len(np.arange(0, stop, ss))
-    P.count = cnt > 0 ? cnt : 0;
+    finish_plan(P, fbh, fbv, qi);
     return P;
 }
 

@@ -223,16 +223,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
         } else if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
         else step *= -0.1;
     }
-    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
-    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
-    P.mode[6] = 0;
-    double ss = 0.1;
-    if (P.length > 100) ss = P.length / 1000;
-    P.sampling_size = ss;
-    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
-    const double stop = P.length + ss;
-    const long cnt = (long)::ceil(stop / ss);
-    P.count = cnt > 0 ? cnt : 0;
+    finish_plan(P, fbh, fbv, qi);
     return P;
 }
 
@@ -319,16 +310,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             if (!(::fabs(step) > 1e-10)) break;
         }
     }
-    P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
-    for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
-    P.mode[6] = 0;
-    double ss = 0.1;
-    if (P.length > 100) ss = P.length / 1000;
-    P.sampling_size = ss;
-    for (int k = 0; k < 5; k++) P.qi[k] = qi[k];
-    const double stop = P.length + ss;
-    const long cnt = (long)::ceil(stop / ss);
-    P.count = cnt > 0 ? cnt : 0;
+    finish_plan(P, fbh, fbv, qi);
     return P;
 }
 
