@@ -197,7 +197,27 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     m.mode[0] = m.mode[1] = m.mode[2] = 0;
     const double d = F.D / c;
     double bcost = INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // device: the four CSC words through the branch-free uniform form (bit-identical to word(0..3)), so that the four
+    // independent chains can be interleaved by the instruction scheduler
+    {
+        const double mbeta = mod2pi(F.beta);
+        double t4[4], p4[4], q4[4]; bool ok4[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const double cost = c * (std::fabs(t4[w]) + std::fabs(p4[w]) + std::fabs(q4[w]));
+            if (ok4[w] && bcost > cost) {
+                m.t = t4[w]; m.p = p4[w]; bcost = cost; m.ok = true;
+                m.mode[0] = (w & 1) ? 'R' : 'L'; m.mode[1] = 'S'; m.mode[2] = (w == 0 || w == 3) ? 'L' : 'R';
+            }
+        }
+    }
+    for (int w = 4; w < 6; w++) {
+#else
     for (int w = 0; w < 6; w++) {                                     // planners = [LSL, RSR, LSR, RSL, RLR, LRL]
+#endif
         double t, p, q; char mode[3];
         if (!word(w, F.alpha, F.beta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t, p, q, mode)) continue;
         const double cost = c * (std::fabs(t) + std::fabs(p) + std::fabs(q));
