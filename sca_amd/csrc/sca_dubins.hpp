@@ -274,8 +274,8 @@ SCA_DHD static void get_coordinates(const Maneuver2D &m, const PathFrame &F, dou
 }
 
 struct Plan3D {
-    Maneuver2D h, v;
-    PathFrame fh, fv;
+    Maneuver2D h{}, v{};
+    PathFrame fh{}, fv{};
     double length = -1.0, sampling_size = 0.1;
     double qi[5] = {0, 0, 0, 0, 0};
     char mode[7] = {0};
