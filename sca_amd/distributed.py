@@ -42,7 +42,13 @@ class ShardedStepper:
         self._cur = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self._moved = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         sol.bind_public_records(self._cur.data_ptr(), self._moved.data_ptr())
-        sol.set_stream(torch.cuda.current_stream().cuda_stream)
+        # The library's kernels and the collective must be ordered on ONE stream.  torch's default stream is the null
+        # stream (handle 0), which sca_set_stream reads as "use the library's own, non-blocking stream" -- nothing would
+        # order the all-gather behind sca_step_begin then.  So the stepper owns a torch stream: the library launches on
+        # it, and the collective is issued with it current (ProcessGroupNCCL waits for / is waited on by the current stream).
+        torch.cuda.synchronize()                      # the two buffers were zeroed on the default stream
+        self._stream = torch.cuda.Stream(device=dev)
+        sol.set_stream(self._stream.cuda_stream)
         self._per = nbytes // self.world
         self._by_ptr = {self._cur.data_ptr(): self._cur, self._moved.data_ptr(): self._moved}
 
@@ -69,7 +75,8 @@ class ShardedStepper:
                 full.copy_(h_full)
                 self.torch.cuda.synchronize()
             else:
-                self.dist.all_gather_into_tensor(full, mine)
+                with self.torch.cuda.stream(self._stream):
+                    self.dist.all_gather_into_tensor(full, mine)
             self.sol.step_end()
 
     def sync(self):

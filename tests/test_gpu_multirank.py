@@ -134,3 +134,52 @@ def test_bench_script_two_rank_path():
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['agents'] == 12000
     assert out['config']['agent_steps_timed'] == 12000 * 6
     assert out['value'] > 0 and 'roofline' in out and 'cpu_baseline' not in out
+
+
+ORDER_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sca_amd import scenarios, solver as S
+from sca_amd.distributed import ShardedStepper
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+n = 60000
+sc = scenarios.circle(n)
+sol = S.BatchedSolver(max_agents=n, max_obstacles=1, device=0)
+sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], np.zeros(n, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
+               scenarios.max_run_dist(sc['start'], sc['goal']))
+sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+st = ShardedStepper(sol, 0, 1, torch_mod=torch, dist_mod=dist, force_exchange=True)
+assert st._stream.cuda_stream != 0                  # a real stream: handle 0 would mean "the library's own stream"
+st.run(3); st.sync(); torch.cuda.synchronize()
+stale = 0
+for it in range(10):
+    st.run(4)                                       # a backlog of queued work on the stepper's stream
+    sol.step_begin(0)
+    full, mine = st._moved_records()
+    tmp = torch.zeros_like(mine)
+    with torch.cuda.stream(st._stream):
+        dist.all_gather_into_tensor(tmp, mine)      # out of place: a gather that ran too early would copy old records
+    sol.step_end()
+    sol.synchronize(); torch.cuda.synchronize()
+    a = tmp.view(-1, 48)[:, :24].cpu().numpy(); b = mine.view(-1, 48)[:, :24].cpu().numpy()   # positions: step_end leaves them alone
+    stale += int((a != b).any())
+print('ORDER', 'OK' if stale == 0 else 'STALE %d' % stale, flush=True)
+dist.destroy_process_group()
+sys.exit(0 if stale == 0 else 1)
+'''
+
+
+def test_collective_is_ordered_behind_the_library_kernels(tmp_path):
+    """The library launches on the stepper's own torch stream and the RCCL collective is issued with that stream current, so
+    an all-gather behind sca_step_begin sees the records that call wrote even when the stream holds a backlog.  (torch's
+    default stream has handle 0, which sca_set_stream takes as "use the library's own stream": nothing would order the two.)"""
+    script = tmp_path / 'order_worker.py'
+    script.write_text(ORDER_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29553', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'ORDER OK' in r.stdout, r.stdout[-3000:]
