@@ -788,7 +788,8 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
         rs = c->trk_stream;
     }
     K.quad = c->trk_quad ? 1 : 0;
-    // both forms are launched; the device-side count of this pass decides which of them does the work
+    // the device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work; k_replan is
+    // only launched when the shard is large enough to need it
     if (c->trk_quad)
         hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, TRK_FEW_BLOCKS)), dim3(64), 0, rs, c->d, c->trk_view, K);
     if (!c->trk_quad || cnt > TRK_QUAD_MAX)
