@@ -152,6 +152,7 @@ struct sca_ctx {
     int k1_force = -1;                  // K1 variant: -1 choose by shard size, 0 one agent per wavefront, 1 four (k_neighbors_kd4)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
+    bool state_fresh = false;           // flags came from sca_set_state: the next env update checks arrived agents against obstacles once
     bool near_valid = false;            // K1's collision-candidate lists describe the current records
     double max_radius = 0, max_obs_radius = 0, max_pref_speed = 0;
     std::string err;
@@ -555,7 +556,7 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
     if (total_dist) CHK(c, hipMemcpyAsync(c->d.total_dist, total_dist, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     if (step_num) CHK(c, hipMemcpyAsync(c->d.step_num, step_num, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
-    c->state_set = true;
+    c->state_set = true; c->state_fresh = true;
     return 0;
 }
 
@@ -871,7 +872,8 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     c->near_valid = false;
     hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K4_WAVES * K4_APW - 1) / (K4_WAVES * K4_APW)), dim3(K4_WAVES * 64), 0,
-                       c->stream, d, c->P, agent_reach, obs_reach);
+                       c->stream, d, c->P, agent_reach, obs_reach, c->state_fresh ? 1 : 0);
+    c->state_fresh = false;
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
     CHK(c, hipGetLastError());

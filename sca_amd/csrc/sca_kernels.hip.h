@@ -1457,7 +1457,8 @@ __device__ __forceinline__ CollideCtx collide_ctx(const DeviceView &d, int agent
     return c;
 }
 // whole wavefront, one agent: range queries in both trees (wave-uniform agent)
-__device__ __forceinline__ bool collide_traverse(const DeviceView &d, double agent_reach, double obs_reach, int *stack, int agent, int lane) {
+__device__ __forceinline__ bool collide_traverse(const DeviceView &d, double agent_reach, double obs_reach, int *stack, int agent, int lane,
+                                                 bool obstacles_only) {
     PubRec me_old;
     const CollideCtx c = collide_ctx(d, agent, me_old);
     bool hit = false;
@@ -1467,6 +1468,7 @@ __device__ __forceinline__ bool collide_traverse(const DeviceView &d, double age
             if (lane < end - begin) hit = hit || collide_obstacle(d, c, d.operm[begin + lane]);
         });
     }
+    if (obstacles_only) return __ballot(hit) != 0;                   // wave-uniform
     const double rq = c.me.radius + agent_reach;
     kd_traverse(d.awide, c.p_old, rq * rq, stack, lane, [&](int begin, int end) {
         if (lane < end - begin) { const int j = d.aperm[begin + lane]; if (j != agent) hit = hit || collide_agent(d, c, j); }
@@ -1478,7 +1480,8 @@ constexpr int K4_WAVES = 4;
 constexpr int K4_APW = 64 / NEAR_MAX;      // agents per wavefront
 static_assert(NEAR_MAX == 8, "k_collide_finish packs 8 lanes per agent");
 
-__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach) {
+__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach,
+                                                                int check_arrived) {
     __shared__ int stacks[K4_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1490,21 +1493,25 @@ __global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, 
     PubRec me_old;
     const CollideCtx c = collide_ctx(d, agent, me_old);
     const int near_n = d.near_n[agent];
-    // an agent that had arrived or collided before this step did not move and cannot gain a flag (mampenv.py:72-75
-    // never flags an agent at its goal; a collided one is flagged already)
+    // an agent that had arrived or collided before this step did not move and cannot gain a flag: mampenv.py:72-75 never
+    // flags an agent at its goal for touching another agent, a collided one is flagged already, and whether it touches an
+    // obstacle (mampenv.py:63-66, checked for EVERY agent) was settled in the step it arrived -- unless the state came from
+    // outside (sca_set_state with the at-goal flag set): then the first update after it looks once (check_arrived)
     const bool settled = (me_old.flags & (FLAG_AT_GOAL | FLAG_COLLISION)) != 0;
+    const bool arrived_only = check_arrived && d.m > 0 && (me_old.flags & (FLAG_AT_GOAL | FLAG_COLLISION)) == FLAG_AT_GOAL;
     bool hit = false;
     if (exists && !settled && sub < near_n) {
         const int id = d.near_id[(size_t)agent * NEAR_MAX + sub];
         hit = (id & NBR_OBSTACLE_BIT) ? collide_obstacle(d, c, id & ~NBR_OBSTACLE_BIT) : collide_agent(d, c, id);
     }
     bool any = ((__ballot(hit) >> (grp * NEAR_MAX)) & ((1ull << NEAR_MAX) - 1ull)) != 0;
-    unsigned long long todo = __ballot(exists && !settled && near_n < 0 && sub == 0);
+    unsigned long long todo = __ballot(exists && sub == 0 && ((!settled && near_n < 0) || arrived_only));
     while (todo) {
         const int l0 = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int ag = __builtin_amdgcn_readlane(agent, l0);
-        const bool r = collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane);
+        const bool obs_only = __builtin_amdgcn_readlane((int)arrived_only, l0) != 0;
+        const bool r = collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane, obs_only);
         if (lane / NEAR_MAX == l0 / NEAR_MAX) any = r;
     }
     if (exists && sub == 0) {
