@@ -178,7 +178,8 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
 /* The same tracker on the device: one lane per agent, tracker records resident in HBM, the re-planning agents of a step
  * compacted into a kernel of their own (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker, compiled for
  * gfx950 with the device library's sin / cos / atan2 / acos, whose last bit differs from glibc's in a few percent of the
- * calls: v_pref equals the host tracker's except for isolated 1e-5 steps of the truncation of scaPolicy.py:338.
+ * calls: v_pref equals the host tracker's except for isolated components (0.03 % in fuzzing) that differ by one step of the
+ * 5-decimal truncation of scaPolicy.py:338, a few steps when the tracked node is within a metre.
  * sca_device_tracker_enable: agents with policy SCA / RVO3D_DUBINS take v_pref from it from now on -- inside every
  * sca_policy_pass / sca_step_begin / sca_run_steps when in_pass != 0 (agent.neighbors[0] of the previous pass is read from
  * the neighbour lists on the device), otherwise only through sca_device_tracker_vpref.  sca_set_agents disables it. */
