@@ -21,6 +21,7 @@ class ShardedStepper:
         self.torch = torch_mod
         self.dist = dist_mod
         self.mode = mode
+        self._stream = None
         n = solver.n
         if self.exchange:
             if n % self.world:
@@ -74,9 +75,11 @@ class ShardedStepper:
                 self.dist.all_gather_into_tensor(h_full, h_mine)
                 full.copy_(h_full)
                 self.torch.cuda.synchronize()
-            else:
-                with self.torch.cuda.stream(self._stream):
+            elif getattr(self, '_stream', None) is not None:
+                with self.torch.cuda.stream(self._stream):           # ordered with the library's kernels (see _setup_exchange)
                     self.dist.all_gather_into_tensor(full, mine)
+            else:                                                    # a backend with its own buffers (the CPU checker of the tests)
+                self.dist.all_gather_into_tensor(full, mine)
             self.sol.step_end()
 
     def sync(self):
