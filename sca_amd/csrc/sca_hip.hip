@@ -337,6 +337,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
+    c->trk.quad_max = getenv("SCA_TRK_QUAD_MAX") ? atoi(getenv("SCA_TRK_QUAD_MAX")) : TRK_QUAD_MAX;
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -792,8 +793,8 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     // the device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work; k_replan is
     // only launched when the shard is large enough to need it
     if (c->trk_quad)
-        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, TRK_FEW_BLOCKS)), dim3(64), 0, rs, c->d, c->trk_view, K);
-    if (!c->trk_quad || cnt > TRK_QUAD_MAX)
+        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16))), dim3(64), 0, rs, c->d, c->trk_view, K);
+    if (!c->trk_quad || cnt > K.quad_max)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
     if (side) CHK(c, hipEventRecord(c->trk_join, c->trk_stream));

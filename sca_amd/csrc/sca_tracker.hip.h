@@ -30,10 +30,12 @@ struct TrackDev {
     int32_t *count;               // [2] list length, double-buffered by pass parity (k_track zeroes the other one)
     int parity;
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
-    int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= TRK_QUAD_MAX re-plans
+    int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= quad_max re-plans
+    int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning)
 };
 
-constexpr int TRK_QUAD_MAX = 16384;       // re-plans per pass up to which the four-lanes-per-plan kernel is used
+constexpr int TRK_QUAD_MAX = 24576;       // re-plans per pass up to which the four-lanes-per-plan form is used (measured crossover with the
+                                          // lane-per-plan kernel: 19 k plans 0.54 vs 0.58 ms per step, 31 k plans 0.65 vs 0.61)
 constexpr int TRK_REPLAN_LANES = 64;      // one wavefront per workgroup: re-plans spread over as many CUs as possible
 
 __device__ __forceinline__ bool track_active(const DeviceView &d, int agent) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = K.count[K.parity];
-    if (idx >= count || (K.quad && count <= TRK_QUAD_MAX)) return;          // few re-plans: k_replan_few's pass
+    if (idx >= count || (K.quad && count <= K.quad_max)) return;            // few re-plans: k_replan_few's pass
     const int agent = K.list[idx];
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -346,7 +348,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
 constexpr int TRK_FEW_BLOCKS = 1024;
 __global__ __launch_bounds__(64) void k_replan_few(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
-    if (count > TRK_QUAD_MAX) return;
+    if (count > K.quad_max) return;
     if (count <= TRK_SPEC4_MAX) replan_group<64>(d, T, K, count);
     else if (count <= TRK_SPEC3_MAX) replan_group<32>(d, T, K, count);
     else if (count <= TRK_SPEC2_MAX) replan_group<16>(d, T, K, count);
