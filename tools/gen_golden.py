@@ -334,6 +334,93 @@ def single_step_cluster(agent_mod, env_mod, classes, name, n, box, policy_id, se
           f'collisions={int(coll_after.sum())} lp4={int(REC.lp4.sum())} {time.time() - t0:.1f} s', flush=True)
 
 
+def single_step_random(agent_mod, env_mod, classes, name, seed, outdir='tests/golden'):
+    """Fuzz fixtures (F12): a random small scene -- all six policies mixed, radii and preferred speeds of several sizes,
+    obstacles that may overlap agents, agents done from the start (at goal / collided / timed out), agents at rest
+    (bootstrap branch), goals straight above the start (is_zAxis), dense or sparse -- and one env.step of the reference."""
+    global REC
+    from mamp.agents.obstacle import Obstacle
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3, 9, 17, 30, 45]))
+    m = int(rng.choice([0, 2, 10]))
+    side = float(rng.choice([3.0, 6.0, 15.0]))
+    xyz = rng.uniform(-side, side, (n, 3))
+    xyz[:, 2] = np.abs(xyz[:, 2]) + float(rng.choice([0.0, 1.0, 20.0]))
+    g = rng.uniform(-side, side, (n, 3))
+    g[:, 2] = np.abs(g[:, 2]) + 1.0
+    if rng.random() < 0.4:
+        g[: n // 2, :2] = xyz[: n // 2, :2]                               # is_zAxis agents (scaPolicy.py:188-190)
+    pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.4, 0.4)), 0.0] for i in range(n)]
+    goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+    policy_ids = [int(x) for x in rng.integers(0, 6, n)]
+    radius_l = [float(x) for x in rng.choice([0.3, 0.5, 1.0], n)]
+    ps_l = [float(x) for x in rng.choice([1.0, 1.0, 0.8, 1.5], n)]
+    agents = [agent_mod.Agent(start_pos=pos[i], goal_pos=goal[i], vel=[0.0, 0.0, 0.0], radius=radius_l[i], pref_speed=ps_l[i],
+                              policy=classes[policy_ids[i]], id=i, dt=0.1) for i in range(n)]
+    rest = rng.random(n) < 0.2
+    for a in agents:
+        v = rng.normal(size=3)
+        v = v / np.linalg.norm(v) * rng.uniform(0.1, 1.0)
+        a.vel_global_frame = np.zeros(3, np.float32) if rest[a.id] else v.astype(np.float32)
+        u = rng.random()
+        if u < 0.05:
+            a.is_at_goal = True
+        elif u < 0.10:
+            a.is_collision = True
+        elif u < 0.13:
+            a.is_out_of_max_time = True
+    obstacles_spec = [(list(map(float, rng.uniform(-side, side, 3) * np.array([1, 1, 0.5]) + np.array([0, 0, side / 2]))),
+                       float(rng.choice([0.2, 1.0, 2.0]))) for _ in range(m)]
+    obstacles = [Obstacle(pos=list(p), shape_dict={'shape': 'sphere', 'feature': r}, id=i)
+                 for i, (p, r) in enumerate(obstacles_spec)]
+    env = env_mod.MACAEnv()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env.set_agents(agents, obstacles=obstacles)
+    REC = Recorder(n)
+    actions = np.zeros((n, 7), np.float32)
+    coll_after = np.zeros(n, np.uint8)
+    orig_upd = env_mod.update_velocitie
+    first_upd = [True]
+
+    def upd(agent, action):
+        if first_upd[0]:
+            first_upd[0] = False
+            for a in agents:
+                coll_after[a.id] = 1 if a.is_collision else 0
+        actions[agent.id] = action
+        return orig_upd(agent, action)
+    env_mod.update_velocitie = upd
+    pre = _snapshot(agents)
+    perm = np.array(env.kdTree.agentIDs, np.int32)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env.step({})
+    env_mod.update_velocitie = orig_upd
+    post = _snapshot(agents)
+    out = dict(name=name, step=np.array([0]), n_steps_run=1, done_step=-1)
+    for k, v in zip(('pos', 'vel', 'heading', 'flags', 'total_dist', 'goal'), pre):
+        out[k] = v[None]
+    out['perm'] = perm[None]
+    for k in ('vpref', 'called', 'nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq', 'n_suit', 'fallback',
+              'plane_fail', 'lp4', 'vpost'):
+        out[k] = getattr(REC, k).copy()[None]
+    out['action'] = actions[None]
+    out['coll_after_policy'] = coll_after[None]
+    for k, v in zip(('pos_after', 'vel_after', 'heading_after', 'flags_after', 'total_dist_after'), post[:5]):
+        out[k] = v[None]
+    out['perm_after'] = np.array(env.kdTree.agentIDs, np.int32)[None]
+    out.update(dict(start=np.array(pos, dtype=np.float64), goal6=np.array(goal, dtype=np.float64), radius=np.array(radius_l),
+                    pref_speed=np.array(ps_l), policy=np.array(policy_ids, np.uint8),
+                    max_run_dist=np.array([a.max_run_dist for a in agents]),
+                    obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
+                    obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64), numpy_version=np.__version__))
+    path = os.path.join(outdir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: n={n} m={m} side={side} called={int(REC.called.sum())} nbr_n max={REC.nbr_n.max()} '
+          f'fallback={int((REC.fallback > 0).sum())} collisions={int(coll_after.sum())} lp4={int((REC.lp4 > 0).sum())} '
+          f'{time.time() - t0:.1f} s', flush=True)
+
+
 def kat_tables(outdir='tests/golden'):
     """F8: per-function known-answer tables for the scalar helpers of mamp/util.py."""
     import mamp.util as u
@@ -517,6 +604,12 @@ def main():
         pos = [[float(v) for v in p_] for p_ in pos]
         goal = [[float(v) for v in g_] for g_ in goal]
         run_env_episode(agent_mod, env_mod, classes, 'F10_sca_exp3_map', pos, goal, [POL_SCA] * 16, obs10, 160, outdir=od)
+    # F12: fuzz -- random small scenes, one step each, everything mixed (found by fuzzing the HIP path against the oracle:
+    # cases no hand-made fixture had, e.g. an agent that is at its goal AND inside an obstacle)
+    for k in range(16):
+        nm = f'F12_fuzz_{k:02d}'
+        if want(nm):
+            single_step_random(agent_mod, env_mod, classes, nm, seed=1200 + k, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
