@@ -610,6 +610,25 @@ def main():
         nm = f'F12_fuzz_{k:02d}'
         if want(nm):
             single_step_random(agent_mod, env_mod, classes, nm, seed=1200 + k, outdir=od)
+    # F13: fuzz episodes for the v_pref tracker -- random starts / goals with pitched and yawed poses, take-off agents,
+    # three preferred speeds, SCA and RVO3D+Dubins among the other policies, 40 steps each
+    for k in range(4):
+        nm = f'F13_fuzz_track_{k:02d}'
+        if want(nm):
+            rng = np.random.default_rng(1300 + k)
+            n = int(rng.choice([8, 12, 16]))
+            side = float(rng.choice([6.0, 12.0, 25.0]))
+            xyz = rng.uniform(-side, side, (n, 3))
+            xyz[:, 2] = np.abs(xyz[:, 2]) + float(rng.choice([0.0, 5.0]))
+            g = rng.uniform(-side, side, (n, 3))
+            g[:, 2] = np.abs(g[:, 2]) + 1.0
+            g[: n // 3, :2] = xyz[: n // 3, :2]                                # take-off / landing agents (is_zAxis)
+            pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.5, 0.5)), 0.0] for i in range(n)]
+            goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.3, 0.3)), 0.0] for i in range(n)]
+            pol = [int(x) for x in rng.choice([POL_SCA, POL_SCA, POL_RVO_DUBINS, POL_SRVO, POL_ORCA_LP], n)]
+            psp = rng.choice([0.8, 1.0, 1.5], n)
+            obs13 = [(list(map(float, rng.uniform(-side, side, 3) * np.array([1, 1, 0.5]) + np.array([0, 0, side / 2]))), 1.0) for _ in range(3)]
+            run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, pol, obs13, 40, pref_speed=psp, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
