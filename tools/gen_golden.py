@@ -629,6 +629,26 @@ def main():
             psp = rng.choice([0.8, 1.0, 1.5], n)
             obs13 = [(list(map(float, rng.uniform(-side, side, 3) * np.array([1, 1, 0.5]) + np.array([0, 0, side / 2]))), 1.0) for _ in range(3)]
             run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, pol, obs13, 40, pref_speed=psp, outdir=od)
+    # F14: fuzz episodes -- dense random boxes, every policy but the two tracked ones, goals close by (arrivals, collisions
+    # and time-outs happen within the 20 recorded steps), obstacles among the agents
+    for k in range(3):
+        nm = f'F14_fuzz_episode_{k:02d}'
+        if want(nm):
+            rng = np.random.default_rng(1400 + k)
+            n = int(rng.choice([20, 30, 40]))
+            side = float(rng.choice([4.0, 7.0]))
+            xyz = rng.uniform(-side, side, (n, 3))
+            xyz[:, 2] = np.abs(xyz[:, 2]) + 1.0
+            g = xyz + rng.normal(0, 1.5, (n, 3))                               # short trips: many arrive
+            g[:, 2] = np.abs(g[:, 2]) + 0.5
+            pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+            goal = [list(map(float, g[i])) + [0.0, 0.0, 0.0] for i in range(n)]
+            pol = [int(x) for x in rng.choice([POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP], n)]
+            rad = rng.choice([0.3, 0.5], n)
+            psp = rng.choice([0.8, 1.0, 1.5], n)
+            obs14 = [(list(map(float, rng.uniform(-side, side, 3) * np.array([1, 1, 0.5]) + np.array([0, 0, side / 2]))),
+                      float(rng.choice([0.3, 1.0]))) for _ in range(4)]
+            run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, pol, obs14, 20, radius=rad, pref_speed=psp, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
