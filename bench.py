@@ -14,7 +14,8 @@ circle of 100000 x n_gpus agents, sharded by id, one all-gather of the moved 48-
 `--scaling strong` keeps the total at the workload's N.
 SCA's preferred velocity comes from the reference's Dubins tracker (scaPolicy.py:264-338), which is outside the path
 north_star names: by default the bench feeds the straight-line rule (rvo3dPolicy.py:182-196) computed on
-the device instead, and says so in `config`.  `--vpref dubins-device` runs the tracker on the device inside every step
+the device instead, and says so in `config`; at --gpus 1 (or with --end-to-end) a second timed leg, `end_to_end_sca`, repeats
+the steps with the tracker on the device.  `--vpref dubins-device` runs the tracker on the device inside every step
 (end-to-end SCA, state still resident); `--vpref dubins` runs the native host tracker (bit-exact, host-bound).
 
 Prints ONE JSON line on rank 0.
@@ -75,6 +76,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true',
                     help='skip the second timed leg (SCA workloads: the same steps with the Dubins v_pref tracker on the device)')
+    ap.add_argument('--end-to-end', action='store_true',
+                    help='run the second leg with several GPUs too (by default only at --gpus 1: the scaling runs measure `value`)')
     ap.add_argument('--vpref', default='straight', choices=['straight', 'dubins', 'dubins-device'],
                     help='dubins: SCA v_pref from the native host-side tracker every step (end-to-end SCA, host-bound); '
                          'dubins-device: from the device tracker inside every step (end-to-end SCA, resident)')
@@ -183,7 +186,7 @@ def main():
     # second leg, SCA workloads only: the same step with SCA's own v_pref -- the Dubins tracker of scaPolicy.py:264-338 as
     # kernels inside every step (SURVEY.md 8d asks for both the solver and the end-to-end throughput)
     e2e = None
-    if args.vpref == 'straight' and not args.no_end_to_end and w['policy'] in ('sca', 'mixed'):
+    if args.vpref == 'straight' and not args.no_end_to_end and w['policy'] in ('sca', 'mixed') and (world == 1 or args.end_to_end):
         # from the start state again, so that both legs time the same stretch of the episode
         sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
         sol.device_tracker_enable(sc['goal'][:, 3:6])

@@ -126,7 +126,7 @@ def test_bench_script_two_rank_path():
     env = dict(os.environ, SCA_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
-                        '--warmup', '3', '--agents', '6000'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        '--warmup', '3', '--agents', '6000', '--end-to-end'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -134,6 +134,7 @@ def test_bench_script_two_rank_path():
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['agents'] == 12000
     assert out['config']['agent_steps_timed'] == 12000 * 6
     assert out['value'] > 0 and 'roofline' in out and 'cpu_baseline' not in out
+    assert out['end_to_end_sca']['agent_steps_timed'] == 12000 * 6 and out['end_to_end_sca']['value'] > 0
 
 
 ORDER_WORKER = r'''
