@@ -236,6 +236,7 @@ def main():
                          # with the tracker's re-plans on a side stream the interval before k_solve also holds the join
                          'neighbors_kernel_ms': kms['neighbors'] if args.vpref != 'dubins-device' else None,
                          'bytes_per_agent_step': BYTES_PER_AGENT_STEP,
+                         'valu_issue_frac': valu_issue_frac(wname, per_launch_agents, solve_s),
                          'note': 'fp64 VALU bound (no contraction, no MFMA): HBM fraction is reported as required'},
         }
         if e2e is not None:
@@ -247,6 +248,23 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4      # SIMDs x clock / cycles per wave64 fp64 VALU instruction
+
+
+def valu_issue_frac(wname, agents_per_launch, kernel_s):
+    """k_solve is bound by fp64 VALU issue, not by HBM: fraction of the chip's VALU issue rate it sustains, from the PMC
+    instruction count per agent (profiles/r01_pmc_traffic.json) and the launch duration measured in this run."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            per_agent = json.load(f).get(wname, {}).get('k_solve_valu_wave_insts_per_agent')
+    except (OSError, ValueError):
+        per_agent = None
+    if not per_agent or kernel_s <= 0:
+        return None
+    return per_agent * agents_per_launch / kernel_s / VALU_PEAK_WAVE_INSTS
 
 
 def measured_traffic(wname):
