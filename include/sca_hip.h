@@ -175,8 +175,9 @@ int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
 int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
                     char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
 
-/* The same tracker on the device: one lane per agent, tracker records resident in HBM, the re-planning agents of a step
- * compacted into a kernel of their own (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker, compiled for
+/* The same tracker on the device: one lane per agent for the tracking, tracker records resident in HBM, the re-planning
+ * agents of a step compacted into kernels of their own -- one lane up to one wavefront per plan, by how many a step has
+ * (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker, compiled for
  * gfx950 with the device library's sin / cos / atan2 / acos, whose last bit differs from glibc's in a few percent of the
  * calls: v_pref equals the host tracker's except for isolated components (0.03 % in fuzzing) that differ by one step of the
  * 5-decimal truncation of scaPolicy.py:338, a few steps when the tracked node is within a metre.
