@@ -59,7 +59,11 @@ enum sca_flag { SCA_FLAG_AT_GOAL = 1, SCA_FLAG_COLLISION = 2, SCA_FLAG_TIMEOUT =
 
 enum sca_neighbor_mode {
     SCA_NBR_KDTREE = 0,           /* replica of the reference kd-tree (built and queried on the device): exact lists */
-    SCA_NBR_GRID = 1,             /* reserved: uniform grid (identical lists whenever <= max_neighbors are in range) */
+    SCA_NBR_GRID = 1,             /* uniform hashed grid, cells of neighbor_dist, rebuilt every step by a counting sort (three short
+                                     launches instead of ~17 dependent tree levels; what multi-GPU runs want).  Lists hold the
+                                     reference's (object, distSq) pairs whenever <= max_neighbors objects are in range; entries of
+                                     equal distSq are ordered obstacles first, then by agent id (the reference: kd visit order);
+                                     with more in range the 16 nearest are kept and SCA_ST_NBR_OVERFLOW is raised */
     SCA_NBR_KDTREE_HOSTBUILD = 2  /* same tree built on the host from a position read-back (debug / A-B reference) */
 };
 
@@ -124,17 +128,37 @@ int sca_set_shard(sca_ctx *ctx, int begin, int count);
  * which = 0: the current records; which = 1: the "moved" records written by sca_step_begin, i.e. the buffer an
  * RCCL all-gather (torch.distributed) exchanges between sca_step_begin and sca_step_end. */
 int sca_public_records(sca_ctx *ctx, int which, void **device_ptr, int64_t *bytes_per_agent);
-/* Use caller-owned device memory (e.g. two torch tensors of max_agents*48 bytes) for the two record arrays;
- * NULL, NULL restores the internal ones. */
-int sca_bind_public_records(sca_ctx *ctx, void *current, void *moved);
+/* Use caller-owned device memory (e.g. two torch tensors of n*48 bytes, n of sca_set_agents; bytes_each says how large each
+ * is and is checked) for the two record arrays; NULL, NULL restores the internal ones.  The n live records are carried over. */
+int sca_bind_public_records(sca_ctx *ctx, void *current, void *moved, int64_t bytes_each /* >= n*48, n of sca_set_agents */);
 /* One step split around the exchange: begin = kd build + neighbours + solve + integrate for this rank's shard
  * (writes the shard's moved records); [all-gather of the moved records]; end = collision / goal flags + publish. */
 int sca_step_begin(sca_ctx *ctx, int neighbor_mode);
 int sca_step_end(sca_ctx *ctx);
-/* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the internal stream. */
+/* Run on a caller-provided hipStream_t, e.g. the torch stream a collective between sca_step_begin and sca_step_end is issued
+ * on: the library's kernels and that collective are ordered only if they share the stream.  NULL is taken literally: HIP's
+ * null stream (which is what torch's default stream is).  sca_use_own_stream() goes back to the context's own non-blocking
+ * stream (the default after sca_create).  Both drain the stream in use first. */
 int sca_set_stream(sca_ctx *ctx, void *hip_stream);
+int sca_use_own_stream(sca_ctx *ctx);
+/* RCCL inside the library (nothing in the reference: it is single-process).  One process per GPU; rank 0 calls
+ * sca_comm_unique_id and hands the 128 bytes (an ncclUniqueId) to the other ranks by any means; every rank then calls
+ * sca_comm_init after sca_set_agents.  From then on this rank owns agents [rank*n/nranks, (rank+1)*n/nranks) (n must divide),
+ * and every step of sca_run_steps is: shard's policy pass + integrate -> ncclAllGather of the shard's moved 48-byte records
+ * on the library's stream -> collision / goal flags, i.e. a multi-GPU episode is ONE host call per k steps.  librccl.so is
+ * loaded with dlopen at the first call; SCA_ERR_UNSUPPORTED when it is missing. */
+int sca_comm_unique_id(void *id_out /*128 bytes*/);
+int sca_comm_init(sca_ctx *ctx, int rank, int nranks, const void *unique_id /*128 bytes*/);
+int sca_comm_destroy(sca_ctx *ctx);
 /* average device time of the kernels of the last sca_policy_pass / sca_run_steps, measured with HIP events */
 int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float *update_ms);
+
+/* the same for the tracker's re-plan kernels (k_replan_few + k_replan), events on the stream they run on */
+int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
+/* Measurement aid for scaling models on one GPU: with a partial shard (sca_set_shard) and no communicator, sca_run_steps
+ * runs what ONE rank of a larger job runs per step -- the replicated neighbour structure over all n agents, everything else
+ * for the shard -- and copies the other agents' records over unchanged where the all-gather would deliver them. */
+int sca_set_shard_emulation(sca_ctx *ctx, int on);
 
 /* with profiling on, sca_run_steps brackets every kernel launch of the policy pass with HIP events on its stream;
  * sca_synchronize() then folds them into the averages sca_last_kernel_ms() returns */

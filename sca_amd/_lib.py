@@ -49,11 +49,17 @@ SIGNATURES = {
     'sca_active_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_set_shard': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'sca_public_records': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
-    'sca_bind_public_records': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sca_bind_public_records': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     'sca_step_begin': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_step_end': (C.c_int, [C.c_void_p]),
     'sca_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'sca_use_own_stream': (C.c_int, [C.c_void_p]),
+    'sca_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'sca_comm_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'sca_comm_destroy': (C.c_int, [C.c_void_p]),
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
+    'sca_last_replan_ms': (C.c_int, [C.c_void_p, fp]),
+    'sca_set_shard_emulation': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     'sca_selftest_l3norm': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp, dp]),

@@ -1,0 +1,361 @@
+// sca_grid.hip.h -- SCA_NBR_GRID: neighbour selection through a uniform hashed grid instead of the reference's kd-tree.
+//
+// Why it exists: the kd-tree of kdTree.py:56-122 is a chain of ~17 dependent tree levels over ALL agents,
+// so on several GPUs every rank repeats it in full.  A counting sort of the agents into cells of neighborDist is three short
+// launches whatever the swarm looks like, and a query reads 27 cells.
+//
+// What it returns.  Agent.insertAgentNeighbor (agent.py:79-99) keeps every object with distSq < rangeSq in a list sorted by
+// distSq; which objects those are does not depend on the visit order as long as no more than maxNeighbors are in range, so
+// for such agents the grid's list holds the same (object, distSq) pairs as the reference's.  Two things do depend on the
+// kd-tree's visit order and are therefore NOT reproduced:
+//   * the order of entries with EQUAL rounded distSq (here: obstacles first, in obstacle-tree order, then agents by id);
+//     it matters to nobody but the LP of orca3dPolicyOfficial.py, whose plane order is the list order;
+//   * which 16 survive when more than 16 are in range (agent.py:87-90 evicts by visit order): the grid keeps
+//     the 16 nearest and raises SCA_ST_NBR_OVERFLOW in the agent's status word.
+// The collision rule (first colliding object clears the list, afterwards only colliding objects are admitted, agent.py:82-99)
+// leaves "all colliding objects in range" whatever the order: reproduced exactly.
+// Obstacles keep their kd-tree (built once on the host, kdTree.py:158-227): the obstacle part of a list is the reference's.
+//
+//   k_grid_count : one lane per agent: cell key -> bucket, arrival slot by atomicAdd (+ the per-agent prologue of the solver)
+//   k_grid_alloc : one lane per bucket: a range of sorted positions per non-empty bucket (block scan + one atomic per block;
+//                  the ranges need no particular order)
+//   k_grid_fill  : one lane per agent: coordinates, id and cell key into bucket order
+//   k_neighbors_grid : four agents per wavefront, 16 lanes each (one DPP row): 27 probes, members 16 at a time, the bounded
+//                  sorted list one entry per lane
+#pragma once
+#include "sca_kernels.hip.h"
+
+namespace sca {
+
+struct GridDev {
+    int *count;                   // [H] members per bucket; all zero between builds (k_grid_alloc clears what it reads)
+    int2 *range;                  // [H] first sorted position and member count of the bucket
+    int *cursor;                  // [1] sorted positions handed out so far
+    int *bucket;                  // [n] bucket of agent i
+    int *slot;                    // [n] arrival slot of agent i inside its bucket
+    double *gx, *gy, *gz;         // [n] coordinates in bucket order
+    int *gid;                     // [n] agent ids in bucket order
+    unsigned long long *gkey;     // [n] cell keys in bucket order: several cells can share a bucket
+    int hbits;                    // H = 1 << hbits
+    int skip_prep;                // 1: the per-agent prologue is left to k_prep_shard (v_pref still being computed)
+    double inv_cell;              // 1 / cell size; the cell is a little larger than neighborDist (see grid_inv_cell)
+};
+
+// Every object with distSq < rangeSq must sit in one of the 27 cells around the agent's.  distSq is rounded to 5 decimals
+// (util.py:100) and the cell index is floor(x * inv_cell) with two roundings, so the cell is made 1e-6 (relative) larger than
+// neighborDist: the slack (1e-5 m) is far above both.
+__host__ __device__ inline double grid_inv_cell(double neighbor_dist) { return 1.0 / (neighbor_dist * 1.000001); }
+
+__device__ __forceinline__ long long grid_cell(double x, double inv_cell) { return (long long)floor(x * inv_cell); }
+__device__ __forceinline__ unsigned long long grid_key(long long cx, long long cy, long long cz) {
+    // 21 bits per axis: two cells alias only if they are 2^21 cells apart, never two of the 27 around one agent
+    return ((unsigned long long)(cx & 0x1fffff) << 42) | ((unsigned long long)(cy & 0x1fffff) << 21) | (unsigned long long)(cz & 0x1fffff);
+}
+__device__ __forceinline__ int grid_bucket(unsigned long long key, int hbits) {
+    return (int)((key * 0x9E3779B97F4A7C15ull) >> (64 - hbits));
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Params P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 256) d.done_count[i * 32] = 0;                                   // start of a step: K4's counters
+    if (i == 0) { *d.fb_count = 0; *g.cursor = 0; }                          // ... an empty fallback list, no position handed out
+    if (i >= d.n) return;
+    const PubRec r = d.rec[i];
+    const unsigned long long key = grid_key(grid_cell(r.px, g.inv_cell), grid_cell(r.py, g.inv_cell), grid_cell(r.pz, g.inv_cell));
+    const int h = grid_bucket(key, g.hbits);
+    g.bucket[i] = h;
+    g.slot[i] = atomicAdd(&g.count[h], 1);
+    if (!g.skip_prep && i >= d.shard_begin && i < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, i);
+}
+
+__global__ __launch_bounds__(256) void k_grid_alloc(GridDev g) {
+    __shared__ int wtot[4];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x * 256 + tid;
+    const int c = g.count[h];
+    // inclusive scan over the wavefront (row shifts, then the row totals), then over the four wavefronts
+    int v = c, t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v += t;
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    const int incl = v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < 4; w++) { const int x = wtot[w]; if (w < wid) woff += x; total += x; }
+    if (tid == 0) base_sh = total ? atomicAdd(g.cursor, total) : 0;
+    __syncthreads();
+    g.range[h] = make_int2(base_sh + woff + incl - c, c);
+    if (c) g.count[h] = 0;                                                   // ready for the next build
+}
+
+__global__ __launch_bounds__(256) void k_grid_fill(DeviceView d, GridDev g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    const PubRec r = d.rec[i];
+    const int at = g.range[g.bucket[i]].x + g.slot[i];
+    g.gx[at] = r.px; g.gy[at] = r.py; g.gz[at] = r.pz;
+    g.gid[at] = i;
+    g.gkey[at] = grid_key(grid_cell(r.px, g.inv_cell), grid_cell(r.py, g.inv_cell), grid_cell(r.pz, g.inv_cell));
+}
+
+__device__ __forceinline__ double shfl_d(double x, int src) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const int lo = __shfl((int)(unsigned)v, src), hi = __shfl((int)(unsigned)(v >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    const int lo = __shfl((int)(unsigned)v, src), hi = __shfl((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// probe q (0..26) of the 27 cells around (cx, cy, cz)
+__device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long long cy, long long cz, int q) {
+    const int dx = q % 3 - 1, dy = (q / 3) % 3 - 1, dz = q / 9 - 1;
+    return grid_key(cx + dx, cy + dy, cz + dz);
+}
+
+// K1 on the grid: FOUR AGENTS PER WAVEFRONT, 16 lanes each (the layout of k_neighbors_kd4).  Obstacles first, through
+// their kd-tree exactly as in the kd kernels (scaPolicy.py:114-116, agent.py:101-124); then the agents of the 27 cells.
+// Every agent that is not done gets its collision candidates for K4 (`near`), also on the bootstrap step, when the
+// reference builds no list (scaPolicy.py:34): K4 then never needs a tree.
+__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
+                                                                  double obs_reach, double max_radius) {
+    __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int grp = lane >> 4, gl = lane & 15, gshift = grp << 4;
+    const int end = d.shard_begin + d.shard_count;
+    const int agent_raw = d.shard_begin + (blockIdx.x * K1P_WAVES + wid) * K1P_APW + grp;
+    const bool exists = agent_raw < end;
+    const int agent = exists ? agent_raw : end - 1;                 // clamp: idle groups read a valid record, write nothing
+    const PubRec me = d.rec[agent];
+    int st = 0;
+    const bool done = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const bool bootstrap = !orca && l3norm_f32zero(vA, false) <= 1e-5;   // scaPolicy.py:34: no computeNeighbors on the bootstrap step
+    const bool scan = exists && !done;
+    const bool want_list = scan && !bootstrap;
+    const V3 pA = v3(me.px, me.py, me.pz);
+    const double rangeSq = P.neighbor_dist * P.neighbor_dist;       // scaPolicy.py:112
+    const int maxn = P.max_neighbors;
+    const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
+    const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
+    const int tk = gl >= 2 ? (gl - 2) >> 2 : 0;                     // box term of this lane (see k_neighbors_kd4)
+    const bool t_is_mx = gl >= 2 && (((gl - 2) >> 1) & 1);
+    const bool t_live = gl >= 2 && gl < 14;
+    const double pk = tk == 0 ? pA.x : (tk == 1 ? pA.y : pA.z);
+    double Ld = 0.0; int Li = -1; int cnt = 0; bool coll = false; int near_cnt = 0;
+    int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
+    int *stack = stacks[wid][grp];
+
+    // one object in range of the group's agent: the list stays sorted by (distSq, obstacles before agents, id); a full list
+    // keeps its 16 smallest and says so
+    auto member = [&](bool act, bool cb, double db, int ib) {
+        if (act && cb && !coll) { coll = true; cnt = 0; }                            // agent.py:83-85
+        bool ins = act && (cb || !coll);
+        const bool e_lt = gl < cnt && (Ld < db || (Ld == db && ((Li & NBR_OBSTACLE_BIT) != 0 || ((ib & NBR_OBSTACLE_BIT) == 0 && Li < ib))));
+        const unsigned bm = (unsigned)((__ballot(ins && e_lt) >> gshift) & 0xffffull);
+        const int pos = __popc(bm);
+        const bool full = ins && cnt == maxn;
+        if (full) { st |= ST_NBR_OVERFLOW; if (pos >= maxn) ins = false; }
+        const int ncnt = (ins && full) ? cnt - 1 : cnt;
+        const double up_d = row_shr1_d(Ld);
+        const int up_i = row_shr1_i(Li);
+        if (ins) {
+            if (gl > pos && gl <= ncnt) { Ld = up_d; Li = up_i; }
+            if (gl == pos) { Ld = db; Li = ib; }
+            cnt = ncnt + 1;
+        }
+    };
+    // the <= 16 objects a group has just measured, lane by lane
+    auto insert_all = [&](unsigned todo, bool c, double dsq, int o) {
+        const int ci = c ? 1 : 0;
+        while (__any(todo != 0)) {
+            const bool act = todo != 0;
+            const int b = act ? __ffs((int)todo) - 1 : 0;
+            todo &= todo - 1;
+            const int src = gshift + b;
+            const bool cb = __shfl(ci, src) != 0;
+            const double db = shfl_d(dsq, src);
+            const int ib = __shfl(o, src);
+            member(act, cb, db, ib);
+        }
+    };
+
+    // ---- obstacles: kd-tree of kdTree.py:232-262, as in k_neighbors_kd4
+    if (d.m > 0) {
+        const double *wd = (const double *)d.owide;
+        int node = 0, sp = 0;
+        bool have = scan;
+        while (__any(have)) {
+            const double w = have ? wd[(size_t)node * 16 + gl] : 0.0;
+            const double h0 = row_bcast_d<0>(w), h1 = row_bcast_d<1>(w);
+            const int nb = lo32(h0), ne = hi32(h0), nl = lo32(h1), nr_ = hi32(h1);
+            const bool leaf = have && (ne - nb <= MAX_LEAF);
+            const bool inner = have && !leaf;
+            bool descend = false; int next = 0;
+            if (__any(inner)) {
+                double t = t_is_mx ? pk - w : w - pk;
+                t = fmax(0.0, t);
+                const double sq = t_live ? t * t : 0.0;
+                double ssum = sq;
+                ssum = ssum + row_shl_d<2>(sq);
+                ssum = ssum + row_shl_d<4>(sq);
+                ssum = ssum + row_shl_d<6>(sq);
+                ssum = ssum + row_shl_d<8>(sq);
+                ssum = ssum + row_shl_d<10>(sq);
+                const double dl = row_bcast_d<2>(ssum), dr = row_bcast_d<3>(ssum);
+                int first, second; double dfirst, dsecond;
+                if (dl < dr) { first = nl; second = nr_; dfirst = dl; dsecond = dr; }
+                else { first = nr_; second = nl; dfirst = dr; dsecond = dl; }
+                if (inner && dfirst < rangeSq) {
+                    if (dsecond < rangeSq) {
+                        if (sp < KD_STACK) { if (gl == 0) stack[sp] = second; sp++; }
+                        else st |= ST_KD_STACK;
+                    }
+                    next = first; descend = true;
+                }
+            }
+            if (__any(leaf)) {
+                const bool valid = leaf && gl < ne - nb;
+                int o = -1; double dsq = 0.0; bool c = false, r = false, nr = false;
+                if (valid) {                                         // agent.py:101-124
+                    o = d.operm[nb + gl];
+                    const ObsRec orec = d.obs_sorted[nb + gl];
+                    const V3 pO = v3(orec.px, orec.py, orec.pz);
+                    const double distSq1 = l3normsq(pA, pO);
+                    const double tt = l3norm(pA, pO) - orec.radius;
+                    dsq = tt * tt;
+                    const double rs = me.radius + orec.radius;
+                    r = dsq < rangeSq;
+                    c = r && distSq1 < rs * rs;
+                    const V3 dd = pA - pO;
+                    nr = (dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) < reach_o * reach_o;
+                    o |= NBR_OBSTACLE_BIT;
+                }
+                {
+                    const unsigned nm = (unsigned)((__ballot(nr) >> gshift) & 0xffffull);
+                    if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
+                    near_cnt += __popc(nm);
+                }
+                insert_all((unsigned)((__ballot(r && want_list) >> gshift) & 0xffffull), c, dsq, o);
+            }
+            if (have) {
+                if (descend) node = next;
+                else if (sp > 0) { sp--; node = stack[sp]; }
+                else have = false;
+            }
+        }
+    }
+
+    // ---- agents: the 27 cells around the agent's (agent.py:79-99).  Lane gl probes cells gl and gl + 16.
+    {
+        const long long cx = grid_cell(pA.x, g.inv_cell), cy = grid_cell(pA.y, g.inv_cell), cz = grid_cell(pA.z, g.inv_cell);
+        const unsigned long long key_a = grid_probe_key(cx, cy, cz, gl);
+        const unsigned long long key_b = grid_probe_key(cx, cy, cz, gl + 16 < 27 ? gl + 16 : 26);
+        int2 ra = make_int2(0, 0), rb = make_int2(0, 0);
+        if (scan) {
+            ra = g.range[grid_bucket(key_a, g.hbits)];
+            if (gl + 16 < 27) rb = g.range[grid_bucket(key_b, g.hbits)];
+        }
+        unsigned pm = (unsigned)((__ballot(ra.y > 0) >> gshift) & 0xffffull) | ((unsigned)((__ballot(rb.y > 0) >> gshift) & 0xffffull) << 16);
+        while (__any(pm != 0)) {
+            const bool pact = pm != 0;
+            const int q = pact ? __ffs((int)pm) - 1 : 0;
+            pm &= pm - 1;
+            const int src = gshift + (q & 15);
+            const bool second = q >= 16;                             // the same for the whole group
+            const int first_pos = __shfl(second ? rb.x : ra.x, src);
+            const int members = pact ? __shfl(second ? rb.y : ra.y, src) : 0;
+            const unsigned long long key = shfl_u64(second ? key_b : key_a, src);
+            for (int off = 0; __any(off < members); off += 16) {
+                const bool valid = off + gl < members;
+                int o = -1; double dsq = 0.0; bool c = false, r = false, nr = false;
+                if (valid) {
+                    const int at = first_pos + off + gl;
+                    o = g.gid[at];
+                    if (g.gkey[at] == key && o != agent) {           // another cell of the same bucket: not this probe's
+                        dsq = l3normsq(pA, v3(g.gx[at], g.gy[at], g.gz[at]));
+                        r = dsq < rangeSq;
+                        if (r && dsq < rmax2) { const double rs = me.radius + d.rec[o].radius; c = dsq < rs * rs; }
+                        nr = dsq < reach_a * reach_a;
+                    }
+                }
+                {
+                    const unsigned nm = (unsigned)((__ballot(nr) >> gshift) & 0xffffull);
+                    if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
+                    near_cnt += __popc(nm);
+                }
+                insert_all((unsigned)((__ballot(r && want_list) >> gshift) & 0xffffull), c, dsq, o);
+            }
+        }
+    }
+    if (!exists) return;
+    const bool complete = near_cnt <= NEAR_MAX && reach_a * reach_a <= rangeSq && reach_o * reach_o <= rangeSq;
+    if (!want_list) {
+        d.nbr_id[agent * K_MAX + gl] = -1; d.nbr_dsq[agent * K_MAX + gl] = 0.0;
+        if (gl == 0) {
+            d.coll_new[agent] = 0; d.nbr_valid[agent] = 0; d.nbr_n[agent] = 0; d.status[agent] = 0;
+            d.near_n[agent] = (scan && complete) ? near_cnt : -1;
+        }
+        return;
+    }
+    d.nbr_id[agent * K_MAX + gl] = (gl < cnt) ? Li : -1;
+    d.nbr_dsq[agent * K_MAX + gl] = (gl < cnt) ? Ld : 0.0;
+    if (gl == 0) {
+        d.nbr_n[agent] = cnt;
+        d.nbr_valid[agent] = 1;
+        d.coll_new[agent] = coll ? 1u : 0u;
+        d.status[agent] = st;
+        d.near_n[agent] = complete ? near_cnt : -1;
+    }
+}
+
+// K4's fallback for an agent without a candidate list (more than NEAR_MAX objects within reach): the whole wavefront looks
+// through the 27 cells around the agent's OLD position (the grid holds the step's old positions).
+__device__ __forceinline__ bool collide_scan_grid(const DeviceView &d, const GridDev &g, const CollideCtx &c, int agent, int lane) {
+    const long long cx = grid_cell(c.p_old.x, g.inv_cell), cy = grid_cell(c.p_old.y, g.inv_cell), cz = grid_cell(c.p_old.z, g.inv_cell);
+    const unsigned long long key = grid_probe_key(cx, cy, cz, lane < 27 ? lane : 26);
+    int2 r = make_int2(0, 0);
+    if (lane < 27) r = g.range[grid_bucket(key, g.hbits)];
+    bool hit = false;
+    unsigned long long pm = __ballot(r.y > 0);
+    while (pm) {
+        const int q = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        const int first_pos = __builtin_amdgcn_readlane(r.x, q), members = __builtin_amdgcn_readlane(r.y, q);
+        const unsigned long long kq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), q) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, q);
+        for (int off = lane; off < members; off += 64) {
+            const int at = first_pos + off;
+            const int j = g.gid[at];
+            if (g.gkey[at] == kq && j != agent) hit = hit || collide_agent(d, c, j);
+        }
+    }
+    return __ballot(hit) != 0;
+}
+
+__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish_grid(DeviceView d, GridDev g, Params P, double agent_reach,
+                                                                     double obs_reach, int check_arrived) {
+    __shared__ int stacks[K4_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    collide_finish_body(d, P, check_arrived, [&](int ag, bool obs_only) {
+        bool r = collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane, true);      // obstacles: their kd-tree
+        if (!obs_only && !r) {
+            PubRec me_old;
+            const CollideCtx c = collide_ctx(d, ag, me_old);
+            r = collide_scan_grid(d, g, c, ag, lane);
+        }
+        return r;
+    });
+}
+
+}  // namespace sca

@@ -1,5 +1,7 @@
 // sca_hip.hip -- host side of libsca_hip.so: context, HBM layout, launches, C-ABI (include/sca_hip.h).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is loaded with dlopen when sca_comm_init is called
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -12,6 +14,7 @@
 #include "../../include/sca_hip.h"
 #include "sca_kernels.hip.h"
 #include "sca_kdbuild.hip.h"
+#include "sca_grid.hip.h"
 #include "sca_dubins.hpp"
 #include "sca_tracker.hip.h"
 
@@ -121,6 +124,33 @@ double cos_threshold(double mhc) {
 
 }  // namespace
 
+// RCCL entry points, resolved at run time (a box without RCCL still loads libsca_hip.so; single-GPU use never touches it)
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static const char *rccl_load() {
+    if (g_rccl.handle) return nullptr;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return "librccl.so not found (dlopen)";
+    RcclApi a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) return "librccl.so lacks an expected symbol";
+    a.handle = h;
+    g_rccl = a;
+    return nullptr;
+}
+
 struct sca_ctx {
     int device = 0;
     int max_n = 0, max_m = 0, n = 0, m = 0;
@@ -134,12 +164,18 @@ struct sca_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> pool;       // 3 events per step: before K1, before K2, after K2
     int pool_used = 0;
+    std::vector<hipEvent_t> pool_trk;   // 2 events per step on the stream the re-plan kernels run on: before / after them
+    int pool_trk_used = 0;
+    float ms_replan = 0;
+    bool shard_emulation = false;       // measurement aid: a partial shard without a communicator, the others stand still
     std::vector<double> h_pos;          // host mirror of positions for the kd build
     bool h_pos_valid = false;
     std::vector<int32_t> h_perm;
     std::vector<KdNode> h_tree;
     std::vector<PubRec> h_rec;
     KdScratch kd{};
+    GridDev grid{};                     // SCA_NBR_GRID (sca_grid.hip.h)
+    int nbr_mode = SCA_NBR_KDTREE;      // neighbour structure of the last policy pass: K4's fallback looks there
     // depth of the large-node part of the tree, read back asynchronously (never waited for) to size the next build
     int *kd_host_counts = nullptr;      // pinned
     hipEvent_t kd_ev = nullptr;
@@ -167,6 +203,9 @@ struct sca_ctx {
     hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
     bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
+    // multi-GPU exchange inside the library (sca_comm_init): one ncclAllGather of the shard's moved records per step
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
 };
 
 #define CHK(ctx, call)                                                                         \
@@ -419,6 +458,18 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
     r |= dalloc(c, &c->kd.chunks[0], (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.chunks[1], (size_t)c->kd.chunk_cap);
     c->kd.nchunks = c->kd.counts ? c->kd.counts + KD_MAX_LEVELS + 2 : nullptr;
+    {   // grid of SCA_NBR_GRID: at least two buckets per agent
+        GridDev &g = c->grid;
+        g.hbits = 10;
+        while (((size_t)1 << g.hbits) < 2 * N) g.hbits++;
+        const size_t H = (size_t)1 << g.hbits;
+        r |= dalloc(c, &g.count, H); r |= dalloc(c, &g.range, H); r |= dalloc(c, &g.cursor, 1);
+        r |= dalloc(c, &g.bucket, N); r |= dalloc(c, &g.slot, N);
+        r |= dalloc(c, &g.gx, N); r |= dalloc(c, &g.gy, N); r |= dalloc(c, &g.gz, N);
+        r |= dalloc(c, &g.gid, N); r |= dalloc(c, &g.gkey, N);
+        g.skip_prep = 0;
+        g.inv_cell = grid_inv_cell(c->P.neighbor_dist);
+    }
     if (!r) {   // the root's accumulators start empty (every build's last kernel resets them for the next one)
         unsigned long long h[12];
         const double pinf = INFINITY, ninf = -INFINITY;
@@ -456,15 +507,19 @@ void sca_destroy(sca_ctx *c) {
     if (!c) return;
     DeviceView &d = c->d;
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
+    if (c->comm) { (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     (void)tracker_free(c);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist};
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
+                    c->grid.count, c->grid.range, c->grid.cursor, c->grid.bucket, c->grid.slot, c->grid.gx, c->grid.gy, c->grid.gz,
+                    c->grid.gid, c->grid.gkey};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
+    for (auto &e : c->pool_trk) (void)hipEventDestroy(e);
     if (c->kd_ev) (void)hipEventDestroy(c->kd_ev);
     if (c->kd_host_counts) (void)hipHostFree(c->kd_host_counts);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
@@ -509,7 +564,9 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
         c->d.hist = nullptr; c->d.hist_cap = 0; c->d.hist_row = 0;
     }
     if (int r = tracker_free(c)) return r;                            // the tracker records belong to the old agent set
+    if (c->comm && n % c->comm_nranks) { c->err = "agent count must be a multiple of the communicator's rank count"; return SCA_ERR_ARG; }
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
+    if (c->comm) { c->d.shard_count = n / c->comm_nranks; c->d.shard_begin = c->comm_rank * c->d.shard_count; }
     c->h_rec.assign(n, PubRec{});
     c->max_radius = 0; c->max_pref_speed = 0;
     for (int i = 0; i < n; i++) {
@@ -652,7 +709,8 @@ int sca_set_vpref(sca_ctx *c, const double *vpref, const uint8_t *mode) {
     return 0;
 }
 
-// KDTree.buildAgentTree (mampenv.py:28).  Round 1: built on the host from the position mirror and uploaded.
+// KDTree.buildAgentTree (mampenv.py:28) on the HOST from a position read-back (SCA_NBR_KDTREE_HOSTBUILD: the A/B reference of
+// the device build below, which is what SCA_NBR_KDTREE runs).
 static int build_agent_tree(sca_ctx *c) {
     const int n = c->n;
     if (!c->h_pos_valid) {
@@ -683,6 +741,9 @@ static int build_agent_tree(sca_ctx *c) {
 static int build_agent_tree_device(sca_ctx *c) {
     const int n = c->n;
     const DeviceView &d = c->d;
+    // the chained scan of a level pass waits on lower-numbered workgroups of the same launch: every chunk of a level must be
+    // resident at once (256 CUs x 4 workgroups of KD_LV_T threads x KD_CHUNK positions)
+    if (n > 256 * 4 * KD_CHUNK) { c->err = "device kd build is limited to 2097152 agents per context: use SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     if (!c->perm_on_device) {
         CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         c->perm_on_device = true;
@@ -743,6 +804,16 @@ static int build_agent_tree_device(sca_ctx *c) {
     }
     return 0;
 }
+// SCA_NBR_GRID: counting sort of all agents into cells of neighborDist (sca_grid.hip.h), three launches
+static int build_agent_grid_device(sca_ctx *c) {
+    const int n = c->n;
+    const int H = 1 << c->grid.hbits;
+    hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid, c->P);
+    hipLaunchKernelGGL(k_grid_alloc, dim3(H / 256), dim3(256), 0, c->stream, c->grid);
+    hipLaunchKernelGGL(k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid);
+    CHK(c, hipGetLastError());
+    return 0;
+}
 static int check_kd_overflow(sca_ctx *c) {
     int flag = 0;
     CHK(c, hipMemcpyAsync(&flag, c->kd.counts + KD_MAX_LEVELS + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -790,6 +861,14 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
         rs = c->trk_stream;
     }
     K.quad = c->trk_quad ? 1 : 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->profiling && c->pool_trk_used + 2 <= 2 * 4096) {
+        for (hipEvent_t *e : {&t0, &t1}) {
+            if (c->pool_trk_used == (int)c->pool_trk.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_trk.push_back(n_); }
+            *e = c->pool_trk[c->pool_trk_used++];
+        }
+        CHK(c, hipEventRecord(t0, rs));
+    }
     // the device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work; k_replan is
     // only launched when the shard is large enough to need it
     if (c->trk_quad)
@@ -797,6 +876,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     if (!c->trk_quad || cnt > K.quad_max)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
+    if (t1) CHK(c, hipEventRecord(t1, rs));
     if (side) CHK(c, hipEventRecord(c->trk_join, c->trk_stream));
     CHK(c, hipGetLastError());
     c->trk.parity ^= 1;
@@ -808,10 +888,21 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
     // v_pref) then moves from k_kd_gather to k_prep_shard behind the join
     const bool tracked = c->trk_on && c->trk_in_pass;
-    const bool overlap = tracked && mode == SCA_NBR_KDTREE && !c->trk_serial;
+    const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
     c->kd.skip_prep = overlap ? 1 : 0;
+    c->grid.skip_prep = overlap ? 1 : 0;
+    if (mode == SCA_NBR_GRID) {
+        // K4's candidate lists and its fallback cover one cell around the agent: the collision reach must fit into it
+        double agent_reach, obs_reach;
+        collide_reach(c, agent_reach, obs_reach);
+        if (c->max_radius + agent_reach > c->P.neighbor_dist || c->max_radius + obs_reach > c->P.neighbor_dist) {
+            c->err = "SCA_NBR_GRID needs radius + collision reach <= neighbor_dist"; return SCA_ERR_UNSUPPORTED;
+        }
+    }
     if (tracked) { if (int r = launch_tracker(c, true, overlap)) return r; }
+    c->nbr_mode = mode;
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
+    else if (mode == SCA_NBR_GRID) { if (int r = build_agent_grid_device(c)) return r; }
     else if (mode == SCA_NBR_KDTREE_HOSTBUILD) {
         if (c->perm_on_device) {
             CHK(c, hipMemcpyAsync(c->h_perm.data(), c->d.aperm, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
@@ -831,7 +922,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
     // below that the one-agent-per-wave form with its record stack has the shorter critical path (4096 random: 30 % faster)
     const bool packed = c->k1_force < 0 ? cnt >= 6144 : c->k1_force != 0;
-    if (packed) {
+    if (mode == SCA_NBR_GRID) {
+        const int per_block = K1P_WAVES * K1P_APW;
+        hipLaunchKernelGGL(k_neighbors_grid, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, c->stream, d, c->grid,
+                           c->P, agent_reach, obs_reach, c->max_radius);
+    } else if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
         hipLaunchKernelGGL(k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, c->stream, d, c->P,
                            agent_reach, obs_reach, c->max_radius);
@@ -871,9 +966,18 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     collide_reach(c, agent_reach, obs_reach);
     if (!c->near_valid) CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));   // no policy pass before
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
+    if (!c->near_valid && c->nbr_mode == SCA_NBR_GRID) {                  // the fallback reads the grid: make it describe these records
+        c->grid.skip_prep = 1;
+        if (int r = build_agent_grid_device(c)) return r;
+    }
     c->near_valid = false;
-    hipLaunchKernelGGL(k_collide_finish, dim3((cnt + K4_WAVES * K4_APW - 1) / (K4_WAVES * K4_APW)), dim3(K4_WAVES * 64), 0,
-                       c->stream, d, c->P, agent_reach, obs_reach, c->state_fresh ? 1 : 0);
+    const dim3 k4grid((cnt + K4_WAVES * K4_APW - 1) / (K4_WAVES * K4_APW));
+    if (c->nbr_mode == SCA_NBR_GRID)
+        hipLaunchKernelGGL(k_collide_finish_grid, k4grid, dim3(K4_WAVES * 64), 0, c->stream, d, c->grid, c->P, agent_reach, obs_reach,
+                           c->state_fresh ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_collide_finish, k4grid, dim3(K4_WAVES * 64), 0, c->stream, d, c->P, agent_reach, obs_reach,
+                           c->state_fresh ? 1 : 0);
     c->state_fresh = false;
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
@@ -929,12 +1033,74 @@ int sca_active_count(sca_ctx *c, int *active) {
     return 0;
 }
 
+// the step's exchange: every rank contributes its shard's moved records, in place
+static int exchange_moved_records(sca_ctx *c) {
+    const size_t bytes = sizeof(PubRec) * (size_t)c->d.shard_count;
+    const ncclResult_t e = g_rccl.AllGather((const char *)c->d.rec_new + sizeof(PubRec) * (size_t)c->d.shard_begin, c->d.rec_new, bytes,
+                                            ncclChar, c->comm, c->stream);
+    if (e != ncclSuccess) { c->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(e); return SCA_ERR_HIP; }
+    return 0;
+}
+
 int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     for (int s = 0; s < steps; s++) {
         if (int r = launch_policy(c, neighbor_mode, false, true)) return r;     // integrate fused into k_solve
+        if (c->comm) { if (int r = exchange_moved_records(c)) return r; }
+        else if (c->shard_emulation && c->d.shard_count < c->n) {
+            // stand-in for the all-gather's arrivals: the other ranks' agents stand still (their records are copied over)
+            const int b = c->d.shard_begin, e = b + c->d.shard_count;
+            if (b > 0) CHK(c, hipMemcpyAsync(c->d.rec_new, c->d.rec, sizeof(PubRec) * (size_t)b, hipMemcpyDeviceToDevice, c->stream));
+            if (e < c->n) CHK(c, hipMemcpyAsync(c->d.rec_new + e, c->d.rec + e, sizeof(PubRec) * (size_t)(c->n - e), hipMemcpyDeviceToDevice, c->stream));
+        }
         if (int r = launch_collide_finish(c, false)) return r;
+    }
+    return 0;
+}
+int sca_set_shard_emulation(sca_ctx *c, int on) {
+    if (!c) return SCA_ERR_ARG;
+    c->shard_emulation = on != 0;
+    return 0;
+}
+int sca_last_replan_ms(sca_ctx *c, float *replan_ms) {
+    if (!c) return SCA_ERR_ARG;
+    if (replan_ms) *replan_ms = c->ms_replan;
+    return 0;
+}
+
+// ---- RCCL inside the library (SURVEY.md 8b `sca_comm_init`, 8e) ---------------------------------------------------------
+int sca_comm_unique_id(void *id_out) {
+    if (!id_out) return SCA_ERR_ARG;
+    if (rccl_load()) return SCA_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return SCA_ERR_HIP;
+    std::memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+int sca_comm_init(sca_ctx *c, int rank, int nranks, const void *unique_id) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, unique_id && nranks >= 1 && rank >= 0 && rank < nranks);
+    if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    if (c->comm) { c->err = "communicator already initialised (sca_comm_destroy first)"; return SCA_ERR_STATE; }
+    if (c->n % nranks) { c->err = "agent count must be a multiple of the rank count"; return SCA_ERR_ARG; }
+    if (const char *e = rccl_load()) { c->err = e; return SCA_ERR_UNSUPPORTED; }
+    CHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t e = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (e != ncclSuccess) { c->comm = nullptr; c->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(e); return SCA_ERR_HIP; }
+    c->comm_rank = rank; c->comm_nranks = nranks;
+    c->d.shard_count = c->n / nranks; c->d.shard_begin = rank * c->d.shard_count;
+    return 0;
+}
+int sca_comm_destroy(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    if (c->comm) {
+        CHK(c, hipStreamSynchronize(c->stream));
+        (void)g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr; c->comm_rank = 0; c->comm_nranks = 1;
+        c->d.shard_begin = 0; c->d.shard_count = c->n;
     }
     return 0;
 }
@@ -965,6 +1131,18 @@ int sca_synchronize(sca_ctx *c) {
         c->ms_nbr = (float)(a / steps); c->ms_solve = (float)(b / steps);
         c->pool_used = 0;
     }
+    if (c->profiling && c->pool_trk_used >= 2) {
+        if (c->trk_stream) CHK(c, hipStreamSynchronize(c->trk_stream));
+        double a = 0;
+        const int steps = c->pool_trk_used / 2;
+        for (int s = 0; s < steps; s++) {
+            float t = 0;
+            CHK(c, hipEventElapsedTime(&t, c->pool_trk[2 * s], c->pool_trk[2 * s + 1]));
+            a += t;
+        }
+        c->ms_replan = (float)(a / steps);
+        c->pool_trk_used = 0;
+    }
     return 0;
 }
 
@@ -972,6 +1150,7 @@ int sca_set_profiling(sca_ctx *c, int on) {
     if (!c) return SCA_ERR_ARG;
     c->profiling = on != 0;
     c->pool_used = 0;
+    c->pool_trk_used = 0;
     return 0;
 }
 
@@ -1117,16 +1296,19 @@ int sca_public_records(sca_ctx *c, int which, void **device_ptr, int64_t *bytes_
     if (bytes_per_agent) *bytes_per_agent = (int64_t)sizeof(PubRec);
     return 0;
 }
-int sca_bind_public_records(sca_ctx *c, void *current, void *moved) {
+int sca_bind_public_records(sca_ctx *c, void *current, void *moved, int64_t bytes_each) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, (current == nullptr) == (moved == nullptr));
+    if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    const size_t live = sizeof(PubRec) * (size_t)c->n;                    // only the n live records move, never max_agents
     if (current) {
+        ARG(c, bytes_each >= (int64_t)live);
         // carry the live records over into the caller's buffer
-        CHK(c, hipMemcpyAsync(current, c->d.rec, sizeof(PubRec) * c->max_n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(current, c->d.rec, live, hipMemcpyDeviceToDevice, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
         c->d.rec = (PubRec *)current; c->d.rec_new = (PubRec *)moved;
     } else {
-        CHK(c, hipMemcpyAsync(c->rec_own, c->d.rec, sizeof(PubRec) * c->max_n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(c->rec_own, c->d.rec, live, hipMemcpyDeviceToDevice, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
         c->d.rec = c->rec_own; c->d.rec_new = c->rec_new_own;
     }
@@ -1134,7 +1316,14 @@ int sca_bind_public_records(sca_ctx *c, void *current, void *moved) {
 }
 int sca_set_stream(sca_ctx *c, void *hip_stream) {
     if (!c) return SCA_ERR_ARG;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->stream_own;
+    CHK(c, hipStreamSynchronize(c->stream));                             // work already enqueued finishes where it was
+    c->stream = (hipStream_t)hip_stream;                                 // NULL is HIP's null stream (torch's default stream), taken literally
+    return 0;
+}
+int sca_use_own_stream(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    CHK(c, hipStreamSynchronize(c->stream));
+    c->stream = c->stream_own;
     return 0;
 }
 int sca_last_kernel_ms(sca_ctx *c, float *neighbors_ms, float *solve_ms, float *update_ms) {

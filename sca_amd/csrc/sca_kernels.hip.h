@@ -1480,9 +1480,10 @@ constexpr int K4_WAVES = 4;
 constexpr int K4_APW = 64 / NEAR_MAX;      // agents per wavefront
 static_assert(NEAR_MAX == 8, "k_collide_finish packs 8 lanes per agent");
 
-__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach,
-                                                                int check_arrived) {
-    __shared__ int stacks[K4_WAVES][KD_STACK];
+// traverse(agent, obstacles_only) -> wave-uniform "touches something": the whole-wavefront fallback for one agent (kd-trees
+// here, the grid in sca_grid.hip.h)
+template <class Traverse>
+__device__ __forceinline__ void collide_finish_body(const DeviceView &d, const Params &P, int check_arrived, Traverse traverse) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane & (NEAR_MAX - 1), grp = lane / NEAR_MAX;
@@ -1511,7 +1512,7 @@ __global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, 
         todo &= todo - 1;
         const int ag = __builtin_amdgcn_readlane(agent, l0);
         const bool obs_only = __builtin_amdgcn_readlane((int)arrived_only, l0) != 0;
-        const bool r = collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane, obs_only);
+        const bool r = traverse(ag, obs_only);
         if (lane / NEAR_MAX == l0 / NEAR_MAX) any = r;
     }
     if (exists && sub == 0) {
@@ -1523,6 +1524,16 @@ __global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, 
         d.rec_new[agent].flags = f;
         if (!(f & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) atomicAdd(&d.done_count[(agent & 255) * 32], 1);
     }
+}
+
+__global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach,
+                                                                int check_arrived) {
+    __shared__ int stacks[K4_WAVES][KD_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    collide_finish_body(d, P, check_arrived, [&](int ag, bool obs_only) {
+        return collide_traverse(d, agent_reach, obs_reach, stacks[wid], ag, lane, obs_only);
+    });
 }
 
 // the near lists belong to the policy pass of the same step; without one, k_collide_finish must traverse

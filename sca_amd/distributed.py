@@ -5,16 +5,25 @@ Per step and rank:
     all-gather : the shard's moved 48-byte public records (RCCL over xGMI; torch.distributed backend "nccl")
     step_end   : collision flags for the shard (needs everyone's moved records), at-goal flags for everyone, publish
 Every rank holds all N public records; private per-agent state is only meaningful for the owner's shard.
+
+Two ways to run the exchange:
+  * inlib=True  -- RCCL inside the library (sca_comm_init): `run(k)` is ONE sca_run_steps call, the ncclAllGather of every
+    step is enqueued by the library on its own stream between its kernels.  What bench.py --gpus N uses.
+  * otherwise   -- the collective is issued from here (torch.distributed) between sca_step_begin and sca_step_end: the path
+    for callers that already own a process group / their own buffers, and the test double of the first.
 The backend only has to offer set_shard / step_begin / step_end / run_steps / synchronize plus `moved_records()`
 returning (full tensor, this rank's slice) -- tests drive the same class on CPU with gloo and a checker backend.
 """
 
 
 class ShardedStepper:
-    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0, staged=False, force_exchange=False):
+    def __init__(self, solver, rank=0, world=1, torch_mod=None, dist_mod=None, mode=0, staged=False, force_exchange=False,
+                 inlib=False, unique_id=None):
         """staged=True exchanges through host memory (for backends without GPU collectives, e.g. gloo when several
-        ranks share one GPU in tests); the default hands the device buffers to the collective directly (RCCL)."""
+        ranks share one GPU in tests); the default hands the device buffers to the collective directly (RCCL).
+        inlib=True: the library's own RCCL communicator (unique_id: the 128 bytes of rank 0's comm_unique_id())."""
         self.staged = staged
+        self.inlib = bool(inlib)
         self.exchange = int(world) > 1 or force_exchange      # force_exchange: the begin / all-gather / end path even alone
         self.sol = solver
         self.rank, self.world = int(rank), int(world)
@@ -28,8 +37,11 @@ class ShardedStepper:
                 raise ValueError(f'{n} agents do not split evenly over {self.world} ranks')
             self.count = n // self.world
             self.begin = self.rank * self.count
-            solver.set_shard(self.begin, self.count)
-            self._setup_exchange()
+            if self.inlib:
+                solver.comm_init(self.rank, self.world, unique_id)      # sets the shard
+            else:
+                solver.set_shard(self.begin, self.count)
+                self._setup_exchange()
         else:
             self.begin, self.count = 0, n
 
@@ -42,11 +54,11 @@ class ShardedStepper:
         dev = torch.device('cuda', torch.cuda.current_device())
         self._cur = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self._moved = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        sol.bind_public_records(self._cur.data_ptr(), self._moved.data_ptr())
-        # The library's kernels and the collective must be ordered on ONE stream.  torch's default stream is the null
-        # stream (handle 0), which sca_set_stream reads as "use the library's own, non-blocking stream" -- nothing would
-        # order the all-gather behind sca_step_begin then.  So the stepper owns a torch stream: the library launches on
-        # it, and the collective is issued with it current (ProcessGroupNCCL waits for / is waited on by the current stream).
+        sol.bind_public_records(self._cur.data_ptr(), self._moved.data_ptr(), nbytes)
+        # The library's kernels and the collective must be ordered on ONE stream: the stepper owns a torch stream, the
+        # library launches on it, and the collective is issued with it current (ProcessGroupNCCL waits for / is waited on
+        # by the current stream).  (The library's default is a non-blocking stream of its own, which nothing in torch
+        # would order against.)
         torch.cuda.synchronize()                      # the two buffers were zeroed on the default stream
         self._stream = torch.cuda.Stream(device=dev)
         sol.set_stream(self._stream.cuda_stream)
@@ -62,8 +74,8 @@ class ShardedStepper:
         return full, full[self.rank * self._per:(self.rank + 1) * self._per]
 
     def run(self, steps):
-        if not self.exchange:
-            self.sol.run_steps(steps, self.mode)
+        if not self.exchange or self.inlib:
+            self.sol.run_steps(steps, self.mode)                     # with a communicator: the exchange is inside
             return
         for _ in range(int(steps)):
             self.sol.step_begin(self.mode)

@@ -195,6 +195,14 @@ class BatchedSolver:
         self._chk(self.L.sca_last_kernel_ms(self.ctx, C.byref(a), C.byref(b), C.byref(c)), 'sca_last_kernel_ms')
         return dict(neighbors=a.value, solve=b.value, update=c.value)
 
+    def replan_ms(self):
+        a = C.c_float(0)
+        self._chk(self.L.sca_last_replan_ms(self.ctx, C.byref(a)), 'sca_last_replan_ms')
+        return a.value
+
+    def set_shard_emulation(self, on=True):
+        self._chk(self.L.sca_set_shard_emulation(self.ctx, 1 if on else 0), 'sca_set_shard_emulation')
+
     def set_profiling(self, on=True):
         self._chk(self.L.sca_set_profiling(self.ctx, 1 if on else 0), 'sca_set_profiling')
 
@@ -235,8 +243,8 @@ class BatchedSolver:
         self._chk(self.L.sca_public_records(self.ctx, int(which), C.byref(p), C.byref(b)), 'sca_public_records')
         return p.value, b.value
 
-    def bind_public_records(self, current_ptr, moved_ptr):
-        self._chk(self.L.sca_bind_public_records(self.ctx, C.c_void_p(current_ptr), C.c_void_p(moved_ptr)),
+    def bind_public_records(self, current_ptr, moved_ptr, bytes_each=0):
+        self._chk(self.L.sca_bind_public_records(self.ctx, C.c_void_p(current_ptr), C.c_void_p(moved_ptr), int(bytes_each)),
                   'sca_bind_public_records')
 
     def step_begin(self, mode=NBR_KDTREE):
@@ -246,7 +254,26 @@ class BatchedSolver:
         self._chk(self.L.sca_step_end(self.ctx), 'sca_step_end')
 
     def set_stream(self, stream_ptr):
+        """Run on this hipStream_t; 0 / None is HIP's null stream (torch's default stream), taken literally."""
         self._chk(self.L.sca_set_stream(self.ctx, C.c_void_p(stream_ptr)), 'sca_set_stream')
+
+    def use_own_stream(self):
+        self._chk(self.L.sca_use_own_stream(self.ctx), 'sca_use_own_stream')
+
+    # RCCL inside the library: run_steps then exchanges the shard's moved records itself, one host call per k steps
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        rc = self.L.sca_comm_unique_id(buf)
+        if rc != 0:
+            raise ScaError(f'sca_comm_unique_id: rc={rc} (librccl.so missing?)')
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.L.sca_comm_init(self.ctx, int(rank), int(nranks), buf), 'sca_comm_init')
+
+    def comm_destroy(self):
+        self._chk(self.L.sca_comm_destroy(self.ctx), 'sca_comm_destroy')
 
 
 def zaxis_flags(start, goal):

@@ -1,0 +1,263 @@
+"""SCA_NBR_GRID (-m gpu): the hashed-grid neighbour structure against the reference's recorded lists (tests/golden), the
+kd-tree path and the CPU oracle.
+
+Contract (include/sca_hip.h, sca_grid.hip.h): for every agent whose status word does not carry SCA_ST_NBR_OVERFLOW the list
+holds the reference's (object, distSq) pairs; entries of equal distSq may come in another order (the reference's order is
+the kd visit order).  The sampled policies do not depend on that order: their velocities must be the reference's, bit for
+bit.  The LP of orca3dPolicyOfficial.py walks the planes in list order: checked only where the orders agree.  With more than
+16 objects in range the list holds the 16 nearest and the status bit is set."""
+import numpy as np
+import pytest
+
+from golden_util import episode_fixtures, load, static_inputs
+from test_gpu_parity import ANG_TOL, _scenario_state, make_solver
+
+pytestmark = pytest.mark.gpu
+OVERFLOW = 32
+
+
+@pytest.fixture(scope='module')
+def S():
+    import sca_amd.solver as S
+    return S
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def canonical(nbr_n, nbr_id, nbr_kind, nbr_dsq):
+    """lists sorted by (distSq, obstacles first, id): the order the grid documents"""
+    n, K = nbr_id.shape
+    col = np.arange(K)[None, :]
+    live = col < nbr_n[:, None]
+    dsq = np.where(live, nbr_dsq, np.inf)
+    kind = np.where(live, 1 - nbr_kind.astype(np.int64), 2)          # obstacles (kind 1) first
+    ids = np.where(live, nbr_id, 1 << 40).astype(np.int64)
+    order = np.lexsort((ids, kind, dsq), axis=1)
+    take = lambda a: np.take_along_axis(a, order, axis=1)
+    return take(ids), take(kind), take(dsq)
+
+
+def compare_lists(nb, ref_n, ref_id, ref_kind, ref_dsq, rows, ctx):
+    assert np.array_equal(nb['nbr_n'][rows], ref_n[rows]), ctx
+    gi, gk, gd = canonical(nb['nbr_n'], nb['nbr_id'], nb['nbr_kind'], nb['nbr_dsq'])
+    ri, rk, rd = canonical(ref_n, ref_id, ref_kind, ref_dsq)
+    assert np.array_equal(gi[rows], ri[rows]), ctx
+    assert np.array_equal(gk[rows], rk[rows]), ctx
+    fin = np.isfinite(rd[rows])
+    assert np.allclose(gd[rows][fin], rd[rows][fin], rtol=4e-16, atol=0), ctx     # obstacle distSq: pow(x, 2) vs x * x, 1 ulp
+    # the grid's own order is the canonical one
+    col = np.arange(nb['nbr_id'].shape[1])[None, :]
+    live = col < nb['nbr_n'][:, None]
+    assert np.array_equal(np.where(live, nb['nbr_id'], 1 << 40)[rows], gi[rows]), ctx + ('grid order',)
+
+
+def same_order(nb, ref_n, ref_id, ref_kind):
+    col = np.arange(ref_id.shape[1])[None, :]
+    live = col < ref_n[:, None]
+    return (np.where(live, nb['nbr_id'] == ref_id, True) & np.where(live, nb['nbr_kind'] == ref_kind, True)).all(axis=1)
+
+
+@pytest.mark.parametrize('name', episode_fixtures())
+def test_grid_pass_vs_golden(S, name):
+    """Every recorded episode of the reference, every (subsampled) step from the recorded state."""
+    fx = load(name)
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    n_over = n_checked = 0
+    for t in range(0, T, max(1, T // 25)):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_GRID)
+        ctx = (name, t)
+        nb = sol.neighbors()
+        dg = sol.diag()
+        valid = fx['nbr_valid'][t].astype(bool)
+        assert np.array_equal(nb['nbr_valid'].astype(bool), valid), ctx
+        over = (dg['status'] & OVERFLOW) != 0
+        assert not (dg['status'] & ~OVERFLOW).any(), ctx
+        # a list of fewer than 16 entries never overflowed (a collision cleared list may have: then the bit is spurious but allowed)
+        rows = valid & ~over
+        compare_lists(nb, fx['nbr_n'][t], fx['nbr_id'][t], fx['nbr_kind'][t], fx['nbr_dsq'][t], rows, ctx)
+        assert not (over & valid & (fx['nbr_n'][t] < 16) & (fx['coll_after_policy'][t] == 0)).any(), ctx + ('spurious overflow',)
+        # velocities: the sampled policies do not see the order of equal distances; the LP does
+        called = fx['called'][t].astype(bool)
+        lp = st['policy'] == 4
+        ok = called & ~over & (~lp | same_order(nb, fx['nbr_n'][t], fx['nbr_id'][t], fx['nbr_kind'][t]) | ~valid)
+        a = sol.actions()
+        assert np.array_equal(a[ok, :4], fx['action'][t][ok, :4]), ctx + ('velocity',)
+        assert np.allclose(a[ok, 4:], fx['action'][t][ok, 4:], rtol=0, atol=ANG_TOL), ctx
+        flags = sol.get_state()['flags']
+        assert np.array_equal((flags >> 1) & 1, fx['coll_after_policy'][t]), ctx + ('collision',)
+        n_over += int((over & valid).sum()); n_checked += int(ok.sum())
+    assert n_checked > 0
+    sol.close()
+
+
+def brute_lists(pos, radius, active_rows):
+    """true 16 nearest agents of each row by the reference's rounded distSq (util.py:100), ties by id; no obstacles"""
+    out = {}
+    for i in active_rows:
+        d = pos - pos[i]
+        s = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+        s = s + d[:, 2] * d[:, 2]
+        dsq = np.rint(s * 1e5) / 1e5
+        dsq[i] = np.inf
+        inr = np.nonzero(dsq < 100.0)[0]
+        order = inr[np.lexsort((inr, dsq[inr]))]
+        out[i] = (order, dsq[order])
+    return out
+
+
+def test_grid_overflow_keeps_the_16_nearest(S):
+    """Dense blob: more than 16 agents in range.  The status bit is set exactly for those agents and their list is the 16
+    nearest (without a collision in range: the collision rule replaces the list by the colliding objects)."""
+    rng = np.random.default_rng(5)
+    n = 600
+    pos = rng.uniform(0, 30, (n, 3)) + np.array([100.0, -40.0, 20.0])
+    # keep everybody at least 1.2 m apart so that nothing collides (radius 0.5)
+    keep = []
+    for i in range(n):
+        if all(np.linalg.norm(pos[i] - pos[j]) > 1.2 for j in keep):
+            keep.append(i)
+    pos = pos[keep]; n = len(pos)
+    vel = np.tile(np.float32([0.6, 0.1, 0.0]), (n, 1))
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.ones(n), pos + 50.0, np.full(n, 1, np.uint8))
+    sol.set_state(pos, vel, np.zeros((n, 3)), np.zeros(n, np.uint8))
+    sol.policy_pass(S.NBR_GRID)
+    nb = sol.neighbors(); dg = sol.diag()
+    ref = brute_lists(pos, np.full(n, 0.5), range(n))
+    n_over = 0
+    for i in range(n):
+        order, dsq = ref[i]
+        over = bool(dg['status'][i] & OVERFLOW)
+        assert over == (len(order) > 16), i
+        k = min(16, len(order))
+        assert nb['nbr_n'][i] == k
+        assert np.array_equal(nb['nbr_id'][i, :k], order[:k]), i
+        assert np.array_equal(nb['nbr_dsq'][i, :k], dsq[:k]), i
+        n_over += over
+    assert n_over > 50
+    sol.close()
+
+
+GRID_CASES = [
+    ('circle1024_sca', 'circle', 1024, 0),
+    ('random4096_orca', 'random', 4096, 3),
+    ('random4096_orcalp', 'random', 4096, 4),
+    ('takeoff1024_mixed', 'takeoff', 1024, -1),
+    ('circle100000_sca', 'circle', 100000, 0),
+    ('takeoff16384_mixed', 'takeoff', 16384, -1),
+]
+
+
+@pytest.mark.parametrize('label,kind,n,pol', GRID_CASES)
+def test_grid_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
+    from sca_amd import scenarios
+    sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=0),
+          'takeoff': lambda: scenarios.takeoff_landing(n)}[kind]()
+    policy = np.where(np.arange(n) % 2 == 0, 0, 2) if pol < 0 else pol
+    s = _scenario_state(S, sc, policy)
+    ref = oracle.policy_step(s['pos'], s['vel'], s['heading'], s['radius'], s['pref_speed'], s['flags'], s['goal'],
+                             s['policy'], s['zaxis'], np.zeros((n, 3)), np.zeros(n, np.uint8), np.arange(n, dtype=np.int32),
+                             s['obs_pos'], s['obs_radius'], nthreads=8)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(s['obs_radius'])))
+    sol.set_obstacles(s['obs_pos'], s['obs_radius'])
+    sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+    sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+    sol.policy_pass(S.NBR_GRID)
+    nb = sol.neighbors(); dg = sol.diag()
+    over = (dg['status'] & OVERFLOW) != 0
+    rows = ~over
+    assert rows.sum() > 0.9 * n
+    compare_lists(nb, ref['nbr_n'], ref['nbr_id'], ref['nbr_kind'], ref['nbr_dsq'], rows, (label,))
+    ok = rows & ((s['policy'] != 4) | same_order(nb, ref['nbr_n'], ref['nbr_id'], ref['nbr_kind']))
+    a = sol.actions()
+    assert np.array_equal(a[ok, :4], ref['action'][ok, :4])
+    assert np.allclose(a[ok, 4:], ref['action'][ok, 4:], rtol=0, atol=ANG_TOL)
+    assert np.array_equal(dg['diag'][ok, :2], ref['diag'][ok, :2])
+    sol.close()
+
+
+@pytest.mark.parametrize('kind,n,pol,steps', [('circle', 1024, 0, 40), ('random', 4096, 3, 25), ('takeoff', 1024, -1, 60)])
+def test_grid_episode_equals_kd_episode(S, kind, n, pol, steps):
+    """Resident stepping in both modes from the same start: as long as no agent has reported an overflow the two runs are
+    the same run (state, flags, collision bookkeeping of K4 included)."""
+    from sca_amd import scenarios
+    sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=3),
+          'takeoff': lambda: scenarios.takeoff_landing(n)}[kind]()
+    nn = len(sc['start'])
+    policy = (np.where(np.arange(nn) % 2 == 0, 0, 2) if pol < 0 else np.full(nn, pol)).astype(np.uint8)
+    sols = []
+    for mode in (S.NBR_KDTREE, S.NBR_GRID):
+        sol = S.BatchedSolver(max_agents=nn, max_obstacles=max(1, len(sc['obs_radius'])))
+        sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
+        sol.set_agents(np.full(nn, 0.5), np.ones(nn), sc['goal'][:, :3], policy, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((nn, 3), np.float32), sc['start'][:, 3:6], np.zeros(nn, np.uint8))
+        sols.append(sol)
+    kd, gr = sols
+    for t in range(steps):
+        kd.run_steps(1, S.NBR_KDTREE); gr.run_steps(1, S.NBR_GRID)
+        kd.synchronize(); gr.synchronize()
+        if (gr.diag()['status'] & OVERFLOW).any():
+            break
+        a, b = kd.get_state(), gr.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(a[k], b[k]), (kind, t, k)
+        assert kd.active_count() == gr.active_count()
+    # the take-off cells (16 agents + 8 obstacles within 10 m) overflow as soon as everybody moves
+    assert t >= (3 if kind == 'takeoff' else min(steps - 1, 10)), t
+    for sol in sols:
+        sol.close()
+
+
+def test_grid_dense_collisions_match_oracle(S, oracle):
+    """Overlapping agents and obstacles inside the agents: the collision rule of agent.py:82-99 (first colliding object clears
+    the list) and K4's flags, step by step from the oracle's state; more than 8 objects within collision reach exercises
+    K4's grid fallback."""
+    rng = np.random.default_rng(11)
+    n, m = 400, 12
+    pos = rng.uniform(0, 14, (n, 3)) + np.array([0.0, 0.0, 5.0])
+    goal = pos + rng.normal(0, 20, (n, 3)); goal[:, 2] = np.abs(goal[:, 2]) + 2
+    vel = rng.normal(0, 0.5, (n, 3)).astype(np.float32)
+    vel[::7] = 0
+    head = np.zeros((n, 3)); head[:, 0] = rng.uniform(-3, 3, n)
+    radius = rng.choice([0.3, 0.5, 0.8], n)
+    ps = np.ones(n)
+    policy = rng.integers(0, 4, n).astype(np.uint8)
+    obs_pos = rng.uniform(0, 14, (m, 3)) + np.array([0.0, 0.0, 5.0]); obs_r = rng.uniform(0.3, 1.5, m)
+    flags = np.zeros(n, np.uint8); td = np.zeros(n); sn = np.zeros(n, np.int32)
+    mrd = np.full(n, 1e9)
+    zaxis = np.zeros(n, np.uint8)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=m)
+    sol.set_obstacles(obs_pos, obs_r)
+    sol.set_agents(radius, ps, goal, policy, zaxis, mrd)
+    perm = np.arange(n, dtype=np.int32)
+    for t in range(5):
+        sol.set_state(pos, vel, head, flags, td, sn)
+        sol.policy_pass(S.NBR_GRID)
+        ref = oracle.policy_step(pos, vel, head, radius, ps, flags, goal, policy, zaxis, np.zeros((n, 3)), np.zeros(n, np.uint8),
+                                 perm, obs_pos, obs_r)
+        perm = ref['perm']
+        dg = sol.diag(); nb = sol.neighbors()
+        over = (dg['status'] & OVERFLOW) != 0
+        rows = ref['nbr_valid'].astype(bool) & ~over
+        compare_lists(nb, ref['nbr_n'], ref['nbr_id'], ref['nbr_kind'], ref['nbr_dsq'], rows, (t,))
+        st_after = sol.get_state()['flags']
+        assert np.array_equal(st_after & 2, ref['flags'] & 2), t          # is_collision of agent.py:84: order independent
+        # K4 from the oracle's actions so that both sides integrate the same velocities
+        sol.env_update()
+        got = sol.get_state()
+        a = sol.actions()
+        u = oracle.env_update(pos, vel, head, radius, ref['flags'], goal, a, td, mrd, sn, obs_pos, obs_r)
+        assert np.array_equal(got['flags'], u['flags']), t
+        assert np.allclose(got['pos'], u['pos'], rtol=0, atol=1e-6)
+        pos, vel, head, flags, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+    sol.close()

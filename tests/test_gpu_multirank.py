@@ -33,31 +33,32 @@ def make():
         sol.device_tracker_enable(sc['goal'][:, 3:6])          # the SCA third of the agents follows Dubins paths, per shard
     return sol
 
+mode = int(os.environ.get('SCA_TEST_MODE', '0'))             # 0 kd-tree, 1 grid
 sol = make()
-st = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=True)
+st = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=True, mode=mode)
 st.run(steps); st.sync()
 got = sol.get_state()
 ref_sol = make()
-ref_sol.run_steps(steps); ref_sol.synchronize()
+ref_sol.run_steps(steps, mode); ref_sol.synchronize()
 ref = ref_sol.get_state()
 lo, hi = st.begin, st.begin + st.count
 ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['vel'])
 ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
 ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
-ok = ok and np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm())
+ok = ok and (mode != 0 or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
 print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('track', [False, True])
-def test_two_ranks_one_gpu_match_single_rank(tmp_path, track):
+@pytest.mark.parametrize('track,mode', [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
-    on a side stream next to the replicated kd build)."""
+    on a side stream next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded)."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode))
     if track:
         env['SCA_TEST_TRACK'] = '1'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -153,7 +154,7 @@ sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], np.zeros(n, np.ui
                scenarios.max_run_dist(sc['start'], sc['goal']))
 sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
 st = ShardedStepper(sol, 0, 1, torch_mod=torch, dist_mod=dist, force_exchange=True)
-assert st._stream.cuda_stream != 0                  # a real stream: handle 0 would mean "the library's own stream"
+assert st._stream.cuda_stream != 0                  # a stream the stepper owns
 st.run(3); st.sync(); torch.cuda.synchronize()
 stale = 0
 for it in range(10):
@@ -175,8 +176,8 @@ sys.exit(0 if stale == 0 else 1)
 
 def test_collective_is_ordered_behind_the_library_kernels(tmp_path):
     """The library launches on the stepper's own torch stream and the RCCL collective is issued with that stream current, so
-    an all-gather behind sca_step_begin sees the records that call wrote even when the stream holds a backlog.  (torch's
-    default stream has handle 0, which sca_set_stream takes as "use the library's own stream": nothing would order the two.)"""
+    an all-gather behind sca_step_begin sees the records that call wrote even when the stream holds a backlog.  (The
+    library's default is a non-blocking stream of its own, which nothing in torch orders against.)"""
     script = tmp_path / 'order_worker.py'
     script.write_text(ORDER_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29553', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
@@ -184,3 +185,84 @@ def test_collective_is_ordered_behind_the_library_kernels(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'ORDER OK' in r.stdout, r.stdout[-3000:]
+
+
+INLIB_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sca_amd import scenarios, solver as S
+from sca_amd.distributed import ShardedStepper
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+local = int(os.environ.get('LOCAL_RANK', '0'))
+torch.cuda.set_device(local)
+dist.init_process_group('gloo')                        # only carries the 128-byte ncclUniqueId; the data path is the library's RCCL
+mode = int(os.environ.get('SCA_TEST_MODE', '0'))
+n, steps = 4096, 12
+sc = scenarios.random_cube(n, seed=4)
+pol = np.where(np.arange(n) % 2 == 0, 0, 3).astype(np.uint8)
+
+def make(dev):
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1, device=dev)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                   scenarios.max_run_dist(sc['start'], sc['goal']))
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    if os.environ.get('SCA_TEST_TRACK'):
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+    return sol
+
+sol = make(local)
+box = [sol.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(box, src=0)
+st = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0], force_exchange=True)
+st.run(steps); st.sync()                              # ONE sca_run_steps call: 12 x (shard pass, ncclAllGather, flags)
+got = sol.get_state()
+ref_sol = make(local)
+ref_sol.run_steps(steps, mode); ref_sol.synchronize()
+ref = ref_sol.get_state()
+lo, hi = st.begin, st.begin + st.count
+ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['vel'])
+ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
+ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
+print('INLIB', rank, 'OK' if ok else 'MISMATCH', flush=True)
+sol.comm_destroy()
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize('track,mode', [(False, 0), (True, 0), (False, 1)])
+def test_rccl_inside_the_library_single_rank(tmp_path, track, mode):
+    """sca_comm_init + sca_run_steps: the library's own ncclAllGather (in place, on its stream, between its kernels) with the
+    one rank a 1-GPU box offers must leave the single-GPU run untouched."""
+    script = tmp_path / 'inlib_worker.py'
+    script.write_text(INLIB_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0', SCA_TEST_MODE=str(mode))
+    if track:
+        env['SCA_TEST_TRACK'] = '1'
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'INLIB 0 OK' in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_rccl_inside_the_library_two_ranks_bit_identical(tmp_path, mode):
+    """Two ranks on two GPUs over RCCL (no gloo on the data path): every rank's copy of the swarm equals the single-GPU run
+    bit for bit.  Needs two GPUs: skipped on the 1-GPU boxes (RCCL refuses two ranks on one device)."""
+    if _gpu_count() < 2:
+        pytest.skip('needs 2 GPUs: RCCL does not run two ranks on one device')
+    script = tmp_path / 'inlib_worker.py'
+    script.write_text(INLIB_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29563', HSA_ENABLE_IPC_MODE_LEGACY='0', SCA_TEST_MODE=str(mode))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29563', str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('OK') == 2, r.stdout[-3000:]
