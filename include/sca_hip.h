@@ -71,7 +71,10 @@ enum sca_status_bit {             /* per-agent status word of the last policy pa
     SCA_ST_SQRT_DOMAIN = 2,       /* reference would raise ValueError (scaPolicy.py:159); clamped here */
     SCA_ST_BAD_PREF_SPEED = 4,    /* np.arange(0.5, ps+0.03, ps-0.5) does not have 2 elements (scaPolicy.py:195) */
     SCA_ST_KD_STACK = 16,         /* kd traversal stack overflow (tree deeper than 48) */
-    SCA_ST_NBR_OVERFLOW = 32      /* grid mode: > max_neighbors in range, reference list is visit-order dependent */
+    SCA_ST_NBR_OVERFLOW = 32,     /* grid mode: > max_neighbors in range, reference list is visit-order dependent */
+    SCA_ST_TRACKER_EDGE = 64      /* device tracker: a 5-decimal rounding between the tracked path node and this pass's v_pref sat within
+                                     1e-8 m of flipping (scaPolicy.py:329-338, util.py:104); the device's libm is not glibc's, so the
+                                     reference's v_pref may be one 1e-5 step away (the velocity picked from it can then differ) */
 };
 
 enum sca_error {
@@ -215,6 +218,12 @@ int sca_device_tracker_disable(sca_ctx *ctx);
  * device's neighbour lists; vpref_out nullable */
 int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*/, double *vpref_out /*n*3, nullable*/);
 int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
+
+/* diagnostics: the tracker record of one agent as 24 doubles -- horizontal maneuver (r_min, t, p, length), vertical maneuver
+ * (the same four), plan length, sampling size, b_unc, kappa, cursor, sample count, tracked node[3], untruncated v_pref[3],
+ * the two words, edge flag, re-plan count -- of the host tracker / the device tracker */
+int sca_tracker_debug(void *tracker, int agent, double *out24);
+int sca_device_tracker_debug(sca_ctx *ctx, int agent, double *out24);
 
 /* host self-test (no GPU needed): the device planner's four-lane form evaluates the four CSC Dubins words
  * (dubinsmaneuver2d.py:33-109) as one sign-parametrised instruction stream; this compares it with the literal words on the

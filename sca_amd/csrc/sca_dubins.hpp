@@ -53,10 +53,8 @@ SCA_DHD static inline void m_sincos(double x, double &s, double &c) { s = h_sin(
 
 static const double PI = 3.141592653589793;
 SCA_DHD static inline double fma3(const double *a, const double *b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); }
-// util.py:113  theta - 2.0 * pi * floor(theta / 2.0 / pi).  The planner's search calls this ~20 times per candidate radius and
-// the division is a third of its arithmetic on the device, so the quotient's floor is taken from a multiplication whenever the
-// product is clear of every non-zero integer by 1e-6 (the two quotients differ by < 4e-10 for |q| < 1e6): same floor, same
-// bits; otherwise (and for nan / inf) the literal division decides.
+// util.py:113  theta - 2.0 * pi * floor(theta / 2.0 / pi), literally (the planner's search calls it ~20 times per candidate
+// radius; a division-free floor was tried on the device and dropped)
 SCA_DHD static inline double mod2pi(double t) { return t - 2.0 * PI * std::floor(t / 2.0 / PI); }
 // Python round(x, 5): correctly rounded (see sca_core.h round5_py)
 SCA_DHD static inline double round5_py(double x) {
@@ -72,6 +70,27 @@ SCA_DHD static inline double round5_np(double x) { return std::rint(x * 100000.0
 SCA_DHD static inline double trunc5(double x) { double t = std::trunc(x * 100000.0); if (t == 0.0) t = 0.0; return t / 100000.0; }
 SCA_DHD static inline double l3norm(const double *a, const double *b) {                                              // util.py:104
     return round5_py(std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0)));
+}
+// Knife edges (SCA_ST_TRACKER_EDGE).  The device tracker runs the same statements as the reference with another libm: its
+// planner settles on a horizontal radius ~1e-10 off and the path nodes come out ~1e-9 m off.  That is invisible
+// unless one of the 5-decimal roundings / truncations between a node and v_pref sits that close to its edge.  EDGE_POS is the
+// position uncertainty assumed for a tracked node (ten times what was observed); a rounding of x whose scaled value x * 1e5
+// lies within the matching distance of flipping marks the agent-step: its v_pref may differ from the reference's by one
+// 5-decimal step (or a few when the rounded norm it is divided by flips).
+constexpr double EDGE_POS = 1e-9;
+SCA_DHD static inline bool near_round5_tie(double x, double tol_scaled) {       // round(x, 5) within tol of a tie
+    const double y = x * 100000.0;
+    return std::fabs(std::fabs(y - std::floor(y) - 0.5)) < tol_scaled;
+}
+SCA_DHD static inline bool near_trunc5_step(double x, double tol_scaled) {      // int(x * 1e5) within tol of stepping
+    const double y = x * 100000.0;
+    return std::fabs(y - std::rint(y)) < tol_scaled;
+}
+SCA_DHD static inline double norm_raw_for_edge(const double *d) { return std::sqrt(m_pow(d[0], 2.0) + m_pow(d[1], 2.0) + m_pow(d[2], 2.0)); }
+SCA_DHD static inline double l3norm_edge(const double *a, const double *b, int &edge) {
+    const double r = std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0));
+    if (near_round5_tie(r, EDGE_POS * 100000.0)) edge = 1;
+    return round5_py(r);
 }
 
 // one 2-D maneuver: what the 3-D planner and the sampler read of dubinsmaneuver2d's result (start yaw, radius, the first two
@@ -280,6 +299,15 @@ struct Plan3D {
     double qi[5] = {0, 0, 0, 0, 0};
     char mode[7] = {0};
     bool ok = false;
+    // knife edges of the plan itself (SCA_ST_TRACKER_EDGE, see near_round5_tie):
+    //  b_unc:  uncertainty of the horizontal radius (in units of Rmin) the search settled on.  Two libms that take the same
+    //          accept / reject decisions (dubinsmaneuver3d.py:93) arrive at the same radius bit for bit; when a comparison was a
+    //          tie within libm noise another libm may have walked the other way from there: 4 x the step at that point;
+    //  kappa:  the relative uncertainty of the vertical radius 1 / sqrt(1/Rmin^2 - 1/hr^2) that follows from it: the search
+    //          drives hr towards Rmin whenever a larger radius only lengthens the path (level flight), where that square
+    //          root is arbitrarily ill-conditioned -- the reference's own vertical maneuver is noise there
+    double b_unc = 0.0;
+    double kappa = 0.0;
     long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
     // sample i of the path, [x, y, z, psi, gamma]: a pure function of i, so the tracker evaluates samples on demand
     // (the reference materialises all ~1000 of them at every re-plan and then discards most)
@@ -294,6 +322,7 @@ struct Plan3D {
 // the tail of dubinsmaneuver3d (:102-113) + compute_sampling's grid (:116-132) for the winning pair of maneuvers
 SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver2D &fbv, const double qi[5]) {
     P.h = fbh; P.v = fbv; P.length = fbv.length; P.ok = true;
+    { const double rr = fbv.r_min / fbh.r_min; P.kappa = P.b_unc * rr * rr; }
     P.fh = path_frame(fbh); P.fv = path_frame(fbv);
     for (int k = 0; k < 3; k++) { P.mode[k] = fbh.mode[k]; P.mode[3 + k] = fbv.mode[k]; }
     P.mode[6] = 0;
@@ -305,6 +334,11 @@ SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver
     const long cnt = (long)std::ceil(stop / ss);                        // len(np.arange(0, stop, ss))
     P.count = cnt > 0 ? cnt : 0;
 }
+
+// a length comparison of the search within noise: 64 ulp of the lengths compared
+SCA_DHD static inline bool length_tie(double a, double b) { return std::fabs(a - b) <= 1.5e-14 * std::fabs(b); }
+
+SCA_DHD static inline void note_tie(Plan3D &P, double step) { const double u = 4.0 * std::fabs(step); if (u > P.b_unc) P.b_unc = u; }
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
 // H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
@@ -342,6 +376,7 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
         if (c < 1.0) c = 1.0;
         const int nfc = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
         if (nfc > 0) {
+            if (c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);
             if (fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
         }
         step *= -0.1;
@@ -359,6 +394,7 @@ struct AgentTrack {
     double sampling_size = 0.1;
     double v_pref[3] = {0, 0, 0};       // agent.v_pref (not truncated), read by is_parallel on the next call
     int replans = 0;
+    int edge = 0;                       // this call's v_pref passed a rounding within EDGE_POS of flipping (see near_round5_tie)
 };
 
 // what the tracker reads of the agents (agent.py:13-36): plain pointers, host or device
@@ -416,20 +452,22 @@ SCA_DHD static void node_pop4(AgentTrack &a) {                                  
     a.next += left < 4 ? (left > 0 ? left : 0) : 4;
 }
 SCA_DHD static void update_dubins(TrackView T, AgentTrack &a, int i, const double *pos) {                         // :243-250
-    const double dis = l3norm(pos, a.now_goal);
+    const double dis = l3norm_edge(pos, a.now_goal, a.edge);
     if (dis < a.sampling_size * 2) {
         if (!path_pop(a, a.now_goal)) { a.now_goal[0] = T.goal[3 * i]; a.now_goal[1] = T.goal[3 * i + 1]; a.now_goal[2] = T.goal[3 * i + 2]; }
     }
 }
 // util.py:125-137 is_parallel(vA float32, v_pref float64)
-SCA_DHD static bool is_parallel(const float *vA, const double *vp) {
+SCA_DHD static bool is_parallel(const float *vA, const double *vp, int *edge = nullptr) {
     const float n1 = std::sqrt((float)((double)(float)(vA[0] * vA[0]) + (double)(float)(vA[1] * vA[1]) + (double)(float)(vA[2] * vA[2])));
     const double n2 = std::sqrt(fma3(vp, vp));
     const float v1[3] = {vA[0] / n1, vA[1] / n1, vA[2] / n1};
     const double v2[3] = {vp[0] / n2, vp[1] / n2, vp[2] / n2};
     if (n1 <= (float)1e-5 || n2 <= 1e-5) return true;
     const double v1d[3] = {(double)v1[0], (double)v1[1], (double)v1[2]};
-    return round5_np(1.0 - std::fabs(fma3(v1d, v2))) < 3e-3;
+    const double rv = 1.0 - std::fabs(fma3(v1d, v2));
+    if (edge && near_round5_tie(rv, 1e-2)) *edge = 1;                   // vp is the previous call's (uncertain) v_pref
+    return round5_np(rv) < 3e-3;
 }
 
 // compute_v_pref (scaPolicy.py:264-338) for one agent, in three parts so that the device can run the (rare, long) re-plans
@@ -441,13 +479,15 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double *goal = &T.goal[3 * i];
     const double dis_goal = l3norm(pos, goal);
     const double k = 3.0 * T.turning_radius;
+    a.edge = 0;
     if (!a.is_use_dubins) {
         a.is_use_dubins = true;
         return true;
     }
     update_dubins(T, a, i, pos);
-    const double dis = l3norm(pos, a.now_goal);
+    const double dis = l3norm_edge(pos, a.now_goal, a.edge);
     const double max_size = round5_py(6 * a.sampling_size);
+    if (near_round5_tie(6 * a.sampling_size, 1e-4)) a.edge = 1;
     const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
     const double vA64[3] = {(double)vel[0], (double)vel[1], (double)vel[2]};
     const float nvA = std::sqrt((float)((double)(float)(vel[0] * vel[0]) + (double)(float)(vel[1] * vel[1]) + (double)(float)(vel[2] * vel[2])));
@@ -458,7 +498,7 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double deg100 = round5_np(100.0 * (PI / 180.0));
     const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
     const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
-    if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
+    if (((is_parallel(vel, a.v_pref, &a.edge) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
         update_dubins(T, a, i, pos);
         if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
         else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
@@ -484,9 +524,35 @@ SCA_DHD static void track_adopt(AgentTrack &a, const Plan3D &P, const double *po
 SCA_DHD static void track_finish(TrackView T, AgentTrack &a, int i, const double *pos, const double dif[3], double *V_des) {
     const double *goal = &T.goal[3 * i];
     const double zero[3] = {0, 0, 0};
-    const double norm = l3norm(dif, zero);
+    const double norm = l3norm_edge(dif, zero, a.edge);
     double v[3];
     for (int q = 0; q < 3; q++) v[q] = dif[q] * T.pref_speed[i] / norm;
+    if (!path_empty(a) || a.next > 0) {
+        // The truncation of :338 and the rounded norm of :332.  How far the tracked node may sit from the reference's:
+        //   horizontally  the radius uncertainty b_unc * Rmin, which moves a node s along the path by ~(s / hr)^2 of itself while
+        //                 the node is on the first arc, by about itself further on; plus the shift of the horizontal progress
+        //                 that the vertical radius' uncertainty causes (a pitched path covers less ground): kappa * s * g^2,
+        //                 g = the pitch angles involved;
+        //   vertically    kappa times the node's distance from the tangent at the plan's start (the part of its height that
+        //                 comes from curvature, i.e. from the vertical radius).
+        // Scaled by 1e5 / norm (v = dif * ps / norm) these are the distances from a truncation step inside which the step is marked.
+        const double nn = norm > 1e-3 ? norm : 1e-3;
+        const double ps = T.pref_speed[i];
+        const double ran = (double)(a.next > 0 ? a.next - 1 : 0) * a.plan.sampling_size;
+        const double kap = a.plan.kappa < 1.0 ? a.plan.kappa : 1.0;
+        const double sr = ran / a.plan.h.r_min;
+        const double g0 = std::fabs(a.plan.qi[4]) + std::fabs(a.plan.v.t);
+        const double g = g0 < 1.0 ? g0 : 1.0;
+        const double dxy = 1e-10 + 2.0 * a.plan.b_unc * T.turning_radius * (sr < 1.0 ? sr * sr : 1.0) + kap * ran * g * g;
+        const double ztan = a.plan.qi[2] + m_sin(a.plan.qi[4]) * ran;
+        const double dz = 1e-10 + kap * std::fabs(a.now_goal[2] - ztan);
+        const double dn = dxy + dz;                                         // what the norm can move by
+        for (int q = 0; q < 3; q++) {
+            const double tq = 100000.0 * ((q == 2 ? dz : dxy) * ps + std::fabs(v[q]) * dn) / nn;
+            if (near_trunc5_step(v[q], tq > 1e-7 ? tq : 1e-7)) a.edge = 1;
+        }
+        if (near_round5_tie(norm_raw_for_edge(dif), 100000.0 * dn)) a.edge = 1;
+    }
     if (l3norm(goal, pos) < 0.2) v[0] = v[1] = v[2] = 0.0;               // util.reached, bound 0.2
     for (int q = 0; q < 3; q++) { a.v_pref[q] = v[q]; V_des[q] = trunc5(v[q]); }
 }

@@ -284,6 +284,23 @@ int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const doubl
     sca_dubins::step_all(*(sca_dubins::Tracker *)tr, pos, vel, heading, active, nbr0_dsq, vpref_out, nthreads);
     return 0;
 }
+// diagnostics: the tracker record of one agent as 24 doubles (host tracker / device tracker): horizontal maneuver r_min, t, p,
+// length; vertical r_min, t, p, length; plan length, sampling size, b_unc, kappa, next, count, now_goal[3], v_pref[3], words
+static void track_dump(const sca_dubins::AgentTrack &a, double *o) {
+    const sca_dubins::Plan3D &P = a.plan;
+    o[0] = P.h.r_min; o[1] = P.h.t; o[2] = P.h.p; o[3] = P.h.length; o[4] = P.v.r_min; o[5] = P.v.t; o[6] = P.v.p; o[7] = P.v.length;
+    o[8] = P.length; o[9] = P.sampling_size; o[10] = P.b_unc; o[11] = P.kappa; o[12] = (double)a.next; o[13] = (double)P.count;
+    for (int q = 0; q < 3; q++) { o[14 + q] = a.now_goal[q]; o[17 + q] = a.v_pref[q]; }
+    o[20] = P.mode[0] * 65536.0 + P.mode[1] * 256.0 + P.mode[2]; o[21] = P.mode[3] * 65536.0 + P.mode[4] * 256.0 + P.mode[5];
+    o[22] = (double)a.edge; o[23] = (double)a.replans;
+}
+int sca_tracker_debug(void *tr, int agent, double *out24) {
+    if (!tr || !out24) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    if (agent < 0 || agent >= T->n) return SCA_ERR_ARG;
+    track_dump(T->st[agent], out24);
+    return 0;
+}
 int sca_tracker_replans(void *tr, int32_t *replans) {
     if (!tr || !replans) return SCA_ERR_ARG;
     auto *T = (sca_dubins::Tracker *)tr;
@@ -369,6 +386,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     for (int i = 0; i < n; i++) mode[i] = (pol[i] == SCA_POLICY_SCA || pol[i] == SCA_POLICY_RVO3D_DUBINS) ? 1 : 0;
     CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode.data(), n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemsetAsync(c->d.vpref_ext, 0, sizeof(double) * 3 * n, c->stream));
+    CHK(c, hipMemsetAsync(c->d.vpref_edge, 0, n, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     c->trk.parity = 0;
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
@@ -390,6 +408,15 @@ int sca_device_tracker_vpref(sca_ctx *c, const double *nbr0_dsq, double *vpref_o
     if (int r = launch_tracker(c, nbr0_dsq == nullptr, false)) return r;
     if (vpref_out) CHK(c, hipMemcpyAsync(vpref_out, c->d.vpref_ext, sizeof(double) * 3 * c->n, hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int sca_device_tracker_debug(sca_ctx *c, int agent, double *out24) {
+    if (!c || !out24) return SCA_ERR_ARG;
+    if (!c->trk_on || agent < 0 || agent >= c->n) { c->err = "no device tracker / bad agent"; return SCA_ERR_STATE; }
+    sca_dubins::AgentTrack a;
+    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipMemcpy(&a, c->trk.st + agent, sizeof(a), hipMemcpyDeviceToHost));
+    track_dump(a, out24);
     return 0;
 }
 int sca_device_tracker_replans(sca_ctx *c, int32_t *replans) {
@@ -434,7 +461,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &c->rec_new_own, N); d.rec_new = c->rec_new_own;
     r |= dalloc(c, &d.heading, 3 * N); r |= dalloc(c, &d.goal, 3 * N); r |= dalloc(c, &d.pref_speed, N);
     r |= dalloc(c, &d.vpref_ext, 3 * N); r |= dalloc(c, &d.total_dist, N); r |= dalloc(c, &d.max_run_dist, N);
-    r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.policy, N);
+    r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.vpref_edge, N); r |= dalloc(c, &d.policy, N);
     r |= dalloc(c, &d.zaxis, N);
     r |= dalloc(c, &d.obs, M); r |= dalloc(c, &d.atree, 2 * N); r |= dalloc(c, &d.aperm, N);
     r |= dalloc(c, &d.obs_sorted, M); r |= dalloc(c, &d.awide, 2 * N); r |= dalloc(c, &d.owide, 2 * M);
@@ -510,7 +537,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->comm) { (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     (void)tracker_free(c);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
-                    d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
+                    d.step_num, d.vpref_mode, d.vpref_edge, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
@@ -705,6 +732,7 @@ int sca_set_vpref(sca_ctx *c, const double *vpref, const uint8_t *mode) {
     ARG(c, vpref && mode && c->agents_set);
     CHK(c, hipMemcpyAsync(c->d.vpref_ext, vpref, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode, c->n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemsetAsync(c->d.vpref_edge, 0, c->n, c->stream));         // v_pref from outside: no device tracker, no edge
     CHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -58,6 +58,7 @@ struct DeviceView {
     double *max_run_dist;    // [n]
     int32_t *step_num;       // [n]
     uint8_t *vpref_mode;     // [n]
+    uint8_t *vpref_edge;     // [n] 1: the tracker's v_pref of this pass passed a rounding edge (SCA_ST_TRACKER_EDGE)
     uint8_t *policy;         // [n]
     uint8_t *zaxis;          // [n]
     // obstacles + trees
@@ -650,7 +651,8 @@ struct alignas(16) Prep {
     double nvA;            // |vA| as float32 norm (util.py:11)
     double rad1;           // second element of np.arange(0.5, ps + 0.03, ps - 0.5)
     unsigned vp_key;       // round5 numerator of |v_pref - v_pref| (= 0) << 10, without the index
-    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint; bits 8..: get_phi numerator of v_pref
+    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint, 8 v_pref came over a rounding
+                           // edge of the device tracker; bits 8..: get_phi numerator of v_pref
 };
 static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
 
@@ -673,6 +675,7 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P,
     if (!candidate_speeds(ps, rad1)) { bits |= 2u; rad1 = ps; }
     r.rad1 = rad1;
     if (posture_ok(P, vA, r.nvA, pA.z, vpref)) bits |= 4u;
+    if (d.vpref_mode[agent] && d.vpref_edge[agent]) bits |= 8u;
     double kn;
     l3norm(vpref, vpref, &kn);
     r.vp_key = pack_key(kn, 0);
@@ -850,7 +853,7 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
     const double ps = d.pref_speed[agent];
-    int st = 0;
+    int st = (d.vpref_mode[agent] && d.vpref_edge[agent]) ? ST_TRACKER_EDGE : 0;
     V3 vpref;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
     else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
@@ -1091,7 +1094,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
     const Prep pr = ((const Prep *)d.prep)[agent];        // per-agent scalar prologue (prep_agent)
-    int st = (pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0;
+    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;

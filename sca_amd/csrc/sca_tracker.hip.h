@@ -42,7 +42,8 @@ __device__ __forceinline__ bool track_active(const DeviceView &d, int agent) {
     const int pol = d.policy[agent];
     return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;   // mampenv.py:35
 }
-__device__ __forceinline__ void track_store(const DeviceView &d, int agent, const double *V) {
+__device__ __forceinline__ void track_store(const DeviceView &d, int agent, const double *V, int edge) {
+    d.vpref_edge[agent] = edge ? 1 : 0;
     for (int q = 0; q < 3; q++) {
         double x = V[q];
         if (x != x) x = 0.0;                                             // what numpy.nan_to_num does on the host path
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
         return;
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V);
+    track_store(d, agent, V, a.edge);
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     double dif[3], V[3];
     sca_dubins::track_replan(T, a, agent, pos, heading, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V);
+    track_store(d, agent, V, a.edge);
 }
 
 // ---- four lanes per plan ---------------------------------------------------------------------------------------------------
@@ -222,8 +223,11 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
             if (phase == 1 && ++guard > 200) return P;
             if (nf >= 2) { fbh = fch; fbv = fcv; phase = 2; }
             else phase = 1;
-        } else if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
-        else step *= -0.1;
+        } else {
+            if (nf > 0 && c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);
+            if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
+            else step *= -0.1;
+        }
     }
     finish_plan(P, fbh, fbv, qi);
     return P;
@@ -302,6 +306,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             double cn = nc[1];
 #pragma unroll
             for (int k = 2; k <= NODES; k++) cn = node == k ? nc[k] : cn;
+            if (nf > 0 && cn != b && length_tie(len, fbv.length)) note_tie(P, step);
             const bool acc = nf > 0 && len < fbv.length;                   // the same in every lane of the group
             if (acc) {
                 b = cn;
@@ -339,7 +344,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     double dif[3], V[3];
     sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V);
+    track_store(d, agent, V, a.edge);
 }
 
 // All the many-lanes-per-plan forms in ONE launch: the device-side count of the pass picks the widest form that still leaves

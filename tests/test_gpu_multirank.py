@@ -122,20 +122,21 @@ def test_rccl_in_place_all_gather_path_single_rank(tmp_path, track):
 
 def test_bench_script_two_rank_path():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), with the ranks sharing
-    GPU 0 through the script's test hook: one JSON line from rank 0, whole-job agent-steps summed over the ranks."""
+    GPU 0 through the script's test hook: one JSON line from rank 0, whole-job agent-steps summed over the ranks, strong
+    scaling by default (the workload's agent count in total)."""
     import json
     env = dict(os.environ, SCA_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
-                        '--warmup', '3', '--agents', '6000', '--end-to-end'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        '--warmup', '3', '--agents', '6000'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['agents'] == 12000
-    assert out['config']['agent_steps_timed'] == 12000 * 6
-    assert out['value'] > 0 and 'roofline' in out and 'cpu_baseline' not in out
-    assert out['end_to_end_sca']['agent_steps_timed'] == 12000 * 6 and out['end_to_end_sca']['value'] > 0
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['agents'] == 6000
+    assert out['config']['agents_per_gpu'] == 3000 and out['config']['agent_steps_timed'] == 6000 * 6
+    assert out['config']['re_plans_timed'] > 0                      # SCA as shipped: the tracker runs inside the step
+    assert out['value'] > 0 and 'roofline' in out and 'cpu_baseline' not in out and 'scale_model' not in out
 
 
 ORDER_WORKER = r'''

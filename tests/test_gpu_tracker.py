@@ -70,6 +70,58 @@ def test_device_tracker_reproduces_reference_v_pref(name):
     sol.close()
 
 
+EDGE = 64                    # SCA_ST_TRACKER_EDGE
+
+
+@pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
+                                  'F4_mixed_takeoff16', 'F10_sca_exp3_map', 'F13_fuzz_track_00', 'F13_fuzz_track_01',
+                                  'F13_fuzz_track_02', 'F13_fuzz_track_03'])
+def test_sca_as_shipped_velocity_parity_with_device_tracker(name):
+    """SCA as the reference ships it (v_pref from the Dubins tracker, scaPolicy.py:32,264-338) with the tracker ON THE
+    DEVICE: new_velocity of every agent-step of the recorded episodes against the reference's action.  Open loop on the
+    states (they come from the fixture), closed loop on the tracker's records.  The bound, as measured (MI355X, round 2) and
+    asserted: the velocity is the reference's bit for bit except on isolated agent-steps (16 of 15 589 over the ten episodes,
+    <= 0.5 % asserted per episode), and there it is off by one or two steps of the 5-decimal grid (max |dv| 2e-5, asserted
+    <= 5e-5): in every one of them the solver's pick was the v_pref candidate itself or the same table candidate, so the
+    flipped truncation of v_pref shows through unamplified -- no case of another candidate being picked was seen.
+    EVERY such agent-step carries SCA_ST_TRACKER_EDGE.  The bit is conservative, not sharp: the reference's radius search
+    (dubinsmaneuver3d.py:86-100) ends on noise-level ties and, for level flight, where its vertical radius
+    1 / sqrt(1/Rmin^2 - 1/hr^2) is ill-conditioned, so in such scenes most agent-steps carry it (printed below)."""
+    fx = load(name)
+    st = static_inputs(fx)
+    n = len(st['radius'])
+    ext = st['vpref_mode'].astype(bool)
+    sol = _solver_for(fx, st, in_pass=False)
+    nb0 = np.full(n, -1.0)
+    steps = deviating = flagged = unflagged_dev = 0
+    worst = 0.0
+    for t in range(len(fx['step'])):
+        called = fx['called'][t].astype(bool)
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_kd_perm(fx['perm'][t])
+        sol.device_tracker_vpref(nb0)                       # compute_v_pref of every tracked agent, on the device
+        sol.policy_pass()                                   # the pass reads that v_pref (tracker not re-run: in_pass=False)
+        a = sol.actions()
+        status = sol.diag()['status']
+        d = np.abs(a[:, :3].astype(np.float64) - fx['action'][t][:, :3].astype(np.float64)).max(axis=1)
+        dev = called & (d > 0)
+        edge = (status & EDGE) != 0
+        assert not (edge & ~ext).any()                      # only tracked agents can carry the bit
+        steps += int((called & ext).sum())
+        deviating += int(dev.sum())
+        flagged += int((edge & called).sum())
+        unflagged_dev += int((dev & ~edge).sum())
+        if dev.any():
+            worst = max(worst, float(d[dev].max()))
+        v = fx['nbr_valid'][t].astype(bool)
+        nb0[v] = np.where(fx['nbr_n'][t] > 0, fx['nbr_dsq'][t][:, 0], -1.0)[v]
+    print(f'{name}: {steps} tracked agent-steps, {deviating} with another velocity (max |dv| {worst:.3g}), {flagged} flagged')
+    assert unflagged_dev == 0, (name, unflagged_dev, deviating)
+    assert deviating <= max(2, 0.005 * steps), (name, deviating, steps)
+    assert worst <= 5e-5, (name, worst)
+    sol.close()
+
+
 def _swarm(n, seed=0):
     from sca_amd import scenarios, solver as S
     sc = scenarios.random_cube(n, seed=seed)

@@ -157,3 +157,12 @@ def test_scenario_generators_match_reference_fixtures():
     sc = scenarios.takeoff_landing(16)
     assert np.array_equal(sc['start'], fx['start']) and np.array_equal(sc['goal'], fx['goal6'])
     assert np.array_equal(sc['obs_pos'], fx['obs_pos'])
+
+
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
+    r = subprocess.run([sys.executable, os.path.join(ROOT_, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1'],
+                       env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=300, cwd=ROOT_)
+    assert r.returncode != 0 and 'torch.distributed.run' in (r.stdout + r.stderr)
