@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
     ap.add_argument('--agents', type=int, default=None)
+    ap.add_argument('--policy', default=None, choices=sorted(POL) + ['mixed'], help='override the workload\'s policy (measurements)')
     ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
                     help='N>1 GPUs: strong = the workload\'s N in total (default; BASELINE c4 is N=100000 on 8 GPUs), weak = N per GPU')
     ap.add_argument('--nbr', default='kd', choices=sorted(NBR), help='neighbour structure of the value leg')
@@ -209,7 +210,10 @@ def main():
     from sca_amd.distributed import ShardedStepper
 
     wname = args.workload or 'c4'
-    w = WORKLOADS[wname]
+    w = dict(WORKLOADS[wname])
+    if args.policy:
+        w['policy'] = args.policy
+        w['desc'] += f' [--policy {args.policy}]'
     has_tracker = w['policy'] in ('sca', 'mixed')
     vpref = args.vpref or ('dubins-device' if has_tracker else 'straight')
     if not has_tracker:

@@ -81,8 +81,8 @@ def main():
             break
     cost = time.time() - t0
     print('All agents finished!' if done else 'step limit reached', step, 'steps,', f'{cost:.2f} s')
-    paths = metrics.write_episode_log(env, args.log_dir, total_policy_time_s=cost)
-    info = metrics.episode_metrics(env, total_policy_time_s=cost)
+    paths = metrics.write_episode_log(env, args.log_dir)                  # AverageCost from agent.total_time, as run_sca.py:241-250
+    info = metrics.episode_metrics(env)
     print({k: info[k] for k in ('SuccessRate', 'ExtraTime', 'ExtraDistance', 'AverageSpeed', 'AverageCost')})
     print('wrote', ', '.join(sorted(paths.values())))
 

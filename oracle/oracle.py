@@ -28,7 +28,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, 'liboracle.so')
+        so = os.environ.get('SCA_ORACLE_SO') or os.path.join(_HERE, 'liboracle.so')    # SCA_ORACLE_SO: the sanitizer build
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

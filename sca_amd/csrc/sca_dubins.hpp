@@ -575,8 +575,11 @@ struct Pool {
         if ((int)th.size() == want) return;
         shutdown();
         n = want; stop = false;
-        for (int t = 0; t < want; t++) th.emplace_back([this, t] {
-            int seen = 0;
+        // a re-sized pool must not mistake the previous generations for work: a fresh thread that started from 0 ran the stale
+        // `job` of the last run (found by ThreadSanitizer, tests/test_sanitizers.py)
+        const int born = gen;
+        for (int t = 0; t < want; t++) th.emplace_back([this, t, born] {
+            int seen = born;
             for (;;) {
                 std::function<void(int)> f;
                 {

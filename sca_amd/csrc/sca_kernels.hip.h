@@ -1129,7 +1129,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
         }
         __builtin_amdgcn_wave_barrier();
         if (pol == POL_ORCA_LP) {
-            // K3: LP3 (+LP4), orca3dPolicyOfficial.py:108-113.  Scalar chain, lane 0 drives.
+            // K3: LP3 (+LP4), orca3dPolicyOfficial.py:108-113.  Scalar chain, lane 0 drives: measured faster than the lanes-over-planes
+            // form (ballots for the next violated plane, wave max / min for LP1) at every BASELINE size but N = 1024, DESIGN.md section 3.
             V3 nv = v3(0, 0, 0);
             int pf = 0, l4 = 0;
             if (lane == 0) {

@@ -123,8 +123,7 @@ class Agent:
         self.maxSpeed = 1.0
         self.dt_nominal = DT
         self.path = []
-        self.v_pref = np.zeros(3)
-        self.total_time = 0.0
+        self._v_pref = np.zeros(3)
         self.is_obstacle = False
         d = float(np.sqrt(((self.initial_pos[:3] - self.goal_pos[:3]) ** 2).sum()))
         self.straight_path_length = round(d, 5) - 0.5               # agent.py:51
@@ -150,6 +149,22 @@ class Agent:
     @property
     def heading_global_frame(self):
         return self._get('heading', self._heading)
+
+    @property
+    def total_time(self):
+        """agent.total_time (scaPolicy.py:30,35-37,62-64): wall time this agent's find_next_action calls took.  The batched
+        pass serves every active agent at once, so a step's wall time is shared equally among the agents it served."""
+        if self._env is None:
+            return 0.0
+        cum = self._env._time_cum
+        return cum[min(self.step_num, len(cum) - 1)]
+
+    @property
+    def v_pref(self):
+        """agent.v_pref as the last find_next_action left it (scaPolicy.py:337, rvo3dPolicy.py:195)"""
+        if self._env is None:
+            return self._v_pref
+        return self._env._vpref_of(self.id)
 
     @property
     def total_dist(self):
@@ -213,9 +228,13 @@ class MACAEnv:
         self.dubins_tracker = v_pref_fn is not None or self.device_tracker
         self.device = device
         self.neighbor_mode = neighbor_mode
-        self.history_capacity = history_capacity      # env steps of Agent.history_info kept on the device (0: no log)
+        self.history_capacity = history_capacity      # env steps of Agent.history_info kept on the device (0: no log);
+        self.history_budget_bytes = 64 << 30          # 64 B per agent per step, allocated up front: capped to this budget
         self._row_cache = None
         self._last_neighbors = None     # neighbour lists of the previous policy pass (read by the v_pref tracker)
+        self._time_cum = [0.0]          # [s] = seconds of policy wall time per served agent over the first s env steps
+        self._active = 0                # agents the next step will serve
+        self._vpref_cache = None
 
     def set_agents(self, agents, obstacles=None):
         if obstacles is None:
@@ -242,8 +261,6 @@ class MACAEnv:
         self.solver.set_agents([a.radius for a in agents], [a.pref_speed for a in agents], self.goal, self.policy_ids,
                                S.zaxis_flags(start, goal6), [a.max_run_dist for a in agents])
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
-        if self.history_capacity:
-            self.solver.history_enable(self.history_capacity)
         if self.device_tracker and self._ext.any():
             self.solver.device_tracker_enable(goal6[:, 3:6])
         for a in agents:
@@ -252,6 +269,18 @@ class MACAEnv:
         self.kdTree = _KdTreeView(self)
         self._row_cache = None
         self._nbr_cache = None
+        self._time_cum = [0.0]
+        self._active = n
+        self._vpref_cache = None
+        # the log costs 64 B x rows x agents of HBM up front: cap it to a budget instead of failing in hipMalloc
+        if self.history_capacity and 64 * self.history_capacity * n > self.history_budget_bytes:
+            capped = max(1, self.history_budget_bytes // (64 * n))
+            import warnings
+            warnings.warn(f'history_capacity {self.history_capacity} x {n} agents x 64 B exceeds the {self.history_budget_bytes >> 30} GiB '
+                          f'budget: keeping the first {capped} env steps (later steps are counted as dropped)')
+            self.history_capacity = capped
+        if self.history_capacity:
+            self.solver.history_enable(self.history_capacity)
 
     # ---- host mirrors of the device state, refreshed on first use after a step (the reference's per-agent attributes) -------
     def _state(self, name):
@@ -286,6 +315,11 @@ class MACAEnv:
     def _policy_row(self, i):
         return list(self._policy_pass()[i])
 
+    def _vpref_of(self, i):
+        if self._vpref_cache is None:
+            self._vpref_cache = np.nan_to_num(self.solver.diag()['vpref'])
+        return self._vpref_cache[i]
+
     def _neighbors_of(self, i):
         if self._nbr_cache is None:
             self._nbr_cache = self.solver.neighbors()
@@ -301,15 +335,24 @@ class MACAEnv:
         """`actions` is ignored, as in the reference (mampenv.py:22).  Without a host-side v_pref_fn the whole step (both loops
         of _take_action, mampenv.py:27-49) is one resident library call and nothing but the done count comes back: the
         per-agent attributes are read from the device the next time somebody looks at them."""
+        import time
+        t0 = time.perf_counter()
+        served = max(1, self._active)
         if self._row_cache is None and self.v_pref_fn is None:
             self.solver.run_steps(1, self.neighbor_mode)
-            done = self.solver.active_count() == 0
+            self._active = self.solver.active_count()           # synchronises: the step is over when this returns
+            t_policy = time.perf_counter() - t0
+            done = self._active == 0
             self._nbr_cache = None
         else:
             self._policy_pass()
+            t_policy = time.perf_counter() - t0                  # the reference times find_next_action only
             done = self.solver.env_update()
+            self._active = self.solver.active_count()
+        self._time_cum.append(self._time_cum[-1] + t_policy / served)
         self._stale = True
         self._row_cache = None
+        self._vpref_cache = None
         return done
 
 

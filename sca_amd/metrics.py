@@ -10,7 +10,9 @@
   * `write_episode_log(env, dir)` — `env_cfg.json` + `trajs.npz` (one [rows, 13] array per agent under the reference's
     sheet name `agent<id>`); `trajs.xlsx` as well when openpyxl is importable (it is what the reference writes).
 
-AverageCost is the reference's wall time of find_next_action per agent-step (run_sca.py:250): pass the measured policy time.
+AverageCost is the reference's wall time of find_next_action per agent-step (run_sca.py:250): by default the sum of
+`agent.total_time`, which MACAEnv.step maintains (a step's policy wall time shared among the agents it served); a measured
+total can be passed instead.
 """
 import json
 import os
@@ -46,13 +48,18 @@ def episode_metrics(env, total_policy_time_s=None):
         'ExtraDistance': (dist - straight) / num if num else float('nan'),
         'AverageSpeed': dist / steps / DT if steps else float('nan'),
     }
-    if total_policy_time_s is not None and steps:
+    if total_policy_time_s is None:                      # run_sca.py:241-250: sum of agent.total_time over the successful agents
+        total_policy_time_s = sum(a.total_time for a, k in zip(agents, ok) if k)
+    if steps:
         out['AverageCost'] = 1000 * total_policy_time_s / steps
     return out
 
 
-def episode_info(env, total_policy_time_s=0.0):
+def episode_info(env, total_policy_time_s=None):
     """The `info_dict_to_visualize` of run_sca.py:199-259."""
+    if total_policy_time_s is None:                      # run_sca.py:241: all_compute_time sums agent.total_time
+        ok = [(not a.is_collision) and (not a.is_out_of_max_time) for a in env.agents]
+        total_policy_time_s = sum(a.total_time for a, k in zip(env.agents, ok) if k)
     m = episode_metrics(env, total_policy_time_s)
     info = {
         'all_agent_info': [{'id': a.id, 'gp': a.group, 'radius': a.radius, 'goal_pos': np.asarray(a.goal_global_frame).tolist()}
@@ -93,7 +100,7 @@ def trajectories(env, agent_begin=0, agent_count=None):
     return out
 
 
-def write_episode_log(env, log_dir, total_policy_time_s=0.0, xlsx=None):
+def write_episode_log(env, log_dir, total_policy_time_s=None, xlsx=None):
     """Writes what run_sca.py:181-259 writes: the trajectories and env_cfg.json.  Returns the paths."""
     os.makedirs(log_dir, exist_ok=True)
     paths = {}

@@ -19,13 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope='module')
 def harness():
-    out = os.path.join(ROOT, 'tests', '_build', 'libcore_harness.so')
+    ubsan = bool(os.environ.get('SCA_HARNESS_UBSAN'))          # tests/test_sanitizers.py re-runs this module with it set
+    out = os.path.join(ROOT, 'tests', '_build', 'libcore_harness_ubsan.so' if ubsan else 'libcore_harness.so')
     src = os.path.join(ROOT, 'tests', 'core_harness.cpp')
     hdr = os.path.join(ROOT, 'sca_amd', 'csrc', 'sca_core.h')
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-mfma',
-                               '-fno-builtin-pow', '-I' + os.path.join(ROOT, 'sca_amd', 'csrc'), '-o', out, src])
+        san = ['-O1', '-g', '-fsanitize=undefined', '-fno-sanitize-recover=all'] if ubsan else ['-O2']
+        subprocess.check_call(['g++', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-mfma',
+                               '-fno-builtin-pow', '-I' + os.path.join(ROOT, 'sca_amd', 'csrc'), '-o', out, src] + san)
     H = C.CDLL(out)
     dp, fp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     H.core_round5_py.restype = C.c_double

@@ -1,6 +1,7 @@
 """CPU tests of the host-side logic: scenario generators against the reference's own start states (golden fixtures),
 the drop-in API surface, and the 2-rank sharded stepping protocol (gloo) with a checker backend built on the oracle."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -159,10 +160,8 @@ def test_scenario_generators_match_reference_fixtures():
     assert np.array_equal(sc['obs_pos'], fx['obs_pos'])
 
 
-ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
 
 def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
-    r = subprocess.run([sys.executable, os.path.join(ROOT_, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1'],
-                       env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=300, cwd=ROOT_)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1'],
+                       env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and 'torch.distributed.run' in (r.stdout + r.stderr)
