@@ -178,6 +178,9 @@ def main():
                          'straight = the solver alone; dubins = the bit-exact host tracker every step (host-bound, 1 GPU)')
     ap.add_argument('--exchange', default='inlib', choices=['inlib', 'torch'],
                     help='N>1 GPUs: inlib = RCCL inside the library (one sca_run_steps call), torch = all_gather_into_tensor from Python')
+    ap.add_argument('--emulate-rank-of', type=int, default=0, metavar='G',
+                    help='1 GPU only: time what ONE rank of G executes per step (neighbour structure over all N, the rest for the '
+                         'middle shard of N/G; the other records are copied over where the all-gather would deliver them)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='value leg only: no solver_only / grid_mode / scale_model / extra_legs')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the c2 / c3 / c3lp / c5 legs')
@@ -238,6 +241,17 @@ def main():
     else:
         stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu, mode=mode)
 
+    emulated = None
+    if args.emulate_rank_of > 1:
+        if world > 1 or n % args.emulate_rank_of:
+            raise SystemExit('--emulate-rank-of G needs --gpus 1 and G | N')
+        G = args.emulate_rank_of
+        sol.set_shard_emulation(True)
+        sol.set_shard((G // 2) * (n // G), n // G)
+        stepper.begin, stepper.count = (G // 2) * (n // G), n // G
+        emulated = {'rank_of': G, 'agents_solved': n // G}
+        args.no_extra = True
+        args.no_cpu_baseline = True
     if vpref == 'dubins':
         if world > 1:
             raise SystemExit('--vpref dubins is a single-GPU measurement')
@@ -298,6 +312,8 @@ def main():
         }
         if roof2 is not None:
             out['roofline_k_solve'] = roof2
+        if emulated:
+            out['emulated'] = emulated
         out.update(extras)
         if cpu is not None:
             out['cpu_baseline'] = cpu

@@ -323,15 +323,19 @@ SCA_HD V3 orca_fallback_vdif(const OrcaOb &o, F3 vA, V3 cand) {
 }
 
 // ---- linear programs (orca3dPolicyOfficial.py:126-300), scalar form --------------------------------
-SCA_HD bool lp1(const Plane *pl, int planeNo, V3 lpnt, V3 ldir, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
+// PL is anything indexable to a Plane: a `const Plane *` (host harness, the wave-per-agent kernels) or an accessor over a
+// lane-transposed LDS array (k_lp: one lane per agent).
+template <class PL>
+SCA_HD bool lp1(const PL &pl, int planeNo, V3 lpnt, V3 ldir, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
     double dotProduct = dot(lpnt, ldir);
     double disc = dotProduct * dotProduct + maxSpeed * maxSpeed - dot(lpnt, lpnt);
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
     double tLeft = -dotProduct - sq, tRight = -dotProduct + sq;
     for (int i = 0; i < planeNo; i++) {
-        double numerator = dot(pl[i].p - lpnt, pl[i].n);
-        double denominator = dot(ldir, pl[i].n);
+        const Plane q = pl[i];
+        double numerator = dot(q.p - lpnt, q.n);
+        double denominator = dot(ldir, q.n);
         if (denominator * denominator <= RVO_EPS) {
             if (numerator > 0.0) return false;
             continue;
@@ -350,7 +354,8 @@ SCA_HD bool lp1(const Plane *pl, int planeNo, V3 lpnt, V3 ldir, double maxSpeed,
     nv = lpnt + tt * ldir;
     return true;
 }
-SCA_HD bool lp2(const Plane *pl, int planeNo, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
+template <class PL>
+SCA_HD bool lp2(const PL &pl, int planeNo, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
     const Plane P = pl[planeNo];
     double planeDist = dot(P.p, P.n);
     double planeDistSq = planeDist * planeDist, radiusSq = maxSpeed * maxSpeed;
@@ -372,26 +377,29 @@ SCA_HD bool lp2(const Plane *pl, int planeNo, double maxSpeed, V3 vpref, bool di
         }
     }
     for (int i = 0; i < planeNo; i++) {
-        if (dot(pl[i].n, pl[i].p - nv) > 0.0) {
-            V3 cp = cross(pl[i].n, P.n);
+        const Plane Q = pl[i];
+        if (dot(Q.n, Q.p - nv) > 0.0) {
+            V3 cp = cross(Q.n, P.n);
             if (dot(cp, cp) <= RVO_EPS) return false;
             V3 ldir = cp / norm(cp);
             V3 lineNormal = cross(ldir, P.n);
-            double dp1 = dot(pl[i].p - P.p, pl[i].n), dp2 = dot(lineNormal, pl[i].n);
+            double dp1 = dot(Q.p - P.p, Q.n), dp2 = dot(lineNormal, Q.n);
             V3 lpnt = P.p + (dp1 / dp2) * lineNormal;
             if (!lp1(pl, i, lpnt, ldir, maxSpeed, vpref, dir_opt, nv)) return false;
         }
     }
     return true;
 }
-SCA_HD int lp3(const Plane *pl, int np, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
+template <class PL>
+SCA_HD int lp3(const PL &pl, int np, double maxSpeed, V3 vpref, bool dir_opt, V3 &nv) {
     if (dir_opt) nv = v3(vpref.x * maxSpeed, vpref.y * maxSpeed, vpref.z * maxSpeed);
     else if (dot(vpref, vpref) > maxSpeed * maxSpeed) {
         V3 t = vpref / norm(vpref);
         nv = v3(t.x * maxSpeed, t.y * maxSpeed, t.z * maxSpeed);
     } else nv = vpref;
     for (int i = 0; i < np; i++) {
-        if (dot(pl[i].n, pl[i].p - nv) > 0.0) {
+        const Plane Q = pl[i];
+        if (dot(Q.n, Q.p - nv) > 0.0) {
             V3 tmp = nv;
             if (!lp2(pl, i, maxSpeed, vpref, dir_opt, nv)) { nv = tmp; return i; }
         }

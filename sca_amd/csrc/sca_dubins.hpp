@@ -167,6 +167,10 @@ SCA_DHD static bool word(int which, double alpha, double beta, double d, double 
 //   becomes atan2(0, p) = +0 for LSL / RSR.
 // Returns false (word not feasible) exactly when word() does; t, p, q are computed unconditionally (nan when infeasible), so
 // that lanes of one plan never diverge.
+// W_KNOWN: w is a compile-time constant at the call (the lane-per-plan planner unrolls the four words): LSL / RSR then skip
+// their second arctangent, which is atan2(+0, p) = +0 for every p >= 0 (p2 = -0 cannot occur: 2 + d^2 > 0 and an exact
+// cancellation rounds to +0), and A1 - (+0) == A1 bit for bit.
+template <bool W_KNOWN = false>
 SCA_DHD static bool csc_word_uniform(int w, double alpha, double beta, double mbeta /* mod2pi(beta) */, double d, double sa,
                                      double sb, double ca, double cb, double c_ab, double &t, double &p, double &q) {
     const bool cross = w >= 2;                         // LSR, RSL
@@ -183,8 +187,12 @@ SCA_DHD static bool csc_word_uniform(int w, double alpha, double beta, double mb
     const double y = ya + yb;
     p = std::sqrt(p2);
     const double A1 = m_atan2(y, x);
-    const double A2 = m_atan2(cross ? (w == 2 ? -2.0 : 2.0) : 0.0, p);
-    const double tmp = A1 - A2;
+    double tmp;
+    if (W_KNOWN && !cross) tmp = A1;
+    else {
+        const double A2 = m_atan2(cross ? (w == 2 ? -2.0 : 2.0) : 0.0, p);
+        tmp = A1 - A2;
+    }
     const double ta = tmp - alpha;
     t = mod2pi(rfirst ? -ta : ta);
     const double qa = (w == 2 ? mbeta : beta) - tmp;
@@ -223,7 +231,7 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
         const double mbeta = mod2pi(F.beta);
         double t4[4], p4[4], q4[4]; bool ok4[4];
 #pragma unroll
-        for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
+        for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform<true>(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const double cost = c * (std::fabs(t4[w]) + std::fabs(p4[w]) + std::fabs(q4[w]));
@@ -308,6 +316,7 @@ struct Plan3D {
     //          root is arbitrarily ill-conditioned -- the reference's own vertical maneuver is noise there
     double b_unc = 0.0;
     double kappa = 0.0;
+    int iters = 0;                       // candidate radii the search tried (statistics; sca_*_tracker_debug)
     long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
     // sample i of the path, [x, y, z, psi, gamma]: a pure function of i, so the tracker evaluates samples on demand
     // (the reference materialises all ~1000 of them at every re-plan and then discards most)
@@ -344,10 +353,12 @@ SCA_DHD static inline void note_tie(Plan3D &P, double step) { const double u = 4
 // H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
 SCA_DHD static int try_to_construct(const Frame2D &H, const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
                                     double hr, Maneuver2D &mh, Maneuver2D &mv) {
-    mh = plan2d(H, qi[3], hr);
-    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
+    // the vertical curvature first: when it fails (:146-147: a candidate clamped to Rmin, `c < 1 -> c = 1`, does every time) the
+    // horizontal maneuver computed before it (:140) is never read by the caller, so it is not computed here
     const double vc = std::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
     if (vc < 1e-5) return 0;
+    mh = plan2d(H, qi[3], hr);
+    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
     const double vr = 1.0 / vc;
     mv = plan2d(frame2d(qi3D, qf3D), qi3D[2], vr);
     if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
@@ -365,15 +376,18 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
     const Frame2D H = frame2d(qi2D, qf2D);
     int nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
     int guard = 0;
+    P.iters = 1;
     while (nfb < 2) {
         b *= 2.0;
         nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+        P.iters++;
         if (++guard > 200) return P;                                   // the reference would loop forever
     }
     double step = 0.1;
     while (std::fabs(step) > 1e-10) {
         double c = b + step;
         if (c < 1.0) c = 1.0;
+        P.iters++;
         const int nfc = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
         if (nfc > 0) {
             if (c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);

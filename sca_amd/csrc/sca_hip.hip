@@ -167,6 +167,9 @@ struct sca_ctx {
     std::vector<hipEvent_t> pool_trk;   // 2 events per step on the stream the re-plan kernels run on: before / after them
     int pool_trk_used = 0;
     float ms_replan = 0;
+    // K3: the ORCA3D-LP agents, ascending ids (static: sca_set_agents), solved one lane per agent by k_lp
+    int32_t *lp_list = nullptr;
+    std::vector<int32_t> h_lp_list;
     bool shard_emulation = false;       // measurement aid: a partial shard without a communicator, the others stand still
     std::vector<double> h_pos;          // host mirror of positions for the kd build
     bool h_pos_valid = false;
@@ -292,7 +295,7 @@ static void track_dump(const sca_dubins::AgentTrack &a, double *o) {
     o[8] = P.length; o[9] = P.sampling_size; o[10] = P.b_unc; o[11] = P.kappa; o[12] = (double)a.next; o[13] = (double)P.count;
     for (int q = 0; q < 3; q++) { o[14 + q] = a.now_goal[q]; o[17 + q] = a.v_pref[q]; }
     o[20] = P.mode[0] * 65536.0 + P.mode[1] * 256.0 + P.mode[2]; o[21] = P.mode[3] * 65536.0 + P.mode[4] * 256.0 + P.mode[5];
-    o[22] = (double)a.edge; o[23] = (double)a.replans;
+    o[22] = (double)a.edge + 2.0 * P.iters; o[23] = (double)a.replans;
 }
 int sca_tracker_debug(void *tr, int agent, double *out24) {
     if (!tr || !out24) return SCA_ERR_ARG;
@@ -462,7 +465,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &d.heading, 3 * N); r |= dalloc(c, &d.goal, 3 * N); r |= dalloc(c, &d.pref_speed, N);
     r |= dalloc(c, &d.vpref_ext, 3 * N); r |= dalloc(c, &d.total_dist, N); r |= dalloc(c, &d.max_run_dist, N);
     r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.vpref_edge, N); r |= dalloc(c, &d.policy, N);
-    r |= dalloc(c, &d.zaxis, N);
+    r |= dalloc(c, &d.zaxis, N); r |= dalloc(c, &c->lp_list, N);
     r |= dalloc(c, &d.obs, M); r |= dalloc(c, &d.atree, 2 * N); r |= dalloc(c, &d.aperm, N);
     r |= dalloc(c, &d.obs_sorted, M); r |= dalloc(c, &d.awide, 2 * N); r |= dalloc(c, &d.owide, 2 * M);
     r |= dalloc(c, &d.otree, 2 * M); r |= dalloc(c, &d.operm, M);
@@ -542,7 +545,7 @@ void sca_destroy(sca_ctx *c) {
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
                     c->grid.count, c->grid.range, c->grid.cursor, c->grid.bucket, c->grid.slot, c->grid.gx, c->grid.gy, c->grid.gz,
-                    c->grid.gid, c->grid.gkey};
+                    c->grid.gid, c->grid.gkey, c->lp_list};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -601,6 +604,11 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
         c->max_radius = std::max(c->max_radius, radius[i]);
         c->max_pref_speed = std::max(c->max_pref_speed, pref_speed[i]);
     }
+    c->h_lp_list.clear();
+    for (int i = 0; i < n; i++) if (policy[i] == SCA_POLICY_ORCA3D_LP) c->h_lp_list.push_back(i);
+    c->d.lp_kernel = 0;                                               // decided per pass from the shard's LP agent count
+    if (!c->h_lp_list.empty())
+        CHK(c, hipMemcpyAsync(c->lp_list, c->h_lp_list.data(), sizeof(int32_t) * c->h_lp_list.size(), hipMemcpyHostToDevice, c->stream));
     c->h_perm.resize(n);
     for (int i = 0; i < n; i++) c->h_perm[i] = i;                     // kdTree.py:43-45
     c->perm_on_device = false;
@@ -911,7 +919,23 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     return 0;
 }
 
+// K3 form for this pass: one lane per agent (k_lp) once the shard has enough LP agents to fill the chip that way -- measured:
+// 100 000 agents 65 vs 106 us, 4096 agents 23 vs 12 us (a lane alone needs ~12 us for its 16 planes and the LP) --, else the
+// wave-per-agent form inside k_solve.  SCA_LP_FORM=lane|wave forces one (A/B measurements).
+constexpr int LP_LANE_MIN = 16384;
+static void choose_lp_form(sca_ctx *c, int &lo, int &hi) {
+    const auto b = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin);
+    const auto e = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin + c->d.shard_count);
+    lo = (int)(b - c->h_lp_list.begin()); hi = (int)(e - c->h_lp_list.begin());
+    const char *f = getenv("SCA_LP_FORM");
+    c->d.lp_kernel = (hi - lo >= LP_LANE_MIN) ? 1 : 0;
+    if (f && f[0] == 'l') c->d.lp_kernel = hi > lo ? 1 : 0;
+    if (f && f[0] == 'w') c->d.lp_kernel = 0;
+}
+
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
+    int lp_lo = 0, lp_hi = 0;
+    choose_lp_form(c, lp_lo, lp_hi);
     const DeviceView &d = c->d;
     // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
     // v_pref) then moves from k_kd_gather to k_prep_shard behind the join
@@ -968,7 +992,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     }
     if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));         // [e1, e2] = k_solve alone (what rocprofv3 reports for it)
+    if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
+        hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
+    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));         // [e1, e2] = k_solve (+ k_lp) (what rocprofv3 reports for them)
     // epilogue (one lane per agent) + the agents without any suitable candidate (rare; one wavefront each), one launch
     const int ablocks = (cnt + 255) / 256;
     if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);

@@ -100,6 +100,7 @@ struct DeviceView {
     HistRow *hist;
     int hist_cap, hist_row;
     int n, m, shard_begin, shard_count;
+    int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1101,6 +1102,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     V3 vpost = v3(0, 0, 0);
     bool defer = false;
     const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    if (pol == POL_ORCA_LP && !first_step && d.lp_kernel) return;                    // K3: k_lp, one lane per agent
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
@@ -1129,7 +1131,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
         }
         __builtin_amdgcn_wave_barrier();
         if (pol == POL_ORCA_LP) {
-            // K3: LP3 (+LP4), orca3dPolicyOfficial.py:108-113.  Scalar chain, lane 0 drives: measured faster than the lanes-over-planes
+            // K3, wave-per-agent form (shards with few LP agents: launch_policy picks): LP3 (+LP4), orca3dPolicyOfficial.py:108-113.
+            // Scalar chain, lane 0 drives: measured faster than the lanes-over-planes
             // form (ballots for the next violated plane, wave max / min for LP1) at every BASELINE size but N = 1024, DESIGN.md section 3.
             V3 nv = v3(0, 0, 0);
             int pf = 0, l4 = 0;
@@ -1342,6 +1345,68 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Par
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
     if (agent < d.shard_begin + d.shard_count) solve_fast(d, P, S, agent, lane, wid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: the "Official" ORCA3D policy (orca3dPolicyOfficial.py:56-113), ONE LANE PER AGENT.  The LP is a sequential walk over
+// <= 16 planes with data-dependent recursion (LP3 -> LP2 -> LP1): inside the one-wavefront-per-agent k_solve it ran on lane 0
+// with 63 lanes idle; here 64 agents share a wavefront, each lane builds its agent's planes (make_orca per neighbour) into a
+// lane-transposed LDS array -- plane j, component c of lane l at [j][c][l]: every access is 64 consecutive doubles -- and
+// walks them with the scalar LP of sca_core.h through an accessor.  Same statements, same order: bit for bit the planes and
+// velocities of the wave-per-agent form.  Agents whose LP3 fails (planeFail < K) need LP4's projected planes: they go to
+// the fallback list and are finished, one wavefront each, by the second half of k_action (solve_one), like the agents
+// without a suitable candidate.
+struct LpPlanes { double v[K_MAX][6][64]; };                       // 48 KB per wavefront
+struct LpAccess {
+    const LpPlanes *S; int lane;
+    __device__ __forceinline__ Plane operator[](int i) const {
+        Plane q;
+        q.p = v3(S->v[i][0][lane], S->v[i][1][lane], S->v[i][2][lane]);
+        q.n = v3(S->v[i][3][lane], S->v[i][4][lane], S->v[i][5][lane]);
+        return q;
+    }
+};
+__global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t *list, int lo, int hi) {
+    __shared__ LpPlanes S;
+    const int lane = threadIdx.x;
+    const int at = lo + blockIdx.x * 64 + lane;
+    if (at >= hi) return;
+    const int agent = list[at];
+    const PubRec me = d.rec[agent];
+    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) return;          // mampenv.py:35 (k_solve wrote the bookkeeping)
+    const Prep pr = ((const Prep *)d.prep)[agent];
+    if (pr.bits & 1u) return;                                                       // bootstrap step: 0.3 v_pref, k_solve's branch
+    const V3 pA = v3(me.px, me.py, me.pz);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
+    const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    for (int j = 0; j < K; j++) {                                                   // orca3dPolicyOfficial.py:56-106
+        const int nid = d.nbr_id[agent * K_MAX + j];
+        V3 pB; F3 vB; double rB; const bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
+        if (isob) {
+            const ObsRec o = d.obs[nid & ~NBR_OBSTACLE_BIT];
+            pB = v3(o.px, o.py, o.pz); vB.x = vB.y = vB.z = 0.0f; rB = o.radius;
+        } else {
+            const PubRec o = d.rec[nid];
+            pB = v3(o.px, o.py, o.pz); vB.x = o.vx; vB.y = o.vy; vB.z = o.vz; rB = o.radius;
+        }
+        const OrcaOb o = make_orca(P, pA, vA, me.radius, pB, vB, rB, isob);
+        S.v[j][0][lane] = o.pl.p.x; S.v[j][1][lane] = o.pl.p.y; S.v[j][2][lane] = o.pl.p.z;
+        S.v[j][3][lane] = o.pl.n.x; S.v[j][4][lane] = o.pl.n.y; S.v[j][5][lane] = o.pl.n.z;
+    }
+    LpAccess pl; pl.S = &S; pl.lane = lane;
+    V3 nv = v3(0, 0, 0);
+    const int pf = lp3(pl, K, P.max_speed, vpref, false, nv);                       // :108
+    if (pf < K) {                                                                   // :110-111 linearProgram4: one wavefront, k_action
+        const int slot = atomicAdd(d.fb_count, 1);
+        d.fb_list[slot] = agent; d.is_fb[agent] = 1;
+        return;
+    }
+    int32_t *diag = d.diag + (size_t)agent * 8;
+    d.vpost[agent * 3 + 0] = nv.x; d.vpost[agent * 3 + 1] = nv.y; d.vpost[agent * 3 + 2] = nv.z;      // :113: not truncated
+    diag[0] = -1; diag[1] = -1; diag[2] = -1; diag[3] = pf; diag[4] = 0;
+    d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
+    if (pr.bits & 2u) atomicOr(&d.status[agent], ST_BAD_PREF_SPEED);
 }
 
 __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {

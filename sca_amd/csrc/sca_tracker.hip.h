@@ -189,10 +189,10 @@ __device__ __forceinline__ int try_to_construct_quad(const QuadFrame &H, const d
                                                      const double pitchlims[2], double hr, sca_dubins::Maneuver2D &mh,
                                                      sca_dubins::Maneuver2D &mv, int sub, int lane) {
     using namespace sca_dubins;
+    const double vc = ::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
+    if (vc < 1e-5) return 0;                                             // see try_to_construct: mh would not be read
     mh = plan2d_quad(H, qi[3], hr, sub, lane);
     const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
-    const double vc = ::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
-    if (vc < 1e-5) return 0;
     const double vr = 1.0 / vc;
     const QuadFrame V = frame2d_quad(qi3D, qf3D, sub);
     mv = plan2d_quad(V, qi3D[2], vr, sub, lane);

@@ -621,3 +621,37 @@ def test_random_scenes_every_step_matches_oracle(S, oracle, block):
             assert np.allclose(g['pos'], p, rtol=0, atol=1e-7), (seed, t)
             assert np.allclose(g['total_dist'], td, rtol=0, atol=1e-12), (seed, t)
         sol.close()
+
+
+def test_lp_lane_per_agent_form_equals_wave_form(S, oracle, monkeypatch):
+    """K3 has two forms (launch_policy picks by the shard's LP agent count): the wave-per-agent chain inside k_solve and
+    k_lp, one lane per agent with the planes lane-transposed in LDS.  Same statements: planeFail, the LP4 hand-over and the
+    velocities must be identical bit for bit, and equal to the oracle's, on a dense circle (16 planes per agent, many LP2 /
+    LP1 calls, some LP4)."""
+    from sca_amd import scenarios
+    n = 20000
+    sc = scenarios.circle(n)
+    s = _scenario_state(S, sc, 4)
+    ref = oracle.policy_step(s['pos'], s['vel'], s['heading'], s['radius'], s['pref_speed'], s['flags'], s['goal'], s['policy'],
+                             s['zaxis'], np.zeros((n, 3)), np.zeros(n, np.uint8), np.arange(n, dtype=np.int32), s['obs_pos'],
+                             s['obs_radius'], nthreads=8)
+    outs = []
+    for form in ('wave', 'lane'):
+        monkeypatch.setenv('SCA_LP_FORM', form)
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+        sol.set_obstacles(s['obs_pos'], s['obs_radius'])
+        sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+        sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+        sol.policy_pass(S.NBR_KDTREE)
+        outs.append((sol.actions(), sol.diag()))
+        sol.run_steps(5)                                      # and resident stepping through the same form
+        sol.synchronize()
+        outs[-1] += (sol.get_state(),)
+        sol.close()
+    (a0, d0, s0), (a1, d1, s1) = outs
+    assert np.array_equal(a0, a1) and np.array_equal(d0['diag'], d1['diag'])
+    for k in ('pos', 'vel', 'heading', 'flags'):
+        assert np.array_equal(s0[k], s1[k]), k
+    assert np.array_equal(a1[:, :4], ref['action'][:, :4])
+    assert np.array_equal(d1['diag'][:, 3:5], ref['diag'][:, 3:5])
+    assert (d1['diag'][:, 3] < 16).any()                      # some agents went through LP4
