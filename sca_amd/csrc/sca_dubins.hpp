@@ -35,12 +35,41 @@ static double (*volatile h_sin)(double) = std::sin;
 static double (*volatile h_cos)(double) = std::cos;
 static double (*volatile h_acos)(double) = std::acos;
 static double (*volatile h_atan2)(double, double) = std::atan2;
+#if defined(__HIPCC__)
+// The device library's double-precision atan2 (ROCm ocml, atan2D): a division and a degree-19 polynomial in t = (min/max)^2 by
+// Horner's rule.  Its coefficients are literals there, and the compiler's two-address form of the Horner step (v_fmac: the
+// addend sits in the destination) makes it re-materialise every coefficient in a VGPR pair at every call: 40 moves per
+// arctangent, 13 arctangents per candidate radius.  m_atan2 below is the same arithmetic in the same order -- bit for bit the
+// library's result (checked on 4 * 10^6 random and special arguments on the device) -- with the coefficients in this
+// constant-memory table: they arrive in SGPRs (five s_load) and feed the three-address v_fma_f64 directly.
+__constant__ double SCA_ATAN_C[20];
+static const unsigned long long SCA_ATAN_BITS[20] = {
+    0x3eeba404b5e68a13ull, 0xbf23e260bd3237f4ull, 0x3f4b2bb069efb384ull, 0xbf67952daf56de9bull, 0x3f7d6d43a595c56full,
+    0xbf8c6ea4a57d9582ull, 0x3f967e295f08b19full, 0xbf9e9ae6fc27006aull, 0x3fa2c15b5711927aull, 0xbfa59976e82d3ff0ull,
+    0x3fa82d5d6ef28734ull, 0xbfaae5ce6a214619ull, 0x3fae1bb48427b883ull, 0xbfb110e48b207f05ull, 0x3fb3b13657b87036ull,
+    0xbfb745d119378e4full, 0x3fbc71c717e1913cull, 0xbfc2492492376b7dull, 0x3fc99999999952ccull, 0xbfd5555555555523ull};
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 SCA_DHD static inline double m_pow(double x, double) { return x * x; }        // only ever called with exponent 2
 SCA_DHD static inline double m_sin(double x) { return ::sin(x); }
 SCA_DHD static inline double m_cos(double x) { return ::cos(x); }
 SCA_DHD static inline double m_acos(double x) { return ::acos(x); }
-SCA_DHD static inline double m_atan2(double y, double x) { return ::atan2(y, x); }
+SCA_DHD static inline double m_atan2(double y, double x) {
+    const double ax = ::fabs(x), ay = ::fabs(y);
+    const double v = ::fmin(ax, ay), u = ::fmax(ax, ay);
+    const double w = v / u;
+    const double t = w * w;
+    double p = SCA_ATAN_C[0];
+#pragma unroll
+    for (int k = 1; k < 20; k++) { const double ck = SCA_ATAN_C[k]; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(t), "s"(ck)); }
+    const double z = t * p;
+    double a = ::fma(w, z, w);
+    a = ay > ax ? 1.5707963267948966 - a : a;
+    const bool xneg = __double2hiint(x) < 0;
+    a = xneg ? 3.141592653589793 - a : a;
+    a = y == 0.0 ? (xneg ? 3.141592653589793 : 0.0) : a;
+    return ::copysign(a, y);
+}
 SCA_DHD static inline void m_sincos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
 #else
 SCA_DHD static inline double m_pow(double x, double y) { return h_pow(x, y); }
@@ -55,7 +84,24 @@ static const double PI = 3.141592653589793;
 SCA_DHD static inline double fma3(const double *a, const double *b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); }
 // util.py:113  theta - 2.0 * pi * floor(theta / 2.0 / pi), literally (the planner's search calls it ~20 times per candidate
 // radius; a division-free floor was tried on the device and dropped)
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device: the quotient fl(fl(t / 2) / pi) by the constant-divisor sequence instead of the division macro (a quarter-rate
+// reciprocal, two Newton steps, scale and fix-up: a quarter of the planner's arithmetic at ~20 calls per candidate radius):
+//     q0 = x * fl(1/pi);   r = fma(-q0, pi, x)  (the residual of a quotient good to an ulp is exact);   q1 = fma(r, fl(1/pi), q0)
+// q1 is the real quotient rounded once, after a relative perturbation below 2^-104: it is the correctly rounded quotient
+// unless that lies within 2^-53 ulp of a rounding midpoint, and even then its floor is the same unless the midpoint sits
+// just below an integer -- no such input exists at a rate that matters (< 1e-30 per call).  No branch: a guarded form that fell
+// back to the division for a whole wavefront cost 68 spilled registers and 15 % of the kernel (measured, round 2).
+SCA_DHD static inline double mod2pi(double t) {
+    const double x = t * 0.5;                                            // exact
+    const double q0 = x * 0.3183098861837907;
+    const double r = std::fma(-q0, PI, x);
+    const double q1 = std::fma(r, 0.3183098861837907, q0);
+    return t - 2.0 * PI * std::floor(q1);
+}
+#else
 SCA_DHD static inline double mod2pi(double t) { return t - 2.0 * PI * std::floor(t / 2.0 / PI); }
+#endif
 // Python round(x, 5): correctly rounded (see sca_core.h round5_py)
 SCA_DHD static inline double round5_py(double x) {
     const double y = x * 100000.0;

@@ -454,6 +454,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     CHK(c, hipSetDevice(device));
     CHK(c, hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
     c->stream = c->stream_own;
+    CHK(c, hipMemcpyToSymbol(HIP_SYMBOL(sca_dubins::SCA_ATAN_C), sca_dubins::SCA_ATAN_BITS, sizeof(sca_dubins::SCA_ATAN_BITS)));   // m_atan2's table
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
     CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
     CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3)));   // counts | nchunks
