@@ -398,6 +398,9 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
     c->trk.quad_max = getenv("SCA_TRK_QUAD_MAX") ? atoi(getenv("SCA_TRK_QUAD_MAX")) : TRK_QUAD_MAX;
+    c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
+    c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;
+    c->trk.spec4_max = getenv("SCA_TRK_SPEC4_MAX") ? atoi(getenv("SCA_TRK_SPEC4_MAX")) : TRK_SPEC4_MAX;
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -909,7 +912,10 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     // the device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work; k_replan is
     // only launched when the shard is large enough to need it
     if (c->trk_quad)
-        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16))), dim3(64), 0, rs, c->d, c->trk_view, K);
+    {   // one wavefront per workgroup; enough of them for the widest form at its largest count
+        const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
+        if (c->trk_quad) hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
+    }
     if (!c->trk_quad || cnt > K.quad_max)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);

@@ -32,9 +32,10 @@ struct TrackDev {
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
     int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= quad_max re-plans
     int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning)
+    int spec2_max, spec3_max, spec4_max;   // TRK_SPEC*_MAX unless overridden (SCA_TRK_SPEC2_MAX ..., tuning)
 };
 
-constexpr int TRK_QUAD_MAX = 24576;       // re-plans per pass up to which the four-lanes-per-plan form is used (measured crossover with the
+constexpr int TRK_QUAD_MAX = 20480;       // re-plans per pass up to which the four-lanes-per-plan form is used (measured crossover with the
                                           // lane-per-plan kernel: 19 k plans 0.54 vs 0.58 ms per step, 31 k plans 0.65 vs 0.61)
 constexpr int TRK_REPLAN_LANES = 64;      // one wavefront per workgroup: re-plans spread over as many CUs as possible
 
@@ -354,9 +355,9 @@ constexpr int TRK_FEW_BLOCKS = 1024;
 __global__ __launch_bounds__(64) void k_replan_few(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
     if (count > K.quad_max) return;
-    if (count <= TRK_SPEC4_MAX) replan_group<64>(d, T, K, count);
-    else if (count <= TRK_SPEC3_MAX) replan_group<32>(d, T, K, count);
-    else if (count <= TRK_SPEC2_MAX) replan_group<16>(d, T, K, count);
+    if (count <= K.spec4_max) replan_group<64>(d, T, K, count);
+    else if (count <= K.spec3_max) replan_group<32>(d, T, K, count);
+    else if (count <= K.spec2_max) replan_group<16>(d, T, K, count);
     else replan_group<4>(d, T, K, count);
 }
 
