@@ -234,11 +234,33 @@ def main():
 
     sol = make_solver(S, scene, local_rank)
     reset_state(sol, scene)
-    if world > 1 and args.exchange == 'inlib' and not share_gpu:
-        box = [sol.comm_unique_id() if rank == 0 else None]
+    exchange = args.exchange if world > 1 and not share_gpu else ('torch' if world > 1 else 'none')
+    stepper = None
+    if exchange == 'inlib':
+        # the library's own RCCL communicator; if any rank cannot set it up (no librccl, init failure) every rank falls back
+        # to the collective issued through torch.distributed -- the ranks agree on that first
+        ok = 1
+        try:
+            box = [sol.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                                  # noqa: BLE001 -- reported below, the fallback still measures
+            box, ok = [None], 0
+            print(f'[bench rank {rank}] sca_comm_unique_id failed: {e}', file=sys.stderr)
         dist.broadcast_object_list(box, src=0, device=torch.device('cuda', local_rank))
-        stepper = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0])
-    else:
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                stepper = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0])
+            except Exception as e:                              # noqa: BLE001
+                ok = 0
+                print(f'[bench rank {rank}] sca_comm_init failed: {e}', file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', local_rank))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if stepper is not None:
+                sol.comm_destroy()
+            stepper, exchange = None, 'torch'
+    if stepper is None:
         stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu, mode=mode)
 
     emulated = None
@@ -286,7 +308,12 @@ def main():
             g['solver_only'] = {'value': leg['value'], 'ms_per_step': leg['ms_per_step'], 'k_solve_ms': leg['k_solve_ms'],
                                 'neighbors_kernel_ms': leg['k1_ms']}
         extras[other + '_mode'] = g
-        extras['scale_model'] = scale_model(sol, scene, S, timer, args.steps, args.warmup, tracked, main_leg, g)
+        extras['scale_model'] = scale_model(sol, scene, S, timer, args.steps, args.warmup, tracked, main_leg if args.nbr == 'kd' else g,
+                                            g if args.nbr == 'kd' else main_leg)
+        if tracked:                                      # the same model for the solver alone (no tracker in the step)
+            so_kd = extras['solver_only'] if args.nbr == 'kd' else g['solver_only']
+            so_grid = g['solver_only'] if args.nbr == 'kd' else extras['solver_only']
+            extras['scale_model']['solver_only'] = scale_model(sol, scene, S, timer, args.steps, args.warmup, False, so_kd, so_grid)['modes']
         if not args.no_extra_legs and wname == 'c4' and not args.agents:
             extras['extra_legs'] = extra_legs(S, timer, local_rank, args.steps, args.warmup)
 
@@ -305,7 +332,7 @@ def main():
                                   'dubins-device': 'SCA as shipped: Dubins tracker + 3-D Dubins planner on the device inside every step '
                                                    '(k_track, k_replan / k_replan_few)'}[vpref],
                        'parallelism': (f'{n} agents sharded over {world} GPUs, one all-gather of 48-B records per step '
-                                       + ('by the library\'s RCCL communicator inside sca_run_steps' if args.exchange == 'inlib' and not share_gpu
+                                       + ('by the library\'s RCCL communicator inside sca_run_steps' if exchange == 'inlib'
                                           else 'through torch.distributed')) if world > 1 else 'single GPU',
                        'agent_steps_timed': main_leg['agent_steps'], 're_plans_timed': main_leg['plans']},
             'roofline': roof,

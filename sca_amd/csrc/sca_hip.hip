@@ -849,7 +849,7 @@ static int build_agent_grid_device(sca_ctx *c) {
     const int n = c->n;
     const int H = 1 << c->grid.hbits;
     hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid, c->P);
-    hipLaunchKernelGGL(k_grid_alloc, dim3(H / 256), dim3(256), 0, c->stream, c->grid);
+    hipLaunchKernelGGL(k_grid_alloc, dim3((H + 256 * GRID_ALLOC_PER - 1) / (256 * GRID_ALLOC_PER)), dim3(256), 0, c->stream, c->grid);
     hipLaunchKernelGGL(k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid);
     CHK(c, hipGetLastError());
     return 0;
