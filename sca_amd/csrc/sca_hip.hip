@@ -158,11 +158,11 @@ struct sca_ctx {
     DeviceView d{};
     PubRec *rec_own = nullptr, *rec_new_own = nullptr;
     hipStream_t stream_own = nullptr, stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // policy pass: 0..3, env update: 4, 5
     float ms_nbr = 0, ms_solve = 0, ms_update = 0;
     // per-launch profiling of sca_run_steps: event pairs around every k_neighbors_kd / k_solve launch
     bool profiling = false;
-    std::vector<hipEvent_t> pool;       // 3 events per step: before K1, before K2, after K2
+    std::vector<hipEvent_t> pool;       // 4 events per profiled pass: around K1 (on its stream), around k_solve
     int pool_used = 0;
     std::vector<hipEvent_t> pool_trk;   // 2 events per step on the stream the re-plan kernels run on: before / after them
     int pool_trk_used = 0;
@@ -202,8 +202,16 @@ struct sca_ctx {
     double *trk_goal_heading = nullptr;
     bool trk_on = false, trk_in_pass = false;
     // the re-plans run on a stream of their own, next to the kd build and the neighbour query of the same pass
-    hipStream_t trk_stream = nullptr;
-    hipEvent_t trk_fork = nullptr, trk_join = nullptr;
+    hipStream_t trk_stream = nullptr;   // round 2: the re-plans are the critical path and stay on the main stream; the neighbour
+                                        // structure (K0) and the neighbour query (K1) of the pass run on this one beside them
+    hipEvent_t trk_fork = nullptr, trk_join = nullptr, trk_tracked = nullptr;
+    hipStream_t nbr_stream = nullptr;   // where K0 / K1 of the current pass go: trk_stream when overlapped, else the main stream
+    int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
+    hipEvent_t trk_count_ev = nullptr;
+    bool trk_count_pending = false;
+    int trk_last_count = -1;            // -1: unknown
+    unsigned trk_passes = 0;
+    unsigned prof_tick = 0;             // with profiling on, every 4th pass carries the event pairs
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
     bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
     // multi-GPU exchange inside the library (sca_comm_init): one ncclAllGather of the shard's moved records per step
@@ -357,6 +365,10 @@ static int tracker_free(sca_ctx *c) {
     if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
     if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
     if (c->trk_join) { (void)hipEventDestroy(c->trk_join); c->trk_join = nullptr; }
+    if (c->trk_tracked) { (void)hipEventDestroy(c->trk_tracked); c->trk_tracked = nullptr; }
+    if (c->trk_count_ev) { (void)hipEventDestroy(c->trk_count_ev); c->trk_count_ev = nullptr; }
+    if (c->trk_host_count) { (void)hipHostFree(c->trk_host_count); c->trk_host_count = nullptr; }
+    c->trk_count_pending = false; c->trk_last_count = -1;
     c->kd.skip_prep = 0;
     c->trk = TrackDev{}; c->trk_goal_heading = nullptr; c->trk_on = false; c->trk_in_pass = false;
     return 0;
@@ -376,6 +388,10 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipStreamCreateWithFlags(&c->trk_stream, hipStreamNonBlocking));
     CHK(c, hipEventCreateWithFlags(&c->trk_fork, hipEventDisableTiming));
     CHK(c, hipEventCreateWithFlags(&c->trk_join, hipEventDisableTiming));
+    CHK(c, hipEventCreateWithFlags(&c->trk_tracked, hipEventDisableTiming));
+    CHK(c, hipEventCreateWithFlags(&c->trk_count_ev, hipEventDisableTiming));
+    CHK(c, hipHostMalloc((void **)&c->trk_host_count, sizeof(int) * 2));
+    c->trk_count_pending = false; c->trk_last_count = -1;
     std::vector<sca_dubins::AgentTrack> init((size_t)n);
     std::vector<double> nb((size_t)n, -1.0);
     std::vector<uint8_t> pol((size_t)n), mode((size_t)n);
@@ -785,7 +801,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     // resident at once (256 CUs x 4 workgroups of KD_LV_T threads x KD_CHUNK positions)
     if (n > 256 * 4 * KD_CHUNK) { c->err = "device kd build is limited to 2097152 agents per context: use SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     if (!c->perm_on_device) {
-        CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->nbr_stream));
         c->perm_on_device = true;
     }
     // size of the subtrees handed to k_kd_block: 1.25 x the average node size of the first level that fits (n / 2^k), so that
@@ -797,7 +813,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         wave_max = std::min(KD_WAVE_CAP, std::max(KD_WAVE_MIN + 1, (int)std::ceil(1.25 * sz)));
     }
     c->kd.wave_max = wave_max;
-    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d, c->kd, c->P);
+    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, d, c->kd, c->P);
     int levels = 0;
     if (n > wave_max) {
         // Level passes: two launches per level (rank | swap) while the nodes span several chunks, then ONE launch
@@ -823,22 +839,22 @@ static int build_agent_tree_device(sca_ctx *c) {
         levels = first_single + 1;
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < first_single; l++) {
-            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->stream, c->kd, l, ++c->kd_token);
-            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, l);
         }
-        hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->stream, d, c->kd, first_single, ++c->kd_token);
+        hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, first_single, ++c->kd_token);
     }
 
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
-    if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->stream, d, c->kd, levels);
-    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->stream, d, c->kd, levels);
+    if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->nbr_stream, d, c->kd, levels);
+    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->nbr_stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
     if (n > wave_max && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
-        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->stream));
-        CHK(c, hipEventRecord(c->kd_ev, c->stream));
+        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->nbr_stream));
+        CHK(c, hipEventRecord(c->kd_ev, c->nbr_stream));
         c->kd_ev_pending = true;
         c->kd_ev_gen = c->kd_gen;
     }
@@ -848,9 +864,9 @@ static int build_agent_tree_device(sca_ctx *c) {
 static int build_agent_grid_device(sca_ctx *c) {
     const int n = c->n;
     const int H = 1 << c->grid.hbits;
-    hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid, c->P);
-    hipLaunchKernelGGL(k_grid_alloc, dim3((H + 256 * GRID_ALLOC_PER - 1) / (256 * GRID_ALLOC_PER)), dim3(256), 0, c->stream, c->grid);
-    hipLaunchKernelGGL(k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->grid);
+    hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, c->d, c->grid, c->P);
+    hipLaunchKernelGGL(k_grid_alloc, dim3((H + 256 * GRID_ALLOC_PER - 1) / (256 * GRID_ALLOC_PER)), dim3(256), 0, c->nbr_stream, c->grid);
+    hipLaunchKernelGGL(k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, c->d, c->grid);
     CHK(c, hipGetLastError());
     return 0;
 }
@@ -889,38 +905,39 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
 // v_pref of the SCA / RVO3D+Dubins agents of the shard, before anything of the pass reads it (the per-agent prologue inside
 // k_kd_gather does)
 // side = true: k_replan goes to the tracker's own stream; the caller waits for trk_join before anything reads v_pref
+// side = true (a pass with the tracker overlapped): the caller has forked trk_stream off the main stream; k_track and the
+// re-plans stay on the main stream (they are the pass's critical path), trk_tracked marks k_track's end for the neighbour
+// query, which overwrites the lists k_track reads.
 static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
     K.nbr0_from_lists = from_lists ? 1 : 0;
     hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
+    if (side) CHK(c, hipEventRecord(c->trk_tracked, c->stream));
     hipStream_t rs = c->stream;
-    if (side) {
-        CHK(c, hipEventRecord(c->trk_fork, c->stream));
-        CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
-        rs = c->trk_stream;
-    }
     K.quad = c->trk_quad ? 1 : 0;
+    // The device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work.  Launching both
+    // every pass costs an empty launch on the critical path; the count of an earlier pass (copied back on the side stream, never
+    // waited for) says when k_replan_few has nothing to do: then only k_replan is launched, told to take whatever count comes.
+    if (c->trk_count_pending && hipEventQuery(c->trk_count_ev) == hipSuccess) { c->trk_last_count = c->trk_host_count[0]; c->trk_count_pending = false; }
+    bool few = c->trk_quad, lane = !c->trk_quad || cnt > K.quad_max;
+    if (few && lane && c->trk_last_count > K.quad_max + K.quad_max / 4) { few = false; K.quad = 0; }
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->profiling && c->pool_trk_used + 2 <= 2 * 4096) {
+    if (c->profiling && (c->prof_tick & 3u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
         for (hipEvent_t *e : {&t0, &t1}) {
             if (c->pool_trk_used == (int)c->pool_trk.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_trk.push_back(n_); }
             *e = c->pool_trk[c->pool_trk_used++];
         }
         CHK(c, hipEventRecord(t0, rs));
     }
-    // the device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work; k_replan is
-    // only launched when the shard is large enough to need it
-    if (c->trk_quad)
-    {   // one wavefront per workgroup; enough of them for the widest form at its largest count
+    if (few) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
         const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
-        if (c->trk_quad) hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
+        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
     }
-    if (!c->trk_quad || cnt > K.quad_max)
+    if (lane)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
     if (t1) CHK(c, hipEventRecord(t1, rs));
-    if (side) CHK(c, hipEventRecord(c->trk_join, c->trk_stream));
     CHK(c, hipGetLastError());
     c->trk.parity ^= 1;
     return 0;
@@ -958,6 +975,18 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->err = "SCA_NBR_GRID needs radius + collision reach <= neighbor_dist"; return SCA_ERR_UNSUPPORTED;
         }
     }
+    // Streams.  Without the tracker everything is one chain on the main stream.  With it (overlap): the pass's critical path
+    // k_track -> re-plans -> prologue -> solve stays on the main stream, and the neighbour structure + query, which depend on
+    // nothing of the tracker except that K1 must not overwrite the lists k_track reads, run beside them on trk_stream:
+    //   main: [fork] k_track [tracked] re-plans ................ [wait join] k_prep_shard k_solve ...
+    //   side: [wait fork] K0 ...... [wait tracked] K1 [join]
+    // (round 1 had the re-plans on the side stream: the fork and the join then sat on the critical path, ~40 us per step)
+    c->nbr_stream = overlap ? c->trk_stream : c->stream;
+    const unsigned parity_now = (unsigned)c->trk.parity;
+    if (overlap) {
+        CHK(c, hipEventRecord(c->trk_fork, c->stream));
+        CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
+    }
     if (tracked) { if (int r = launch_tracker(c, true, overlap)) return r; }
     c->nbr_mode = mode;
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
@@ -972,10 +1001,12 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_prep, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d, c->P);
     } else { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     const int cnt = d.shard_count;
-    hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
-    const bool prof = !timed && c->profiling && c->pool_used + 3 <= 3 * 4096;
-    if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2)) return SCA_ERR_HIP; }
-    if (timed || prof) CHK(c, hipEventRecord(e0, c->stream));
+    hipStream_t ns = c->nbr_stream;
+    if (overlap) CHK(c, hipStreamWaitEvent(ns, c->trk_tracked, 0));
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2], e3 = c->ev[3];
+    const bool prof = !timed && c->profiling && (c->prof_tick++ & 3u) == 0 && c->pool_used + 4 <= 4 * 4096;
+    if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2) || pool_event(c, &e3)) return SCA_ERR_HIP; }
+    if (timed || prof) CHK(c, hipEventRecord(e0, ns));
     double agent_reach, obs_reach;
     collide_reach(c, agent_reach, obs_reach);
     // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
@@ -983,25 +1014,33 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool packed = c->k1_force < 0 ? cnt >= 6144 : c->k1_force != 0;
     if (mode == SCA_NBR_GRID) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_grid, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, c->stream, d, c->grid,
+        hipLaunchKernelGGL(k_neighbors_grid, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
                            c->P, agent_reach, obs_reach, c->max_radius);
     } else if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, c->stream, d, c->P,
+        hipLaunchKernelGGL(k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->P,
                            agent_reach, obs_reach, c->max_radius);
     } else
         hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
-                           c->stream, d, c->P, agent_reach, obs_reach, c->max_radius);
+                           ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
+    if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
     if (overlap) {
+        // the re-plan count of this pass for a later pass's launch decision: on the side stream, every 4th pass, never waited for
+        if (!c->trk_count_pending && (c->trk_passes++ & 3u) == 0) {
+            CHK(c, hipMemcpyAsync(c->trk_host_count, c->trk.count + parity_now, sizeof(int), hipMemcpyDeviceToHost, ns));
+            CHK(c, hipEventRecord(c->trk_count_ev, ns));
+            c->trk_count_pending = true;
+        }
+        CHK(c, hipEventRecord(c->trk_join, ns));
         CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));
         hipLaunchKernelGGL(k_prep_shard, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     }
-    if (timed || prof) CHK(c, hipEventRecord(e1, c->stream));
+    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
-    if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));         // [e1, e2] = k_solve (+ k_lp) (what rocprofv3 reports for them)
+    if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)
     // epilogue (one lane per agent) + the agents without any suitable candidate (rare; one wavefront each), one launch
     const int ablocks = (cnt + 255) / 256;
     if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
@@ -1029,6 +1068,7 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     if (!c->near_valid && c->nbr_mode == SCA_NBR_GRID) {                  // the fallback reads the grid: make it describe these records
         c->grid.skip_prep = 1;
+        c->nbr_stream = c->stream;
         if (int r = build_agent_grid_device(c)) return r;
     }
     c->near_valid = false;
@@ -1041,7 +1081,7 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
                            c->state_fresh ? 1 : 0);
     c->state_fresh = false;
     if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
-    if (timed) CHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (timed) CHK(c, hipEventRecord(c->ev[5], c->stream));
     CHK(c, hipGetLastError());
     std::swap(d.rec, d.rec_new);
     c->h_pos_valid = false;
@@ -1059,20 +1099,20 @@ int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
     CHK(c, hipStreamSynchronize(c->stream));
     if (neighbor_mode == SCA_NBR_KDTREE) { if (int r = check_kd_overflow(c)) return r; }
     CHK(c, hipEventElapsedTime(&c->ms_nbr, c->ev[0], c->ev[1]));
-    CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[1], c->ev[2]));
+    CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[2], c->ev[3]));
     return 0;
 }
 
 int sca_env_update(sca_ctx *c, int *all_done) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
-    CHK(c, hipEventRecord(c->ev[2], c->stream));
+    CHK(c, hipEventRecord(c->ev[4], c->stream));
     if (int r = launch_update(c, true)) return r;
     if (all_done) {
         std::vector<int32_t> parts(256 * 32);
         CHK(c, hipMemcpyAsync(parts.data(), c->d.done_count, sizeof(int32_t) * parts.size(), hipMemcpyDeviceToHost, c->stream));
         CHK(c, hipStreamSynchronize(c->stream));
-        CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[2], c->ev[3]));
+        CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[4], c->ev[5]));
         int active = 0;
         for (int v : parts) active += v;
         *all_done = (active == 0);
@@ -1180,13 +1220,13 @@ int sca_synchronize(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
     CHK(c, hipStreamSynchronize(c->stream));
     if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
-    if (c->profiling && c->pool_used >= 3) {
+    if (c->profiling && c->pool_used >= 4) {
         double a = 0, b = 0;
-        const int steps = c->pool_used / 3;
+        const int steps = c->pool_used / 4;
         for (int s = 0; s < steps; s++) {
             float t0 = 0, t1 = 0;
-            CHK(c, hipEventElapsedTime(&t0, c->pool[3 * s], c->pool[3 * s + 1]));
-            CHK(c, hipEventElapsedTime(&t1, c->pool[3 * s + 1], c->pool[3 * s + 2]));
+            CHK(c, hipEventElapsedTime(&t0, c->pool[4 * s], c->pool[4 * s + 1]));          // K1, on the stream it ran on
+            CHK(c, hipEventElapsedTime(&t1, c->pool[4 * s + 2], c->pool[4 * s + 3]));      // k_solve (+ k_lp)
             a += t0; b += t1;
         }
         c->ms_nbr = (float)(a / steps); c->ms_solve = (float)(b / steps);
@@ -1212,6 +1252,7 @@ int sca_set_profiling(sca_ctx *c, int on) {
     c->profiling = on != 0;
     c->pool_used = 0;
     c->pool_trk_used = 0;
+    c->prof_tick = 0;
     return 0;
 }
 
