@@ -72,6 +72,9 @@ enum sca_status_bit {             /* per-agent status word of the last policy pa
     SCA_ST_BAD_PREF_SPEED = 4,    /* np.arange(0.5, ps+0.03, ps-0.5) does not have 2 elements (scaPolicy.py:195) */
     SCA_ST_KD_STACK = 16,         /* kd traversal stack overflow (tree deeper than 48) */
     SCA_ST_NBR_OVERFLOW = 32,     /* grid mode: > max_neighbors in range, reference list is visit-order dependent */
+    SCA_ST_VPREF_EDGE = 128,      /* straight-line v_pref (rvo3dPolicy.py:182-196): one of its 5-decimal roundings sat within 1e-9 of
+                                     flipping.  On identical inputs the pass is the reference's bit for bit; in a free-running episode
+                                     positions carry ~1e-14 m of sin / cos rounding noise, which matters exactly here */
     SCA_ST_TRACKER_EDGE = 64      /* device tracker: a 5-decimal rounding between the tracked path node and this pass's v_pref sat within
                                      1e-8 m of flipping (scaPolicy.py:329-338, util.py:104); the device's libm is not glibc's, so the
                                      reference's v_pref may be one 1e-5 step away (the velocity picked from it can then differ) */

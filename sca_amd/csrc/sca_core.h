@@ -35,6 +35,7 @@ enum Status : int32_t {
     ST_KD_STACK = 16,          // kd traversal stack overflow
     ST_NBR_OVERFLOW = 32,      // grid mode: more than K objects in range (reference list is order dependent)
     ST_TRACKER_EDGE = 64,      // device tracker: this pass's v_pref crossed a rounding within noise of flipping (sca_dubins.hpp)
+    ST_VPREF_EDGE = 128,       // straight-line v_pref: a 5-decimal rounding of it sat within 1e-9 of flipping (straight_v_pref)
 };
 constexpr int NBR_OBSTACLE_BIT = 1 << 30;
 
@@ -172,12 +173,25 @@ SCA_HD void cartesian2spherical(double yaw, double pitch, V3 v, bool official, d
 }
 
 // straight-line compute_v_pref: rvo3dPolicy.py:182-196 (l3norm) / orca3dPolicy.py:348-362 (distance)
-SCA_HD V3 straight_v_pref(V3 goal, V3 pos, double pref_speed, bool use_distance) {
+// *edge (optional): set when one of the 5-decimal roundings on the way -- the rounded norm (util.py:104 / :140), the truncation of
+// the three components (:195) -- sits within 1e-9 of flipping.  On identical inputs this function is the reference's bit for
+// bit; in a free-running episode the positions differ from the reference's by the rounding noise of sin / cos in
+// update_velocitie (~1e-14 m), which can only matter at such an edge: SCA_ST_VPREF_EDGE tells the caller where.
+SCA_HD V3 straight_v_pref(V3 goal, V3 pos, double pref_speed, bool use_distance, bool *edge = nullptr) {
     V3 zero = v3(0, 0, 0);
     V3 dif = goal - pos;
     double nrm = use_distance ? distance5(dif, zero) : l3norm(dif, zero);
     nrm = trunc5(nrm);
     V3 v = v3(dif.x * pref_speed / nrm, dif.y * pref_speed / nrm, dif.z * pref_speed / nrm);
+    if (edge) {
+        const double r = sqrt(dot(dif, dif)) + (use_distance ? 1e-5 : 0.0), y = r * EPS5;
+        bool e = fabs(fabs(y - floor(y) - 0.5)) < 1e-4;                                  // round(., 5) near a tie
+        const double c[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; k++) { const double q = c[k] * EPS5; if (fabs(q - rint(q)) < 1e-4 && q != 0.0) e = true; }   // int(. * 1e5) near a step
+        const double g = sqrt(dot(dif, dif)) * EPS5;                                     // util.reached: l3norm(goal, pos) < 0.2
+        if (fabs(g - 19999.5) < 1e-4) e = true;
+        *edge = e;
+    }
     if (l3norm(goal, pos) < 0.2) v = zero;                 // util.reached :23
     return trunc5(v);
 }

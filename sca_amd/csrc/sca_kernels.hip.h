@@ -653,7 +653,8 @@ struct alignas(16) Prep {
     double rad1;           // second element of np.arange(0.5, ps + 0.03, ps - 0.5)
     unsigned vp_key;       // round5 numerator of |v_pref - v_pref| (= 0) << 10, without the index
     unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint, 8 v_pref came over a rounding
-                           // edge of the device tracker; bits 8..: get_phi numerator of v_pref
+                           // edge of the device tracker, 16 the straight-line v_pref sits on a rounding edge; bits 8..: get_phi
+                           // numerator of v_pref
 };
 static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
 
@@ -665,8 +666,9 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P,
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const double ps = d.pref_speed[agent];
     V3 vpref;
+    bool vedge = false;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
-    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca, &vedge);
     Prep r;
     r.vpref[0] = vpref.x; r.vpref[1] = vpref.y; r.vpref[2] = vpref.z;
     r.nvA = (double)normf(vA);
@@ -677,6 +679,7 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P,
     r.rad1 = rad1;
     if (posture_ok(P, vA, r.nvA, pA.z, vpref)) bits |= 4u;
     if (d.vpref_mode[agent] && d.vpref_edge[agent]) bits |= 8u;
+    if (vedge) bits |= 16u;
     double kn;
     l3norm(vpref, vpref, &kn);
     r.vp_key = pack_key(kn, 0);
@@ -856,8 +859,10 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     const double ps = d.pref_speed[agent];
     int st = (d.vpref_mode[agent] && d.vpref_edge[agent]) ? ST_TRACKER_EDGE : 0;
     V3 vpref;
+    bool vedge = false;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
-    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca, &vedge);
+    if (vedge) st |= ST_VPREF_EDGE;
     const bool first_step = l3norm_f32zero(vA, orca) <= 1e-5;                        // scaPolicy.py:34 / orca3dPolicy.py:53
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
     V3 vpost;
@@ -1095,7 +1100,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
     const Prep pr = ((const Prep *)d.prep)[agent];        // per-agent scalar prologue (prep_agent)
-    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0);
+    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
@@ -1406,7 +1411,8 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t
     d.vpost[agent * 3 + 0] = nv.x; d.vpost[agent * 3 + 1] = nv.y; d.vpost[agent * 3 + 2] = nv.z;      // :113: not truncated
     diag[0] = -1; diag[1] = -1; diag[2] = -1; diag[3] = pf; diag[4] = 0;
     d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
-    if (pr.bits & 2u) atomicOr(&d.status[agent], ST_BAD_PREF_SPEED);
+    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    if (st) atomicOr(&d.status[agent], st);
 }
 
 __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {

@@ -79,7 +79,7 @@ def test_grid_pass_vs_golden(S, name):
         valid = fx['nbr_valid'][t].astype(bool)
         assert np.array_equal(nb['nbr_valid'].astype(bool), valid), ctx
         over = (dg['status'] & OVERFLOW) != 0
-        assert not (dg['status'] & ~OVERFLOW).any(), ctx
+        assert not (dg['status'] & ~(OVERFLOW | 64 | 128)).any(), ctx       # the two edge bits are informational
         # a list of fewer than 16 entries never overflowed (a collision cleared list may have: then the bit is spurious but allowed)
         rows = valid & ~over
         compare_lists(nb, fx['nbr_n'][t], fx['nbr_id'][t], fx['nbr_kind'][t], fx['nbr_dsq'][t], rows, ctx)

@@ -59,7 +59,8 @@ def test_policy_pass_vs_golden(S, name):
         assert np.array_equal(nb['nbr_dsq'][ag], fx['nbr_dsq'][t][ag]), ctx
         assert np.allclose(nb['nbr_dsq'][valid], fx['nbr_dsq'][t][valid], rtol=4e-16, atol=0), ctx
         dg = sol.diag()
-        assert not dg['status'].any(), ctx + (dg['status'][dg['status'] != 0],)
+        hard = dg['status'] & ~(64 | 128)                    # SCA_ST_TRACKER_EDGE / SCA_ST_VPREF_EDGE are informational
+        assert not hard.any(), ctx + (hard[hard != 0],)
         called = fx['called'][t].astype(bool)
         own = called & ~st['vpref_mode'].astype(bool)
         assert np.array_equal(dg['vpref'][own], fx['vpref'][t][own]), ctx + ('v_pref',)
@@ -655,3 +656,47 @@ def test_lp_lane_per_agent_form_equals_wave_form(S, oracle, monkeypatch):
     assert np.array_equal(a1[:, :4], ref['action'][:, :4])
     assert np.array_equal(d1['diag'][:, 3:5], ref['diag'][:, 3:5])
     assert (d1['diag'][:, 3] < 16).any()                      # some agents went through LP4
+
+
+def test_free_running_episode_first_deviation_is_flagged(S, oracle):
+    """Closed loop, nothing re-synchronised: 1500 RVO3D / ORCA3D agents stepped resident on the device and by the oracle on the
+    host.  On identical inputs a pass is the reference's bit for bit, but the device's sin / cos in update_velocitie differ from
+    glibc's in the last bit, positions drift by ~1e-14 m, and that can flip a 5-decimal rounding of the straight-line v_pref
+    (rvo3dPolicy.py:182-196) -- after which the two runs are different episodes.  The agent-step where a velocity first differs
+    from the oracle's must carry SCA_ST_VPREF_EDGE; few agent-steps carry it at all (measured 1.3 %: more than the 0.08 % a
+    uniform distribution would give, because an agent that flies trunc5(v_pref) steers v_pref onto the 5-decimal grid)."""
+    from sca_amd import scenarios
+    n, steps = 1500, 250
+    sc = scenarios.random_cube(n, seed=17)
+    s = _scenario_state(S, sc, np.where(np.arange(n) % 2 == 0, 1, 3))
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
+    sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
+    pos, vel, head, flags = s['pos'].copy(), s['vel'].copy(), s['heading'].copy(), s['flags'].copy()
+    td = np.zeros(n); sn = np.zeros(n, np.int32); perm = np.arange(n, dtype=np.int32)
+    flagged = served = 0
+    first = None
+    for t in range(steps):
+        sol.run_steps(1)
+        sol.synchronize()
+        st = sol.diag()['status']
+        r = oracle.policy_step(pos, vel, head, s['radius'], s['pref_speed'], flags, s['goal'], s['policy'], s['zaxis'],
+                               np.zeros((n, 3)), np.zeros(n, np.uint8), perm, s['obs_pos'], s['obs_radius'], nthreads=8)
+        perm = r['perm']
+        active = (flags & 7) == 0
+        u = oracle.env_update(pos, vel, head, s['radius'], r['flags'], s['goal'], r['action'], td, s['max_run_dist'], sn,
+                              s['obs_pos'], s['obs_radius'])
+        pos, vel, head, flags, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+        g = sol.get_state()
+        served += int(active.sum()); flagged += int(((st & 128) != 0)[active].sum())
+        diff = np.nonzero((g['vel'] != vel).any(axis=1))[0]
+        if diff.size:
+            first = (t, diff, st[diff])
+            break
+    print('served', served, 'flagged', flagged, 'first deviation', None if first is None else (first[0], first[1][:5], first[2][:5]))
+    assert flagged <= 0.03 * served, (flagged, served)
+    if first is not None:
+        t, who, stw = first
+        assert ((stw & 128) != 0).all(), first
+    sol.close()
