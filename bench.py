@@ -157,6 +157,8 @@ def roofline_of(leg, steps, tracked, wname):
     k_replan = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                 'traffic': measured_traffic(wname, 'k_replan'), 'kernel': 'k_replan (+ k_replan_few), on its own stream beside the kd build',
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
+                'valu_issue_frac': (_pmc(wname).get('k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
+                                    / VALU_PEAK_WAVE_INSTS) or None,
                 'note': 'a sequential fp64 search per plan (~65 candidate radii x 13 arctangents): pure compute, the HBM fraction is '
                         'reported as required'}
     return k_replan, k_solve
