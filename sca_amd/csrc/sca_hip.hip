@@ -188,6 +188,8 @@ struct sca_ctx {
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
     int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
+    int solve_split = -1;               // k_solve in two launches (k_solve_sweep beside the re-plans, k_solve_pick behind them): -1 when the
+                                        // tracker is overlapped, 0 never, 1 always (SCA_SOLVE_SPLIT; the parity tests run both)
     int k1_force = -1;                  // K1 variant: -1 choose by shard size, 0 one agent per wavefront, 1 four (k_neighbors_kd4)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
     bool agents_set = false, state_set = false;
@@ -466,6 +468,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0;
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
+    if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     int ndev = 0;
     CHK(c, hipGetDeviceCount(&ndev));
@@ -565,7 +568,7 @@ void sca_destroy(sca_ctx *c) {
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
                     c->grid.count, c->grid.range, c->grid.cursor, c->grid.bucket, c->grid.slot, c->grid.gx, c->grid.gy, c->grid.gz,
-                    c->grid.gid, c->grid.gkey, c->lp_list};
+                    c->grid.gid, c->grid.gkey, c->lp_list, d.sw_slot, d.sw_surv, d.sw_n};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
@@ -957,6 +960,20 @@ static void choose_lp_form(sca_ctx *c, int &lo, int &hi) {
     if (f && f[0] == 'w') c->d.lp_kernel = 0;
 }
 
+// k_solve as k_solve_sweep (beside the re-plans) + k_solve_pick (behind them)?  It pays while the re-plans are the longer
+// branch of the pass: the lane-per-plan kernel takes ~0.2 + 0.235 * (wavefronts per SIMD, rounded up) ms whatever the
+// count inside a round, the neighbour chain grows with the shard.  Measured on the circle (96 % of the agents re-plan per
+// step), shard sizes 24 576 ... 262 144: a gain of 5-10 % of the step up to 61 440 agents in the first round and up to
+// ~114 000 in the second, a loss of 3-7 % elsewhere (the sweep then lengthens the branch that already ends last).
+static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
+    if (c->solve_split >= 0) return c->solve_split != 0;
+    if (!overlap) return false;
+    const int est = c->trk_last_count >= 0 ? c->trk_last_count : cnt;    // re-plans of a recent pass (all agents before the first readback)
+    if (est <= c->trk.quad_max + c->trk.quad_max / 4) return false;     // the many-lanes-per-plan forms: short re-plans, nothing to hide behind
+    const int rounds = (est + 65535) / 65536;
+    return rounds == 1 ? cnt <= 61440 : (rounds == 2 ? cnt <= 114688 : false);
+}
+
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
     int lp_lo = 0, lp_hi = 0;
     choose_lp_form(c, lp_lo, lp_hi);
@@ -1025,6 +1042,17 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                            ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
+    // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
+    const bool split = choose_solve_split(c, overlap, cnt);
+    if (split) {
+        if (!c->d.sw_slot) {
+            const size_t N = (size_t)c->max_n;
+            CHK(c, hipMalloc((void **)&c->d.sw_slot, sizeof(double) * N * K_MAX * SLOTF));
+            CHK(c, hipMalloc((void **)&c->d.sw_surv, sizeof(uint16_t) * N * 512));
+            CHK(c, hipMalloc((void **)&c->d.sw_n, sizeof(int32_t) * N));
+        }
+        hipLaunchKernelGGL(k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, ns, d, c->P);
+    }
     if (overlap) {
         // the re-plan count of this pass for a later pass's launch decision: on the side stream, every 4th pass, never waited for
         if (!c->trk_count_pending && (c->trk_passes++ & 3u) == 0) {
@@ -1037,7 +1065,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_prep_shard, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     }
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
-    hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (split) hipLaunchKernelGGL(k_solve_pick, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    else hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
     if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)

@@ -101,6 +101,10 @@ struct DeviceView {
     int hist_cap, hist_row;
     int n, m, shard_begin, shard_count;
     int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
+    // k_solve in two launches (k_solve_sweep / k_solve_pick, see solve_fast): what the first leaves for the second
+    double *sw_slot;         // [n][K_MAX][SLOTF] cones / planes of the agent's neighbours
+    uint16_t *sw_surv;       // [n][512] generation indices of the table candidates outside every cone / inside every half-space
+    int32_t *sw_n;           // [n] how many
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1084,11 +1088,19 @@ struct FastLds {
     } u[SOLVE_WAVES];
 };
 
+// PHASE 0: the whole of it in one launch (k_solve).  Nothing up to the list of table candidates that survive the cones depends
+// on v_pref -- the cones, the posture filter and the sweep read positions, velocities and the static tables only -- so a pass
+// whose v_pref comes from the device tracker runs that part (PHASE 1, k_solve_sweep) beside the re-plans, on the stream of
+// the neighbour query, and only the rest behind them (PHASE 2, k_solve_pick: distances to v_pref, the v_pref candidate
+// itself, the selection).  Phase 1 leaves the cones and the survivors' generation indices in global memory; the same
+// statements run in the same order either way, so the split changes no bit.
+template <int PHASE>
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
-    if (lane == 0) d.is_fb[agent] = 0;
+    if (PHASE != 1 && lane == 0) d.is_fb[agent] = 0;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
+        if (PHASE == 1) return;
         if (lane < 8) diag[lane] = -1;
         if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
         return;
@@ -1099,7 +1111,19 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
-    const Prep pr = ((const Prep *)d.prep)[agent];        // per-agent scalar prologue (prep_agent)
+    Prep pr;                                              // per-agent scalar prologue (prep_agent)
+    if (PHASE == 1) {
+        // the prologue of this pass is written behind the re-plans (it holds v_pref); what the sweep reads of it, recomputed
+        // by the same expressions (prep_agent): bootstrap test, |vA|, the second candidate speed
+        pr.vpref[0] = pr.vpref[1] = pr.vpref[2] = 0.0;
+        pr.nvA = (double)normf(vA);
+        pr.bits = (l3norm_f32zero(vA, orca) <= 1e-5) ? 1u : 0u;
+        double rad1;
+        if (!candidate_speeds(d.pref_speed[agent], rad1)) rad1 = d.pref_speed[agent];
+        pr.rad1 = rad1;
+        pr.vp_key = 0;
+        if (pol == POL_ORCA_LP || (pr.bits & 1u)) return;                            // no candidate sweep for these
+    } else pr = ((const Prep *)d.prep)[agent];
     int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
@@ -1112,7 +1136,14 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
         double (*slot)[SLOTF] = S.slot[wid];
-        if (lane < K) {                                   // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
+        if (PHASE == 2 && pol != POL_ORCA_LP) {           // the cones / planes k_solve_sweep built
+            if (lane < K) {
+                const double *g = d.sw_slot + ((size_t)agent * K_MAX + lane) * SLOTF;
+                double *sl = slot[lane];
+#pragma unroll
+                for (int q = 0; q < 7; q++) sl[q] = g[q];
+            }
+        } else if (lane < K) {                            // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
             const int nid = d.nbr_id[agent * K_MAX + lane];
             V3 pB; F3 vB; double rB; bool stat; const bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
             if (isob) {
@@ -1131,7 +1162,12 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 const OrcaOb o = make_orca(P, pA, vA, rA, pB, vB, rB, isob);
                 sl[0] = o.pl.p.x; sl[1] = o.pl.p.y; sl[2] = o.pl.p.z; sl[3] = o.pl.n.x; sl[4] = o.pl.n.y; sl[5] = o.pl.n.z; sl[6] = 0.0;
                 Plane pl; pl.p = o.pl.p; pl.n = o.pl.n;
-                S.u[wid].lp.planes[lane] = pl;
+                if (pol == POL_ORCA_LP) S.u[wid].lp.planes[lane] = pl;
+            }
+            if (PHASE == 1) {
+                double *g = d.sw_slot + ((size_t)agent * K_MAX + lane) * SLOTF;
+#pragma unroll
+                for (int q = 0; q < 7; q++) g[q] = sl[q];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1165,7 +1201,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             const double T2 = tn * tn;
             // Both speeds of a direction share the verdict whenever it is "sure": c = dot / (|vA||v|) does not depend on the
             // candidate's length beyond rounding (<= 1e-15 relative here, the margin is 1e-13); the z floor is per speed.
-            int nA = 0;
+            int nA = 0, nS = 0;
+            if (PHASE != 2) {
             const bool filter_ok = thr > 1e-6;
             const int ndir = T.num_N >> 6;
             // util.py:16 `pos.z + dt * v.z >= 0` holds for every candidate once the agent is higher than the fastest one can sink
@@ -1196,11 +1233,13 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             __builtin_amdgcn_wave_barrier();
             // ---- sweep of the compacted candidates; survivors -> packed keys.  Full groups of 128: two candidates per lane;
             //      then one group of 64; a tail of <= 32 candidates splits the neighbours across lane groups instead.
-            int nS = 0;
+            uint16_t *surv = PHASE == 1 ? d.sw_surv + (size_t)agent * 512 : nullptr;
             auto emit = [&](bool a, V3 cdq, int ixq) {
                 const unsigned long long m = __ballot(a);
                 if (a) {
-                    pkS[nS + __popcll(m & ((1ull << lane) - 1ull))] = pack_key(l3norm_num(cdq, vpref), ixq);   // scaPolicy.py:219
+                    const int at = nS + __popcll(m & ((1ull << lane) - 1ull));
+                    if (PHASE == 1) surv[at] = (uint16_t)ixq;
+                    else pkS[at] = pack_key(l3norm_num(cdq, vpref), ixq);                                       // scaPolicy.py:219
                 }
                 nS += __popcll(m);
             };
@@ -1242,6 +1281,16 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                     for (int w = 32; w >= Rp; w >>= 1) m |= m >> w;                       // OR over the neighbour groups
                     emit((lane < rem) & !((m >> t) & 1ull), cd, ix);
                     c0 += rem;
+                }
+            }
+            if (PHASE == 1) { if (lane == 0) d.sw_n[agent] = nS; return; }
+            } else {
+                // the survivors of k_solve_sweep: their distance to v_pref (scaPolicy.py:219) into the packed keys
+                nS = d.sw_n[agent];
+                const uint16_t *surv = d.sw_surv + (size_t)agent * 512;
+                for (int e = lane; e < nS; e += 64) {
+                    const int ix = (int)surv[e];
+                    pkS[e] = pack_key(l3norm_num(cand_from_idx(T, ix, vpref), vpref), ix);
                 }
             }
             // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j
@@ -1349,7 +1398,22 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Par
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast(d, P, S, agent, lane, wid);
+    if (agent < d.shard_begin + d.shard_count) solve_fast<0>(d, P, S, agent, lane, wid);
+}
+// the two halves of k_solve for passes whose v_pref arrives late (solve_fast)
+__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve_sweep(DeviceView d, Params P) {
+    __shared__ FastLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) solve_fast<1>(d, P, S, agent, lane, wid);
+}
+__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve_pick(DeviceView d, Params P) {
+    __shared__ FastLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
+    if (agent < d.shard_begin + d.shard_count) solve_fast<2>(d, P, S, agent, lane, wid);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -37,7 +37,10 @@ struct TrackDev {
 
 constexpr int TRK_QUAD_MAX = 20480;       // re-plans per pass up to which the four-lanes-per-plan form is used (measured crossover with the
                                           // lane-per-plan kernel: 19 k plans 0.54 vs 0.58 ms per step, 31 k plans 0.65 vs 0.61)
-constexpr int TRK_REPLAN_LANES = 64;      // one wavefront per workgroup: re-plans spread over as many CUs as possible
+constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one per SIMD of a CU: the dispatcher then loads the SIMDs evenly
+                                          // (65 536 plans as 1024 one-wave workgroups: 0.63 ms, some SIMDs drew two; as 256 of these: 0.44)
+                                          // and, above one wave per SIMD, doubles up whole CUs, which leaves the others room for the
+                                          // 512-thread workgroups of the kd build running beside the re-plans (k_kd_block 154 -> 99 us at c4)
 
 __device__ __forceinline__ bool track_active(const DeviceView &d, int agent) {
     const int pol = d.policy[agent];

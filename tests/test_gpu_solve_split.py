@@ -1,0 +1,111 @@
+"""k_solve in two launches (k_solve_sweep beside the tracker's re-plans, k_solve_pick behind them; sca_kernels.hip.h,
+solve_fast): the split must not change a bit.  SCA_SOLVE_SPLIT=1 forces it for every pass (it is normally chosen only for
+large tracked shards), =0 forbids it.
+
+* every golden episode fixture of the reference through the forced split: actions, n_suit, fallback flags as recorded from
+  scaPolicy.py / rvo3dPolicy.py / srvo3dPolicy.py / orca3dPolicy.py;
+* big scenes of every policy, stepped resident for whole episodes in both forms: state, actions, diagnostics equal;
+* the real thing: a tracked shard with the sweep on the side stream beside the re-plans against the one-launch form.
+"""
+import numpy as np
+import pytest
+
+from golden_util import episode_fixtures, load, static_inputs
+from test_gpu_parity import check_actions, make_solver
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def S():
+    import sca_amd.solver as S
+    return S
+
+
+@pytest.mark.parametrize('name', episode_fixtures())
+def test_forced_split_vs_golden(S, name, monkeypatch):
+    monkeypatch.setenv('SCA_SOLVE_SPLIT', '1')
+    fx = load(name)
+    st = static_inputs(fx)
+    sol = make_solver(S, fx, st)
+    T = len(fx['step'])
+    for t in range(0, T, max(1, T // 40)):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_kd_perm(fx['perm'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        sol.policy_pass(S.NBR_KDTREE)
+        ctx = (name, t)
+        dg = sol.diag()
+        sel = fx['n_suit'][t] >= 0
+        assert np.array_equal(dg['diag'][sel, 0], fx['n_suit'][t][sel]), ctx + ('n_suit',)
+        assert np.array_equal(dg['diag'][sel, 1], fx['fallback'][t][sel]), ctx + ('fallback',)
+        check_actions(sol.actions(), fx['action'][t], ctx)
+    sol.close()
+
+
+def _pair(S, monkeypatch, sc, policy, tracker=False):
+    from sca_amd import scenarios
+    n = len(sc['start'])
+    sols = []
+    for split in ('0', '1'):
+        monkeypatch.setenv('SCA_SOLVE_SPLIT', split)                      # read by sca_create
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])))
+        sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], policy, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        if tracker:
+            sol.device_tracker_enable(sc['goal'][:, 3:6])
+        sols.append(sol)
+    return sols
+
+
+def _same(a, b, ctx):
+    sa, sb = a.get_state(), b.get_state()
+    for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+        assert np.array_equal(sa[k], sb[k]), ctx + (k,)
+    assert np.array_equal(a.actions(), b.actions(), equal_nan=True), ctx + ('actions',)
+    da, db = a.diag(), b.diag()
+    assert np.array_equal(da['diag'], db['diag']), ctx + ('diag',)
+    assert np.array_equal(da['status'], db['status']), ctx + ('status',)
+    assert np.array_equal(da['vpref'], db['vpref'], equal_nan=True), ctx + ('vpref',)
+
+
+@pytest.mark.parametrize('kind,n,pol,steps', [('circle', 2048, 0, 40), ('random', 4096, 1, 25), ('random', 4096, 2, 25),
+                                              ('random', 4096, 3, 25), ('takeoff', 1024, -1, 60), ('random', 20000, -2, 12)])
+def test_split_episode_equals_one_launch_episode(S, monkeypatch, kind, n, pol, steps):
+    from sca_amd import scenarios
+    sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=5),
+          'takeoff': lambda: scenarios.takeoff_landing(n)}[kind]()
+    nn = len(sc['start'])
+    if pol == -1:
+        policy = np.where(np.arange(nn) % 2 == 0, 0, 2)
+    elif pol == -2:
+        policy = np.arange(nn) % 5                                      # all five policies in one shard, LP agents included
+    else:
+        policy = np.full(nn, pol)
+    one, two = _pair(S, monkeypatch, sc, policy.astype(np.uint8))
+    for t in range(steps):
+        one.run_steps(1)
+        two.run_steps(1)
+        one.synchronize(); two.synchronize()
+        _same(one, two, (kind, n, pol, t))
+    assert one.active_count() == two.active_count()
+    one.close(); two.close()
+
+
+@pytest.mark.parametrize('n', [700, 30000])
+def test_split_beside_the_replans_equals_one_launch(S, monkeypatch, n):
+    """Tracker in the pass: k_solve_sweep runs on the neighbour stream while the re-plans run on the main one
+    (30 000 agents: the lane-per-plan kernel, the configuration the split is chosen for; 700: the speculative forms)."""
+    from sca_amd import scenarios
+    sc = scenarios.circle(n)
+    policy = np.where(np.arange(n) % 7 == 3, 3, 0).astype(np.uint8)       # SCA, every seventh agent ORCA3D (not tracked)
+    one, two = _pair(S, monkeypatch, sc, policy, tracker=True)
+    for t in range(14):
+        one.run_steps(1)
+        two.run_steps(1)
+        one.synchronize(); two.synchronize()
+        _same(one, two, ('tracked', n, t))
+    assert np.array_equal(one.device_tracker_replans(), two.device_tracker_replans())
+    one.close(); two.close()
