@@ -188,7 +188,7 @@ struct sca_ctx {
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
     int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
-    int solve_split = -1;               // k_solve in two launches (k_solve_sweep beside the re-plans, k_solve_pick behind them): -1 when the
+    int solve_split = -1;               // k_solve in two launches (k_solve_sweep beside the re-plans, k_solve_pick4 behind them): -1 when the
                                         // tracker is overlapped, 0 never, 1 always (SCA_SOLVE_SPLIT; the parity tests run both)
     int k1_force = -1;                  // K1 variant: -1 choose by shard size, 0 one agent per wavefront, 1 four (k_neighbors_kd4)
     bool perm_on_device = false;        // the live agentIDs permutation is d.aperm (device build) rather than h_perm
@@ -960,7 +960,7 @@ static void choose_lp_form(sca_ctx *c, int &lo, int &hi) {
     if (f && f[0] == 'w') c->d.lp_kernel = 0;
 }
 
-// k_solve as k_solve_sweep (beside the re-plans) + k_solve_pick (behind them)?  It pays while the re-plans are the longer
+// k_solve as k_solve_sweep (beside the re-plans) + k_solve_pick4 (behind them)?  It pays while the re-plans are the longer
 // branch of the pass: the lane-per-plan kernel takes ~0.2 + 0.235 * (wavefronts per SIMD, rounded up) ms whatever the
 // count inside a round, the neighbour chain grows with the shard.  Measured on the circle (96 % of the agents re-plan per
 // step), shard sizes 24 576 ... 262 144: a gain of 5-10 % of the step up to 61 440 agents in the first round and up to
@@ -982,6 +982,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // v_pref) then moves from k_kd_gather to k_prep_shard behind the join
     const bool tracked = c->trk_on && c->trk_in_pass;
     const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
+    // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
+    const bool split = choose_solve_split(c, overlap, d.shard_count);
+    if (split && lp_hi > lp_lo) c->d.lp_kernel = 1;                     // k_solve_pick4 carries no LP: its agents go to k_lp
     c->kd.skip_prep = overlap ? 1 : 0;
     c->grid.skip_prep = overlap ? 1 : 0;
     if (mode == SCA_NBR_GRID) {
@@ -1042,8 +1045,6 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                            ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
-    // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
-    const bool split = choose_solve_split(c, overlap, cnt);
     if (split) {
         if (!c->d.sw_slot) {
             const size_t N = (size_t)c->max_n;
@@ -1065,7 +1066,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_prep_shard, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     }
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
-    if (split) hipLaunchKernelGGL(k_solve_pick, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (split) {
+        const int per_block = SOLVE_WAVES * PICK_APW;
+        hipLaunchKernelGGL(k_solve_pick4, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    }
     else hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);

@@ -101,7 +101,7 @@ struct DeviceView {
     int hist_cap, hist_row;
     int n, m, shard_begin, shard_count;
     int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
-    // k_solve in two launches (k_solve_sweep / k_solve_pick, see solve_fast): what the first leaves for the second
+    // k_solve in two launches (k_solve_sweep / k_solve_pick4, see solve_fast): what the first leaves for the second
     double *sw_slot;         // [n][K_MAX][SLOTF] cones / planes of the agent's neighbours
     uint16_t *sw_surv;       // [n][512] generation indices of the table candidates outside every cone / inside every half-space
     int32_t *sw_n;           // [n] how many
@@ -1091,9 +1091,9 @@ struct FastLds {
 // PHASE 0: the whole of it in one launch (k_solve).  Nothing up to the list of table candidates that survive the cones depends
 // on v_pref -- the cones, the posture filter and the sweep read positions, velocities and the static tables only -- so a pass
 // whose v_pref comes from the device tracker runs that part (PHASE 1, k_solve_sweep) beside the re-plans, on the stream of
-// the neighbour query, and only the rest behind them (PHASE 2, k_solve_pick: distances to v_pref, the v_pref candidate
-// itself, the selection).  Phase 1 leaves the cones and the survivors' generation indices in global memory; the same
-// statements run in the same order either way, so the split changes no bit.
+// the neighbour query, and only the rest behind them (k_solve_pick4 / solve_pick4 below: distances to v_pref, the v_pref
+// candidate itself, the selection).  Phase 1 leaves the cones and the survivors' generation indices in global memory; the
+// same expressions on the same values either way, so the split changes no bit.
 template <int PHASE>
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
@@ -1136,14 +1136,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
         double (*slot)[SLOTF] = S.slot[wid];
-        if (PHASE == 2 && pol != POL_ORCA_LP) {           // the cones / planes k_solve_sweep built
-            if (lane < K) {
-                const double *g = d.sw_slot + ((size_t)agent * K_MAX + lane) * SLOTF;
-                double *sl = slot[lane];
-#pragma unroll
-                for (int q = 0; q < 7; q++) sl[q] = g[q];
-            }
-        } else if (lane < K) {                            // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
+        if (lane < K) {                                   // lane j builds neighbour j (scaPolicy.py:47-60 / orca :57-107)
             const int nid = d.nbr_id[agent * K_MAX + lane];
             V3 pB; F3 vB; double rB; bool stat; const bool isob = (nid & NBR_OBSTACLE_BIT) != 0;
             if (isob) {
@@ -1202,7 +1195,6 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             // Both speeds of a direction share the verdict whenever it is "sure": c = dot / (|vA||v|) does not depend on the
             // candidate's length beyond rounding (<= 1e-15 relative here, the margin is 1e-13); the z floor is per speed.
             int nA = 0, nS = 0;
-            if (PHASE != 2) {
             const bool filter_ok = thr > 1e-6;
             const int ndir = T.num_N >> 6;
             // util.py:16 `pos.z + dt * v.z >= 0` holds for every candidate once the agent is higher than the fastest one can sink
@@ -1284,15 +1276,6 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 }
             }
             if (PHASE == 1) { if (lane == 0) d.sw_n[agent] = nS; return; }
-            } else {
-                // the survivors of k_solve_sweep: their distance to v_pref (scaPolicy.py:219) into the packed keys
-                nS = d.sw_n[agent];
-                const uint16_t *surv = d.sw_surv + (size_t)agent * 512;
-                for (int e = lane; e < nS; e += 64) {
-                    const int ix = (int)surv[e];
-                    pkS[e] = pack_key(l3norm_num(cand_from_idx(T, ix, vpref), vpref), ix);
-                }
-            }
             // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j
             bool vp_hit = false;
             if (lane < K) {
@@ -1400,20 +1383,163 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Par
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
     if (agent < d.shard_begin + d.shard_count) solve_fast<0>(d, P, S, agent, lane, wid);
 }
-// the two halves of k_solve for passes whose v_pref arrives late (solve_fast)
-__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve_sweep(DeviceView d, Params P) {
+// the first half of k_solve for passes whose v_pref arrives late (solve_fast); the second is k_solve_pick4
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, Params P) {
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
     if (agent < d.shard_begin + d.shard_count) solve_fast<1>(d, P, S, agent, lane, wid);
 }
-__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve_pick(DeviceView d, Params P) {
-    __shared__ FastLds S;
+
+
+// ------------------------------------------------------------------------------------------------
+// k_solve_pick4, FOUR AGENTS PER WAVEFRONT.  What is left of find_next_action behind the sweep is short per agent -- a few
+// dozen survivors, <= 16 neighbours for the v_pref candidate -- and a wavefront per agent spends most of its instructions on
+// 64-lane reductions and per-agent scalars.  Here an agent owns one 16-lane DPP row: lane j of the row tests neighbour j and
+// holds survivors j, j + 16, ...; every reduction is four DPP steps inside the row; rows finish independently.  Same
+// expressions as solve_fast<0> (the selection is order-free: the packed keys carry the generation index), so the result is
+// the one-launch kernel's bit for bit (tests/test_gpu_solve_split.py).
+constexpr int PICK_APW = 4;
+constexpr int PICK_CAP = 144;             // packed keys per agent cached in LDS (9 per lane); longer lists recompute the rest
+struct PickLds { unsigned int pk[SOLVE_WAVES][PICK_APW][PICK_CAP]; };
+
+__device__ __forceinline__ unsigned row_min_u32(unsigned x) {             // every lane of the row gets the row's minimum
+    int v = (int)x;
+    v = (int)umin32((unsigned)v, (unsigned)dpp_mov<0xb1, 0xf>(v));        // quad_perm [1,0,3,2]
+    v = (int)umin32((unsigned)v, (unsigned)dpp_mov<0x4e, 0xf>(v));        // quad_perm [2,3,0,1]
+    v = (int)umin32((unsigned)v, (unsigned)dpp_mov<0x124, 0xf>(v));       // row_ror:4
+    v = (int)umin32((unsigned)v, (unsigned)dpp_mov<0x128, 0xf>(v));       // row_ror:8
+    return (unsigned)v;
+}
+
+__device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P, unsigned int *pk, int agent, int j, int row) {
+    const PubRec me = d.rec[agent];
+    int32_t *diag = d.diag + (size_t)agent * 8;
+    if (j == 0) d.is_fb[agent] = 0;
+    if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
+        if (j < 8) diag[j] = -1;
+        if (j < 3) d.vpref_used[agent * 3 + j] = __builtin_nan("");
+        return;
+    }
+    const int pol = d.policy[agent];
+    const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
+    const V3 pA = v3(me.px, me.py, me.pz);
+    F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
+    const V3 vA64 = to_v3(vA);
+    const Prep pr = ((const Prep *)d.prep)[agent];
+    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
+    const bool first_step = (pr.bits & 1u) != 0;
+    int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1;
+    V3 vpost = v3(0, 0, 0);
+    bool defer = false;
+    const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    if (pol == POL_ORCA_LP && !first_step) return;                                   // K3: k_lp
+    if (first_step) {
+        vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
+    } else {
+        CandTab T;
+        T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;                     // scaPolicy.py:188-190
+        T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
+        T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
+        T.vp_idx = 2 * T.num_N;
+        T.rad1 = pr.rad1;
+        // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j against the cone / plane of the sweep
+        bool vp_hit = false;
+        if (j < K) {
+            const double *sl = d.sw_slot + ((size_t)agent * K_MAX + j) * SLOTF;
+            if (!orca) {
+                Cone c; c.apex = v3(sl[0], sl[1], sl[2]); c.pAB = v3(sl[3], sl[4], sl[5]); c.g = sl[6];
+                vp_hit = cone_hit(c, vpref + pA);
+            } else {
+                Plane pl; pl.p = v3(sl[0], sl[1], sl[2]); pl.n = v3(sl[3], sl[4], sl[5]);
+                vp_hit = !in_orca(pl, vpref);
+            }
+        }
+        const unsigned long long hits = __ballot(vp_hit);
+        const bool vp_ok = (pr.bits & 4u) && (((hits >> (16 * row)) & 0xffffull) == 0);
+        // ---- packed keys of the survivors: (round5 numerator of |v - v_pref|) << 10 | generation index (scaPolicy.py:219)
+        const int nT = d.sw_n[agent];
+        const uint16_t *surv = d.sw_surv + (size_t)agent * 512;
+        auto key_of = [&](int e) {
+            const int ix = (int)surv[e];
+            return pack_key(l3norm_num(cand_from_idx(T, ix, vpref), vpref), ix);
+        };
+        unsigned best = 0xffffffffu;
+        for (int e = j; e < nT; e += 16) {
+            const unsigned k = key_of(e);
+            if (e < PICK_CAP) pk[e] = k;
+            best = k < best ? k : best;
+        }
+        auto entry = [&](int e) { return e < PICK_CAP ? pk[e] : key_of(e); };       // a lane re-reads only what it wrote itself
+        const unsigned vpk = vp_ok ? (pr.vp_key | (unsigned)T.vp_idx) : 0xffffffffu;
+        const int nS = nT + (vp_ok ? 1 : 0);
+        dg_nsuit = nS;
+        if (nS == 0) {
+            // no suitable candidate: compute_without_suitV needs all 513 candidates -> the epilogue's second half finishes this agent
+            if (j == 0) { const int at = atomicAdd(d.fb_count, 1); d.fb_list[at] = agent; d.is_fb[agent] = 1; }
+            return;
+        }
+        dg_fallback = 0;
+        best = vpk < best ? vpk : best;
+        best = row_min_u32(best);
+        int chosen = (int)(best & 1023u);
+        const bool shunted = (pol == POL_SCA || pol == POL_SRVO);
+        if (shunted && nS > 1) {                                                         // scaPolicy.py:119-145, as in solve_fast
+            const double sthr = pol == POL_SCA ? 3e-2 : 1e-1;
+            const double kthr = pol == POL_SCA ? 3000.0 : 10000.0;
+            const double k0 = l3norm_num(cand_from_idx(T, chosen, vpref), vA64);
+            auto passes = [&](double kv) {
+                const double dk = fabs(k0 - kv);
+                bool pass = dk < kthr;
+                if (dk == kthr) pass = fabs(k0 / EPS5 - kv / EPS5) < sthr;
+                return pass;
+            };
+            unsigned fail = 0xffffffffu;                                                 // first list element that breaks the prefix
+            for (int e = j; e < nT; e += 16) {
+                const unsigned k = entry(e);
+                if (!passes(l3norm_num(cand_from_idx(T, (int)(k & 1023u), vpref), vA64))) fail = k < fail ? k : fail;
+            }
+            if (vp_ok) { if (!passes(l3norm_num(vpref, vA64))) fail = vpk < fail ? vpk : fail; }
+            fail = row_min_u32(fail);
+            unsigned pmin = 0xffffffffu, kpmin = 0xffffffffu, pmax = 0xffffffffu, kpmax = 0xffffffffu;   // pmax holds 0xfffff - phi
+            auto consider = [&](unsigned k) {
+                if (k < fail) {
+                    const int ci = (int)(k & 1023u);
+                    const unsigned ph = ci >= T.vp_idx ? (pr.bits >> 8) : (unsigned)T.phi[ci >= T.num_N ? ci - T.num_N : ci];
+                    const unsigned ih = 0xfffffu - ph;
+                    if (ph < pmin || (ph == pmin && k < kpmin)) { pmin = ph; kpmin = k; }
+                    if (ih < pmax || (ih == pmax && k < kpmax)) { pmax = ih; kpmax = k; }
+                }
+            };
+            for (int e = j; e < nT; e += 16) consider(entry(e));
+            consider(vpk);
+            const unsigned wpmin = row_min_u32(pmin), wpmax = row_min_u32(pmax);
+            const unsigned kmin = row_min_u32(pmin == wpmin ? kpmin : 0xffffffffu);
+            const unsigned kmax = row_min_u32(pmax == wpmax ? kpmax : 0xffffffffu);
+            const double phi_min = (double)wpmin / EPS5, phi_max = (double)(0xfffffu - wpmax) / EPS5;
+            chosen = (fabs(phi_max - phi_min) <= PI) ? (int)(kmin & 1023u) : (int)(kmax & 1023u);
+        }
+        dg_chosen = chosen;
+        defer = true;
+    }
+    if (j == 0) {
+        if (defer) d.is_fb[agent] = 2;
+        else { d.vpost[agent * 3 + 0] = vpost.x; d.vpost[agent * 3 + 1] = vpost.y; d.vpost[agent * 3 + 2] = vpost.z; }
+        diag[0] = dg_nsuit; diag[1] = dg_fallback; diag[2] = dg_chosen; diag[3] = -1; diag[4] = -1;
+        d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
+        if (st) atomicOr(&d.status[agent], st);
+    }
+}
+
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, Params P) {
+    __shared__ PickLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast<2>(d, P, S, agent, lane, wid);
+    const int row = lane >> 4;
+    const int agent = d.shard_begin + (blockIdx.x * SOLVE_WAVES + wid) * PICK_APW + row;
+    if (agent < d.shard_begin + d.shard_count) solve_pick4(d, P, S.pk[wid][row], agent, lane & 15, row);   // whole rows leave together
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""k_solve in two launches (k_solve_sweep beside the tracker's re-plans, k_solve_pick behind them; sca_kernels.hip.h,
+"""k_solve in two launches (k_solve_sweep beside the tracker's re-plans, k_solve_pick4 behind them; sca_kernels.hip.h,
 solve_fast): the split must not change a bit.  SCA_SOLVE_SPLIT=1 forces it for every pass (it is normally chosen only for
 large tracked shards), =0 forbids it.
 
@@ -43,13 +43,13 @@ def test_forced_split_vs_golden(S, name, monkeypatch):
     sol.close()
 
 
-def _pair(S, monkeypatch, sc, policy, tracker=False):
+def _pair(S, monkeypatch, sc, policy, tracker=False, params=None):
     from sca_amd import scenarios
     n = len(sc['start'])
     sols = []
     for split in ('0', '1'):
         monkeypatch.setenv('SCA_SOLVE_SPLIT', split)                      # read by sca_create
-        sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])))
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])), params=params)
         sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
         sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], policy, S.zaxis_flags(sc['start'], sc['goal']),
                        scenarios.max_run_dist(sc['start'], sc['goal']))
@@ -91,6 +91,25 @@ def test_split_episode_equals_one_launch_episode(S, monkeypatch, kind, n, pol, s
         one.synchronize(); two.synchronize()
         _same(one, two, (kind, n, pol, t))
     assert one.active_count() == two.active_count()
+    one.close(); two.close()
+
+
+@pytest.mark.parametrize('pol', [0, 1, 2, 3])
+def test_split_with_the_heading_limit_off(S, monkeypatch, pol):
+    """max_heading_change = pi: the posture constraint of util.py:6-20 passes every direction, the survivor lists grow to
+    hundreds of candidates -- beyond what k_solve_pick4 caches per agent (PICK_CAP), the recomputing path."""
+    import math
+    from sca_amd import scenarios
+    sc = scenarios.random_cube(1500, seed=11)
+    one, two = _pair(S, monkeypatch, sc, np.full(1500, pol, np.uint8), params=dict(max_heading_change=math.pi))
+    longest = 0
+    for t in range(12):
+        one.run_steps(1)
+        two.run_steps(1)
+        one.synchronize(); two.synchronize()
+        _same(one, two, ('wide', pol, t))
+        longest = max(longest, int(one.diag()['diag'][:, 0].max()))
+    assert longest > 300, longest
     one.close(); two.close()
 
 
