@@ -21,7 +21,11 @@
 #include <thread>
 #include <vector>
 
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
+// device: everything inlined into its kernel whatever the number of kernels that use it (with two callers the inliner left
+// the planner as a function: 31 more registers and scratch in k_replan)
+#define SCA_DHD __host__ __device__ __attribute__((always_inline))
+#elif defined(__HIPCC__)
 #define SCA_DHD __host__ __device__
 #else
 #define SCA_DHD

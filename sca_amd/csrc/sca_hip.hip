@@ -206,13 +206,14 @@ struct sca_ctx {
     // the re-plans run on a stream of their own, next to the kd build and the neighbour query of the same pass
     hipStream_t trk_stream = nullptr;   // round 2: the re-plans are the critical path and stay on the main stream; the neighbour
                                         // structure (K0) and the neighbour query (K1) of the pass run on this one beside them
-    hipEvent_t trk_fork = nullptr, trk_join = nullptr, trk_tracked = nullptr;
+    hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     hipStream_t nbr_stream = nullptr;   // where K0 / K1 of the current pass go: trk_stream when overlapped, else the main stream
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
     bool trk_count_pending = false;
     int trk_last_count = -1;            // -1: unknown
     unsigned trk_passes = 0;
+    bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 4th pass carries the event pairs
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
     bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
@@ -358,7 +359,7 @@ int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, co
 }
 
 // ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
-static int launch_tracker(sca_ctx *c, bool from_lists, bool side);
+static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass);
 static int tracker_free(sca_ctx *c) {
     if (!c->trk.st) { c->trk_on = false; return 0; }
     CHK(c, hipStreamSynchronize(c->stream));
@@ -367,12 +368,12 @@ static int tracker_free(sca_ctx *c) {
     if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
     if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
     if (c->trk_join) { (void)hipEventDestroy(c->trk_join); c->trk_join = nullptr; }
-    if (c->trk_tracked) { (void)hipEventDestroy(c->trk_tracked); c->trk_tracked = nullptr; }
     if (c->trk_count_ev) { (void)hipEventDestroy(c->trk_count_ev); c->trk_count_ev = nullptr; }
     if (c->trk_host_count) { (void)hipHostFree(c->trk_host_count); c->trk_host_count = nullptr; }
     c->trk_count_pending = false; c->trk_last_count = -1;
     c->kd.skip_prep = 0;
     c->trk = TrackDev{}; c->trk_goal_heading = nullptr; c->trk_on = false; c->trk_in_pass = false;
+    c->d.trk_nbr0 = nullptr;
     return 0;
 }
 int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double turning_radius, double pitch_min, double pitch_max,
@@ -385,12 +386,11 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipMalloc((void **)&c->trk.st, sizeof(sca_dubins::AgentTrack) * n));
     CHK(c, hipMalloc((void **)&c->trk.nbr0, sizeof(double) * n));
     CHK(c, hipMalloc((void **)&c->trk.list, sizeof(int32_t) * n));
-    CHK(c, hipMalloc((void **)&c->trk.count, sizeof(int32_t) * 2));
+    CHK(c, hipMalloc((void **)&c->trk.count, sizeof(int32_t) * 4));
     CHK(c, hipMalloc((void **)&c->trk_goal_heading, sizeof(double) * 3 * n));
     CHK(c, hipStreamCreateWithFlags(&c->trk_stream, hipStreamNonBlocking));
     CHK(c, hipEventCreateWithFlags(&c->trk_fork, hipEventDisableTiming));
     CHK(c, hipEventCreateWithFlags(&c->trk_join, hipEventDisableTiming));
-    CHK(c, hipEventCreateWithFlags(&c->trk_tracked, hipEventDisableTiming));
     CHK(c, hipEventCreateWithFlags(&c->trk_count_ev, hipEventDisableTiming));
     CHK(c, hipHostMalloc((void **)&c->trk_host_count, sizeof(int) * 2));
     c->trk_count_pending = false; c->trk_last_count = -1;
@@ -401,7 +401,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipMemcpyAsync(c->trk.st, init.data(), sizeof(sca_dubins::AgentTrack) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->trk.nbr0, nb.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->trk_goal_heading, goal_heading, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipMemsetAsync(c->trk.count, 0, sizeof(int32_t) * 2, c->stream));
+    CHK(c, hipMemsetAsync(c->trk.count, 0, sizeof(int32_t) * 4, c->stream));
     CHK(c, hipMemsetAsync(c->d.nbr_valid, 0, n, c->stream));            // no policy pass of this agent set has left lists yet
     CHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) mode[i] = (pol[i] == SCA_POLICY_SCA || pol[i] == SCA_POLICY_RVO3D_DUBINS) ? 1 : 0;
@@ -413,8 +413,11 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
                                         pitch_max, c->P.neighbor_dist};
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
+    c->d.trk_nbr0 = c->trk_in_pass ? c->trk.nbr0 : nullptr;
+    c->trk_passes = 0;
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
+    c->trk_fuse = getenv("SCA_TRACKER_NOFUSE") == nullptr;
     c->trk.quad_max = getenv("SCA_TRK_QUAD_MAX") ? atoi(getenv("SCA_TRK_QUAD_MAX")) : TRK_QUAD_MAX;
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
     c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;
@@ -905,26 +908,25 @@ static int pool_event(sca_ctx *c, hipEvent_t *out) {
     return 0;
 }
 
-// v_pref of the SCA / RVO3D+Dubins agents of the shard, before anything of the pass reads it (the per-agent prologue inside
-// k_kd_gather does)
-// side = true: k_replan goes to the tracker's own stream; the caller waits for trk_join before anything reads v_pref
-// side = true (a pass with the tracker overlapped): the caller has forked trk_stream off the main stream; k_track and the
-// re-plans stay on the main stream (they are the pass's critical path), trk_tracked marks k_track's end for the neighbour
-// query, which overwrites the lists k_track reads.
-static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
+// v_pref of the SCA / RVO3D+Dubins agents of the shard, before anything of the pass reads it (the per-agent prologue does).
+// in_pass = true (a policy pass with the tracker inside): agent.neighbors[0] comes from trk.nbr0, which the previous pass's
+// epilogue saved -- so nothing here reads the neighbour lists, and the neighbour query of this pass may run beside it.
+// in_pass = false (sca_device_tracker_vpref): from the lists as they are (from_lists) or from what the caller uploaded.
+static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
-    K.nbr0_from_lists = from_lists ? 1 : 0;
-    hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
-    if (side) CHK(c, hipEventRecord(c->trk_tracked, c->stream));
-    hipStream_t rs = c->stream;
+    K.nbr0_from_lists = (from_lists && !in_pass) ? 1 : 0;
     K.quad = c->trk_quad ? 1 : 0;
     // The device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work.  Launching both
     // every pass costs an empty launch on the critical path; the count of an earlier pass (copied back on the side stream, never
-    // waited for) says when k_replan_few has nothing to do: then only k_replan is launched, told to take whatever count comes.
+    // waited for) says when k_replan_few has nothing to do: then only k_replan is launched, told to take whatever count comes --
+    // and when nearly the whole shard re-plans, k_track's list is not worth its launch either: k_track_replan does both.
     if (c->trk_count_pending && hipEventQuery(c->trk_count_ev) == hipSuccess) { c->trk_last_count = c->trk_host_count[0]; c->trk_count_pending = false; }
     bool few = c->trk_quad, lane = !c->trk_quad || cnt > K.quad_max;
     if (few && lane && c->trk_last_count > K.quad_max + K.quad_max / 4) { few = false; K.quad = 0; }
+    const bool fused = in_pass && lane && !few && c->trk_fuse && (long long)c->trk_last_count * 4 >= (long long)cnt * 3;
+    if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
+    hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->profiling && (c->prof_tick & 3u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
         for (hipEvent_t *e : {&t0, &t1}) {
@@ -933,16 +935,19 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool side) {
         }
         CHK(c, hipEventRecord(t0, rs));
     }
-    if (few) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
+    if (fused)
+        hipLaunchKernelGGL(k_track_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
+                           c->trk_view, K);
+    if (few && !fused) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
         const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
         hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
     }
-    if (lane)
+    if (lane && !fused)
         hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
     if (t1) CHK(c, hipEventRecord(t1, rs));
     CHK(c, hipGetLastError());
-    c->trk.parity ^= 1;
+    c->trk.parity = (c->trk.parity + 1) & 3;
     return 0;
 }
 
@@ -996,10 +1001,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         }
     }
     // Streams.  Without the tracker everything is one chain on the main stream.  With it (overlap): the pass's critical path
-    // k_track -> re-plans -> prologue -> solve stays on the main stream, and the neighbour structure + query, which depend on
-    // nothing of the tracker except that K1 must not overwrite the lists k_track reads, run beside them on trk_stream:
-    //   main: [fork] k_track [tracked] re-plans ................ [wait join] k_prep_shard k_solve ...
-    //   side: [wait fork] K0 ...... [wait tracked] K1 [join]
+    // k_track -> re-plans -> prologue -> pick stays on the main stream, and the neighbour structure + query (+ the sweep half of
+    // k_solve), which depend on nothing of the tracker -- it reads agent.neighbors[0] from what the previous pass's epilogue
+    // saved, not from the lists K1 overwrites -- run beside them on trk_stream:
+    //   main: [fork] k_track re-plans (or k_track_replan) ........ [wait join] k_prep_shard k_solve / k_solve_pick4 ...
+    //   side: [wait fork] K0 ...... K1 (k_solve_sweep) [join]
     // (round 1 had the re-plans on the side stream: the fork and the join then sat on the critical path, ~40 us per step)
     c->nbr_stream = overlap ? c->trk_stream : c->stream;
     const unsigned parity_now = (unsigned)c->trk.parity;
@@ -1007,7 +1013,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipEventRecord(c->trk_fork, c->stream));
         CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
     }
-    if (tracked) { if (int r = launch_tracker(c, true, overlap)) return r; }
+    if (tracked) { if (int r = launch_tracker(c, true, true)) return r; }
     c->nbr_mode = mode;
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
     else if (mode == SCA_NBR_GRID) { if (int r = build_agent_grid_device(c)) return r; }
@@ -1022,7 +1028,6 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     } else { c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED; }
     const int cnt = d.shard_count;
     hipStream_t ns = c->nbr_stream;
-    if (overlap) CHK(c, hipStreamWaitEvent(ns, c->trk_tracked, 0));
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2], e3 = c->ev[3];
     const bool prof = !timed && c->profiling && (c->prof_tick++ & 3u) == 0 && c->pool_used + 4 <= 4 * 4096;
     if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2) || pool_event(c, &e3)) return SCA_ERR_HIP; }
@@ -1056,8 +1061,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     }
     if (overlap) {
         // the re-plan count of this pass for a later pass's launch decision: on the side stream, every 4th pass, never waited for
-        if (!c->trk_count_pending && (c->trk_passes++ & 3u) == 0) {
-            CHK(c, hipMemcpyAsync(c->trk_host_count, c->trk.count + parity_now, sizeof(int), hipMemcpyDeviceToHost, ns));
+        const unsigned pass = c->trk_passes++;
+        if (!c->trk_count_pending && pass != 0 && (pass & 3u) == 0) {       // the previous pass's slot: final since before the fork
+            CHK(c, hipMemcpyAsync(c->trk_host_count, c->trk.count + ((parity_now + 3u) & 3u), sizeof(int), hipMemcpyDeviceToHost, ns));
             CHK(c, hipEventRecord(c->trk_count_ev, ns));
             c->trk_count_pending = true;
         }

@@ -105,6 +105,8 @@ struct DeviceView {
     double *sw_slot;         // [n][K_MAX][SLOTF] cones / planes of the agent's neighbours
     uint16_t *sw_surv;       // [n][512] generation indices of the table candidates outside every cone / inside every half-space
     int32_t *sw_n;           // [n] how many
+    double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
+                             // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1648,6 +1650,7 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
 #pragma unroll
     for (int k = 0; k < 7; k++) out[k] = actf[k];
     out[7] = 0.0f;
+    if (d.trk_nbr0 && d.nbr_valid[agent]) d.trk_nbr0[agent] = d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0;   // agent.py:79-99
     if (FUSE_INTEGRATE) integrate_agent(d, P, agent, me, actf);
 }
 

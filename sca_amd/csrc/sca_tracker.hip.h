@@ -27,8 +27,9 @@ struct TrackDev {
     sca_dubins::AgentTrack *st;   // [n]
     double *nbr0;                 // [n] distSq of agent.neighbors[0] as the previous pass left it (-1: empty list)
     int32_t *list;                // [n] agents that re-plan in this pass
-    int32_t *count;               // [2] list length, double-buffered by pass parity (k_track zeroes the other one)
-    int parity;
+    int32_t *count;               // [4] re-plans of the pass (= list length), a ring over the passes: pass p counts in slot p & 3 and
+                                  // zeroes slot (p + 1) & 3; the host reads the previous pass's slot, which is final, without waiting
+    int parity;                   // the slot of this pass
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
     int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= quad_max re-plans
     int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning)
@@ -58,7 +59,7 @@ __device__ __forceinline__ void track_store(const DeviceView &d, int agent, cons
 }
 
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) K.count[K.parity ^ 1] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.shard_begin + d.shard_count) return;
     double nb0 = K.nbr0[agent];
@@ -99,6 +100,31 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
     sca_dubins::track_replan(T, a, agent, pos, heading, dif);
+    sca_dubins::track_finish(T, a, agent, pos, dif, V);
+    track_store(d, agent, V, a.edge);
+}
+
+// k_track + k_replan in ONE launch, one lane per agent of the shard: for passes in which nearly every tracked agent re-plans
+// (the circle: 96 %), where compacting the re-planners into a list buys nothing and costs a launch on the pass's critical
+// path.  Lanes that follow their path finish early inside their wavefront.  Only counts the re-plans (no list).
+__global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    const double nb0 = K.nbr0[agent];                                    // saved by the previous pass's epilogue
+    if (!track_active(d, agent)) return;
+    const PubRec r = d.rec[agent];
+    const double pos[3] = {r.px, r.py, r.pz};
+    const float vel[3] = {r.vx, r.vy, r.vz};
+    sca_dubins::AgentTrack &a = K.st[agent];
+    double dif[3], V[3];
+    const bool replan = sca_dubins::track_decide(T, a, agent, pos, vel, nb0, dif);
+    const unsigned long long m = __ballot(replan);
+    if (m != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&K.count[K.parity], __popcll(m));
+    if (replan) {
+        const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
+        sca_dubins::track_replan(T, a, agent, pos, heading, dif);
+    }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
     track_store(d, agent, V, a.edge);
 }
