@@ -137,7 +137,7 @@ def timed_leg(sol, scene, stepper, timer, steps, warmup, tracked):
     rp = sol.replan_ms() if tracked else 0.0
     dt, (total, plans_all) = timer.reduce(dt, (my_steps, plans))
     return dict(value=total / dt, ms_per_step=dt / steps * 1e3, agent_steps=total, my_agent_steps=my_steps, plans=plans_all,
-                my_plans=plans, k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=rp)
+                my_plans=plans, k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=rp, forms=sol.pass_forms())
 
 
 def roofline_of(leg, steps, tracked, wname):
@@ -155,13 +155,19 @@ def roofline_of(leg, steps, tracked, wname):
     plans_per_launch = leg['my_plans'] / max(steps, 1)
     gbs = BYTES_PER_REPLAN * plans_per_launch / (leg['replan_ms'] * 1e-3) / 1e9
     k_replan = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                'traffic': measured_traffic(wname, 'k_replan'), 'kernel': 'k_replan (+ k_replan_few), on its own stream beside the kd build',
+                'traffic': measured_traffic(wname, 'k_track_replan' if leg['forms'] & 2 else 'k_replan'),
+                'kernel': ('k_track_replan (follow-or-re-plan decision + the re-plan, one lane per agent)' if leg['forms'] & 2 else
+                           'k_replan (+ k_replan_few)') + ', beside the kd build, the neighbour query'
+                          + (' and k_solve_sweep' if leg['forms'] & 1 else '') + ' of the same pass',
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
-                'valu_issue_frac': (_pmc(wname).get('k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
+                'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if leg['forms'] & 2 else
+                                                    'k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
                                     / VALU_PEAK_WAVE_INSTS) or None,
                 'note': 'a sequential fp64 search per plan (~65 candidate radii x 13 arctangents): pure compute, the HBM fraction is '
                         'reported as required'}
-    return k_replan, k_solve
+    # a split pass: the timed [solve] interval is k_solve_pick4 only (k_solve_sweep runs beside the re-plans); k_solve's own
+    # roofline entry then comes from the solver_only leg, where it is one kernel
+    return k_replan, (None if leg['forms'] & 1 else k_solve)
 
 
 def main():
@@ -339,6 +345,11 @@ def main():
                        'agent_steps_timed': main_leg['agent_steps'], 're_plans_timed': main_leg['plans']},
             'roofline': roof,
         }
+        FORMS = {1: 'k_solve_sweep + k_solve_pick4', 2: 'k_track_replan', 4: 'lane-per-plan re-plan kernel', 8: 'k_replan_few', 16: 'k_lp'}
+        out['config']['kernel_forms'] = [v for k, v in FORMS.items() if main_leg['forms'] & k] or ['k_solve']
+        if roof2 is None and tracked and 'solver_only' in extras:
+            roof2 = dict(extras['solver_only']['roofline'], source='the solver_only leg (in the tracked step k_solve runs as k_solve_sweep '
+                         'beside the re-plans + k_solve_pick4 behind them: pick alone %.4f ms)' % main_leg['k_solve_ms'])
         if roof2 is not None:
             out['roofline_k_solve'] = roof2
         if emulated:

@@ -161,6 +161,19 @@ int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float
 
 /* the same for the tracker's re-plan kernels (k_replan_few + k_replan), events on the stream they run on */
 int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
+/* Which kernel forms the last policy pass was launched with (the library picks them per pass from the shard size and the
+ * re-plan count of a recent pass; none of them changes a result bit -- tests/test_gpu_solve_split.py, test_gpu_tracker.py):
+ *   SCA_FORM_SOLVE_SPLIT   k_solve as k_solve_sweep (beside the tracker's re-plans) + k_solve_pick4 (behind them)
+ *   SCA_FORM_TRACK_FUSED   k_track_replan instead of k_track + k_replan
+ *   SCA_FORM_REPLAN_LANE   the lane-per-plan re-plan kernel was launched (k_replan or k_track_replan)
+ *   SCA_FORM_REPLAN_FEW    k_replan_few (4 .. 64 lanes per plan) was launched
+ *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent) */
+#define SCA_FORM_SOLVE_SPLIT 1
+#define SCA_FORM_TRACK_FUSED 2
+#define SCA_FORM_REPLAN_LANE 4
+#define SCA_FORM_REPLAN_FEW 8
+#define SCA_FORM_LP_LANE 16
+int sca_last_pass_forms(sca_ctx *ctx, int *forms);
 /* Measurement aid for scaling models on one GPU: with a partial shard (sca_set_shard) and no communicator, sca_run_steps
  * runs what ONE rank of a larger job runs per step -- the replicated neighbour structure over all n agents, everything else
  * for the shard -- and copies the other agents' records over unchanged where the all-gather would deliver them. */

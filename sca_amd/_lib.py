@@ -59,6 +59,7 @@ SIGNATURES = {
     'sca_comm_destroy': (C.c_int, [C.c_void_p]),
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
     'sca_last_replan_ms': (C.c_int, [C.c_void_p, fp]),
+    'sca_last_pass_forms': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_set_shard_emulation': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

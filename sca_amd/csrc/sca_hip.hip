@@ -213,6 +213,7 @@ struct sca_ctx {
     bool trk_count_pending = false;
     int trk_last_count = -1;            // -1: unknown
     unsigned trk_passes = 0;
+    int forms = 0;                      // SCA_FORM_* of the last policy pass
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 4th pass carries the event pairs
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
@@ -925,6 +926,8 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     bool few = c->trk_quad, lane = !c->trk_quad || cnt > K.quad_max;
     if (few && lane && c->trk_last_count > K.quad_max + K.quad_max / 4) { few = false; K.quad = 0; }
     const bool fused = in_pass && lane && !few && c->trk_fuse && (long long)c->trk_last_count * 4 >= (long long)cnt * 3;
+    c->forms |= (fused ? SCA_FORM_TRACK_FUSED | SCA_FORM_REPLAN_LANE : 0) | (few && !fused ? SCA_FORM_REPLAN_FEW : 0) |
+                (lane && !fused ? SCA_FORM_REPLAN_LANE : 0);
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -989,6 +992,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
     // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
     const bool split = choose_solve_split(c, overlap, d.shard_count);
+    c->forms = (split ? SCA_FORM_SOLVE_SPLIT : 0);
     if (split && lp_hi > lp_lo) c->d.lp_kernel = 1;                     // k_solve_pick4 carries no LP: its agents go to k_lp
     c->kd.skip_prep = overlap ? 1 : 0;
     c->grid.skip_prep = overlap ? 1 : 0;
@@ -1077,6 +1081,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_solve_pick4, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     }
     else hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    if (d.lp_kernel) c->forms |= SCA_FORM_LP_LANE;
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
     if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)
@@ -1201,6 +1206,12 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
 int sca_set_shard_emulation(sca_ctx *c, int on) {
     if (!c) return SCA_ERR_ARG;
     c->shard_emulation = on != 0;
+    return 0;
+}
+int sca_last_pass_forms(sca_ctx *c, int *forms) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, forms);
+    *forms = c->forms;
     return 0;
 }
 int sca_last_replan_ms(sca_ctx *c, float *replan_ms) {

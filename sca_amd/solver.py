@@ -13,6 +13,7 @@ from . import _lib
 POL_SCA, POL_RVO3D, POL_SRVO3D, POL_ORCA3D, POL_ORCA3D_LP, POL_RVO3D_DUBINS = range(6)
 FLAG_AT_GOAL, FLAG_COLLISION, FLAG_TIMEOUT = 1, 2, 4
 NBR_KDTREE, NBR_GRID, NBR_KDTREE_HOSTBUILD = 0, 1, 2
+FORM_SOLVE_SPLIT, FORM_TRACK_FUSED, FORM_REPLAN_LANE, FORM_REPLAN_FEW, FORM_LP_LANE = 1, 2, 4, 8, 16   # sca_last_pass_forms
 K = _lib.K
 
 
@@ -198,6 +199,12 @@ class BatchedSolver:
     def replan_ms(self):
         a = C.c_float(0)
         self._chk(self.L.sca_last_replan_ms(self.ctx, C.byref(a)), 'sca_last_replan_ms')
+        return a.value
+
+    def pass_forms(self):
+        """SCA_FORM_* bits of the last policy pass (which kernel forms the library picked)"""
+        a = C.c_int(0)
+        self._chk(self.L.sca_last_pass_forms(self.ctx, C.byref(a)), 'sca_last_pass_forms')
         return a.value
 
     def set_shard_emulation(self, on=True):

@@ -128,3 +128,32 @@ def test_split_beside_the_replans_equals_one_launch(S, monkeypatch, n):
         _same(one, two, ('tracked', n, t))
     assert np.array_equal(one.device_tracker_replans(), two.device_tracker_replans())
     one.close(); two.close()
+
+
+def test_forms_the_library_picks_by_itself(S):
+    """No switches: a large tracked shard on the circle (nearly every agent re-plans every step) gets the fused tracker kernel and
+    the split solve once the first re-plan count has come back; a small one keeps k_track + k_replan_few and the one-launch
+    k_solve; without the tracker nothing is split."""
+    from sca_amd import scenarios
+
+    def run(n, tracker, steps):
+        sc = scenarios.circle(n)
+        sol = S.BatchedSolver(max_agents=n)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], np.zeros(n, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        if tracker:
+            sol.device_tracker_enable(sc['goal'][:, 3:6])
+        for _ in range(steps):
+            sol.run_steps(1)
+            sol.synchronize()
+        f = sol.pass_forms()
+        sol.close()
+        return f
+
+    big = run(40000, True, 16)
+    assert big & S.FORM_SOLVE_SPLIT and big & S.FORM_TRACK_FUSED and big & S.FORM_REPLAN_LANE and not big & S.FORM_REPLAN_FEW, big
+    small = run(3000, True, 16)
+    assert small & S.FORM_REPLAN_FEW and not small & (S.FORM_SOLVE_SPLIT | S.FORM_TRACK_FUSED | S.FORM_REPLAN_LANE), small
+    assert run(40000, False, 3) == 0
