@@ -847,7 +847,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < first_single; l++) {
             hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
-            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, l);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T + 64), 0, c->nbr_stream, d, c->kd, l);   // + the bookkeeping wavefront
         }
         hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, first_single, ++c->kd_token);
     }

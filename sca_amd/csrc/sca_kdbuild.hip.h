@@ -286,7 +286,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
     const int b = c.node_begin, e = c.node_end;
     const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
     const int lim = c.end < b + L ? c.end : b + L;
-    for (int p = c.begin + tid; p < lim; p += KD_LV_T) {
+    for (int p = c.begin + tid; p < lim && tid < KD_LV_T; p += KD_LV_T) {
         if (!(kc[p] < split)) {
             // the k-th ">= split" member of the left part (k = ps - 1) takes the k-th "< split" member from the right,
             // i.e. the (L - k)-th "< split" member of the node
@@ -298,38 +298,61 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
             s.kx[q] = xp; s.ky[q] = yp; s.kz[q] = zp;
         }
     }
-    if (tid == 0 && c.begin == b) {
+    // The node's bookkeeping (its record, the children and their chunk records) is a chain of dependent loads and atomics
+    // with returns, ~5 us long and independent of the swaps: k_kd_lv_swap gives it a wavefront of its own (thread KD_LV_T of
+    // a KD_LV_T + 64 workgroup) so that it runs beside the swaps, not behind thread 0's; the tail launch keeps thread 0.
+    // Everything it reads was completed by the rank pass; all loads and all four atomics are issued before anything waits.
+    const int keeper = blockDim.x > KD_LV_T ? KD_LV_T : 0;
+    if (tid == keeper && c.begin == b) {
         if (tail) tail->n = 0;
         const KdJob job = in[c.job];
-        double mn[3], mx[3];
-        { int ax_; double sp_; kd_node_split(s, level, c.job, ax_, sp_, mn, mx); }
+        const unsigned long long *nb_ = s.nbox + ((size_t)(level & 1) * s.job_cap + c.job) * 6;
+        const unsigned long long *cb_ = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
+        unsigned long long bk[6], cb[12];
+#pragma unroll
+        for (int q = 0; q < 6; q++) bk[q] = nb_[q];
+#pragma unroll
+        for (int q = 0; q < 12; q++) cb[q] = cb_[q];
         const int leftSize = L == 0 ? 1 : L;                 // degenerate: every member on the split plane
+        const int cbeg[2] = {b, b + leftSize}, cend[2] = {b + leftSize, e};
+        bool big[2]; int nch[2], arrival[2] = {0, 0}, base[2] = {0, 0}, slot[2] = {0, 0}, small_at[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            big[k] = cend[k] - cbeg[k] > s.wave_max;
+            nch[k] = (cend[k] - cbeg[k] + KD_CHUNK - 1) / KD_CHUNK;
+            if (big[k]) {
+                if (level + 1 < KD_MAX_LEVELS) {
+                    // table slot of the child.  A level launch owns the level's slots: index = arrival order.  In the tail
+                    // launch workgroups are at DIFFERENT levels at the same time, so slots (and chunk records) indexed per
+                    // level parity would collide: there the index comes from one counter that starts behind the tail
+                    // level's own nodes (unique over both parities), the chunk records stay in the workgroup's stack, and
+                    // the per-level counters are only statistics for the host.
+                    arrival[k] = atomicAdd(&s.counts[level + 1], 1);
+                    base[k] = atomicAdd(&s.nchunks[level + 1], nch[k]);
+                    if (tail) slot[k] = atomicAdd(&s.counts[2 * KD_MAX_LEVELS + 3], 1);
+                }
+            } else small_at[k] = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
+        }
+        double mn[3], mx[3];
+        for (int k = 0; k < 3; k++) { mn[k] = dunkey(bk[k]); mx[k] = dunkey(bk[3 + k]); }
         KdNode nd;
         nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
         for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
         if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
         kd_publish(d.awide, nd, job.node, job.pad);
-        unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
         if (L == 0) {
             // nobody below the midpoint: the box has no extent, every member sits on one point (kdTree.py:113-116 then puts
             // one of them left, the rest right) -- both children have the parent's box
             for (int q = 0; q < 3; q++) { cb[q] = cb[6 + q] = dkey(mn[q]); cb[3 + q] = cb[9 + q] = dkey(mx[q]); }
         }
         KdJob ch[2];
-        ch[0].begin = b; ch[0].end = b + leftSize; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
-        ch[1].begin = b + leftSize; ch[1].end = e; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
+        ch[0].begin = cbeg[0]; ch[0].end = cend[0]; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
+        ch[1].begin = cbeg[1]; ch[1].end = cend[1]; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
+#pragma unroll
         for (int k = 0; k < 2; k++) {
-            if (ch[k].end - ch[k].begin > s.wave_max) {
+            if (big[k]) {
                 if (level + 1 < KD_MAX_LEVELS) {
-                    const int nch = (ch[k].end - ch[k].begin + KD_CHUNK - 1) / KD_CHUNK;
-                    // table slot of the child.  A level launch owns the level's slots: index = arrival order.  In the tail
-                    // launch workgroups are at DIFFERENT levels at the same time, so slots (and chunk records) indexed per
-                    // level parity would collide: there the index comes from one counter that starts behind the tail
-                    // level's own nodes (unique over both parities), the chunk records stay in the workgroup's stack, and
-                    // the per-level counters are only statistics for the host.
-                    const int arrival = atomicAdd(&s.counts[level + 1], 1);
-                    const int base = atomicAdd(&s.nchunks[level + 1], nch);
-                    const int at = tail ? tail->slot_base + atomicAdd(&s.counts[2 * KD_MAX_LEVELS + 3], 1) : arrival;
+                    const int at = tail ? tail->slot_base + slot[k] : arrival[k];
                     if (at < s.job_cap) {
                         out[at] = ch[k];
                         unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
@@ -337,28 +360,25 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
                         unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
                         for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
                         // the child's workgroups of the next level
-                        if (tail || base + nch <= s.chunk_cap) {
-                            KdChunkRec r; r.job = at; r.first = base; r.nb = ch[k].begin; r.ne = ch[k].end; r.pad = 0;
+                        if (tail || base[k] + nch[k] <= s.chunk_cap) {
+                            KdChunkRec r; r.job = at; r.first = base[k]; r.nb = ch[k].begin; r.ne = ch[k].end; r.pad = 0;
                             double cmn[3], cmx[3];
                             for (int q = 0; q < 3; q++) { cmn[q] = dunkey(cb[k * 6 + q]); cmx[q] = dunkey(cb[k * 6 + 3 + q]); }
                             kd_split(cmn, cmx, r.axis, r.split);
                             if (tail) tail->r[tail->n++] = r;
                             else {
                                 KdChunkRec *tab = s.chunks[(level + 1) & 1];
-                                for (int q = 0; q < nch; q++) tab[base + q] = r;
+                                for (int q = 0; q < nch[k]; q++) tab[base[k] + q] = r;
                             }
                         } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_CHUNKS);
                     } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
                 } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
-            } else {
-                const int at = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
-                s.small[at] = ch[k];
-            }
+            } else s.small[small_at[k]] = ch[k];
         }
     }
 }
 
-__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+__global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
     kd_swap_part(d, s, level, c);
