@@ -311,3 +311,41 @@ def test_device_tracker_on_random_scenes_vs_host_tracker():
     assert tot > 100000
     assert diff <= 0.002 * tot, (diff, tot)
     assert worst <= 2e-4, worst
+
+
+def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
+    """k_track_replan (decision + re-plan in one launch, picked once >= 75 % of a large shard re-planned in a recent pass)
+    against k_track + k_replan (SCA_TRACKER_NOFUSE): whole resident episodes equal bit for bit, across the pass where the
+    library switches from one form to the other, and the re-plan counters agree."""
+    from sca_amd import scenarios, solver as S
+    n = 30000
+    sc = scenarios.circle(n)
+    pol = np.where(np.arange(n) % 9 == 4, 2, 0).astype(np.uint8)          # SCA, every ninth agent S-RVO3D (not tracked)
+    sols = []
+    for nofuse in (True, False):
+        if nofuse:
+            monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
+        else:
+            monkeypatch.delenv('SCA_TRACKER_NOFUSE', raising=False)
+        sol = S.BatchedSolver(max_agents=n)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])                     # read SCA_TRACKER_NOFUSE
+        sols.append(sol)
+    plain, fused = sols
+    seen_fused = False
+    for t in range(20):
+        plain.run_steps(1); fused.run_steps(1)
+        plain.synchronize(); fused.synchronize()
+        assert not plain.pass_forms() & S.FORM_TRACK_FUSED
+        seen_fused |= bool(fused.pass_forms() & S.FORM_TRACK_FUSED)
+        a, b = plain.get_state(), fused.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(a[k], b[k]), (t, k)
+        assert np.array_equal(plain.diag()['vpref'], fused.diag()['vpref'], equal_nan=True), t
+        assert np.array_equal(plain.diag()['status'], fused.diag()['status']), t
+    assert seen_fused
+    assert np.array_equal(plain.device_tracker_replans(), fused.device_tracker_replans())
+    plain.close(); fused.close()
