@@ -1080,7 +1080,12 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         const int per_block = SOLVE_WAVES * PICK_APW;
         hipLaunchKernelGGL(k_solve_pick4, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     }
-    else hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+    else {
+        hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        if (!d.lp_kernel && lp_hi > lp_lo)                            // K3, one wavefront per LP agent (few of them)
+            hipLaunchKernelGGL(k_solve_lpw, dim3((lp_hi - lp_lo + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P,
+                               c->lp_list, lp_lo, lp_hi);
+    }
     if (d.lp_kernel) c->forms |= SCA_FORM_LP_LANE;
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);

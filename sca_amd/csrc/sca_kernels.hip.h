@@ -1096,13 +1096,16 @@ struct FastLds {
 // the neighbour query, and only the rest behind them (k_solve_pick4 / solve_pick4 below: distances to v_pref, the v_pref
 // candidate itself, the selection).  Phase 1 leaves the cones and the survivors' generation indices in global memory; the
 // same expressions on the same values either way, so the split changes no bit.
-template <int PHASE>
+// LPMODE 1: compiled without the LP chain (the scalar LP1-4 on lane 0 cost every other policy 22 registers and the spills of
+// a 7-waves-per-SIMD build): an ORCA3D-Official agent past its bootstrap step is left to k_solve_lpw / k_lp, everything else
+// about it (done flags, bootstrap velocity) is still handled here.  LPMODE 2 (k_solve_lpw): those agents only, after k_solve.
+template <int PHASE, int LPMODE>
 __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
-    if (PHASE != 1 && lane == 0) d.is_fb[agent] = 0;
+    if (PHASE != 1 && LPMODE != 2 && lane == 0) d.is_fb[agent] = 0;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
-        if (PHASE == 1) return;
+        if (PHASE == 1 || LPMODE == 2) return;
         if (lane < 8) diag[lane] = -1;
         if (lane < 3) d.vpref_used[agent * 3 + lane] = __builtin_nan("");
         return;
@@ -1133,7 +1136,8 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     V3 vpost = v3(0, 0, 0);
     bool defer = false;
     const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
-    if (pol == POL_ORCA_LP && !first_step && d.lp_kernel) return;                    // K3: k_lp, one lane per agent
+    if (pol == POL_ORCA_LP && !first_step && (LPMODE == 1 || d.lp_kernel)) return;   // K3: k_lp (one lane per agent) or k_solve_lpw
+    if (LPMODE == 2 && first_step) return;                                           // k_solve has done the bootstrap step
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
@@ -1166,7 +1170,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (pol == POL_ORCA_LP) {
+        if (LPMODE != 1 && pol == POL_ORCA_LP) {
             // K3, wave-per-agent form (shards with few LP agents: launch_policy picks): LP3 (+LP4), orca3dPolicyOfficial.py:108-113.
             // Scalar chain, lane 0 drives: measured faster than the lanes-over-planes
             // form (ballots for the next violated plane, wave max / min for LP1) at every BASELINE size but N = 1024, DESIGN.md section 3.
@@ -1179,7 +1183,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
             vpost = v3(__shfl(nv.x, 0), __shfl(nv.y, 0), __shfl(nv.z, 0));
             dg_pfail = __shfl(pf, 0);
             dg_lp4 = __shfl(l4, 0);
-        } else {
+        } else if (LPMODE != 2) {
             CandTab T;
             T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;                 // scaPolicy.py:188-190
             T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
@@ -1383,7 +1387,16 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Par
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast<0>(d, P, S, agent, lane, wid);
+    if (agent < d.shard_begin + d.shard_count) solve_fast<0, 1>(d, P, S, agent, lane, wid);
+}
+// K3, wave-per-agent form: the ORCA3D-Official agents of the shard (positions [lo, hi) of the sorted list of their ids) when
+// they are too few for k_lp to fill the chip
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_lpw(DeviceView d, Params P, const int32_t *list, int lo, int hi) {
+    __shared__ FastLds S;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = lo + blockIdx.x * SOLVE_WAVES + wid;
+    if (idx < hi) solve_fast<0, 2>(d, P, S, list[idx], lane, wid);
 }
 // the first half of k_solve for passes whose v_pref arrives late (solve_fast); the second is k_solve_pick4
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, Params P) {
@@ -1391,7 +1404,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast<1>(d, P, S, agent, lane, wid);
+    if (agent < d.shard_begin + d.shard_count) solve_fast<1, 1>(d, P, S, agent, lane, wid);
 }
 
 
