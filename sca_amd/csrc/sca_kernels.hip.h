@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
     }
 }
 
-__global__ __launch_bounds__(SOLVE_WAVES * 64, 7) void k_solve(DeviceView d, Params P) {
+__global__ __launch_bounds__(SOLVE_WAVES * 64, 8) void k_solve(DeviceView d, Params P) {
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
