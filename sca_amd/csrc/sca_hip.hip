@@ -420,6 +420,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
     c->trk_fuse = getenv("SCA_TRACKER_NOFUSE") == nullptr;
     c->trk.quad_max = getenv("SCA_TRK_QUAD_MAX") ? atoi(getenv("SCA_TRK_QUAD_MAX")) : TRK_QUAD_MAX;
+    c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : TRK_MID_MAX;
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
     c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;
     c->trk.spec4_max = getenv("SCA_TRK_SPEC4_MAX") ? atoi(getenv("SCA_TRK_SPEC4_MAX")) : TRK_SPEC4_MAX;
@@ -917,17 +918,21 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
     K.nbr0_from_lists = (from_lists && !in_pass) ? 1 : 0;
-    K.quad = c->trk_quad ? 1 : 0;
-    // The device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work.  Launching both
-    // every pass costs an empty launch on the critical path; the count of an earlier pass (copied back on the side stream, never
-    // waited for) says when k_replan_few has nothing to do: then only k_replan is launched, told to take whatever count comes --
-    // and when nearly the whole shard re-plans, k_track's list is not worth its launch either: k_track_replan does both.
+    // The device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work: every launched
+    // kernel reads it and returns unless it falls into its range (lo, hi].  Launching all three every pass costs two empty
+    // launches on the critical path; the count of an earlier pass (copied back on the side stream, never waited for) says
+    // which of them can be left out -- the ranges of those that are launched are widened so that every count is still somebody's
+    // (a count that jumps is then re-planned by a form that is slower for it, never by nobody).  When nearly the whole shard
+    // re-plans in the lane-per-plan form, k_track's list is not worth its launch either: k_track_replan does both.
     if (c->trk_count_pending && hipEventQuery(c->trk_count_ev) == hipSuccess) { c->trk_last_count = c->trk_host_count[0]; c->trk_count_pending = false; }
-    bool few = c->trk_quad, lane = !c->trk_quad || cnt > K.quad_max;
-    if (few && lane && c->trk_last_count > K.quad_max + K.quad_max / 4) { few = false; K.quad = 0; }
-    const bool fused = in_pass && lane && !few && c->trk_fuse && (long long)c->trk_last_count * 4 >= (long long)cnt * 3;
-    c->forms |= (fused ? SCA_FORM_TRACK_FUSED | SCA_FORM_REPLAN_LANE : 0) | (few && !fused ? SCA_FORM_REPLAN_FEW : 0) |
-                (lane && !fused ? SCA_FORM_REPLAN_LANE : 0);
+    const int Q1 = K.quad_max, Q2 = std::max(K.mid_max, K.quad_max), lc = c->trk_last_count;
+    const bool known = lc >= 0;
+    bool few = c->trk_quad && (!known || lc <= Q1 + Q1 / 4);
+    bool mid = c->trk_quad && cnt > Q1 && Q2 > Q1 && (!known || (lc > Q1 - Q1 / 4 && lc <= Q2 + Q2 / 4));
+    bool lane = !c->trk_quad || (cnt > Q2 && (!known || lc > Q2 - Q2 / 4));
+    if (!few && !mid && !lane) { if (cnt > Q2) lane = true; else if (cnt > Q1 && Q2 > Q1) mid = true; else few = true; }
+    const bool fused = in_pass && lane && !few && !mid && c->trk_fuse && (long long)lc * 4 >= (long long)cnt * 3;
+    c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (few || mid ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -938,16 +943,28 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
         }
         CHK(c, hipEventRecord(t0, rs));
     }
-    if (fused)
+    if (fused) {
+        K.lo = -1; K.hi = INT_MAX;
         hipLaunchKernelGGL(k_track_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
-    if (few && !fused) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
-        const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (K.quad_max + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
-        hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
+    } else {
+        if (few) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
+            K.lo = -1; K.hi = (mid || lane) ? Q1 : INT_MAX;
+            const int top = K.hi == INT_MAX ? cnt : Q1;
+            const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (top + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
+            hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
+        }
+        if (mid) {
+            K.lo = few ? Q1 : -1; K.hi = lane ? Q2 : INT_MAX;
+            const int top = K.hi == INT_MAX ? cnt : std::min(cnt, Q2);
+            hipLaunchKernelGGL(k_replan_mid, dim3((top + 15) / 16), dim3(64), 0, rs, c->d, c->trk_view, K);
+        }
+        if (lane) {
+            K.lo = mid ? Q2 : (few ? Q1 : -1); K.hi = INT_MAX;
+            hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
+                               c->trk_view, K);
+        }
     }
-    if (lane && !fused)
-        hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
-                           c->trk_view, K);
     if (t1) CHK(c, hipEventRecord(t1, rs));
     CHK(c, hipGetLastError());
     c->trk.parity = (c->trk.parity + 1) & 3;
@@ -978,6 +995,7 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
     if (!overlap) return false;
     const int est = c->trk_last_count >= 0 ? c->trk_last_count : cnt;    // re-plans of a recent pass (all agents before the first readback)
     if (est <= c->trk.quad_max + c->trk.quad_max / 4) return false;     // the many-lanes-per-plan forms: short re-plans, nothing to hide behind
+    if (est <= c->trk.mid_max) return false;                            // k_replan_mid's range: measured equal with and without (18 000 .. 30 000 agents)
     const int rounds = (est + 65535) / 65536;
     return rounds == 1 ? cnt <= 61440 : (rounds == 2 ? cnt <= 114688 : false);
 }

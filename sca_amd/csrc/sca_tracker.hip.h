@@ -31,13 +31,20 @@ struct TrackDev {
                                   // zeroes slot (p + 1) & 3; the host reads the previous pass's slot, which is final, without waiting
     int parity;                   // the slot of this pass
     int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
-    int quad;                     // 1: k_replan_few (4 .. 64 lanes per plan) takes the passes with <= quad_max re-plans
-    int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning)
+    int lo, hi;                   // this launch takes the pass when lo < (re-plans of the pass) <= hi; the launches of a pass cover every count
+    int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning): k_replan_few's range
+    int mid_max;                  // TRK_MID_MAX (SCA_TRK_MID_MAX): k_replan_mid's
     int spec2_max, spec3_max, spec4_max;   // TRK_SPEC*_MAX unless overridden (SCA_TRK_SPEC2_MAX ..., tuning)
 };
 
-constexpr int TRK_QUAD_MAX = 20480;       // re-plans per pass up to which the four-lanes-per-plan form is used (measured crossover with the
-                                          // lane-per-plan kernel: 19 k plans 0.54 vs 0.58 ms per step, 31 k plans 0.65 vs 0.61)
+// Which kernel re-plans a pass, by the pass's re-plan count (read on the device; the host launches the kernels whose range a recent
+// count makes possible and widens the outermost ranges so that every count is covered):
+//   <= TRK_QUAD_MAX   k_replan_few: 64 .. 4 lanes per plan, one wavefront per SIMD (258 registers): 16 384 plans = 1024 wavefronts
+//   <= TRK_MID_MAX    k_replan_mid: 4 lanes per plan compiled for two wavefronts per SIMD (255 registers, 12 B of scratch: 13 %
+//                     slower per wavefront, which is why the few-kernel is not built that way): 24 576 agents 0.55 -> 0.47 ms per step
+//   above             k_replan / k_track_replan: one lane per plan (0.44 ms up to 65 536 plans, 0.63 up to 131 072)
+constexpr int TRK_QUAD_MAX = 16384;
+constexpr int TRK_MID_MAX = 32768;
 constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one per SIMD of a CU: the dispatcher then loads the SIMDs evenly
                                           // (65 536 plans as 1024 one-wave workgroups: 0.63 ms, some SIMDs drew two; as 256 of these: 0.44)
                                           // and, above one wave per SIMD, doubles up whole CUs, which leaves the others room for the
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = K.count[K.parity];
-    if (idx >= count || (K.quad && count <= K.quad_max)) return;            // few re-plans: k_replan_few's pass
+    if (idx >= count || count <= K.lo) return;                              // fewer re-plans: k_replan_few's / k_replan_mid's pass
     const int agent = K.list[idx];
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -383,11 +390,18 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
 constexpr int TRK_FEW_BLOCKS = 1024;
 __global__ __launch_bounds__(64) void k_replan_few(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
-    if (count > K.quad_max) return;
+    if (count > K.hi) return;
     if (count <= K.spec4_max) replan_group<64>(d, T, K, count);
     else if (count <= K.spec3_max) replan_group<32>(d, T, K, count);
     else if (count <= K.spec2_max) replan_group<16>(d, T, K, count);
     else replan_group<4>(d, T, K, count);
+}
+
+// the four-lanes-per-plan form for passes with more re-plans than one wavefront per SIMD holds: two wavefronts per SIMD
+__global__ __launch_bounds__(64, 2) void k_replan_mid(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    const int count = K.count[K.parity];
+    if (count <= K.lo || count > K.hi) return;
+    replan_group<4>(d, T, K, count);
 }
 
 __global__ __launch_bounds__(256) void k_track_replans(const sca_dubins::AgentTrack *st, int32_t *out, int n) {

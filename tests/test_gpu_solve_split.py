@@ -152,8 +152,8 @@ def test_forms_the_library_picks_by_itself(S):
         sol.close()
         return f
 
-    big = run(40000, True, 16)
+    big = run(60000, True, 16)
     assert big & S.FORM_SOLVE_SPLIT and big & S.FORM_TRACK_FUSED and big & S.FORM_REPLAN_LANE and not big & S.FORM_REPLAN_FEW, big
     small = run(3000, True, 16)
     assert small & S.FORM_REPLAN_FEW and not small & (S.FORM_SOLVE_SPLIT | S.FORM_TRACK_FUSED | S.FORM_REPLAN_LANE), small
-    assert run(40000, False, 3) == 0
+    assert run(60000, False, 3) == 0

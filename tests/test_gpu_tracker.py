@@ -318,7 +318,7 @@ def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
     against k_track + k_replan (SCA_TRACKER_NOFUSE): whole resident episodes equal bit for bit, across the pass where the
     library switches from one form to the other, and the re-plan counters agree."""
     from sca_amd import scenarios, solver as S
-    n = 30000
+    n = 50000                                                             # ~42 000 re-plans per pass: the lane-per-plan range
     sc = scenarios.circle(n)
     pol = np.where(np.arange(n) % 9 == 4, 2, 0).astype(np.uint8)          # SCA, every ninth agent S-RVO3D (not tracked)
     sols = []
@@ -349,3 +349,39 @@ def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
     assert seen_fused
     assert np.array_equal(plain.device_tracker_replans(), fused.device_tracker_replans())
     plain.close(); fused.close()
+
+
+@pytest.mark.parametrize('n,form', [(3000, 'few'), (24000, 'mid'), (45000, 'lane')])
+def test_replan_kernel_ranges_give_the_same_episode(n, form, monkeypatch):
+    """The re-plan kernel is picked per pass by the pass's re-plan count (k_replan_few: <= 16 384, k_replan_mid: <= 32 768,
+    k_replan above).  Every one of them is the same planner: an episode with the ranges as they are equals the episode with the
+    ranges moved so that another kernel does the work (SCA_TRK_QUAD_MAX / SCA_TRK_MID_MAX), bit for bit."""
+    from sca_amd import scenarios, solver as S
+    sc = scenarios.circle(n)
+    pol = np.zeros(n, np.uint8)
+    other = {'few': ('1', '2'), 'mid': ('1000000', '1000000'), 'lane': ('1000000', '1000000')}[form]   # -> lane / few / few
+    sols = []
+    for moved in (False, True):
+        for k, v in zip(('SCA_TRK_QUAD_MAX', 'SCA_TRK_MID_MAX'), other):
+            if moved:
+                monkeypatch.setenv(k, v)
+            else:
+                monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
+        sol = S.BatchedSolver(max_agents=n)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+        sols.append(sol)
+    a, b = sols
+    for t in range(10):
+        a.run_steps(1); b.run_steps(1)
+        a.synchronize(); b.synchronize()
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags'):
+            assert np.array_equal(sa[k], sb[k]), (form, t, k)
+        assert np.array_equal(a.diag()['vpref'], b.diag()['vpref'], equal_nan=True), (form, t)
+    assert np.array_equal(a.device_tracker_replans(), b.device_tracker_replans())
+    a.close(); b.close()
