@@ -19,9 +19,13 @@ from sca_amd.distributed import ShardedStepper
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 torch.cuda.set_device(0)
 dist.init_process_group('gloo')
-n, steps = 3000, 12
-sc = scenarios.random_cube(n, seed=2)
-pol = np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 3 == 1, 3, 4)).astype(np.uint8)
+n, steps = int(os.environ.get('SCA_TEST_N', '3000')), 12
+if n > 50000:                                                 # a swarm whose shards get the split solve and the fused tracker kernel
+    sc = scenarios.circle(n)
+    pol = np.where(np.arange(n) % 11 == 5, 2, 0).astype(np.uint8)
+else:
+    sc = scenarios.random_cube(n, seed=2)
+    pol = np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 3 == 1, 3, 4)).astype(np.uint8)
 
 def make():
     sol = S.BatchedSolver(max_agents=n, max_obstacles=1, device=0)
@@ -46,19 +50,23 @@ ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['
 ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
 ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
 ok = ok and (mode != 0 or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
+if n > 50000 and os.environ.get('SCA_TEST_TRACK'):
+    f = sol.pass_forms()
+    ok = ok and bool(f & S.FORM_SOLVE_SPLIT) and bool(f & S.FORM_TRACK_FUSED)
 print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('track,mode', [(False, 0), (True, 0), (False, 1), (True, 1)])
-def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode):
+@pytest.mark.parametrize('track,mode,n', [(False, 0, 3000), (True, 0, 3000), (False, 1, 3000), (True, 1, 3000), (True, 0, 120000)])
+def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
-    on a side stream next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded)."""
+    next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  n = 120 000: shards
+    of 60 000 agents, which get k_track_replan and the split solve (asserted), the second one with shard_begin != 0."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode), SCA_TEST_N=str(n))
     if track:
         env['SCA_TEST_TRACK'] = '1'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
