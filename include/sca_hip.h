@@ -188,6 +188,9 @@ int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 /* device self-test: numerators of l3norm(a_i, b_i) = round(|a_i - b_i|, 5) (mamp/util.py:104) as the solver's fast path
  * computes them (fast[]) and as the literal restatement does (exact[]); they must be identical */
 int sca_selftest_l3norm(sca_ctx *ctx, int n, const double *a /*n*3*/, const double *b /*n*3*/, double *fast /*n*/, double *exact /*n*/);
+/* the device planner's arctangent (coefficients from constant memory, division without the scaling instructions) and the
+ * device library's atan2 on the same n argument pairs: tests assert bit equality (dubinsmaneuver2d.py's atan2 calls) */
+int sca_selftest_atan2(sca_ctx *ctx, int n, const double *y, const double *x, double *fast /*n*/, double *lib /*n*/);
 
 /* Trajectory log = Agent.history_info (mamp/agents/agent.py:75-77, filled by to_vector :126-148 at the end of every
  * update_velocitie, mamp/envs/mampenv.py:105): one 64-byte row per agent per env step, kept in HBM so that resident

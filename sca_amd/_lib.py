@@ -64,6 +64,7 @@ SIGNATURES = {
     'sca_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_agent_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     'sca_selftest_l3norm': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp, dp]),
+    'sca_selftest_atan2': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp, dp]),
     'sca_history_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'sca_history_rows': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sca_get_history': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, fp]),

@@ -1368,6 +1368,21 @@ int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, dou
     return 0;
 }
 
+int sca_selftest_atan2(sca_ctx *c, int n, const double *y, const double *x, double *fast, double *lib) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, n > 0 && y && x && fast && lib);
+    double *dy = nullptr, *dx = nullptr, *df = nullptr, *dl = nullptr;
+    for (double **p : {&dy, &dx, &df, &dl}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
+    CHK(c, hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((n + 255) / 256), dim3(256), 0, c->stream, dy, dx, n, df, dl);
+    CHK(c, hipMemcpyAsync(fast, df, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipMemcpyAsync(lib, dl, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (double *p : {dy, dx, df, dl}) (void)hipFree(p);
+    return 0;
+}
+
 // ---- trajectory log (Agent.history_info, agent.py:75-77,126-148) kept in HBM --------------------------------------
 int sca_history_enable(sca_ctx *c, int capacity_rows) {
     if (!c || capacity_rows < 0) return SCA_ERR_ARG;

@@ -404,6 +404,14 @@ __global__ __launch_bounds__(64, 2) void k_replan_mid(DeviceView d, sca_dubins::
     replan_group<4>(d, T, K, count);
 }
 
+// self-test: m_atan2 (coefficients from SGPRs, the lean division) against the device library's atan2, bit for bit
+__global__ __launch_bounds__(256) void k_selftest_atan2(const double *y, const double *x, int n, double *fast, double *lib) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = sca_dubins::m_atan2(y[i], x[i]);
+    lib[i] = ::atan2(y[i], x[i]);
+}
+
 __global__ __launch_bounds__(256) void k_track_replans(const sca_dubins::AgentTrack *st, int32_t *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = st[i].replans;
