@@ -413,6 +413,13 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk.parity = 0;
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
                                         pitch_max, c->P.neighbor_dist};
+    {   // resolve the tracker's kernels now: the first launch of a kernel pays for looking it up in the code object, and the
+        // forms are picked while the episode runs (k_track_replan's first launch used to fall into a timed step)
+        hipFuncAttributes fa;
+        for (const void *f : {(const void *)k_track, (const void *)k_replan, (const void *)k_replan_few, (const void *)k_replan_mid,
+                              (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4, (const void *)k_prep_shard})
+            (void)hipFuncGetAttributes(&fa, f);
+    }
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
     c->d.trk_nbr0 = c->trk_in_pass ? c->trk.nbr0 : nullptr;
     c->trk_passes = 0;
@@ -1084,7 +1091,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (overlap) {
         // the re-plan count of this pass for a later pass's launch decision: on the side stream, every 4th pass, never waited for
         const unsigned pass = c->trk_passes++;
-        if (!c->trk_count_pending && pass != 0 && (pass & 3u) == 0) {       // the previous pass's slot: final since before the fork
+        if (!c->trk_count_pending && (pass & 3u) == 1) {                    // the previous pass's slot: final since before the fork
+                                                                            // (first at the second pass: the forms settle within three)
             CHK(c, hipMemcpyAsync(c->trk_host_count, c->trk.count + ((parity_now + 3u) & 3u), sizeof(int), hipMemcpyDeviceToHost, ns));
             CHK(c, hipEventRecord(c->trk_count_ev, ns));
             c->trk_count_pending = true;

@@ -102,7 +102,8 @@ struct DeviceView {
     int n, m, shard_begin, shard_count;
     int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
     // k_solve in two launches (k_solve_sweep / k_solve_pick4, see solve_fast): what the first leaves for the second
-    double *sw_slot;         // [n][K_MAX][SLOTF] cones / planes of the agent's neighbours
+    double *sw_slot;         // [n][SLOTF][K_MAX] cones / planes of the agent's neighbours, component-major (neighbour j's component q at
+                             // [q][j]: the 16 lanes of a store / load touch 128 consecutive bytes)
     uint16_t *sw_surv;       // [n][512] generation indices of the table candidates outside every cone / inside every half-space
     int32_t *sw_n;           // [n] how many
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
@@ -1164,9 +1165,9 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
                 if (pol == POL_ORCA_LP) S.u[wid].lp.planes[lane] = pl;
             }
             if (PHASE == 1) {
-                double *g = d.sw_slot + ((size_t)agent * K_MAX + lane) * SLOTF;
+                double *g = d.sw_slot + (size_t)agent * K_MAX * SLOTF + lane;
 #pragma unroll
-                for (int q = 0; q < 7; q++) g[q] = sl[q];
+                for (int q = 0; q < 7; q++) g[q * K_MAX] = sl[q];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1463,12 +1464,12 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
         // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j against the cone / plane of the sweep
         bool vp_hit = false;
         if (j < K) {
-            const double *sl = d.sw_slot + ((size_t)agent * K_MAX + j) * SLOTF;
+            const double *sl = d.sw_slot + (size_t)agent * K_MAX * SLOTF + j;
             if (!orca) {
-                Cone c; c.apex = v3(sl[0], sl[1], sl[2]); c.pAB = v3(sl[3], sl[4], sl[5]); c.g = sl[6];
+                Cone c; c.apex = v3(sl[0], sl[K_MAX], sl[2 * K_MAX]); c.pAB = v3(sl[3 * K_MAX], sl[4 * K_MAX], sl[5 * K_MAX]); c.g = sl[6 * K_MAX];
                 vp_hit = cone_hit(c, vpref + pA);
             } else {
-                Plane pl; pl.p = v3(sl[0], sl[1], sl[2]); pl.n = v3(sl[3], sl[4], sl[5]);
+                Plane pl; pl.p = v3(sl[0], sl[K_MAX], sl[2 * K_MAX]); pl.n = v3(sl[3 * K_MAX], sl[4 * K_MAX], sl[5 * K_MAX]);
                 vp_hit = !in_orca(pl, vpref);
             }
         }
