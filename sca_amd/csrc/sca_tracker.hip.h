@@ -10,9 +10,12 @@
 //             2-D plans, ~10^5 fp64 instructions), the first tracked node, v_pref.  Compacting the re-planning agents into
 //             dense wavefronts keeps the long plans from stalling the followers that would share their wave.
 //   k_replan_few  the same with 4, 16, 32 or 64 lanes per plan, for passes with few re-plans (see below).
-// Both re-plan kernels are launched every pass (k_replan only when the shard is large enough to need it) -- on a stream of
-// their own, beside the kd build and the neighbour query, joined before k_solve -- and the device-side count of the pass
-// decides which of them, and which form, does the work.
+//   k_replan_mid  four lanes per plan at two wavefronts per SIMD, for the counts in between.
+//   k_track_replan  k_track + k_replan in one launch (no list) for passes in which nearly the whole shard re-plans.
+// They run on the library's main stream -- they are the pass's critical path; the kd build, the neighbour query and the
+// v_pref-independent half of the solve run beside them on a second stream, joined before the prologue that reads v_pref.
+// The host launches the re-plan kernels a recent pass's count makes possible (launch_tracker); the device-side count of the
+// pass decides which of them, and which form inside k_replan_few, does the work.
 //
 // The arithmetic is sca_dubins.hpp compiled for gfx950: same statements as the host tracker, the device library's
 // sin / cos / atan2 / acos instead of glibc's.  State: one AgentTrack record per agent, resident in HBM.
@@ -30,7 +33,8 @@ struct TrackDev {
     int32_t *count;               // [4] re-plans of the pass (= list length), a ring over the passes: pass p counts in slot p & 3 and
                                   // zeroes slot (p + 1) & 3; the host reads the previous pass's slot, which is final, without waiting
     int parity;                   // the slot of this pass
-    int nbr0_from_lists;          // 1: refresh nbr0 from the neighbour lists of the previous pass (resident stepping)
+    int nbr0_from_lists;          // 1: take nbr0 from the neighbour lists as they are (sca_device_tracker_vpref without an upload); inside a
+                                  // pass it is what the previous pass's epilogue saved (DeviceView::trk_nbr0)
     int lo, hi;                   // this launch takes the pass when lo < (re-plans of the pass) <= hi; the launches of a pass cover every count
     int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning): k_replan_few's range
     int mid_max;                  // TRK_MID_MAX (SCA_TRK_MID_MAX): k_replan_mid's
