@@ -157,3 +157,36 @@ def test_forms_the_library_picks_by_itself(S):
     small = run(3000, True, 16)
     assert small & S.FORM_REPLAN_FEW and not small & (S.FORM_SOLVE_SPLIT | S.FORM_TRACK_FUSED | S.FORM_REPLAN_LANE), small
     assert run(60000, False, 3) == 0
+
+
+def test_long_tracked_episode_all_forms_against_the_plain_ones(S, monkeypatch):
+    """A soak for the stream choreography: 240 resident steps of a 60 000-agent tracked shard with everything the library
+    picks by itself (split solve on two streams, k_track_replan, count readbacks, form switches as the re-plan count moves)
+    against the same episode with the plain forms (k_track + k_replan, one-launch k_solve), compared every 20 steps."""
+    from sca_amd import scenarios
+    n = 60000
+    sc = scenarios.circle(n)
+    policy = np.where(np.arange(n) % 13 == 6, 3, 0).astype(np.uint8)
+    sols = []
+    for plain in (True, False):
+        if plain:
+            monkeypatch.setenv('SCA_SOLVE_SPLIT', '0'); monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
+        else:
+            monkeypatch.delenv('SCA_SOLVE_SPLIT', raising=False); monkeypatch.delenv('SCA_TRACKER_NOFUSE', raising=False)
+        sol = S.BatchedSolver(max_agents=n)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], policy, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+        sols.append(sol)
+    a, b = sols
+    seen = 0
+    for blk in range(12):
+        a.run_steps(20); b.run_steps(20)
+        a.synchronize(); b.synchronize()
+        _same(a, b, ('soak', blk))
+        seen |= b.pass_forms()
+    assert seen & S.FORM_SOLVE_SPLIT and seen & S.FORM_TRACK_FUSED, seen
+    assert np.array_equal(a.device_tracker_replans(), b.device_tracker_replans())
+    a.close(); b.close()
