@@ -157,7 +157,7 @@ def roofline_of(leg, steps, tracked, wname):
     k_replan = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                 'traffic': measured_traffic(wname, 'k_track_replan' if leg['forms'] & 2 else 'k_replan'),
                 'kernel': ('k_track_replan (follow-or-re-plan decision + the re-plan, one lane per agent)' if leg['forms'] & 2 else
-                           'k_replan (+ k_replan_few)') + ', beside the kd build, the neighbour query'
+                           'k_replan (or k_replan_group<lanes per plan>)') + ', beside the kd build, the neighbour query'
                           + (' and k_solve_sweep' if leg['forms'] & 1 else '') + ' of the same pass',
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
                 'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if leg['forms'] & 2 else
@@ -338,14 +338,14 @@ def main():
                        'v_pref': {'straight': 'straight-line rule on the device' + (' (SCA\'s Dubins tracker left out: --vpref)' if has_tracker else ''),
                                   'dubins': 'native Dubins tracker on the host every step (end-to-end SCA, bit-exact, host-bound)',
                                   'dubins-device': 'SCA as shipped: Dubins tracker + 3-D Dubins planner on the device inside every step '
-                                                   '(k_track, k_replan / k_replan_few)'}[vpref],
+                                                   '(k_track, k_replan / k_replan_group / k_track_replan)'}[vpref],
                        'parallelism': (f'{n} agents sharded over {world} GPUs, one all-gather of 48-B records per step '
                                        + ('by the library\'s RCCL communicator inside sca_run_steps' if exchange == 'inlib'
                                           else 'through torch.distributed')) if world > 1 else 'single GPU',
                        'agent_steps_timed': main_leg['agent_steps'], 're_plans_timed': main_leg['plans']},
             'roofline': roof,
         }
-        FORMS = {1: 'k_solve_sweep + k_solve_pick4', 2: 'k_track_replan', 4: 'lane-per-plan re-plan kernel', 8: 'k_replan_few', 16: 'k_lp'}
+        FORMS = {1: 'k_solve_sweep + k_solve_pick4', 2: 'k_track_replan', 4: 'lane-per-plan re-plan kernel', 8: 'k_replan_group (4 .. 64 lanes per plan)', 16: 'k_lp'}
         out['config']['kernel_forms'] = [v for k, v in FORMS.items() if main_leg['forms'] & k] or ['k_solve']
         if roof2 is None and tracked and 'solver_only' in extras:
             roof2 = dict(extras['solver_only']['roofline'], source='the solver_only leg (in the tracked step k_solve runs as k_solve_sweep '

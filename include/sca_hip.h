@@ -159,14 +159,14 @@ int sca_comm_destroy(sca_ctx *ctx);
 /* average device time of the kernels of the last sca_policy_pass / sca_run_steps, measured with HIP events */
 int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float *update_ms);
 
-/* the same for the tracker's re-plan kernels (k_replan_few + k_replan), events on the stream they run on */
+/* the same for the tracker's re-plan kernels (k_replan_group<4 .. 64 lanes per plan>, k_replan, k_track_replan), events on the stream they run on */
 int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
 /* Which kernel forms the last policy pass was launched with (the library picks them per pass from the shard size and the
  * re-plan count of a recent pass; none of them changes a result bit -- tests/test_gpu_solve_split.py, test_gpu_tracker.py):
  *   SCA_FORM_SOLVE_SPLIT   k_solve as k_solve_sweep (beside the tracker's re-plans) + k_solve_pick4 (behind them)
  *   SCA_FORM_TRACK_FUSED   k_track_replan instead of k_track + k_replan
  *   SCA_FORM_REPLAN_LANE   the lane-per-plan re-plan kernel was launched (k_replan or k_track_replan)
- *   SCA_FORM_REPLAN_FEW    k_replan_few (4 .. 64 lanes per plan) was launched
+ *   SCA_FORM_REPLAN_FEW    a k_replan_group kernel (4 .. 64 lanes per plan) was launched
  *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent) */
 #define SCA_FORM_SOLVE_SPLIT 1
 #define SCA_FORM_TRACK_FUSED 2

@@ -416,7 +416,8 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     {   // resolve the tracker's kernels now: the first launch of a kernel pays for looking it up in the code object, and the
         // forms are picked while the episode runs (k_track_replan's first launch used to fall into a timed step)
         hipFuncAttributes fa;
-        for (const void *f : {(const void *)k_track, (const void *)k_replan, (const void *)k_replan_few, (const void *)k_replan_mid,
+        for (const void *f : {(const void *)k_track, (const void *)k_replan, (const void *)k_replan_group<64>, (const void *)k_replan_group<32>,
+                              (const void *)k_replan_group<16>, (const void *)k_replan_group<4>,
                               (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4, (const void *)k_prep_shard})
             (void)hipFuncGetAttributes(&fa, f);
     }
@@ -426,7 +427,6 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
     c->trk_fuse = getenv("SCA_TRACKER_NOFUSE") == nullptr;
-    c->trk.quad_max = getenv("SCA_TRK_QUAD_MAX") ? atoi(getenv("SCA_TRK_QUAD_MAX")) : TRK_QUAD_MAX;
     c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : TRK_MID_MAX;
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
     c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;
@@ -925,21 +925,31 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
     K.nbr0_from_lists = (from_lists && !in_pass) ? 1 : 0;
-    // The device-side count of this pass decides which kernel, and which form inside k_replan_few, does the work: every launched
-    // kernel reads it and returns unless it falls into its range (lo, hi].  Launching all three every pass costs two empty
-    // launches on the critical path; the count of an earlier pass (copied back on the side stream, never waited for) says
+    // The device-side count of this pass decides which re-plan kernel does the work: every launched kernel reads it and returns
+    // unless it falls into its range (lo, hi].  Launching all five every pass would cost four empty launches on the critical
+    // path; the count of an earlier pass (copied back on the side stream, never waited for) says
     // which of them can be left out -- the ranges of those that are launched are widened so that every count is still somebody's
     // (a count that jumps is then re-planned by a form that is slower for it, never by nobody).  When nearly the whole shard
     // re-plans in the lane-per-plan form, k_track's list is not worth its launch either: k_track_replan does both.
     if (c->trk_count_pending && hipEventQuery(c->trk_count_ev) == hipSuccess) { c->trk_last_count = c->trk_host_count[0]; c->trk_count_pending = false; }
-    const int Q1 = K.quad_max, Q2 = std::max(K.mid_max, K.quad_max), lc = c->trk_last_count;
+    // forms 0..3: k_replan_group<64 / 32 / 16 / 4> with the natural ranges (up[i - 1], up[i]]; form 4: one lane per plan, above
+    const int lc = c->trk_last_count;
     const bool known = lc >= 0;
-    bool few = c->trk_quad && (!known || lc <= Q1 + Q1 / 4);
-    bool mid = c->trk_quad && cnt > Q1 && Q2 > Q1 && (!known || (lc > Q1 - Q1 / 4 && lc <= Q2 + Q2 / 4));
-    bool lane = !c->trk_quad || (cnt > Q2 && (!known || lc > Q2 - Q2 / 4));
-    if (!few && !mid && !lane) { if (cnt > Q2) lane = true; else if (cnt > Q1 && Q2 > Q1) mid = true; else few = true; }
-    const bool fused = in_pass && lane && !few && !mid && c->trk_fuse && (long long)lc * 4 >= (long long)cnt * 3;
-    c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (few || mid ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
+    int up[5] = {K.spec4_max, K.spec3_max, K.spec2_max, K.mid_max, INT_MAX};
+    for (int i = 1; i < 4; i++) up[i] = std::max(up[i], up[i - 1]);
+    bool want[5];
+    int nwant = 0;
+    for (int i = 0; i < 5; i++) {
+        const long long lower = i ? up[i - 1] : -1, upper = up[i];
+        const bool possible = cnt > lower && upper > lower && (i == 4 || c->trk_quad);
+        want[i] = possible && (!known || (lc > lower - lower / 4 && (i == 4 || lc <= upper + upper / 4)));
+        nwant += want[i];
+    }
+    if (!c->trk_quad) { for (int i = 0; i < 4; i++) want[i] = false; want[4] = true; nwant = 1; }
+    if (nwant == 0) { want[4] = true; nwant = 1; }
+    const bool lane = want[4];
+    const bool fused = in_pass && lane && nwant == 1 && c->trk_fuse && (long long)lc * 4 >= (long long)cnt * 3;
+    c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (nwant > (lane ? 1 : 0) ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -955,21 +965,27 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
         hipLaunchKernelGGL(k_track_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);
     } else {
-        if (few) {   // one wavefront per workgroup; enough of them for the widest form at its largest count
-            K.lo = -1; K.hi = (mid || lane) ? Q1 : INT_MAX;
-            const int top = K.hi == INT_MAX ? cnt : Q1;
-            const int blocks = std::max(std::max(TRK_FEW_BLOCKS, (top + 15) / 16), std::max((K.spec2_max + 3) / 4, std::max((K.spec3_max + 1) / 2, K.spec4_max)));
-            hipLaunchKernelGGL(k_replan_few, dim3(std::min(cnt, blocks)), dim3(64), 0, rs, c->d, c->trk_view, K);
-        }
-        if (mid) {
-            K.lo = few ? Q1 : -1; K.hi = lane ? Q2 : INT_MAX;
-            const int top = K.hi == INT_MAX ? cnt : std::min(cnt, Q2);
-            hipLaunchKernelGGL(k_replan_mid, dim3((top + 15) / 16), dim3(64), 0, rs, c->d, c->trk_view, K);
-        }
-        if (lane) {
-            K.lo = mid ? Q2 : (few ? Q1 : -1); K.hi = INT_MAX;
-            hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
-                               c->trk_view, K);
+        int prev_up = -1, left = nwant;
+        for (int i = 0; i < 5; i++) {
+            if (!want[i]) continue;
+            left--;
+            K.lo = prev_up; K.hi = left ? up[i] : INT_MAX;               // the first launched form starts at 0, the last one takes the rest
+            prev_up = up[i];
+            const int top = K.hi == INT_MAX ? cnt : std::min(cnt, up[i]);  // plans this launch must be able to hold
+            if (top <= 0) continue;                                        // (a range moved to nothing by the tuning switches)
+            // workgroups of four wavefronts, one per SIMD of a CU: the forms need <= 256 registers, so a SIMD can hold two of
+            // their wavefronts, and with one-wavefront workgroups the dispatcher doubles some SIMDs up while others stay empty
+            const dim3 blk(TRK_GROUP_THREADS);
+            const auto blocks = [&](int lanes) { return dim3((unsigned)(((long long)top * lanes + TRK_GROUP_THREADS - 1) / TRK_GROUP_THREADS)); };
+            switch (i) {
+            case 0: hipLaunchKernelGGL(k_replan_group<64>, blocks(64), blk, 0, rs, c->d, c->trk_view, K); break;
+            case 1: hipLaunchKernelGGL(k_replan_group<32>, blocks(32), blk, 0, rs, c->d, c->trk_view, K); break;
+            case 2: hipLaunchKernelGGL(k_replan_group<16>, blocks(16), blk, 0, rs, c->d, c->trk_view, K); break;
+            case 3: hipLaunchKernelGGL(k_replan_group<4>, blocks(4), blk, 0, rs, c->d, c->trk_view, K); break;
+            default:
+                hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
+                                   c->trk_view, K);
+            }
         }
     }
     if (t1) CHK(c, hipEventRecord(t1, rs));
@@ -1001,8 +1017,8 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
     if (c->solve_split >= 0) return c->solve_split != 0;
     if (!overlap) return false;
     const int est = c->trk_last_count >= 0 ? c->trk_last_count : cnt;    // re-plans of a recent pass (all agents before the first readback)
-    if (est <= c->trk.quad_max + c->trk.quad_max / 4) return false;     // the many-lanes-per-plan forms: short re-plans, nothing to hide behind
-    if (est <= c->trk.mid_max) return false;                            // k_replan_mid's range: measured equal with and without (18 000 .. 30 000 agents)
+    if (est <= c->trk.mid_max) return false;      // the many-lanes-per-plan forms: short re-plans, nothing to hide behind (measured equal
+                                                  // with and without at 18 000 .. 30 000 agents)
     const int rounds = (est + 65535) / 65536;
     return rounds == 1 ? cnt <= 61440 : (rounds == 2 ? cnt <= 114688 : false);
 }

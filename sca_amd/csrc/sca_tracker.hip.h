@@ -36,18 +36,15 @@ struct TrackDev {
     int nbr0_from_lists;          // 1: take nbr0 from the neighbour lists as they are (sca_device_tracker_vpref without an upload); inside a
                                   // pass it is what the previous pass's epilogue saved (DeviceView::trk_nbr0)
     int lo, hi;                   // this launch takes the pass when lo < (re-plans of the pass) <= hi; the launches of a pass cover every count
-    int quad_max;                 // TRK_QUAD_MAX unless overridden (SCA_TRK_QUAD_MAX, tuning): k_replan_few's range
-    int mid_max;                  // TRK_MID_MAX (SCA_TRK_MID_MAX): k_replan_mid's
+    int mid_max;                  // TRK_MID_MAX unless overridden (SCA_TRK_MID_MAX, tuning): the quad form's upper end
     int spec2_max, spec3_max, spec4_max;   // TRK_SPEC*_MAX unless overridden (SCA_TRK_SPEC2_MAX ..., tuning)
 };
 
 // Which kernel re-plans a pass, by the pass's re-plan count (read on the device; the host launches the kernels whose range a recent
 // count makes possible and widens the outermost ranges so that every count is covered):
-//   <= TRK_QUAD_MAX   k_replan_few: 64 .. 4 lanes per plan, one wavefront per SIMD (258 registers): 16 384 plans = 1024 wavefronts
-//   <= TRK_MID_MAX    k_replan_mid: 4 lanes per plan compiled for two wavefronts per SIMD (255 registers, 12 B of scratch: 13 %
-//                     slower per wavefront, which is why the few-kernel is not built that way): 24 576 agents 0.55 -> 0.47 ms per step
+//   <= TRK_SPEC4_MAX / SPEC3 / SPEC2   k_replan_group<64 / 32 / 16>: the search 4 / 3 / 2 steps per round (below)
+//   <= TRK_MID_MAX    k_replan_group<4>: four lanes per plan, two wavefronts per SIMD (217 registers): 32 768 plans = 2048 wavefronts
 //   above             k_replan / k_track_replan: one lane per plan (0.44 ms up to 65 536 plans, 0.63 up to 131 072)
-constexpr int TRK_QUAD_MAX = 16384;
 constexpr int TRK_MID_MAX = 32768;
 constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one per SIMD of a CU: the dispatcher then loads the SIMDs evenly
                                           // (65 536 plans as 1024 one-wave workgroups: 0.63 ms, some SIMDs drew two; as 256 of these: 0.44)
@@ -282,9 +279,9 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
 // along the path that loop would have taken -- same expressions for the candidates, same comparisons, results off the path are
 // dropped -- so every round advances the chain by D steps.  3/2 (7/3, 15/4) of the four-lane form's work, 1/2 (1/3, 1/4) of its critical
 // path: used while a pass has so few re-plans that most SIMDs would idle anyway.
-constexpr int TRK_SPEC2_MAX = 4096;        // <= this many re-plans in the pass: two steps per round, 16 lanes per plan
-constexpr int TRK_SPEC3_MAX = 2048;        // <= this many: three steps per round, 32 lanes per plan
-constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: four steps per round, a whole wavefront per plan
+constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass: two steps per round, 16 lanes per plan (2048 wavefronts: two per SIMD)
+constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: three steps per round, 32 lanes per plan (2048 wavefronts)
+constexpr int TRK_SPEC4_MAX = 1280;        // <= this many: four steps per round, a whole wavefront per plan
 
 __device__ __forceinline__ void fetch_maneuver(sca_dubins::Maneuver2D &dst, const sca_dubins::Maneuver2D &mine, int src) {
     const double r = lane_fetch_d(mine.r_min, src);
@@ -338,24 +335,41 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
 #pragma unroll
         for (int k = 2; k <= NODES; k++) myc = quad == k - 1 ? nc[k] : myc;
         const int nfc = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * myc, fch, fcv, sub, lane);
-        int node = 1;
+        // Every node's verdict inputs (feasible?, length) into every lane FIRST -- independent cross-lane reads, and for a whole
+        // wavefront per plan plain v_readlane of a fixed lane -- then the walk along the sequential loop's path is register
+        // arithmetic; the two maneuvers of the last accepted node are fetched once per round (the walk only needs lengths).
+        // Before, every depth step waited for three dependent ds_bpermute round trips and an accept for eighteen more:
+        // more than half of a round (c2: k_replan_few 121 -> 93 us).
+        int nfk[NODES + 1];
+        double lenk[NODES + 1];
+#pragma unroll
+        for (int k = 1; k <= NODES; k++) {
+            if constexpr (LANES == 64) {
+                nfk[k] = __builtin_amdgcn_readlane(nfc, 4 * (k - 1));
+                lenk[k] = readlane_f64(fcv.length, 4 * (k - 1));
+            } else {
+                nfk[k] = __shfl(nfc, base + 4 * (k - 1));
+                lenk[k] = lane_fetch_d(fcv.length, base + 4 * (k - 1));
+            }
+        }
+        int node = 1, accepted = 0;
+        double best_len = fbv.length;
 #pragma unroll
         for (int depth = 0; depth < D; depth++) {
-            const int src = base + 4 * (node - 1);
-            const int nf = __shfl(nfc, src);
-            const double len = lane_fetch_d(fcv.length, src);
-            double cn = nc[1];
+            int nf = nfk[1];
+            double len = lenk[1], cn = nc[1];
 #pragma unroll
-            for (int k = 2; k <= NODES; k++) cn = node == k ? nc[k] : cn;
-            if (nf > 0 && cn != b && length_tie(len, fbv.length)) note_tie(P, step);
-            const bool acc = nf > 0 && len < fbv.length;                   // the same in every lane of the group
-            if (acc) {
-                b = cn;
-                fetch_maneuver(fbh, fch, src);                             // whole groups take this branch together
-                fetch_maneuver(fbv, fcv, src);
-                step *= 2.; node = 2 * node;
-            } else { step *= -0.1; node = 2 * node + 1; }
+            for (int k = 2; k <= NODES; k++) { nf = node == k ? nfk[k] : nf; len = node == k ? lenk[k] : len; cn = node == k ? nc[k] : cn; }
+            if (nf > 0 && cn != b && length_tie(len, best_len)) note_tie(P, step);
+            const bool acc = nf > 0 && len < best_len;                     // the same in every lane of the group
+            if (acc) { b = cn; best_len = len; accepted = node; step *= 2.; node = 2 * node; }
+            else { step *= -0.1; node = 2 * node + 1; }
             if (!(::fabs(step) > 1e-10)) break;
+        }
+        if (accepted) {                                                    // whole groups take this branch together
+            const int src = base + 4 * (accepted - 1);
+            fetch_maneuver(fbh, fch, src);
+            fetch_maneuver(fbv, fcv, src);
         }
     }
     finish_plan(P, fbh, fbv, qi);
@@ -388,24 +402,16 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     track_store(d, agent, V, a.edge);
 }
 
-// All the many-lanes-per-plan forms in ONE launch: the device-side count of the pass picks the widest form that still leaves
-// no SIMD with more than one wavefront (every form needs <= 1024 workgroups).  Passes with more re-plans than TRK_QUAD_MAX
-// belong to k_replan.
-constexpr int TRK_FEW_BLOCKS = 1024;
-__global__ __launch_bounds__(64) void k_replan_few(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
-    const int count = K.count[K.parity];
-    if (count > K.hi) return;
-    if (count <= K.spec4_max) replan_group<64>(d, T, K, count);
-    else if (count <= K.spec3_max) replan_group<32>(d, T, K, count);
-    else if (count <= K.spec2_max) replan_group<16>(d, T, K, count);
-    else replan_group<4>(d, T, K, count);
-}
-
-// the four-lanes-per-plan form for passes with more re-plans than one wavefront per SIMD holds: two wavefronts per SIMD
-__global__ __launch_bounds__(64, 2) void k_replan_mid(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+// The many-lanes-per-plan forms, ONE KERNEL EACH (round 2; they used to share one kernel that picked the form by the count:
+// its register allocation was the union's -- 258, one wavefront per SIMD -- and moved with every change to any form; alone the
+// quad form takes 217 registers and runs two wavefronts per SIMD, which is what 16 385 .. 32 768 plans need).  Every launch
+// reads the pass's count and returns unless it falls into its range (lo, hi] (launch_tracker).
+constexpr int TRK_GROUP_THREADS = 256;
+template <int LANES>
+__global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_replan_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     const int count = K.count[K.parity];
     if (count <= K.lo || count > K.hi) return;
-    replan_group<4>(d, T, K, count);
+    replan_group<LANES>(d, T, K, count);
 }
 
 // self-test: m_atan2 (coefficients from SGPRs, the lean division) against the device library's atan2, bit for bit

@@ -351,18 +351,24 @@ def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
     plain.close(); fused.close()
 
 
-@pytest.mark.parametrize('n,form', [(3000, 'few'), (24000, 'mid'), (45000, 'lane')])
+@pytest.mark.parametrize('n,form', [(600, 'spec4'), (1500, 'spec3'), (3000, 'spec2'), (24000, 'quad'), (45000, 'lane')])
 def test_replan_kernel_ranges_give_the_same_episode(n, form, monkeypatch):
-    """The re-plan kernel is picked per pass by the pass's re-plan count (k_replan_few: <= 16 384, k_replan_mid: <= 32 768,
-    k_replan above).  Every one of them is the same planner: an episode with the ranges as they are equals the episode with the
-    ranges moved so that another kernel does the work (SCA_TRK_QUAD_MAX / SCA_TRK_MID_MAX), bit for bit."""
+    """The re-plan kernel is picked per pass by the pass's re-plan count (k_replan_group<64 / 32 / 16 / 4>: <= 1024 / 2048 /
+    4096 / 32 768 re-plans, k_replan above).  Every one of them is the same planner: an episode with the ranges as they are
+    equals the episode with the ranges moved so that another kernel does the work (SCA_TRK_SPEC*_MAX / SCA_TRK_MID_MAX), bit
+    for bit."""
     from sca_amd import scenarios, solver as S
     sc = scenarios.circle(n)
     pol = np.zeros(n, np.uint8)
-    other = {'few': ('1', '2'), 'mid': ('1000000', '1000000'), 'lane': ('1000000', '1000000')}[form]   # -> lane / few / few
+    keys = ('SCA_TRK_SPEC4_MAX', 'SCA_TRK_SPEC3_MAX', 'SCA_TRK_SPEC2_MAX', 'SCA_TRK_MID_MAX')
+    other = {'spec4': ('0', '0', '0', '1000000'),          # -> the quad form
+             'spec3': ('0', '0', '1000000', '1000000'),    # -> 16 lanes per plan
+             'spec2': ('1000000', '1000000', '1000000', '1000000'),   # -> a wavefront per plan
+             'quad': ('0', '0', '0', '1'),                 # -> one lane per plan
+             'lane': ('0', '0', '0', '1000000')}[form]     # -> the quad form
     sols = []
     for moved in (False, True):
-        for k, v in zip(('SCA_TRK_QUAD_MAX', 'SCA_TRK_MID_MAX'), other):
+        for k, v in zip(keys, other):
             if moved:
                 monkeypatch.setenv(k, v)
             else:
