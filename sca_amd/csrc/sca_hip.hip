@@ -215,7 +215,7 @@ struct sca_ctx {
     unsigned trk_passes = 0;
     int forms = 0;                      // SCA_FORM_* of the last policy pass
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
-    unsigned prof_tick = 0;             // with profiling on, every 4th pass carries the event pairs
+    unsigned prof_tick = 0;             // with profiling on, every 8th pass carries the event pairs
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
     bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
     // multi-GPU exchange inside the library (sca_comm_init): one ncclAllGather of the shard's moved records per step
@@ -953,7 +953,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->profiling && (c->prof_tick & 3u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
+    if (c->profiling && (c->prof_tick & 7u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
         for (hipEvent_t *e : {&t0, &t1}) {
             if (c->pool_trk_used == (int)c->pool_trk.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_trk.push_back(n_); }
             *e = c->pool_trk[c->pool_trk_used++];
@@ -1074,7 +1074,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const int cnt = d.shard_count;
     hipStream_t ns = c->nbr_stream;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2], e3 = c->ev[3];
-    const bool prof = !timed && c->profiling && (c->prof_tick++ & 3u) == 0 && c->pool_used + 4 <= 4 * 4096;
+    const bool prof = !timed && c->profiling && (c->prof_tick++ & 7u) == 0 && c->pool_used + 4 <= 4 * 4096;
     if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2) || pool_event(c, &e3)) return SCA_ERR_HIP; }
     if (timed || prof) CHK(c, hipEventRecord(e0, ns));
     double agent_reach, obs_reach;
