@@ -1430,7 +1430,19 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned x) {             // eve
 }
 
 __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P, unsigned int *pk, int agent, int j, int row) {
+    // Everything the row reads that is addressed by the agent id alone is loaded up front, before the first branch: the kernel is
+    // a chain of dependent memory round trips (record -> prologue -> cones / survivors), not arithmetic, and the loads below the
+    // early exits would each wait for the previous one's data (45 -> 41 us at c4).  All addresses are valid for any agent.
     const PubRec me = d.rec[agent];
+    const int pol_ = d.policy[agent];
+    const Prep pr_ = ((const Prep *)d.prep)[agent];
+    const int nbrv_ = d.nbr_valid[agent], nbrn_ = d.nbr_n[agent], zax_ = d.zaxis[agent], nT_ = d.sw_n[agent];
+    double sl_[7];
+    {
+        const double *g = d.sw_slot + (size_t)agent * K_MAX * SLOTF + j;
+#pragma unroll
+        for (int q = 0; q < 7; q++) sl_[q] = g[q * K_MAX];
+    }
     int32_t *diag = d.diag + (size_t)agent * 8;
     if (j == 0) d.is_fb[agent] = 0;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
@@ -1438,25 +1450,25 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
         if (j < 3) d.vpref_used[agent * 3 + j] = __builtin_nan("");
         return;
     }
-    const int pol = d.policy[agent];
+    const int pol = pol_;
     const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
     const V3 pA = v3(me.px, me.py, me.pz);
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const V3 vA64 = to_v3(vA);
-    const Prep pr = ((const Prep *)d.prep)[agent];
+    const Prep pr = pr_;
     const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1;
     V3 vpost = v3(0, 0, 0);
     bool defer = false;
-    const int K = d.nbr_valid[agent] ? d.nbr_n[agent] : 0;
+    const int K = nbrv_ ? nbrn_ : 0;
     if (pol == POL_ORCA_LP && !first_step) return;                                   // K3: k_lp
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
         CandTab T;
-        T.num_N = (pol == POL_SCA && d.zaxis[agent]) ? 128 : 256;                     // scaPolicy.py:188-190
+        T.num_N = (pol == POL_SCA && zax_) ? 128 : 256;                               // scaPolicy.py:188-190
         T.unit = (T.num_N == 256) ? d.unit256 : d.unit128;
         T.phi = (T.num_N == 256) ? d.phi256 : d.phi128;
         T.vp_idx = 2 * T.num_N;
@@ -1464,19 +1476,18 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
         // ---- the v_pref candidate (scaPolicy.py:206-211): lane j tests neighbour j against the cone / plane of the sweep
         bool vp_hit = false;
         if (j < K) {
-            const double *sl = d.sw_slot + (size_t)agent * K_MAX * SLOTF + j;
             if (!orca) {
-                Cone c; c.apex = v3(sl[0], sl[K_MAX], sl[2 * K_MAX]); c.pAB = v3(sl[3 * K_MAX], sl[4 * K_MAX], sl[5 * K_MAX]); c.g = sl[6 * K_MAX];
+                Cone c; c.apex = v3(sl_[0], sl_[1], sl_[2]); c.pAB = v3(sl_[3], sl_[4], sl_[5]); c.g = sl_[6];
                 vp_hit = cone_hit(c, vpref + pA);
             } else {
-                Plane pl; pl.p = v3(sl[0], sl[K_MAX], sl[2 * K_MAX]); pl.n = v3(sl[3 * K_MAX], sl[4 * K_MAX], sl[5 * K_MAX]);
+                Plane pl; pl.p = v3(sl_[0], sl_[1], sl_[2]); pl.n = v3(sl_[3], sl_[4], sl_[5]);
                 vp_hit = !in_orca(pl, vpref);
             }
         }
         const unsigned long long hits = __ballot(vp_hit);
         const bool vp_ok = (pr.bits & 4u) && (((hits >> (16 * row)) & 0xffffull) == 0);
         // ---- packed keys of the survivors: (round5 numerator of |v - v_pref|) << 10 | generation index (scaPolicy.py:219)
-        const int nT = d.sw_n[agent];
+        const int nT = nT_;
         const uint16_t *surv = d.sw_surv + (size_t)agent * 512;
         auto key_of = [&](int e) {
             const int ix = (int)surv[e];
