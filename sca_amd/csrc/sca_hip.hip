@@ -215,7 +215,7 @@ struct sca_ctx {
     unsigned trk_passes = 0;
     int forms = 0;                      // SCA_FORM_* of the last policy pass
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
-    unsigned prof_tick = 0;             // with profiling on, every 8th pass carries the event pairs
+    unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
     bool trk_quad = true;               // SCA_TRACKER_NOQUAD=1: lane-per-plan kernel only (diagnostics)
     // multi-GPU exchange inside the library (sca_comm_init): one ncclAllGather of the shard's moved records per step
@@ -932,6 +932,9 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     // which of them can be left out -- the ranges of those that are launched are widened so that every count is still somebody's
     // (a count that jumps is then re-planned by a form that is slower for it, never by nobody).  When nearly the whole shard
     // re-plans in the lane-per-plan form, k_track's list is not worth its launch either: k_track_replan does both.
+    // (the first count of an episode is waited for once: a caller that enqueues a long burst of steps runs far ahead of the device,
+    // and without it the whole burst would be launched with the forms of "count unknown")
+    if (c->trk_count_pending && c->trk_last_count < 0) CHK(c, hipEventSynchronize(c->trk_count_ev));
     if (c->trk_count_pending && hipEventQuery(c->trk_count_ev) == hipSuccess) { c->trk_last_count = c->trk_host_count[0]; c->trk_count_pending = false; }
     // forms 0..3: k_replan_group<64 / 32 / 16 / 4> with the natural ranges (up[i - 1], up[i]]; form 4: one lane per plan, above
     const int lc = c->trk_last_count;
@@ -954,7 +957,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->profiling && (c->prof_tick & 7u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
+    if (c->profiling && (c->prof_tick & 15u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
         for (hipEvent_t *e : {&t0, &t1}) {
             if (c->pool_trk_used == (int)c->pool_trk.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_trk.push_back(n_); }
             *e = c->pool_trk[c->pool_trk_used++];
@@ -1075,7 +1078,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const int cnt = d.shard_count;
     hipStream_t ns = c->nbr_stream;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2], e3 = c->ev[3];
-    const bool prof = !timed && c->profiling && (c->prof_tick++ & 7u) == 0 && c->pool_used + 4 <= 4 * 4096;
+    const bool prof = !timed && c->profiling && (c->prof_tick++ & 15u) == 0 && c->pool_used + 4 <= 4 * 4096;
     if (prof) { if (pool_event(c, &e0) || pool_event(c, &e1) || pool_event(c, &e2) || pool_event(c, &e3)) return SCA_ERR_HIP; }
     if (timed || prof) CHK(c, hipEventRecord(e0, ns));
     double agent_reach, obs_reach;

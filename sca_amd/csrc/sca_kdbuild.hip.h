@@ -266,10 +266,12 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, const KdBuf B, i
         for (int w = 1; w < W; w++) v = is_min ? (red[w][tid] < v ? red[w][tid] : v) : (red[w][tid] > v ? red[w][tid] : v);
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
         if (is_min) atomicMin(&cb[tid], dkey(v)); else atomicMax(&cb[tid], dkey(v));
+        // The children's boxes before the chain word: whoever has seen every chunk's word of a node (the chunk that ends the
+        // chain: kd_bookkeep) must read complete boxes.  This needs the device-scope fence: with the barrier alone (which does
+        // wait for the workgroup's outstanding memory operations) a box was read incomplete about once in 10^3 builds when the
+        // GPU was shared with another process -- a subtree with another split plane, found by the two-rank soak test.
+        __threadfence();
     }
-    // The children's boxes before the chain word: whoever has seen every chunk's word of a node (the chunk that ends the chain:
-    // kd_bookkeep) must read complete boxes.  The barrier waits for the acknowledgement of every outstanding memory operation
-    // of the workgroup (s_waitcnt vmcnt(0)), the atomics are performed at device scope, and the word is stored after it.
     __syncthreads();
     // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident).
     //      The first wavefront reads 64 predecessors at a time: the words are independent, only their arrival is awaited.

@@ -51,11 +51,17 @@ ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.arra
 ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
 ok = ok and (mode != 0 or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
 state_ok = ok
+if not ok:                                                    # say what differs (a bug report's worth)
+    for k in ('pos', 'vel', 'heading', 'flags', 'total_dist'):
+        dif = np.flatnonzero((got[k] != ref[k]).reshape(n, -1).any(1))
+        if dif.size:
+            print('RANK', rank, 'DIFF', k, dif.size, 'agents, first', dif[:8].tolist(), 'last', int(dif[-1]), 'shard', (lo, hi),
+                  'max', float(np.abs(got[k].astype(np.float64) - ref[k].astype(np.float64)).max()), flush=True)
 if n > 50000 and os.environ.get('SCA_TEST_TRACK'):
     f = sol.pass_forms()
     # the split is decided from the shard size; k_track_replan needs a re-plan count to have come back (asynchronous): the fused
     # form against the plain one is tests/test_gpu_tracker.py's business, here it may or may not have been reached yet
-    ok = ok and bool(f & S.FORM_SOLVE_SPLIT)
+    ok = ok and (bool(f & S.FORM_SOLVE_SPLIT) or os.environ.get('SCA_SOLVE_SPLIT') == '0')
     print('RANK', rank, 'forms', f, 'state', state_ok, flush=True)
 print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
 dist.destroy_process_group()
