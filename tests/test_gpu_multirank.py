@@ -20,7 +20,10 @@ rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 torch.cuda.set_device(0)
 dist.init_process_group('gloo')
 n, steps = int(os.environ.get('SCA_TEST_N', '3000')), 12
-if n > 50000:                                                 # a swarm whose shards get the split solve and the fused tracker kernel
+if n > 50000 and os.environ.get('SCA_TEST_SCENE') == 'mixed':  # every policy in every shard (LP agents through k_lp), random cube
+    sc = scenarios.random_cube(n, seed=4)
+    pol = (np.arange(n) % 5).astype(np.uint8)
+elif n > 50000:                                               # a swarm whose shards get the split solve and the fused tracker kernel
     sc = scenarios.circle(n)
     pol = np.where(np.arange(n) % 11 == 5, 2, 0).astype(np.uint8)
 else:
@@ -61,7 +64,7 @@ if n > 50000 and os.environ.get('SCA_TEST_TRACK'):
     f = sol.pass_forms()
     # the split is decided from the shard size; k_track_replan needs a re-plan count to have come back (asynchronous): the fused
     # form against the plain one is tests/test_gpu_tracker.py's business, here it may or may not have been reached yet
-    ok = ok and (bool(f & S.FORM_SOLVE_SPLIT) or os.environ.get('SCA_SOLVE_SPLIT') == '0')
+    ok = ok and (bool(f & S.FORM_SOLVE_SPLIT) or os.environ.get('SCA_SOLVE_SPLIT') == '0' or os.environ.get('SCA_TEST_SCENE') == 'mixed')
     print('RANK', rank, 'forms', f, 'state', state_ok, flush=True)
 print('RANK', rank, 'OK' if ok else 'MISMATCH', flush=True)
 dist.destroy_process_group()
@@ -69,14 +72,19 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('track,mode,n', [(False, 0, 3000), (True, 0, 3000), (False, 1, 3000), (True, 1, 3000), (True, 0, 120000)])
+@pytest.mark.parametrize('track,mode,n', [(False, 0, 3000), (True, 0, 3000), (False, 1, 3000), (True, 1, 3000), (True, 0, 120000),
+                                          (True, 0, -60000)])
 def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
     next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  n = 120 000: shards
-    of 60 000 agents, which get k_track_replan and the split solve (asserted), the second one with shard_begin != 0."""
+    of 60 000 agents, which get k_track_replan and the split solve, the second one with shard_begin != 0 -- the case that found
+    the missing fence of the one-launch-per-level kd build (two processes on one GPU is also a scheduling stress).  n < 0: |n|
+    agents of all five policies in a random cube."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode), SCA_TEST_N=str(n))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode), SCA_TEST_N=str(abs(n)))
+    if n < 0:
+        env['SCA_TEST_SCENE'] = 'mixed'                         # every policy in every shard, random cube
     if track:
         env['SCA_TEST_TRACK'] = '1'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
