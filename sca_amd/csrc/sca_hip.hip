@@ -491,7 +491,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     CHK(c, hipMemcpyToSymbol(HIP_SYMBOL(sca_dubins::SCA_ATAN_C), sca_dubins::SCA_ATAN_BITS, sizeof(sca_dubins::SCA_ATAN_BITS)));   // m_atan2's table
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
     CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
-    CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * KD_COUNTS));   // counts | nchunks | ... (layout: sca_kdbuild.hip.h)
+    CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3)));   // counts | nchunks
     const size_t N = (size_t)max_agents, M = (size_t)max_obstacles;
     DeviceView &d = c->d;
     int r = 0;
@@ -512,16 +512,14 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     { Prep *pp = nullptr; r |= dalloc(c, &pp, N); d.prep = pp; } r |= dalloc(c, &d.diag, N * 8);
     r |= dalloc(c, &d.status, N); r |= dalloc(c, &d.done_count, 256 * 32); r |= dalloc(c, &d.agent_steps, 256 * 16);
     r |= dalloc(c, &c->kd.kx, N); r |= dalloc(c, &c->kd.ky, N); r |= dalloc(c, &c->kd.kz, N);
-    for (int b = 0; b < 2; b++) {
-        r |= dalloc(c, &c->kd.wx[b], N); r |= dalloc(c, &c->kd.wy[b], N); r |= dalloc(c, &c->kd.wz[b], N); r |= dalloc(c, &c->kd.wid[b], N);
-        r |= dalloc(c, &c->kd.mr[b], N); r |= dalloc(c, &c->kd.gr[b], N); r |= dalloc(c, &c->kd.ps[b], N);
-    }
+    r |= dalloc(c, &c->kd.mr, N);
     d.kx = c->kd.kx; d.ky = c->kd.ky; d.kz = c->kd.kz;
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
-    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)KD_COUNTS);   // counts | nchunks | tail slot counter | copy-only workgroups (one readback)
+    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 4);   // counts | nchunks (one readback) | tail slot counter
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MIN + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
+    r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
     r |= dalloc(c, &c->kd.chunks[0], (size_t)c->kd.chunk_cap); r |= dalloc(c, &c->kd.chunks[1], (size_t)c->kd.chunk_cap);
     c->kd.nchunks = c->kd.counts ? c->kd.counts + KD_MAX_LEVELS + 2 : nullptr;
@@ -579,9 +577,8 @@ void sca_destroy(sca_ctx *c) {
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.vpref_edge, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
-                    d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr[0], c->kd.mr[1], c->kd.gr[0], c->kd.gr[1],
-                    c->kd.ps[0], c->kd.ps[1], c->kd.wx[0], c->kd.wx[1], c->kd.wy[0], c->kd.wy[1], c->kd.wz[0], c->kd.wz[1], c->kd.wid[0], c->kd.wid[1],
-                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
+                    d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
+                    c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
                     c->grid.count, c->grid.range, c->grid.cursor, c->grid.bucket, c->grid.slot, c->grid.gx, c->grid.gy, c->grid.gz,
                     c->grid.gid, c->grid.gkey, c->lp_list, d.sw_slot, d.sw_surv, d.sw_n};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -834,7 +831,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, d, c->kd, c->P);
     int levels = 0;
     if (n > wave_max) {
-        // Level passes: one launch per level (k_kd_level) while the nodes span several chunks, then ONE launch
+        // Level passes: two launches per level (rank | swap) while the nodes span several chunks, then ONE launch
         // (k_kd_level_tail) in which every remaining node's workgroup finishes its whole subtree down to wave_max.  Where the
         // switch happens only sets the speed -- the tail handles any node size and any depth -- so it is taken from the
         // statistics of an earlier build when they have arrived (the first level whose nodes all fit one chunk), otherwise
@@ -846,9 +843,9 @@ static int build_agent_tree_device(sca_ctx *c) {
         if (c->kd_ev_pending && hipEventQuery(c->kd_ev) == hipSuccess) {
             int depth = 0;
             while (depth < KD_MAX_LEVELS && c->kd_host_counts[depth] > 0) depth++;
-            const int *nch = c->kd_host_counts + KD_MAX_LEVELS + 2, *nsm = c->kd_host_counts + KD_NSMALL_OFF;
-            int single = depth;                      // (a level's workgroups: one per chunk of its large nodes + one per small child)
-            while (single > 0 && nch[single - 1] - nsm[single - 1] == c->kd_host_counts[single - 1]) single--;
+            const int *nch = c->kd_host_counts + KD_MAX_LEVELS + 2;
+            int single = depth;
+            while (single > 0 && nch[single - 1] == c->kd_host_counts[single - 1]) single--;
             c->kd_single_hint = c->kd_host_counts[KD_MAX_LEVELS + 1] ? 0 : single + 1;        // 1-based
             c->kd_ev_pending = false;
         }
@@ -856,8 +853,10 @@ static int build_agent_tree_device(sca_ctx *c) {
         first_single = std::min(first_single, KD_MAX_LEVELS - 2);
         levels = first_single + 1;
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
-        for (int l = 0; l < first_single; l++)
-            hipLaunchKernelGGL(k_kd_level, dim3(grid), dim3(KD_LV_THREADS), 0, c->nbr_stream, d, c->kd, l, ++c->kd_token);
+        for (int l = 0; l < first_single; l++) {
+            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T + 64), 0, c->nbr_stream, d, c->kd, l);   // + the bookkeeping wavefront
+        }
         hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, first_single, ++c->kd_token);
     }
 
@@ -869,7 +868,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
     if (n > wave_max && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
-        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * KD_COUNTS, hipMemcpyDeviceToHost, c->nbr_stream));
+        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->nbr_stream));
         CHK(c, hipEventRecord(c->kd_ev, c->nbr_stream));
         c->kd_ev_pending = true;
         c->kd_ev_gen = c->kd_gen;
@@ -1375,7 +1374,7 @@ int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
 #ifdef SCA_KB_TIMING
 int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds only: k_kd_block's per-phase ticks
     CHK(c, hipStreamSynchronize(c->stream));
-    CHK(c, hipMemcpy(out, c->kd.ps[0], sizeof(int) * count, hipMemcpyDeviceToHost));
+    CHK(c, hipMemcpy(out, c->kd.ps, sizeof(int) * count, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -11,14 +11,11 @@
 //     every other element stays where it is.
 // That form is data-parallel: one prefix count per element.
 //
-//   k_kd_gather : coordinates and ids into position order (work buffer 0) -> every later pass is coalesced;
+//   k_kd_gather : coordinates into position order (kx/ky/kz[p] = pos of ids[p]) -> every later pass is coalesced;
 //                 root box; the per-agent prologue of the solver for the rank's shard
-//   k_kd_level  : ONE launch per tree level for the nodes with more than wave_max members; a node is cut into chunks
-//                 of KD_CHUNK positions, one workgroup per chunk: the members are read THROUGH the parent level's
-//                 partition (the swaps are never a pass of their own) into this level's buffer, then flags + chained
-//                 scan + ranks + children's boxes; the chunk that ends a node's scan writes the query record, the
-//                 children and their chunk records
-//   k_kd_level_tail : the last level launch: one workgroup per node finishes everything above wave_max below it, in place
+//   k_kd_lv_*   : two launches per tree level for the nodes with more than wave_max members; a node is cut into
+//                 chunks of KD_CHUNK positions, one workgroup per chunk: (flags + chained scan + ranks + children's
+//                 boxes) -> (swaps + query record + children and their chunk records)
 //   k_kd_block  : every subtree of <= wave_max members is finished by ONE WORKGROUP entirely in LDS, level by level,
 //                 all nodes of a level at once (element-parallel; boxes as DPP minima of order-preserving keys, LDS
 //                 atomics for what is left, one lane per node for the records)
@@ -38,24 +35,15 @@ constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level p
 // why a build reported failure (bits of counts[KD_MAX_LEVELS + 1]; sticky across builds until sca_synchronize reports them)
 enum { KD_ERR_SPIN = 1, KD_ERR_CHUNKS = 4, KD_ERR_JOBS = 8, KD_ERR_LEVELS = 16, KD_ERR_BLOCK = 128 };
 struct KdJob { int begin, end, node, pad; };
-struct alignas(16) KdSmall { int begin, end, node, pad, par, r0, r1, r2; };   // par: which work buffer holds the subtree's members
 // workgroup -> node of a level pass: job index, first workgroup of the node, the node's extent and its split plane
-// (axis < 0: not known when the record was written -- the root -- take it from the node's box), and what the workgroup needs
-// of the node's PARENT to read its positions through the parent's partition (pL < 0: nothing to read through).
-// copy = 1: a child small enough for k_kd_block: its workgroup only carries the members over (no ranks).
-struct alignas(16) KdChunkRec { int job, first, nb, ne, axis, copy; double split; int pb, pL, paxis, pad; double psplit; };
+// (axis < 0: not known when the record was written -- the root -- take it from the node's box)
+struct alignas(16) KdChunkRec { int job, first, nb, ne, axis, pad; double split; };
 
 struct KdScratch {
-    double *kx, *ky, *kz;     // [n] coordinates in FINAL position order (k_kd_block writes them, K1 reads leaves from here)
-    // work buffers of the level passes, by level parity: level l reads its positions from buffer (l + 1) & 1 THROUGH the
-    // partition of the parent level (the swaps of kdTree.py:108-111 are never executed as a pass of their own) and leaves them
-    // in buffer l & 1 in its own order
-    double *wx[2], *wy[2], *wz[2];
-    int *wid[2];              // [n] agent ids in position order
-    int *mr[2];               // [n] mr[b + j - 1] = position of the j-th "< split" member of the node that starts at b
-    int *gr[2];               // [n] gr[b + k - 1] = position of the k-th ">= split" member
+    double *kx, *ky, *kz;     // [n] coordinates in position order
+    int *mr;                  // [n] mr[b + j - 1] = position of the j-th "< split" member of the node that starts at b
     KdJob *jobs[2];           // ping-pong lists of nodes with > wave_max members
-    KdSmall *small;           // [n] subtrees handed to k_kd_block
+    KdJob *small;             // [n] subtrees handed to k_kd_block
     int *counts;              // [KD_MAX_LEVELS + 2] jobs per level; [KD_MAX_LEVELS] = small count; [KD_MAX_LEVELS+1] = overflow flag;
                               // behind nchunks, [2 * KD_MAX_LEVELS + 3] = table slots handed out by the tail launch
     int job_cap;
@@ -63,7 +51,7 @@ struct KdScratch {
     // multi-workgroup level passes
     unsigned long long *nbox; // [2][job_cap][6] order-preserving keys of the node boxes (per level parity)
     int *nge;                 // [2][job_cap] number of members >= split per node
-    int *ps[2];               // [n] inclusive count of ">= split" members inside the node up to the position
+    int *ps;                  // [n] inclusive count of ">= split" members inside the node up to the position
     int chunk_cap;
     unsigned long long *cbox; // [2][job_cap][2][6] boxes of the two children, accumulated while the parent is partitioned
     unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
@@ -87,18 +75,7 @@ __device__ __forceinline__ double wave_min_d(double v) { return wave_min_f64(v);
 __device__ __forceinline__ double wave_max_d(double v) { return wave_max_f64(v); }
 __device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 
-// counts[] layout: [0 .. MAX) jobs per level | [MAX] small subtrees | [MAX + 1] error bits | [MAX + 2 .. 2 MAX + 2] workgroups per
-// level (nchunks) | [2 MAX + 3] table slots handed out by the tail launch | [KD_NSMALL_OFF ..] copy-only workgroups per level
-constexpr int KD_NSMALL_OFF = 2 * KD_MAX_LEVELS + 4;
-constexpr int KD_COUNTS = 3 * KD_MAX_LEVELS + 6;
-
-struct KdBuf { double *x, *y, *z; int *id, *ps, *mr, *gr; };
-__device__ __forceinline__ KdBuf kd_buf(const KdScratch &s, int par) {
-    KdBuf B; B.x = s.wx[par]; B.y = s.wy[par]; B.z = s.wz[par]; B.id = s.wid[par]; B.ps = s.ps[par]; B.mr = s.mr[par]; B.gr = s.gr[par];
-    return B;
-}
-
-// Coordinates into position order (work buffer 0), and the root's box (its accumulator was reset by the previous build's last kernel).
+// Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
 __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Params P) {
     __shared__ double red[4][6];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,18 +84,13 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         for (int i = 0; i < KD_MAX_LEVELS + 1; i++) s.counts[i] = 0;      // not the error word: it stays until the host has read it
         KdJob j; j.begin = 0; j.end = d.n; j.node = 0; j.pad = -1;          // pad = 2 * parent + side, -1 for the root
         if (d.n > s.wave_max) { s.jobs[0][0] = j; s.counts[0] = 1; }
-        else {
-            KdSmall m; m.begin = 0; m.end = d.n; m.node = 0; m.pad = -1; m.par = 0; m.r0 = m.r1 = m.r2 = 0;
-            s.small[0] = m; s.counts[KD_MAX_LEVELS] = 1;
-        }
+        else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
         for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
-        for (int i = 0; i <= KD_MAX_LEVELS; i++) s.counts[KD_NSMALL_OFF + i] = 0;
         s.counts[2 * KD_MAX_LEVELS + 3] = 0;                                 // table slots handed out by the tail launch
         s.nchunks[0] = d.n > s.wave_max ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
     if (d.n > s.wave_max && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
-        KdChunkRec r; r.job = 0; r.first = 0; r.nb = 0; r.ne = d.n; r.axis = -1; r.copy = 0; r.split = 0.0;
-        r.pb = 0; r.pL = -1; r.paxis = 0; r.pad = 0; r.psplit = 0.0;
+        KdChunkRec r; r.job = 0; r.first = 0; r.nb = 0; r.ne = d.n; r.axis = -1; r.pad = 0; r.split = 0.0;
         s.chunks[0][p] = r;
     }
     if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
@@ -127,7 +99,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
     if (p < d.n) {
         const int id = d.aperm[p];
         const PubRec r = d.rec[id];
-        s.wx[0][p] = r.px; s.wy[0][p] = r.py; s.wz[0][p] = r.pz; s.wid[0][p] = id;
+        s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
         mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
         if (!s.skip_prep && id >= d.shard_begin && id < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, id);
@@ -166,23 +138,21 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
 
 // ---- level passes over the large nodes, one workgroup per chunk of KD_CHUNK positions ---------------------------------
 constexpr int KD_LV_T = 512;
-constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // strided positions per thread (tile t covers [t*T, (t+1)*T))
-constexpr int KD_LV_THREADS = KD_LV_T + 64;     // + one wavefront for the node's bookkeeping (see kd_bookkeep)
+constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
 
-// workgroup -> (node, chunk, split plane) through the level's chunk table (written by the parent level's bookkeeping)
-struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid, axis, copy, pb, pL, paxis; double split, psplit; };
+
+// workgroup -> (node, chunk, split plane) through the level's chunk table (written by the parent level's swap pass)
+struct KdChunk { int job, begin, end, node_begin, node_end, first_chunk, valid, axis; double split; };
 __device__ __forceinline__ KdChunk kd_find_chunk(const KdScratch &s, int level, int blk) {
     KdChunk c; c.valid = 0; c.job = 0; c.begin = c.end = c.node_begin = c.node_end = c.first_chunk = 0; c.axis = 0; c.split = 0.0;
-    c.copy = 0; c.pb = 0; c.pL = -1; c.paxis = 0; c.psplit = 0.0;
     const int nch = s.nchunks[level];
     const KdChunkRec rec = s.chunks[level & 1][blk];             // blk < chunk_cap always: read before the bound is known
     if (blk >= nch) return c;
     c.valid = 1; c.job = rec.job; c.node_begin = rec.nb; c.node_end = rec.ne; c.first_chunk = rec.first;
     c.begin = rec.nb + (blk - rec.first) * KD_CHUNK;
     c.end = c.begin + KD_CHUNK < rec.ne ? c.begin + KD_CHUNK : rec.ne;
-    c.axis = rec.axis; c.split = rec.split; c.copy = rec.copy;
-    c.pb = rec.pb; c.pL = rec.pL; c.paxis = rec.paxis; c.psplit = rec.psplit;
-    if (rec.axis < 0 && !rec.copy) {
+    c.axis = rec.axis; c.split = rec.split;
+    if (rec.axis < 0) {
         const unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + rec.job) * 6;
         double mn[3], mx[3];
         for (int k = 0; k < 3; k++) { mn[k] = dunkey(box[k]); mx[k] = dunkey(box[3 + k]); }
@@ -191,34 +161,22 @@ __device__ __forceinline__ KdChunk kd_find_chunk(const KdScratch &s, int level, 
     return c;
 }
 
-// Where position p of a node's range gets its member from when the node's parent [pb, ..) with L members below its split plane
-// is partitioned (kdTree.py:101-111 in closed form): the k-th ">= split" member of the left part [pb, pb + L) and the k-th
-// "< split" member of the right part counted from the right change places, everybody else stays.  In = the parent level's
-// buffers (its own order, its ps / mr / gr).
-__device__ __forceinline__ int kd_pull_src(const KdBuf &In, int p, int pb, int pL, int paxis, double psplit) {
-    const double *kc = paxis == 0 ? In.x : (paxis == 1 ? In.y : In.z);
-    const bool ge = !(kc[p] < psplit);
-    const int G = In.ps[p];                                     // ">= split" members of the parent up to and including p
-    if (p < pb + pL) return ge ? In.mr[pb + (pL - (G - 1)) - 1] : p;          // the (L - k + 1)-th "<" member, k = G
-    if (ge) return p;
-    const int j = (p - pb + 1) - G;                             // p holds the j-th "<" member of the parent
-    return In.gr[pb + (pL - j + 1) - 1];                        // ... which trades places with the (L - j + 1)-th ">=" member
+__device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int job, int &axis, double &split, double mn[3], double mx[3]) {
+    const unsigned long long *box = s.nbox + ((size_t)(level & 1) * s.job_cap + job) * 6;
+    for (int k = 0; k < 3; k++) { mn[k] = dunkey(box[k]); mx[k] = dunkey(box[3 + k]); }
+    kd_split(mn, mx, axis, split);
 }
 
-// Ranks of one chunk.  The node's box is complete (accumulated by the parent's pass), so the chunk can flag its members
-// against the split plane, scan the flags (chained across the chunks of the node through one 64-bit word per chunk: launch
-// token | count), write the in-node ranks into the node's own buffers B, and accumulate the boxes of the two children.
-// X / Y / Z: the coordinates of the thread's KD_LV_E positions (the caller read them in place or through the parent's
-// partition).  Every thread of the workgroup must call it (barriers); threads >= KD_LV_T carry no positions.
-struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; int node_ge; double red[KD_LV_T / 64][12]; int tile[KD_CHUNK / KD_LV_T][KD_LV_T / 64]; };
-__device__ __forceinline__ void kd_rank_part(const KdScratch s, const KdBuf B, int level, unsigned token, const KdChunk c, KdRankLds &SH, int blk,
-                                             const double (&X)[KD_LV_E], const double (&Y)[KD_LV_E], const double (&Z)[KD_LV_E]) {
+// Level pass A: one workgroup per chunk.  The node's box is complete (accumulated by the parent's pass), so the chunk
+// can flag its members against the split plane, scan the flags (chained across the chunks of the node through one
+// 64-bit word per chunk: launch token | count), write the in-node ranks, and accumulate the boxes of the two children.
+struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; double red[KD_LV_T / 64][12]; };
+__device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsigned token, const KdChunk c, KdRankLds &SH, int blk) {
     constexpr int W = KD_LV_T / 64;
     int (&wtot)[W] = SH.wtot;
     int &carry_sh = SH.carry_sh;
     double (&red)[W][12] = SH.red;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool worker = tid < KD_LV_T;
     const int axis = c.axis;
     const double split = c.split;
     const int b = c.node_begin;
@@ -227,36 +185,29 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, const KdBuf B, i
     int mine = 0;
     double cmn[2][3] = {{INFINITY, INFINITY, INFINITY}, {INFINITY, INFINITY, INFINITY}};
     double cmx[2][3] = {{-INFINITY, -INFINITY, -INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
-    if (worker) {
 #pragma unroll
-        for (int t = 0; t < KD_LV_E; t++) {
-            const int p = c.begin + t * KD_LV_T + tid;
-            if (p < c.end) {
-                const double x = X[t], y = Y[t], z = Z[t];
-                const double cv = axis == 0 ? x : (axis == 1 ? y : z);
-                const int side = cv < split ? 0 : 1;
-                if (side) { flags |= 1u << t; mine++; }
-                cmn[side][0] = x < cmn[side][0] ? x : cmn[side][0]; cmx[side][0] = x > cmx[side][0] ? x : cmx[side][0];
-                cmn[side][1] = y < cmn[side][1] ? y : cmn[side][1]; cmx[side][1] = y > cmx[side][1] ? y : cmx[side][1];
-                cmn[side][2] = z < cmn[side][2] ? z : cmn[side][2]; cmx[side][2] = z > cmx[side][2] ? z : cmx[side][2];
-            }
+    for (int t = 0; t < KD_LV_E; t++) {
+        const int p = c.begin + t * KD_LV_T + tid;
+        if (p < c.end) {
+            const double x = s.kx[p], y = s.ky[p], z = s.kz[p];
+            const double cv = axis == 0 ? x : (axis == 1 ? y : z);
+            const int side = cv < split ? 0 : 1;
+            if (side) { flags |= 1u << t; mine++; }
+            cmn[side][0] = x < cmn[side][0] ? x : cmn[side][0]; cmx[side][0] = x > cmx[side][0] ? x : cmx[side][0];
+            cmn[side][1] = y < cmn[side][1] ? y : cmn[side][1]; cmx[side][1] = y > cmx[side][1] ? y : cmx[side][1];
+            cmn[side][2] = z < cmn[side][2] ? z : cmn[side][2]; cmx[side][2] = z > cmx[side][2] ? z : cmx[side][2];
         }
-        const int wsum = wave_sum_i(mine);
-        if (lane == 0) wtot[wid] = wsum;
-#pragma unroll
-        for (int t = 0; t < KD_LV_E; t++) {                        // per tile and wavefront, for the ranks below (no barrier there)
-            const unsigned long long m = __ballot((flags >> t) & 1u);
-            if (lane == 0) SH.tile[t][wid] = __popcll(m);
-        }
-        // children boxes: wave reduce, then one set of atomics per workgroup
-#pragma unroll
-        for (int sd = 0; sd < 2; sd++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) { cmn[sd][k] = wave_min_d(cmn[sd][k]); cmx[sd][k] = wave_max_d(cmx[sd][k]); }
-        if (lane == 0)
-            for (int sd = 0; sd < 2; sd++)
-                for (int k = 0; k < 3; k++) { red[wid][sd * 6 + k] = cmn[sd][k]; red[wid][sd * 6 + 3 + k] = cmx[sd][k]; }
     }
+    const int wsum = wave_sum_i(mine);
+    if (lane == 0) wtot[wid] = wsum;
+    // children boxes: wave reduce, then one set of atomics per workgroup
+#pragma unroll
+    for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cmn[sd][k] = wave_min_d(cmn[sd][k]); cmx[sd][k] = wave_max_d(cmx[sd][k]); }
+    if (lane == 0)
+        for (int sd = 0; sd < 2; sd++)
+            for (int k = 0; k < 3; k++) { red[wid][sd * 6 + k] = cmn[sd][k]; red[wid][sd * 6 + 3 + k] = cmx[sd][k]; }
     __syncthreads();
     int total = 0;
     for (int w = 0; w < W; w++) total += wtot[w];
@@ -266,13 +217,7 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, const KdBuf B, i
         for (int w = 1; w < W; w++) v = is_min ? (red[w][tid] < v ? red[w][tid] : v) : (red[w][tid] > v ? red[w][tid] : v);
         unsigned long long *cb = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
         if (is_min) atomicMin(&cb[tid], dkey(v)); else atomicMax(&cb[tid], dkey(v));
-        // The children's boxes before the chain word: whoever has seen every chunk's word of a node (the chunk that ends the
-        // chain: kd_bookkeep) must read complete boxes.  This needs the device-scope fence: with the barrier alone (which does
-        // wait for the workgroup's outstanding memory operations) a box was read incomplete about once in 10^3 builds when the
-        // GPU was shared with another process -- a subtree with another split plane, found by the two-rank soak test.
-        __threadfence();
     }
-    __syncthreads();
     // ---- chained scan: publish this chunk's count, collect the predecessors' (all chunks of a level are co-resident).
     //      The first wavefront reads 64 predecessors at a time: the words are independent, only their arrival is awaited.
     if (tid == 0)
@@ -295,251 +240,155 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, const KdBuf B, i
         if (lane == 0) {
             carry_sh = carry;
             const int nch = (c.node_end - b + KD_CHUNK - 1) / KD_CHUNK;
-            SH.node_ge = -1;
-            if (blk == c.first_chunk + nch - 1) { s.nge[(level & 1) * s.job_cap + c.job] = carry + total; SH.node_ge = carry + total; }
+            if (blk == c.first_chunk + nch - 1) s.nge[(level & 1) * s.job_cap + c.job] = carry + total;
         }
     }
     __syncthreads();
     int carry = carry_sh;
-    // ---- ranks: ps = inclusive ">= split" count inside the node; mr[b + j - 1] = position of the j-th "< split" member,
-    //      gr[b + k - 1] = position of the k-th ">= split" member
-    //      (no barrier from here on: the workgroup's bookkeeping wavefront, if it has one, works beside this)
-    if (!worker) return;
+    // ---- ranks: ps = inclusive ">= split" count inside the node; mr[b + j - 1] = position of the j-th "< split" member
 #pragma unroll
     for (int t = 0; t < KD_LV_E; t++) {
         const int p = c.begin + t * KD_LV_T + tid;
         const bool ge = (flags >> t) & 1u;
         const unsigned long long m = __ballot(ge);
         const int incl_w = __popcll(m & ((2ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wtot[wid] = __popcll(m);
+        __syncthreads();
         int woff = 0, ttot = 0;
-        for (int w = 0; w < W; w++) { const int v = SH.tile[t][w]; if (w < wid) woff += v; ttot += v; }
+        for (int w = 0; w < W; w++) { const int v = wtot[w]; if (w < wid) woff += v; ttot += v; }
         const int G = carry + woff + incl_w;
         if (p < c.end) {
-            B.ps[p] = G;
-            if (!ge) B.mr[b + ((p - b + 1) - G) - 1] = p; else B.gr[b + G - 1] = p;
+            s.ps[p] = G;
+            if (!ge) s.mr[b + ((p - b + 1) - G) - 1] = p;
         }
         carry += ttot;
     }
 }
 
-// The node's record, its children and what the next level needs of them (kdTree.py:112-122), by ONE thread: a chain of
-// dependent loads and atomics with returns, ~5 us long.  In the level launches it is done by the chunk that ends the node's
-// chained scan (it knows L, and every chunk's boxes are in) on a wavefront that carries no positions, beside the ranks; in the
-// tail launch by thread 0 behind the node's swaps.  All loads and all atomics are issued before anything waits.
-//   tail == nullptr (level launch): the children are read THROUGH this node's partition by the next launch: their chunk records
-//        carry (b, L, axis, split); a child small enough for k_kd_block gets one copy-only workgroup there and its subtree
-//        record says which buffer it ends up in.
-//   tail != nullptr: the node was partitioned in place in buffer par; children inherit it as it is.
-struct KdTailOut { int n; int slot_base; KdChunkRec r[2]; };   // slot_base: first free table slot of the tail launch
-struct KdNodePre { KdJob job; unsigned long long bk[6]; };       // what the bookkeeping reads that is complete before the level starts
-__device__ __forceinline__ KdNodePre kd_node_pre(const KdScratch &s, int level, int jobidx) {
-    KdNodePre P;
-    P.job = s.jobs[level & 1][jobidx];
-    const unsigned long long *nb_ = s.nbox + ((size_t)(level & 1) * s.job_cap + jobidx) * 6;
-#pragma unroll
-    for (int q = 0; q < 6; q++) P.bk[q] = nb_[q];
-    return P;
-}
-__device__ __forceinline__ void kd_bookkeep(const DeviceView d, const KdScratch s, int level, const KdChunk c, int L, int par, KdTailOut *tail,
-                                            const KdNodePre &pre) {
-    KdJob *out = s.jobs[(level + 1) & 1];
-    const int b = c.node_begin, e = c.node_end;
-    if (tail) tail->n = 0;
-    const KdJob job = pre.job;
-    const unsigned long long *cb_ = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
-    unsigned long long bk[6], cb[12];
-#pragma unroll
-    for (int q = 0; q < 6; q++) bk[q] = pre.bk[q];
-#pragma unroll
-    for (int q = 0; q < 12; q++) cb[q] = __hip_atomic_load(&cb_[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int leftSize = L == 0 ? 1 : L;                 // degenerate: every member on the split plane
-    const int cbeg[2] = {b, b + leftSize}, cend[2] = {b + leftSize, e};
-    bool big[2]; int nch[2], arrival[2] = {0, 0}, base[2] = {0, 0}, slot[2] = {0, 0}, small_at[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        big[k] = cend[k] - cbeg[k] > s.wave_max;
-        nch[k] = big[k] ? (cend[k] - cbeg[k] + KD_CHUNK - 1) / KD_CHUNK : 1;
-        if (big[k]) {
-            if (level + 1 < KD_MAX_LEVELS) {
-                // table slot of the child.  A level launch owns the level's slots: index = arrival order.  In the tail
-                // launch workgroups are at DIFFERENT levels at the same time, so slots (and chunk records) indexed per
-                // level parity would collide: there the index comes from one counter that starts behind the tail
-                // level's own nodes (unique over both parities), the chunk records stay in the workgroup's stack, and
-                // the per-level counters are only statistics for the host.
-                arrival[k] = atomicAdd(&s.counts[level + 1], 1);
-                base[k] = atomicAdd(&s.nchunks[level + 1], nch[k]);
-                if (tail) slot[k] = atomicAdd(&s.counts[2 * KD_MAX_LEVELS + 3], 1);
-            }
-        } else {
-            small_at[k] = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
-            if (!tail && level + 1 < KD_MAX_LEVELS) {
-                base[k] = atomicAdd(&s.nchunks[level + 1], 1);
-                atomicAdd(&s.counts[KD_NSMALL_OFF + level + 1], 1);
-            }
-        }
-    }
-    double mn[3], mx[3];
-    for (int k = 0; k < 3; k++) { mn[k] = dunkey(bk[k]); mx[k] = dunkey(bk[3 + k]); }
-    KdNode nd;
-    nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
-    for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
-    if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
-    kd_publish(d.awide, nd, job.node, job.pad);
-    if (L == 0) {
-        // nobody below the midpoint: the box has no extent, every member sits on one point (kdTree.py:113-116 then puts
-        // one of them left, the rest right) -- both children have the parent's box
-        for (int q = 0; q < 3; q++) { cb[q] = cb[6 + q] = dkey(mn[q]); cb[3 + q] = cb[9 + q] = dkey(mx[q]); }
-    }
-    const int cnode[2] = {nd.left, nd.right};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        KdChunkRec r; r.job = 0; r.first = base[k]; r.nb = cbeg[k]; r.ne = cend[k]; r.axis = 0; r.copy = 0; r.split = 0.0; r.pad = 0;
-        r.pb = b; r.pL = tail ? -1 : L; r.paxis = c.axis; r.psplit = c.split;
-        if (big[k]) {
-            if (level + 1 < KD_MAX_LEVELS) {
-                const int at = tail ? tail->slot_base + slot[k] : arrival[k];
-                if (at < s.job_cap) {
-                    KdJob ch; ch.begin = cbeg[k]; ch.end = cend[k]; ch.node = cnode[k]; ch.pad = 2 * job.node + k;
-                    out[at] = ch;
-                    unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
-                    for (int q = 0; q < 6; q++) box[q] = cb[k * 6 + q];          // the child's box is already known
-                    unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
-                    for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
-                    // the child's workgroups of the next level
-                    if (tail || base[k] + nch[k] <= s.chunk_cap) {
-                        r.job = at;
-                        double cmn[3], cmx[3];
-                        for (int q = 0; q < 3; q++) { cmn[q] = dunkey(cb[k * 6 + q]); cmx[q] = dunkey(cb[k * 6 + 3 + q]); }
-                        kd_split(cmn, cmx, r.axis, r.split);
-                        if (tail) tail->r[tail->n++] = r;
-                        else {
-                            KdChunkRec *tab = s.chunks[(level + 1) & 1];
-                            for (int q = 0; q < nch[k]; q++) tab[base[k] + q] = r;
-                        }
-                    } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_CHUNKS);
-                } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
-            } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
-        } else {
-            KdSmall m; m.begin = cbeg[k]; m.end = cend[k]; m.node = cnode[k]; m.pad = 2 * job.node + k; m.r0 = m.r1 = m.r2 = 0;
-            m.par = tail ? par : ((level + 1) & 1);
-            s.small[small_at[k]] = m;
-            if (!tail) {
-                if (level + 1 < KD_MAX_LEVELS && base[k] + 1 <= s.chunk_cap) { r.copy = 1; s.chunks[(level + 1) & 1][base[k]] = r; }
-                else atomicOr(&s.counts[KD_MAX_LEVELS + 1], level + 1 < KD_MAX_LEVELS ? KD_ERR_CHUNKS : KD_ERR_LEVELS);
-            }
-        }
-    }
-}
-
-// the members of [lo, hi) of a node read through its parent's partition (record c: pb, pL, ...) from In into Out
-__device__ __forceinline__ void kd_pull_copy(const KdBuf &In, const KdBuf &Out, const KdChunk &c, int lo, int hi) {
-    for (int p = lo + (int)threadIdx.x; p < hi; p += (int)blockDim.x) {
-        const int src = kd_pull_src(In, p, c.pb, c.pL, c.paxis, c.psplit);
-        Out.x[p] = In.x[src]; Out.y[p] = In.y[src]; Out.z[p] = In.z[src]; Out.id[p] = In.id[src];
-    }
-}
-
-// ONE launch per tree level (round 2; two before: ranks, then the swaps): every workgroup first reads its positions through the
-// partition of the parent level -- which is therefore never executed as a pass of its own --, leaves them in this level's
-// buffer, and ranks them for the next level's reads.
-__global__ __launch_bounds__(KD_LV_THREADS) void k_kd_level(DeviceView d, KdScratch s, int level, unsigned token) {
+__global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
     __shared__ KdRankLds SH;
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
-    const KdBuf In = kd_buf(s, (level + 1) & 1), Out = kd_buf(s, level & 1);
-    if (c.copy) { kd_pull_copy(In, Out, c, c.begin, c.end); return; }
-    const int tid = threadIdx.x;
-    double X[KD_LV_E], Y[KD_LV_E], Z[KD_LV_E];
-    int ids[KD_LV_E];
-#pragma unroll
-    for (int t = 0; t < KD_LV_E; t++) { X[t] = Y[t] = Z[t] = 0.0; ids[t] = 0; }
-    if (tid < KD_LV_T) {
-        if (c.pL >= 0) {
-            // The permutation is carried from step to step (kdTree.py:43-45), so the array arrives nearly partitioned: few
-            // members change places.  Everything a position needs if it STAYS -- its own coordinates, id and rank -- is
-            // loaded at once (one memory round trip, as the in-place ranks need anyway); only the wavefronts that hold a
-            // member that moves take the two further dependent reads (partner position, partner's data).
-            int G[KD_LV_E];
-            bool mis[KD_LV_E];
-            bool any = false;
-#pragma unroll
-            for (int t = 0; t < KD_LV_E; t++) {
-                const int p = c.begin + t * KD_LV_T + tid;
-                const int pp = p < c.end ? p : c.begin;
-                X[t] = In.x[pp]; Y[t] = In.y[pp]; Z[t] = In.z[pp]; ids[t] = In.id[pp]; G[t] = In.ps[pp];
-            }
-#pragma unroll
-            for (int t = 0; t < KD_LV_E; t++) {
-                const int p = c.begin + t * KD_LV_T + tid;
-                const double kv = c.paxis == 0 ? X[t] : (c.paxis == 1 ? Y[t] : Z[t]);
-                const bool ge = !(kv < c.psplit);
-                mis[t] = p < c.end && ((p < c.pb + c.pL) ? ge : !ge);        // a ">=" member in the left part, a "<" one in the right
-                any |= mis[t];
-            }
-            if (__any(any)) {
-#pragma unroll
-                for (int t = 0; t < KD_LV_E; t++) {
-                    if (mis[t]) {
-                        const int p = c.begin + t * KD_LV_T + tid;
-                        // left: the k-th ">=" member (k = G) takes the (L - k + 1)-th "<" member; right: the j-th "<" member
-                        // (j = members up to p minus G) takes the (L - j + 1)-th ">=" member
-                        const int src = p < c.pb + c.pL ? In.mr[c.pb + (c.pL - (G[t] - 1)) - 1]
-                                                        : In.gr[c.pb + (c.pL - ((p - c.pb + 1) - G[t]) + 1) - 1];
-                        X[t] = In.x[src]; Y[t] = In.y[src]; Z[t] = In.z[src]; ids[t] = In.id[src];
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < KD_LV_E; t++) {
-                const int p = c.begin + t * KD_LV_T + tid;
-                if (p < c.end) { X[t] = Out.x[p]; Y[t] = Out.y[p]; Z[t] = Out.z[p]; }
-            }
-        }
-    }
-    KdNodePre pre;
-    if (tid == KD_LV_T) pre = kd_node_pre(s, level, c.job);       // the idle wavefront's loads fly while the others rank
-    kd_rank_part(s, Out, level, token, c, SH, (int)blockIdx.x, X, Y, Z);
-    if (tid == KD_LV_T && SH.node_ge >= 0) kd_bookkeep(d, s, level, c, (c.node_end - c.node_begin) - SH.node_ge, level & 1, nullptr, pre);
-    // the members in this level's order, for the next launch: stored last, so that no barrier above waits for their acknowledgement
-    if (tid < KD_LV_T && c.pL >= 0) {
-#pragma unroll
-        for (int t = 0; t < KD_LV_E; t++) {
-            const int p = c.begin + t * KD_LV_T + tid;
-            if (p < c.end) { Out.x[p] = X[t]; Out.y[p] = Y[t]; Out.z[p] = Z[t]; Out.id[p] = ids[t]; }
-        }
-    }
+    kd_rank_part(s, level, token, c, SH, (int)blockIdx.x);
 }
 
-// In-place swaps of one chunk of a node whose ranks are complete (kdTree.py:108-111), for the tail launch
-__device__ __forceinline__ void kd_swap_part(const KdScratch s, const KdBuf B, int level, const KdChunk c) {
+// Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)
+// the children that need another level pass, as the chunk records written for them (for k_kd_level_tail)
+struct KdTailOut { int n; int slot_base; KdChunkRec r[2]; };   // slot_base: first free table slot of the tail launch
+__device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch s, int level, const KdChunk c, KdTailOut *tail = nullptr) {
     const int tid = threadIdx.x;
+    const KdJob *in = s.jobs[level & 1];
+    KdJob *out = s.jobs[(level + 1) & 1];
     const int axis = c.axis;
     const double split = c.split;
-    const double *kc = axis == 0 ? B.x : (axis == 1 ? B.y : B.z);
+    const double *kc = axis == 0 ? s.kx : (axis == 1 ? s.ky : s.kz);
     const int b = c.node_begin, e = c.node_end;
     const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
     const int lim = c.end < b + L ? c.end : b + L;
-    for (int p = c.begin + tid; p < lim; p += (int)blockDim.x) {
+    for (int p = c.begin + tid; p < lim && tid < KD_LV_T; p += KD_LV_T) {
         if (!(kc[p] < split)) {
-            // the k-th ">= split" member of the left part (k = ps) takes the k-th "< split" member from the right,
-            // i.e. the (L - k + 1)-th "< split" member of the node
-            const int q = B.mr[b + (L - (B.ps[p] - 1)) - 1];
-            const int ip = B.id[p], iq = B.id[q];
-            B.id[p] = iq; B.id[q] = ip;
-            const double xp = B.x[p], yp = B.y[p], zp = B.z[p];
-            B.x[p] = B.x[q]; B.y[p] = B.y[q]; B.z[p] = B.z[q];
-            B.x[q] = xp; B.y[q] = yp; B.z[q] = zp;
+            // the k-th ">= split" member of the left part (k = ps - 1) takes the k-th "< split" member from the right,
+            // i.e. the (L - k)-th "< split" member of the node
+            const int q = s.mr[b + (L - (s.ps[p] - 1)) - 1];
+            const int ip = d.aperm[p], iq = d.aperm[q];
+            d.aperm[p] = iq; d.aperm[q] = ip;
+            const double xp = s.kx[p], yp = s.ky[p], zp = s.kz[p];
+            s.kx[p] = s.kx[q]; s.ky[p] = s.ky[q]; s.kz[p] = s.kz[q];
+            s.kx[q] = xp; s.ky[q] = yp; s.kz[q] = zp;
+        }
+    }
+    // The node's bookkeeping (its record, the children and their chunk records) is a chain of dependent loads and atomics
+    // with returns, ~5 us long and independent of the swaps: k_kd_lv_swap gives it a wavefront of its own (thread KD_LV_T of
+    // a KD_LV_T + 64 workgroup) so that it runs beside the swaps, not behind thread 0's; the tail launch keeps thread 0.
+    // Everything it reads was completed by the rank pass; all loads and all four atomics are issued before anything waits.
+    const int keeper = blockDim.x > KD_LV_T ? KD_LV_T : 0;
+    if (tid == keeper && c.begin == b) {
+        if (tail) tail->n = 0;
+        const KdJob job = in[c.job];
+        const unsigned long long *nb_ = s.nbox + ((size_t)(level & 1) * s.job_cap + c.job) * 6;
+        const unsigned long long *cb_ = s.cbox + ((size_t)(level & 1) * s.job_cap + c.job) * 12;
+        unsigned long long bk[6], cb[12];
+#pragma unroll
+        for (int q = 0; q < 6; q++) bk[q] = nb_[q];
+#pragma unroll
+        for (int q = 0; q < 12; q++) cb[q] = cb_[q];
+        const int leftSize = L == 0 ? 1 : L;                 // degenerate: every member on the split plane
+        const int cbeg[2] = {b, b + leftSize}, cend[2] = {b + leftSize, e};
+        bool big[2]; int nch[2], arrival[2] = {0, 0}, base[2] = {0, 0}, slot[2] = {0, 0}, small_at[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            big[k] = cend[k] - cbeg[k] > s.wave_max;
+            nch[k] = (cend[k] - cbeg[k] + KD_CHUNK - 1) / KD_CHUNK;
+            if (big[k]) {
+                if (level + 1 < KD_MAX_LEVELS) {
+                    // table slot of the child.  A level launch owns the level's slots: index = arrival order.  In the tail
+                    // launch workgroups are at DIFFERENT levels at the same time, so slots (and chunk records) indexed per
+                    // level parity would collide: there the index comes from one counter that starts behind the tail
+                    // level's own nodes (unique over both parities), the chunk records stay in the workgroup's stack, and
+                    // the per-level counters are only statistics for the host.
+                    arrival[k] = atomicAdd(&s.counts[level + 1], 1);
+                    base[k] = atomicAdd(&s.nchunks[level + 1], nch[k]);
+                    if (tail) slot[k] = atomicAdd(&s.counts[2 * KD_MAX_LEVELS + 3], 1);
+                }
+            } else small_at[k] = atomicAdd(&s.counts[KD_MAX_LEVELS], 1);
+        }
+        double mn[3], mx[3];
+        for (int k = 0; k < 3; k++) { mn[k] = dunkey(bk[k]); mx[k] = dunkey(bk[3 + k]); }
+        KdNode nd;
+        nd.begin = b; nd.end = e; nd.left = job.node + 1; nd.right = job.node + 2 * leftSize;
+        for (int k = 0; k < 3; k++) { nd.mn[k] = mn[k]; nd.mx[k] = mx[k]; }
+        if (job.node == 0) d.atree[0] = nd;             // the root's box has no parent record to live in
+        kd_publish(d.awide, nd, job.node, job.pad);
+        if (L == 0) {
+            // nobody below the midpoint: the box has no extent, every member sits on one point (kdTree.py:113-116 then puts
+            // one of them left, the rest right) -- both children have the parent's box
+            for (int q = 0; q < 3; q++) { cb[q] = cb[6 + q] = dkey(mn[q]); cb[3 + q] = cb[9 + q] = dkey(mx[q]); }
+        }
+        KdJob ch[2];
+        ch[0].begin = cbeg[0]; ch[0].end = cend[0]; ch[0].node = nd.left; ch[0].pad = 2 * job.node;
+        ch[1].begin = cbeg[1]; ch[1].end = cend[1]; ch[1].node = nd.right; ch[1].pad = 2 * job.node + 1;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (big[k]) {
+                if (level + 1 < KD_MAX_LEVELS) {
+                    const int at = tail ? tail->slot_base + slot[k] : arrival[k];
+                    if (at < s.job_cap) {
+                        out[at] = ch[k];
+                        unsigned long long *box = s.nbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 6;
+                        for (int q = 0; q < 6; q++) box[q] = cb[k * 6 + q];          // the child's box is already known
+                        unsigned long long *ncb = s.cbox + ((size_t)((level + 1) & 1) * s.job_cap + at) * 12;
+                        for (int q = 0; q < 12; q++) ncb[q] = (q % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
+                        // the child's workgroups of the next level
+                        if (tail || base[k] + nch[k] <= s.chunk_cap) {
+                            KdChunkRec r; r.job = at; r.first = base[k]; r.nb = ch[k].begin; r.ne = ch[k].end; r.pad = 0;
+                            double cmn[3], cmx[3];
+                            for (int q = 0; q < 3; q++) { cmn[q] = dunkey(cb[k * 6 + q]); cmx[q] = dunkey(cb[k * 6 + 3 + q]); }
+                            kd_split(cmn, cmx, r.axis, r.split);
+                            if (tail) tail->r[tail->n++] = r;
+                            else {
+                                KdChunkRec *tab = s.chunks[(level + 1) & 1];
+                                for (int q = 0; q < nch[k]; q++) tab[base[k] + q] = r;
+                            }
+                        } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_CHUNKS);
+                    } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
+                } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_LEVELS);
+            } else s.small[small_at[k]] = ch[k];
         }
     }
 }
 
-// The LAST level launch of a build: one workgroup per node of that level finishes everything that is left below it -- it reads
-// the node's members through the parent's partition into this level's buffer, then works in place: both passes of the node (its
-// chunks one after the other: ranks, `__syncthreads`, swaps), then the same for every child that still has more than wave_max
-// members, depth first from a small stack.  At the level the host picks (from the previous builds' statistics: the first one
-// whose nodes are about one chunk) that is one short pass per workgroup; if the tree has changed since -- a node with many
-// chunks, more levels -- it is slower, never wrong: the statistics only set the speed.
+__global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
+    if (!c.valid) return;
+    kd_swap_part(d, s, level, c);
+}
+
+// The LAST level launch of a build: one workgroup per node of that level finishes everything that is left below it -- both
+// passes of the node (its chunks one after the other: ranks, `__syncthreads`, swaps), then the same for every child that
+// still has more than wave_max members, depth first from a small stack.  At the level the host picks (from the previous
+// builds' statistics: the first one whose nodes are about one chunk) that is one short pass per workgroup; if the tree has
+// changed since -- a node with many chunks, more levels -- it is slower, never wrong: the statistics only set the speed.
 constexpr int KD_TAIL_STACK = 2 * KD_MAX_LEVELS;
 __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScratch s, int level, unsigned token) {
     __shared__ KdRankLds SH;
@@ -552,14 +401,9 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScrat
     const int blk = (int)blockIdx.x;
     if (blk >= s.nchunks[level]) return;
     const KdChunk c0 = kd_find_chunk(s, level, blk);
-    const int par = level & 1;
-    const KdBuf In = kd_buf(s, par ^ 1), B = kd_buf(s, par);
-    if (c0.copy) { kd_pull_copy(In, B, c0, c0.begin, c0.end); return; }
     if (c0.first_chunk != blk) return;                              // one workgroup per node: the one of its first chunk
-    if (c0.pL >= 0) kd_pull_copy(In, B, c0, c0.node_begin, c0.node_end);
     if (threadIdx.x == 0) {
-        KdChunkRec r; r.job = c0.job; r.first = c0.first_chunk; r.nb = c0.node_begin; r.ne = c0.node_end; r.axis = c0.axis; r.copy = 0; r.split = c0.split;
-        r.pb = 0; r.pL = -1; r.paxis = 0; r.pad = 0; r.psplit = 0.0;
+        KdChunkRec r; r.job = c0.job; r.first = c0.first_chunk; r.nb = c0.node_begin; r.ne = c0.node_end; r.axis = c0.axis; r.pad = 0; r.split = c0.split;
         stack[0] = r; stack_lv[0] = level; sp_sh = 1;
         out.slot_base = s.counts[level];                           // behind the nodes this launch starts from
     }
@@ -576,26 +420,17 @@ __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScrat
         const KdChunkRec r = cur_rec;
         const int nch = (r.ne - r.nb + KD_CHUNK - 1) / KD_CHUNK;
         KdChunk c; c.valid = 1; c.job = r.job; c.node_begin = r.nb; c.node_end = r.ne; c.first_chunk = chain0; c.axis = r.axis; c.split = r.split;
-        c.copy = 0; c.pb = 0; c.pL = -1; c.paxis = 0; c.psplit = 0.0;
         for (int t = 0; t < nch; t++) {
             c.begin = r.nb + t * KD_CHUNK;
             c.end = c.begin + KD_CHUNK < r.ne ? c.begin + KD_CHUNK : r.ne;
-            double X[KD_LV_E], Y[KD_LV_E], Z[KD_LV_E];
-#pragma unroll
-            for (int q = 0; q < KD_LV_E; q++) {
-                const int p = c.begin + q * KD_LV_T + (int)threadIdx.x;
-                X[q] = Y[q] = Z[q] = 0.0;
-                if (p < c.end) { X[q] = B.x[p]; Y[q] = B.y[p]; Z[q] = B.z[p]; }
-            }
-            kd_rank_part(s, B, lv, token, c, SH, chain0 + t, X, Y, Z);
+            kd_rank_part(s, lv, token, c, SH, chain0 + t);
             __syncthreads();
         }
         for (int t = 0; t < nch; t++) {
             c.begin = r.nb + t * KD_CHUNK;
             c.end = c.begin + KD_CHUNK < r.ne ? c.begin + KD_CHUNK : r.ne;
-            kd_swap_part(s, B, lv, c);
+            kd_swap_part(d, s, lv, c, &out);
         }
-        if (threadIdx.x == 0) kd_bookkeep(d, s, lv, c, (r.ne - r.nb) - s.nge[(lv & 1) * s.job_cap + r.job], par, &out, kd_node_pre(s, lv, r.job));
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int k = 0; k < out.n; k++) {
@@ -670,7 +505,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 
 #ifdef SCA_KB_TIMING   // per-phase wall-clock ticks of workgroup 0's first job into s.ps (debug builds only)
 #define KB_MARK_INIT() int dbg_i = 0; long long dbg_t = wall_clock64()
-#define KB_MARK() do { if (jb == 0 && blockIdx.x == 0 && tid == 0 && dbg_i < 200) { const long long t_ = wall_clock64(); s.ps[0][dbg_i++] = (int)(t_ - dbg_t); dbg_t = t_; } } while (0)
+#define KB_MARK() do { if (jb == 0 && blockIdx.x == 0 && tid == 0 && dbg_i < 200) { const long long t_ = wall_clock64(); s.ps[dbg_i++] = (int)(t_ - dbg_t); dbg_t = t_; } } while (0)
 #else
 #define KB_MARK_INIT() do { } while (0)
 #define KB_MARK() do { } while (0)
@@ -690,13 +525,12 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
         s.cbox[tid] = (tid % 6) < 3 ? dkey(INFINITY) : dkey(-INFINITY);
     }
     for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
-        const KdSmall job = s.small[jb];
+        const KdJob job = s.small[jb];
         const int base = job.begin, size = job.end - job.begin;
-        const KdBuf B = kd_buf(s, job.par);                       // where the level passes left the subtree's members
         if (size > KB_MAX) { if (tid == 0) atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_BLOCK); continue; }
         __syncthreads();
         for (int i = tid; i < size; i += KB_T) {
-            S.x[KB_SW(i)] = B.x[base + i]; S.y[KB_SW(i)] = B.y[base + i]; S.z[KB_SW(i)] = B.z[base + i]; S.id[i] = B.id[base + i];
+            S.x[KB_SW(i)] = s.kx[base + i]; S.y[KB_SW(i)] = s.ky[base + i]; S.z[KB_SW(i)] = s.kz[base + i]; S.id[i] = d.aperm[base + i];
             S.slot[KB_SW(i)] = 0;
         }
         if (tid == 0) {
