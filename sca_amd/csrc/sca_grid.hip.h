@@ -37,7 +37,7 @@ struct GridDev {
     int *gid;                     // [n] agent ids in bucket order
     unsigned long long *gkey;     // [n] cell keys in bucket order: several cells can share a bucket
     int hbits;                    // H = 1 << hbits
-    int skip_prep;                // 1: the per-agent prologue is left to k_prep_shard (v_pref still being computed)
+    int skip_prep;                // 1: the prologue of the tracker's agents is left to the tracker's kernels (v_pref still being computed); 2: nobody's
     double inv_cell;              // 1 / cell size; the cell is a little larger than neighborDist (see grid_inv_cell)
 };
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
     const int h = grid_bucket(key, g.hbits);
     g.bucket[i] = h;
     g.slot[i] = atomicAdd(&g.count[h], 1);
-    if (!g.skip_prep && i >= d.shard_begin && i < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, i);
+    if (i >= d.shard_begin && i < d.shard_begin + d.shard_count && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, i))) prep_agent(d, P, (Prep *)d.prep, i);
 }
 
 // GRID_ALLOC_PER buckets per lane: one atomic on the cursor per 2048 buckets (an atomic per 256 buckets, 1024 of them on one

@@ -418,7 +418,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
         hipFuncAttributes fa;
         for (const void *f : {(const void *)k_track, (const void *)k_replan, (const void *)k_replan_group<64>, (const void *)k_replan_group<32>,
                               (const void *)k_replan_group<16>, (const void *)k_replan_group<4>,
-                              (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4, (const void *)k_prep_shard})
+                              (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4})
             (void)hipFuncGetAttributes(&fa, f);
     }
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
@@ -925,6 +925,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     const int cnt = c->d.shard_count;
     TrackDev K = c->trk;
     K.nbr0_from_lists = (from_lists && !in_pass) ? 1 : 0;
+    if (!in_pass) K.prep = 0;
     // The device-side count of this pass decides which re-plan kernel does the work: every launched kernel reads it and returns
     // unless it falls into its range (lo, hi].  Launching all five every pass would cost four empty launches on the critical
     // path; the count of an earlier pass (copied back on the side stream, never waited for) says
@@ -1031,7 +1032,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     choose_lp_form(c, lp_lo, lp_hi);
     const DeviceView &d = c->d;
     // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
-    // v_pref) then moves from k_kd_gather to k_prep_shard behind the join
+    // v_pref) of the tracker's agents then moves from k_kd_gather to the tracker's kernels (track_store)
     const bool tracked = c->trk_on && c->trk_in_pass;
     const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
     // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
@@ -1052,7 +1053,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // k_track -> re-plans -> prologue -> pick stays on the main stream, and the neighbour structure + query (+ the sweep half of
     // k_solve), which depend on nothing of the tracker -- it reads agent.neighbors[0] from what the previous pass's epilogue
     // saved, not from the lists K1 overwrites -- run beside them on trk_stream:
-    //   main: [fork] k_track re-plans (or k_track_replan) ........ [wait join] k_prep_shard k_solve / k_solve_pick4 ...
+    //   main: [fork] k_track re-plans (or k_track_replan) ........ [wait join] k_solve / k_solve_pick4 ...
     //   side: [wait fork] K0 ...... K1 (k_solve_sweep) [join]
     // (round 1 had the re-plans on the side stream: the fork and the join then sat on the critical path, ~40 us per step)
     c->nbr_stream = overlap ? c->trk_stream : c->stream;
@@ -1061,6 +1062,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipEventRecord(c->trk_fork, c->stream));
         CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
     }
+    c->trk.prep = overlap ? 1 : 0;
+    c->trk.P = c->P;
     if (tracked) { if (int r = launch_tracker(c, true, true)) return r; }
     c->nbr_mode = mode;
     if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
@@ -1117,8 +1120,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->trk_count_pending = true;
         }
         CHK(c, hipEventRecord(c->trk_join, ns));
-        CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));
-        hipLaunchKernelGGL(k_prep_shard, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+        CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));                // (the prologue: track_store / the gather)
     }
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
     if (split) {
@@ -1161,7 +1163,7 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     if (!c->near_valid) CHK(c, hipMemsetAsync(d.done_count, 0, sizeof(int32_t) * 256 * 32, c->stream));   // no policy pass before
     if (!c->near_valid) hipLaunchKernelGGL(k_invalidate_near, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d);
     if (!c->near_valid && c->nbr_mode == SCA_NBR_GRID) {                  // the fallback reads the grid: make it describe these records
-        c->grid.skip_prep = 1;
+        c->grid.skip_prep = 2;
         c->nbr_stream = c->stream;
         if (int r = build_agent_grid_device(c)) return r;
     }

@@ -57,7 +57,7 @@ struct KdScratch {
     unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
     KdChunkRec *chunks[2];    // [chunk_cap] per level parity: everything a workgroup of a level pass needs, in one 32-byte read
     int *nchunks;             // [KD_MAX_LEVELS + 1] workgroups with work per level
-    int skip_prep;            // 1: k_kd_gather leaves the per-agent prologue to k_prep_shard (v_pref is still being computed by
+    int skip_prep;            // 1: k_kd_gather leaves the prologue of the tracker's agents to the tracker's kernels (v_pref is still being computed by
                               //    the tracker on another stream)
 };
 
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
         mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
-        if (!s.skip_prep && id >= d.shard_begin && id < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, id);
+        if (id >= d.shard_begin && id < d.shard_begin + d.shard_count && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
     }
     if (d.n > s.wave_max) {
 #pragma unroll

@@ -665,6 +665,12 @@ struct alignas(16) Prep {
 };
 static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
 
+// the agents whose v_pref the device tracker computes in this pass (mampenv.py:35 + the policy): their prologue is written by the
+// tracker's kernels right behind v_pref (track_store), everybody else's by the neighbour structure's first kernel
+__device__ __forceinline__ bool tracker_owns(const DeviceView &d, int agent) {
+    const int pol = d.policy[agent];
+    return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;
+}
 __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P, Prep *out, int agent) {
     const PubRec me = d.rec[agent];
     const int pol = d.policy[agent];
@@ -1636,12 +1642,6 @@ __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
     const int agent = blockIdx.x * blockDim.x + threadIdx.x;
     if (agent == 0) *d.fb_count = 0;                                       // start of a pass: empty fallback list
     if (agent < d.n) prep_agent(d, P, (Prep *)d.prep, agent);
-}
-
-// the prologue of the rank's own shard only, after the tracker's v_pref has arrived (k_kd_gather skipped it)
-__global__ __launch_bounds__(256) void k_prep_shard(DeviceView d, Params P) {
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent < d.shard_begin + d.shard_count) prep_agent(d, P, (Prep *)d.prep, agent);
 }
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the

@@ -36,6 +36,8 @@ struct TrackDev {
     int nbr0_from_lists;          // 1: take nbr0 from the neighbour lists as they are (sca_device_tracker_vpref without an upload); inside a
                                   // pass it is what the previous pass's epilogue saved (DeviceView::trk_nbr0)
     int lo, hi;                   // this launch takes the pass when lo < (re-plans of the pass) <= hi; the launches of a pass cover every count
+    int prep;                     // 1: the kernels also write the solve's per-agent prologue (inside a pass whose neighbour branch overlaps)
+    Params P;
     int mid_max;                  // TRK_MID_MAX unless overridden (SCA_TRK_MID_MAX, tuning): the quad form's upper end
     int spec2_max, spec3_max, spec4_max;   // TRK_SPEC*_MAX unless overridden (SCA_TRK_SPEC2_MAX ..., tuning)
 };
@@ -51,11 +53,8 @@ constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one
                                           // and, above one wave per SIMD, doubles up whole CUs, which leaves the others room for the
                                           // 512-thread workgroups of the kd build running beside the re-plans (k_kd_block 154 -> 99 us at c4)
 
-__device__ __forceinline__ bool track_active(const DeviceView &d, int agent) {
-    const int pol = d.policy[agent];
-    return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;   // mampenv.py:35
-}
-__device__ __forceinline__ void track_store(const DeviceView &d, int agent, const double *V, int edge) {
+__device__ __forceinline__ bool track_active(const DeviceView &d, int agent) { return tracker_owns(d, agent); }   // mampenv.py:35
+__device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev &K, int agent, const double *V, int edge) {
     d.vpref_edge[agent] = edge ? 1 : 0;
     for (int q = 0; q < 3; q++) {
         double x = V[q];
@@ -64,6 +63,9 @@ __device__ __forceinline__ void track_store(const DeviceView &d, int agent, cons
         else if (x < -1.7976931348623157e308) x = -1.7976931348623157e308;
         d.vpref_ext[agent * 3 + q] = x;
     }
+    // inside a policy pass: the agent's prologue for the solve (it reads the v_pref just stored), by the lane that has it --
+    // a launch of its own behind the join (k_prep_shard, 6.5 us + its gap on the critical path) until the end of round 2
+    if (K.prep) prep_agent(d, K.P, (Prep *)d.prep, agent);
 }
 
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
         return;
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V, a.edge);
+    track_store(d, K, agent, V, a.edge);
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     double dif[3], V[3];
     sca_dubins::track_replan(T, a, agent, pos, heading, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V, a.edge);
+    track_store(d, K, agent, V, a.edge);
 }
 
 // k_track + k_replan in ONE launch, one lane per agent of the shard: for passes in which nearly every tracked agent re-plans
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView
         sca_dubins::track_replan(T, a, agent, pos, heading, dif);
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V, a.edge);
+    track_store(d, K, agent, V, a.edge);
 }
 
 // ---- four lanes per plan ---------------------------------------------------------------------------------------------------
@@ -399,7 +401,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     double dif[3], V[3];
     sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, agent, V, a.edge);
+    track_store(d, K, agent, V, a.edge);
 }
 
 // The many-lanes-per-plan forms, ONE KERNEL EACH (round 2; they used to share one kernel that picked the form by the count:
