@@ -52,3 +52,21 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for pat in ('liboracle', 'from oracle', 'import oracle', 'orc_', 'oracle.py'):
                     assert pat not in txt, (f, pat)
+
+
+def test_python_constants_mirror_the_header():
+    """solver.py's NBR_* / POL_* / FORM_* are the header's SCA_NBR_* / SCA_POLICY_* / SCA_FORM_* values (a drop-in host reads
+    either)."""
+    from sca_amd import solver as S
+    txt = open(os.path.join(ROOT, 'include', 'sca_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    hdr = {k: int(v) for k, v in re.findall(r'\b(SCA_[A-Z0-9_]+)\s*=\s*(-?\d+)', txt)}
+    hdr.update({k: int(v) for k, v in re.findall(r'#define\s+(SCA_[A-Z0-9_]+)\s+(-?\d+)\b', txt)})
+    pairs = {'SCA_NBR_KDTREE': S.NBR_KDTREE, 'SCA_NBR_GRID': S.NBR_GRID, 'SCA_NBR_KDTREE_HOSTBUILD': S.NBR_KDTREE_HOSTBUILD,
+             'SCA_POLICY_SCA': S.POL_SCA, 'SCA_POLICY_RVO3D': S.POL_RVO3D, 'SCA_POLICY_SRVO3D': S.POL_SRVO3D,
+             'SCA_POLICY_ORCA3D': S.POL_ORCA3D, 'SCA_POLICY_ORCA3D_LP': S.POL_ORCA3D_LP, 'SCA_POLICY_RVO3D_DUBINS': S.POL_RVO3D_DUBINS,
+             'SCA_FORM_SOLVE_SPLIT': S.FORM_SOLVE_SPLIT, 'SCA_FORM_TRACK_FUSED': S.FORM_TRACK_FUSED,
+             'SCA_FORM_REPLAN_LANE': S.FORM_REPLAN_LANE, 'SCA_FORM_REPLAN_FEW': S.FORM_REPLAN_FEW, 'SCA_FORM_LP_LANE': S.FORM_LP_LANE,
+             'SCA_MAX_NEIGHBORS': S.K}
+    for name, val in pairs.items():
+        assert hdr.get(name) == val, (name, hdr.get(name), val)
