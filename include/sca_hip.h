@@ -188,9 +188,12 @@ int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 /* device self-test: numerators of l3norm(a_i, b_i) = round(|a_i - b_i|, 5) (mamp/util.py:104) as the solver's fast path
  * computes them (fast[]) and as the literal restatement does (exact[]); they must be identical */
 int sca_selftest_l3norm(sca_ctx *ctx, int n, const double *a /*n*3*/, const double *b /*n*3*/, double *fast /*n*/, double *exact /*n*/);
-/* the device planner's arctangent (coefficients from constant memory, division without the scaling instructions) and the
- * device library's atan2 on the same n argument pairs: tests assert bit equality (dubinsmaneuver2d.py's atan2 calls) */
-int sca_selftest_atan2(sca_ctx *ctx, int n, const double *y, const double *x, double *fast /*n*/, double *lib /*n*/);
+/* The tracker's libm (sca_amd/csrc/sca_glibc_math.h: glibc 2.35's sin / cos / atan2 / acos / pow(x, 2) restated operation for
+ * operation, so that the device computes the reference's -- i.e. Python's math module's -- bits).  fn: 0 sin(a), 1 cos(a),
+ * 2 acos(a), 3 atan2(a, b), 4 pow(a, 2); b may be NULL unless fn == 3.  sca_selftest_libm evaluates on the device,
+ * sca_selftest_libm_host on the host (no GPU needed); tests demand both equal the running glibc bit for bit. */
+int sca_selftest_libm(sca_ctx *ctx, int fn, int n, const double *a, const double *b, double *out /*n*/);
+int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out /*n*/);
 
 /* Trajectory log = Agent.history_info (mamp/agents/agent.py:75-77, filled by to_vector :126-148 at the end of every
  * update_velocitie, mamp/envs/mampenv.py:105): one 64-byte row per agent per env step, kept in HBM so that resident
@@ -217,6 +220,13 @@ void sca_tracker_destroy(void *tracker);
 int sca_tracker_vpref(void *tracker, const double *pos /*n*3*/, const float *vel /*n*3*/, const double *heading /*n*3*/,
                       const uint8_t *active /*n*/, const double *nbr0_dsq /*n*/, double *vpref_out /*n*3*/, int nthreads);
 int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
+/* why the last sca_tracker_vpref's result for agent i may differ from another libm's (0: it cannot): bits 1 = pop decision,
+ * 2 = follow-or-re-plan distance, 4 = is_parallel, 8 = truncation of v_pref (scaPolicy.py:338), 16 = rounded norm (util.py:104).
+ * The host tracker IS the reference bit for bit; the same code on the device sets SCA_ST_TRACKER_EDGE from this word. */
+int sca_tracker_edges(void *tracker, uint8_t *edges /*n*/);
+/* test hook, host tracker only: seed != 0 swaps glibc's sin / cos / atan2 / acos for versions whose last bit differs in 1/8 of
+ * the calls (deterministic per argument) and pow(x, 2) for x * x, i.e. a libm like the device's; 0 restores glibc */
+int sca_selftest_libm_noise(uint64_t seed);
 /* dubinsmaneuver3d (dubinsmaneuver3d.py:34): q = [x, y, z, yaw, pitch]; samples = [x, y, z, psi, gamma] rows */
 int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
                     char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
@@ -239,10 +249,13 @@ int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*
 int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
 
 /* diagnostics: the tracker record of one agent as 24 doubles -- horizontal maneuver (r_min, t, p, length), vertical maneuver
- * (the same four), plan length, sampling size, b_unc, kappa, cursor, sample count, tracked node[3], untruncated v_pref[3],
- * the two words, edge flag, re-plan count -- of the host tracker / the device tracker */
+ * (the same four), plan length, sampling size, b_unc, twin state, cursor, sample count, tracked node[3], untruncated v_pref[3],
+ * the two words, edge reasons (bits 0..5) + 64 x candidate radii tried, re-plan count -- of the host tracker / the device tracker */
 int sca_tracker_debug(void *tracker, int agent, double *out24);
 int sca_device_tracker_debug(sca_ctx *ctx, int agent, double *out24);
+/* diagnostics of the edge mark (host tracker): the tracked node on the plan [0..2] and on its twin plan [3..5], the node
+ * uncertainty derived from them [6..8], the twin's horizontal / vertical radius and sampling size [9..11] */
+int sca_tracker_debug_node(void *tracker, int agent, double *out12);
 
 /* host self-test (no GPU needed): the device planner's four-lane form evaluates the four CSC Dubins words
  * (dubinsmaneuver2d.py:33-109) as one sign-parametrised instruction stream; this compares it with the literal words on the

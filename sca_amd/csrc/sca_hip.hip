@@ -300,20 +300,75 @@ int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const doubl
     return 0;
 }
 // diagnostics: the tracker record of one agent as 24 doubles (host tracker / device tracker): horizontal maneuver r_min, t, p,
-// length; vertical r_min, t, p, length; plan length, sampling size, b_unc, kappa, next, count, now_goal[3], v_pref[3], words
+// length; vertical r_min, t, p, length; plan length, sampling size, b_unc, twin state, next, count, now_goal[3], v_pref[3], words
 static void track_dump(const sca_dubins::AgentTrack &a, double *o) {
     const sca_dubins::Plan3D &P = a.plan;
     o[0] = P.h.r_min; o[1] = P.h.t; o[2] = P.h.p; o[3] = P.h.length; o[4] = P.v.r_min; o[5] = P.v.t; o[6] = P.v.p; o[7] = P.v.length;
-    o[8] = P.length; o[9] = P.sampling_size; o[10] = P.b_unc; o[11] = P.kappa; o[12] = (double)a.next; o[13] = (double)P.count;
+    o[8] = P.length; o[9] = P.sampling_size; o[10] = P.b_unc; o[11] = (double)P.twin; o[12] = (double)a.next; o[13] = (double)P.count;
     for (int q = 0; q < 3; q++) { o[14 + q] = a.now_goal[q]; o[17 + q] = a.v_pref[q]; }
     o[20] = P.mode[0] * 65536.0 + P.mode[1] * 256.0 + P.mode[2]; o[21] = P.mode[3] * 65536.0 + P.mode[4] * 256.0 + P.mode[5];
-    o[22] = (double)a.edge + 2.0 * P.iters; o[23] = (double)a.replans;
+    o[22] = (double)a.edge + 64.0 * P.iters; o[23] = (double)a.replans;
 }
 int sca_tracker_debug(void *tr, int agent, double *out24) {
     if (!tr || !out24) return SCA_ERR_ARG;
     auto *T = (sca_dubins::Tracker *)tr;
     if (agent < 0 || agent >= T->n) return SCA_ERR_ARG;
     track_dump(T->st[agent], out24);
+    return 0;
+}
+// diagnostics of the edge mark: the tracked node on the plan [0..2] and on its twin [3..5], node_unc [6..8], the twin's radii
+// and sampling size [9..11]
+int sca_tracker_debug_node(void *tr, int agent, double *out12) {
+    if (!tr || !out12) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    if (agent < 0 || agent >= T->n) return SCA_ERR_ARG;
+    const sca_dubins::AgentTrack &a = T->st[agent];
+    for (int q = 0; q < 12; q++) out12[q] = 0.0;
+    if (a.next <= 0) return 0;
+    double s5[5];
+    a.plan.sample(a.next - 1, s5);
+    for (int q = 0; q < 3; q++) out12[q] = s5[q];
+    if (a.plan.twin == 1) { a.plan.sample_twin(a.next - 1, s5); for (int q = 0; q < 3; q++) out12[3 + q] = s5[q]; }
+    sca_dubins::node_unc(T->view(), a, agent, out12 + 6);
+    out12[9] = a.plan.h2.r_min; out12[10] = a.plan.v2.r_min; out12[11] = a.plan.ss2;
+    return 0;
+}
+int sca_tracker_edges(void *tr, uint8_t *edges) {
+    if (!tr || !edges) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    for (int i = 0; i < T->n; i++) edges[i] = (uint8_t)T->st[i].edge;
+    return 0;
+}
+// Test hook (host tracker only): replace glibc's sin / cos / atan2 / acos by versions whose last bit differs in ~1/8 of the
+// calls (a deterministic function of the argument bits and `seed`, as another libm's would be) and pow(x, 2) by x * x -- the
+// kind of libm the device tracker runs on.  seed == 0 restores glibc.  tests/test_tracker.py uses it to check, without a GPU,
+// that every v_pref such a tracker gets wrong carries the edge mark.
+namespace {
+unsigned long long g_noise_seed = 0;
+inline double noisy(double r, double x, double y) {
+    if (!(r == r) || r == 0.0 || std::isinf(r)) return r;
+    unsigned long long a, b;
+    std::memcpy(&a, &x, 8); std::memcpy(&b, &y, 8);
+    unsigned long long h = (a ^ (b * 0x9E3779B97F4A7C15ull) ^ g_noise_seed) * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+    if ((h & 7) != 0) return r;
+    return std::nextafter(r, (h & 8) ? INFINITY : -INFINITY);
+}
+double n_sin(double x) { return noisy(std::sin(x), x, 1.0); }
+double n_cos(double x) { return noisy(std::cos(x), x, 2.0); }
+double n_acos(double x) { return noisy(std::acos(x), x, 3.0); }
+double n_atan2(double y, double x) { return noisy(std::atan2(y, x), y, x); }
+double n_pow(double x, double y) { return y == 2.0 ? x * x : std::pow(x, y); }
+}
+int sca_selftest_libm_noise(uint64_t seed) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (getenv("SCA_TIE_ULPS")) sca_dubins::g_tie_ulps = atof(getenv("SCA_TIE_ULPS"));
+    if (getenv("SCA_B_FACTOR")) sca_dubins::g_b_factor = atof(getenv("SCA_B_FACTOR"));
+    if (getenv("SCA_SHIFT_FACTOR")) sca_dubins::g_shift_factor = atof(getenv("SCA_SHIFT_FACTOR"));
+#endif
+    g_noise_seed = seed;
+    if (seed) { sca_dubins::h_sin = n_sin; sca_dubins::h_cos = n_cos; sca_dubins::h_acos = n_acos; sca_dubins::h_atan2 = n_atan2; sca_dubins::h_pow = n_pow; }
+    else { sca_dubins::h_sin = std::sin; sca_dubins::h_cos = std::cos; sca_dubins::h_acos = std::acos; sca_dubins::h_atan2 = std::atan2; sca_dubins::h_pow = std::pow; }
     return 0;
 }
 int sca_tracker_replans(void *tr, int32_t *replans) {
@@ -488,7 +543,6 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     CHK(c, hipSetDevice(device));
     CHK(c, hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
     c->stream = c->stream_own;
-    CHK(c, hipMemcpyToSymbol(HIP_SYMBOL(sca_dubins::SCA_ATAN_C), sca_dubins::SCA_ATAN_BITS, sizeof(sca_dubins::SCA_ATAN_BITS)));   // m_atan2's table
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
     CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
     CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3)));   // counts | nchunks
@@ -1397,18 +1451,33 @@ int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, dou
     return 0;
 }
 
-int sca_selftest_atan2(sca_ctx *c, int n, const double *y, const double *x, double *fast, double *lib) {
+// the restated glibc functions (sca_glibc_math.h): fn 0 sin(a), 1 cos(a), 2 acos(a), 3 atan2(a, b), 4 pow(a, 2)
+static double libm_eval_host(int fn, double a, double b) {
+    switch (fn) {
+    case 0: return sca_gm::g_sin(a);
+    case 1: return sca_gm::g_cos(a);
+    case 2: return sca_gm::g_acos(a);
+    case 3: return sca_gm::g_atan2(a, b);
+    default: return sca_gm::g_pow2(a);
+    }
+}
+int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out) {
+    if (fn < 0 || fn > 4 || n < 0 || !a || !out || (fn == 3 && !b)) return SCA_ERR_ARG;
+    for (int i = 0; i < n; i++) out[i] = libm_eval_host(fn, a[i], b ? b[i] : 0.0);
+    return 0;
+}
+int sca_selftest_libm(sca_ctx *c, int fn, int n, const double *a, const double *b, double *out) {
     if (!c) return SCA_ERR_ARG;
-    ARG(c, n > 0 && y && x && fast && lib);
-    double *dy = nullptr, *dx = nullptr, *df = nullptr, *dl = nullptr;
-    for (double **p : {&dy, &dx, &df, &dl}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
-    CHK(c, hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_selftest_atan2, dim3((n + 255) / 256), dim3(256), 0, c->stream, dy, dx, n, df, dl);
-    CHK(c, hipMemcpyAsync(fast, df, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    CHK(c, hipMemcpyAsync(lib, dl, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    ARG(c, fn >= 0 && fn <= 4 && n > 0 && a && out && (fn != 3 || b));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    for (double **p : {&da, &db, &dout}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
+    CHK(c, hipMemcpyAsync(da, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    if (b) CHK(c, hipMemcpyAsync(db, b, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    else CHK(c, hipMemsetAsync(db, 0, sizeof(double) * n, c->stream));
+    hipLaunchKernelGGL(k_selftest_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, fn, da, db, n, dout);
+    CHK(c, hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
-    for (double *p : {dy, dx, df, dl}) (void)hipFree(p);
+    for (double *p : {da, db, dout}) (void)hipFree(p);
     return 0;
 }
 

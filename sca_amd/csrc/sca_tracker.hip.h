@@ -253,23 +253,30 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
     int phase = 0, guard = 0;
-    while (phase < 2 || ::fabs(step) > 1e-10) {
+    bool have_twin = false;
+    for (;;) {
         double c;
         if (phase == 0) c = b;
         else if (phase == 1) { b *= 2.0; c = b; }
-        else { c = b + step; if (c < 1.0) c = 1.0; }
+        else if (phase == 2) {
+            if (::fabs(step) > 1e-10) { c = b + step; if (c < 1.0) c = 1.0; }
+            else if (P.b_unc > 0.0) { phase = 3; c = b + P.b_unc; }          // the twin's radius (Plan3D::twin), same call site
+            else break;
+        } else if (phase == 3 && b - P.b_unc >= 1.0) { phase = 4; c = b - P.b_unc; }
+        else break;
         const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv, sub, lane);
         if (phase < 2) {
             if (phase == 1 && ++guard > 200) return P;
             if (nf >= 2) { fbh = fch; fbv = fcv; phase = 2; }
             else phase = 1;
-        } else {
+        } else if (phase == 2) {
             if (nf > 0 && c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);
             if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
             else step *= -0.1;
-        }
+        } else if (nf > 0) { have_twin = true; break; }
     }
     finish_plan(P, fbh, fbv, qi);
+    adopt_twin(P, have_twin, fch, fcv);
     return P;
 }
 
@@ -374,7 +381,15 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             fetch_maneuver(fbv, fcv, src);
         }
     }
+    // the twin (Plan3D::twin): all quads evaluate the same radius
+    bool have_twin = false;
+    if (P.b_unc > 0.0) {
+        have_twin = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * (b + P.b_unc), fch, fcv, sub, lane) > 0;
+        if (!have_twin && b - P.b_unc >= 1.0)
+            have_twin = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * (b - P.b_unc), fch, fcv, sub, lane) > 0;
+    }
     finish_plan(P, fbh, fbv, qi);
+    adopt_twin(P, have_twin, fch, fcv);
     return P;
 }
 
@@ -416,12 +431,19 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_repla
     replan_group<LANES>(d, T, K, count);
 }
 
-// self-test: m_atan2 (coefficients from SGPRs, the lean division) against the device library's atan2, bit for bit
-__global__ __launch_bounds__(256) void k_selftest_atan2(const double *y, const double *x, int n, double *fast, double *lib) {
+// self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them)
+__global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, const double *b, int n, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fast[i] = sca_dubins::m_atan2(y[i], x[i]);
-    lib[i] = ::atan2(y[i], x[i]);
+    double r;
+    switch (fn) {
+    case 0: r = sca_gm::g_sin(a[i]); break;
+    case 1: r = sca_gm::g_cos(a[i]); break;
+    case 2: r = sca_gm::g_acos(a[i]); break;
+    case 3: r = sca_gm::g_atan2(a[i], b[i]); break;
+    default: r = sca_gm::g_pow2(a[i]); break;
+    }
+    out[i] = r;
 }
 
 __global__ __launch_bounds__(256) void k_track_replans(const sca_dubins::AgentTrack *st, int32_t *out, int n) {
