@@ -75,9 +75,9 @@ enum sca_status_bit {             /* per-agent status word of the last policy pa
     SCA_ST_VPREF_EDGE = 128,      /* straight-line v_pref (rvo3dPolicy.py:182-196): one of its 5-decimal roundings sat within 1e-9 of
                                      flipping.  On identical inputs the pass is the reference's bit for bit; in a free-running episode
                                      positions carry ~1e-14 m of sin / cos rounding noise, which matters exactly here */
-    SCA_ST_TRACKER_EDGE = 64      /* device tracker: a 5-decimal rounding between the tracked path node and this pass's v_pref sat within
-                                     1e-8 m of flipping (scaPolicy.py:329-338, util.py:104); the device's libm is not glibc's, so the
-                                     reference's v_pref may be one 1e-5 step away (the velocity picked from it can then differ) */
+    SCA_ST_TRACKER_EDGE = 64      /* reserved, never set.  Rounds 1-2 marked agent-steps whose device-tracker v_pref might differ from the
+                                     reference's by a 5-decimal step (the device ran on another libm); since round 3 the device tracker
+                                     computes glibc's bits (sca_amd/csrc/sca_glibc_math.h) and equals the host tracker bit for bit */
 };
 
 enum sca_error {
@@ -220,23 +220,16 @@ void sca_tracker_destroy(void *tracker);
 int sca_tracker_vpref(void *tracker, const double *pos /*n*3*/, const float *vel /*n*3*/, const double *heading /*n*3*/,
                       const uint8_t *active /*n*/, const double *nbr0_dsq /*n*/, double *vpref_out /*n*3*/, int nthreads);
 int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
-/* why the last sca_tracker_vpref's result for agent i may differ from another libm's (0: it cannot): bits 1 = pop decision,
- * 2 = follow-or-re-plan distance, 4 = is_parallel, 8 = truncation of v_pref (scaPolicy.py:338), 16 = rounded norm (util.py:104).
- * The host tracker IS the reference bit for bit; the same code on the device sets SCA_ST_TRACKER_EDGE from this word. */
-int sca_tracker_edges(void *tracker, uint8_t *edges /*n*/);
-/* test hook, host tracker only: seed != 0 swaps glibc's sin / cos / atan2 / acos for versions whose last bit differs in 1/8 of
- * the calls (deterministic per argument) and pow(x, 2) for x * x, i.e. a libm like the device's; 0 restores glibc */
-int sca_selftest_libm_noise(uint64_t seed);
 /* dubinsmaneuver3d (dubinsmaneuver3d.py:34): q = [x, y, z, yaw, pitch]; samples = [x, y, z, psi, gamma] rows */
 int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
                     char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
 
 /* The same tracker on the device: one lane per agent for the tracking, tracker records resident in HBM, the re-planning
  * agents of a step compacted into kernels of their own -- one lane up to one wavefront per plan, by how many a step has
- * (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker, compiled for
- * gfx950 with the device library's sin / cos / atan2 / acos, whose last bit differs from glibc's in a few percent of the
- * calls: v_pref equals the host tracker's except for isolated components (0.03 % in fuzzing) that differ by one step of the
- * 5-decimal truncation of scaPolicy.py:338, a few steps when the tracked node is within a metre.
+ * (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker AND the same libm (sca_glibc_math.h: glibc's sin / cos /
+ * atan2 / acos / pow restated operation for operation, device build checked against the host's bit for bit): v_pref, every
+ * follow-or-re-plan decision and every plan equal the host tracker's -- i.e. the reference's -- bit for bit
+ * (tests/test_gpu_tracker.py).
  * sca_device_tracker_enable: agents with policy SCA / RVO3D_DUBINS take v_pref from it from now on -- inside every
  * sca_policy_pass / sca_step_begin / sca_run_steps when in_pass != 0 (agent.neighbors[0] of the previous pass is read from
  * the neighbour lists on the device), otherwise only through sca_device_tracker_vpref.  sca_set_agents disables it. */
@@ -249,14 +242,10 @@ int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*
 int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
 
 /* diagnostics: the tracker record of one agent as 24 doubles -- horizontal maneuver (r_min, t, p, length), vertical maneuver
- * (the same four), plan length, sampling size, b_unc, twin state, cursor, sample count, tracked node[3], untruncated v_pref[3],
- * the two words, edge reasons (bits 0..5) + 64 x candidate radii tried, re-plan count -- of the host tracker / the device tracker */
+ * (the same four), plan length, sampling size, two unused slots, cursor, sample count, tracked node[3], untruncated v_pref[3],
+ * the two words, 64 x candidate radii tried, re-plan count -- of the host tracker / the device tracker */
 int sca_tracker_debug(void *tracker, int agent, double *out24);
 int sca_device_tracker_debug(sca_ctx *ctx, int agent, double *out24);
-/* diagnostics of the edge mark (host tracker): the tracked node on the plan [0..2] and on its twin plan [3..5], the node
- * uncertainty derived from them [6..8], the twin's horizontal / vertical radius and sampling size [9..11] */
-int sca_tracker_debug_node(void *tracker, int agent, double *out12);
-
 /* host self-test (no GPU needed): the device planner's four-lane form evaluates the four CSC Dubins words
  * (dubinsmaneuver2d.py:33-109) as one sign-parametrised instruction stream; this compares it with the literal words on the
  * given frames (alpha, beta in [0, 2 pi), d >= 0) and counts results that are not bit-identical (must be 0) */

@@ -73,10 +73,7 @@ SIGNATURES = {
     'sca_tracker_destroy': (None, [C.c_void_p]),
     'sca_tracker_vpref': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, dp, C.c_int]),
     'sca_tracker_replans': (C.c_int, [C.c_void_p, ip]),
-    'sca_tracker_edges': (C.c_int, [C.c_void_p, bp]),
-    'sca_selftest_libm_noise': (C.c_int, [C.c_uint64]),
     'sca_tracker_debug': (C.c_int, [C.c_void_p, C.c_int, dp]),
-    'sca_tracker_debug_node': (C.c_int, [C.c_void_p, C.c_int, dp]),
     'sca_device_tracker_debug': (C.c_int, [C.c_void_p, C.c_int, dp]),
     'sca_device_tracker_enable': (C.c_int, [C.c_void_p, dp, C.c_double, C.c_double, C.c_double, C.c_int]),
     'sca_device_tracker_disable': (C.c_int, [C.c_void_p]),

@@ -34,7 +34,7 @@ enum Status : int32_t {
     ST_BAD_PREF_SPEED = 4,     // np.arange(0.5, ps+0.03, ps-0.5) not of length 2 (scaPolicy.py:195)
     ST_KD_STACK = 16,          // kd traversal stack overflow
     ST_NBR_OVERFLOW = 32,      // grid mode: more than K objects in range (reference list is order dependent)
-    ST_TRACKER_EDGE = 64,      // device tracker: this pass's v_pref crossed a rounding within noise of flipping (sca_dubins.hpp)
+    ST_TRACKER_EDGE = 64,      // never set since round 3 (the device tracker computes the reference's bits: sca_glibc_math.h)
     ST_VPREF_EDGE = 128,       // straight-line v_pref: a 5-decimal rounding of it sat within 1e-9 of flipping (straight_v_pref)
 };
 constexpr int NBR_OBSTACLE_BIT = 1 << 30;

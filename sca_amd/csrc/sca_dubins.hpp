@@ -98,27 +98,6 @@ SCA_DHD static inline double trunc5(double x) { double t = std::trunc(x * 100000
 SCA_DHD static inline double l3norm(const double *a, const double *b) {                                              // util.py:104
     return round5_py(std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0)));
 }
-// Knife edges (SCA_ST_TRACKER_EDGE).  The device tracker runs the same statements as the reference with another libm.  Its
-// planner's search ends on comparisons of path lengths that are equal to within rounding noise, so it may settle on a horizontal
-// radius that is not the reference's, and its path nodes then sit elsewhere.  That is invisible unless one of the
-// 5-decimal roundings / truncations or one of the comparisons between a node and v_pref sits that close to its edge.  How close
-// is measured per agent-step (node_unc below: the same node on a twin plan built at the edge of the radius' uncertainty);
-// a step whose v_pref, or whose pop / follow-or-re-plan decision, could come out differently within that distance is marked.
-SCA_DHD static inline bool near_round5_tie(double x, double tol_scaled) {       // round(x, 5) within tol of a tie
-    const double y = x * 100000.0;
-    return std::fabs(std::fabs(y - std::floor(y) - 0.5)) < tol_scaled;
-}
-SCA_DHD static inline bool near_trunc5_step(double x, double tol_scaled) {      // int(x * 1e5) within tol of stepping
-    const double y = x * 100000.0;
-    const double r = std::rint(y);
-    if (r == 0.0) return false;          // int() truncates towards zero: (-1, 1) -> 0 on both sides, no step at 0
-    return std::fabs(y - r) < tol_scaled;
-}
-SCA_DHD static inline double norm_raw_for_edge(const double *d) { return std::sqrt(m_pow(d[0], 2.0) + m_pow(d[1], 2.0) + m_pow(d[2], 2.0)); }
-SCA_DHD static inline double norm_raw_for_edge3(const double *a, const double *b) {
-    return std::sqrt(m_pow(a[0] - b[0], 2.0) + m_pow(a[1] - b[1], 2.0) + m_pow(a[2] - b[2], 2.0));
-}
-
 // one 2-D maneuver: what the 3-D planner and the sampler read of dubinsmaneuver2d's result (start yaw, radius, the first two
 // segment lengths, total length, word)
 struct Maneuver2D { double yaw, r_min, t, p, length; char mode[3]; bool ok; };
@@ -341,29 +320,11 @@ struct Plan3D {
     double qi[5] = {0, 0, 0, 0, 0};
     char mode[7] = {0};
     bool ok = false;
-    // Knife edges of the plan itself (SCA_ST_TRACKER_EDGE, see near_round5_tie).
-    //  b_unc:  uncertainty of the horizontal radius (in units of Rmin) the search settled on.  Two libms that take the same
-    //          accept / reject decisions (dubinsmaneuver3d.py:93) arrive at the same radius bit for bit; when a comparison was a
-    //          tie within libm noise another libm may have walked the other way from there: 4 x the step at that point.
-    //  twin:   what that uncertainty does to the PATH is not modelled but measured: the plan at the radius b + b_unc (b - b_unc
-    //          when that one is infeasible) -- its two maneuvers, their frames, its sampling size.  The tracker evaluates the
-    //          tracked node on both plans; the difference is how far the reference's node may sit from this one
-    //          (track_finish).  0: no tie, the radius is certain; 1: twin present; 2: no feasible twin (every step is marked).
-    //          In level flight the search ends on ties at every scale (a straight path is equally long for every radius) and
-    //          drives hr towards Rmin, where the vertical radius 1 / sqrt(1/Rmin^2 - 1/hr^2) is arbitrarily ill-conditioned:
-    //          the radii of plan and twin then differ by per cents -- and the nodes by nothing, which is what the twin shows
-    //          and a conditioning bound cannot (round 2 marked every step of such scenes).
-    double b_unc = 0.0;
-    int twin = 0;
-    Maneuver2D h2{}, v2{};
-    PathFrame fh2{}, fv2{};
-    double ss2 = 0.1;
     int iters = 0;                       // candidate radii the search tried (statistics; sca_*_tracker_debug)
     long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
     // sample i of the path: a pure function of i, so the tracker evaluates samples on demand
     // (the reference materialises all ~1000 of them at every re-plan and then discards most)
     SCA_DHD void sample(long i, double s[5]) const { sample_path(h, fh, v, fv, qi, (double)i * sampling_size, s); }
-    SCA_DHD void sample_twin(long i, double s[5]) const { sample_path(h2, fh2, v2, fv2, qi, (double)i * ss2, s); }
 };
 // the tail of dubinsmaneuver3d (:102-113) + compute_sampling's grid (:116-132) for the winning pair of maneuvers
 SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver2D &fbv, const double qi[5]) {
@@ -379,34 +340,6 @@ SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver
     const long cnt = (long)std::ceil(stop / ss);                        // len(np.arange(0, stop, ss))
     P.count = cnt > 0 ? cnt : 0;
 }
-
-// the twin of a plan (Plan3D::twin): the pair of maneuvers at the perturbed radius, when one was feasible
-SCA_DHD static void adopt_twin(Plan3D &P, bool have, const Maneuver2D &th, const Maneuver2D &tv) {
-    if (!(P.b_unc > 0.0)) { P.twin = 0; return; }
-    if (!have) { P.twin = 2; return; }
-    P.twin = 1;
-    P.h2 = th; P.v2 = tv;
-    P.fh2 = path_frame(th); P.fv2 = path_frame(tv);
-    P.ss2 = tv.length > 100 ? tv.length / 1000 : 0.1;
-}
-
-// a length comparison of the search within noise: 64 ulp of the lengths compared
-#if !defined(__HIP_DEVICE_COMPILE__)
-static volatile double g_tie_ulps = 64, g_b_factor = 4.0, g_shift_factor = 2.0;
-#define TIE_ULPS g_tie_ulps
-#define B_FACTOR g_b_factor
-#define SHIFT_FACTOR g_shift_factor
-#else
-#define TIE_ULPS 64.0
-#define B_FACTOR 4.0
-#define SHIFT_FACTOR 2.0
-#endif
-SCA_DHD static inline bool length_tie(double a, double b) {
-    const double ulp = std::fabs(b) * 2.220446049250313e-16;      // >= ulp(b)
-    return std::fabs(a - b) <= TIE_ULPS * ulp;
-}
-
-SCA_DHD static inline void note_tie(Plan3D &P, double step) { const double u = B_FACTOR * std::fabs(step); if (u > P.b_unc) P.b_unc = u; }
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
 // H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
@@ -443,29 +376,15 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
         if (++guard > 200) return P;                                   // the reference would loop forever
     }
     double step = 0.1;
-    // the local search (:86-100); when it is over, up to two more rounds of the same loop evaluate the twin's radius (b + b_unc,
-    // then b - b_unc) -- through the same call of the planner, which the device inlines once per call site
-    int twin_round = 0;
-    bool have_twin = false;
-    for (;;) {
-        double c;
-        if (std::fabs(step) > 1e-10) { c = b + step; if (c < 1.0) c = 1.0; P.iters++; }
-        else if (twin_round == 0 && P.b_unc > 0.0) { twin_round = 1; c = b + P.b_unc; }
-        else if (twin_round == 1 && b - P.b_unc >= 1.0) { twin_round = 2; c = b - P.b_unc; }
-        else break;
+    while (std::fabs(step) > 1e-10) {                                      // the local search (:86-100)
+        double c = b + step;
+        if (c < 1.0) c = 1.0;
+        P.iters++;
         const int nfc = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
-        if (twin_round) {
-            if (nfc > 0) { have_twin = true; break; }
-            continue;
-        }
-        if (nfc > 0) {
-            if (c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);
-            if (fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
-        }
+        if (nfc > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
         step *= -0.1;
     }
     finish_plan(P, fbh, fbv, qi);
-    adopt_twin(P, have_twin, fch, fcv);
     return P;
 }
 
@@ -478,9 +397,6 @@ struct AgentTrack {
     double sampling_size = 0.1;
     double v_pref[3] = {0, 0, 0};       // agent.v_pref (not truncated), read by is_parallel on the next call
     int replans = 0;
-    int edge = 0;                       // why this call's v_pref may not be the reference's (bits: 1 pop decision, 2 follow-or-re-plan
-                                        // distance, 4 is_parallel, 8 truncation of v_pref, 16 rounded norm); see node_unc
-    double v_unc = 0.0;                 // what a component of v_pref may be off by (read by the next call's is_parallel)
 };
 
 // what the tracker reads of the agents (agent.py:13-36): plain pointers, host or device
@@ -537,44 +453,14 @@ SCA_DHD static void node_pop4(AgentTrack &a) {                                  
     const long left = a.plan.count - a.next;
     a.next += left < 4 ? (left > 0 ? left : 0) : 4;
 }
-// How far the reference's tracked node may sit from this tracker's now_goal (SCA_ST_TRACKER_EDGE), per component; 0 when
-// now_goal is the goal itself (path used up: update_dubins' else branch), which no plan moves.
-//   * same accept / reject decisions in the search (no tie, twin == 0): the same radius bit for bit; the maneuvers and their
-//     frames differ in the last bits of their arctangents, sines and cosines, scaled by the radii and the distance covered;
-//   * a tie: the reference's radius is at most b_unc away -- the same node of the twin plan, built at that distance, measures
-//     what that does to this very node; twice the difference is taken (the twin is one-sided);
-//   * no feasible twin (twin == 2): unknown -- the caller marks the step.
-SCA_DHD static bool node_unc(TrackView T, const AgentTrack &a, int i, double dq[3]) {
-    dq[0] = dq[1] = dq[2] = 0.0;
-    const double *goal = &T.goal[3 * i];
-    if (a.next <= 0 || (a.now_goal[0] == goal[0] && a.now_goal[1] == goal[1] && a.now_goal[2] == goal[2])) return true;
-    const double ran = (double)(a.next - 1) * a.plan.sampling_size;
-    const double rr = a.plan.h.r_min + a.plan.v.r_min;
-    for (int q = 0; q < 3; q++) dq[q] = 4e-15 * (rr + ran + std::fabs(a.plan.qi[q])) + 1e-13;
-    if (a.plan.twin == 2) return false;
-    if (a.plan.twin == 1) {
-        double s5[5];
-        a.plan.sample_twin(a.next - 1, s5);
-        for (int q = 0; q < 3; q++) dq[q] += SHIFT_FACTOR * std::fabs(s5[q] - a.now_goal[q]);
-    }
-    return true;
-}
-// `round(|a - b|, 5) < bound` (util.py:104 and a comparison): can a node that is dn away decide the other way?  The rounded
-// value steps at the 5-decimal ties, so the verdict can only change while the raw distance is within half a step + dn of the bound
-SCA_DHD static inline bool near_bound(double raw, double bound, double dn) { return std::fabs(raw - bound) <= 5.0e-6 + dn + 1e-12; }
-
 SCA_DHD static void update_dubins(TrackView T, AgentTrack &a, int i, const double *pos) {                         // :243-250
-    double dq[3];
-    if (!node_unc(T, a, i, dq)) a.edge |= 1;
-    const double raw = norm_raw_for_edge3(pos, a.now_goal);
-    if (near_bound(raw, a.sampling_size * 2, dq[0] + dq[1] + dq[2])) a.edge |= 1;
-    const double dis = round5_py(raw);
+    const double dis = l3norm(pos, a.now_goal);
     if (dis < a.sampling_size * 2) {
         if (!path_pop(a, a.now_goal)) { a.now_goal[0] = T.goal[3 * i]; a.now_goal[1] = T.goal[3 * i + 1]; a.now_goal[2] = T.goal[3 * i + 2]; }
     }
 }
-// util.py:125-137 is_parallel(vA float32, v_pref float64); v_unc = what a component of vp (the previous call's v_pref) may be off by
-SCA_DHD static bool is_parallel(const float *vA, const double *vp, int *edge = nullptr, double v_unc = 0.0) {
+// util.py:125-137 is_parallel(vA float32, v_pref float64)
+SCA_DHD static bool is_parallel(const float *vA, const double *vp) {
     const float n1 = std::sqrt((float)((double)(float)(vA[0] * vA[0]) + (double)(float)(vA[1] * vA[1]) + (double)(float)(vA[2] * vA[2])));
     const double n2 = std::sqrt(fma3(vp, vp));
     const float v1[3] = {vA[0] / n1, vA[1] / n1, vA[2] / n1};
@@ -582,8 +468,6 @@ SCA_DHD static bool is_parallel(const float *vA, const double *vp, int *edge = n
     if (n1 <= (float)1e-5 || n2 <= 1e-5) return true;
     const double v1d[3] = {(double)v1[0], (double)v1[1], (double)v1[2]};
     const double rv = 1.0 - std::fabs(fma3(v1d, v2));
-    // round(rv, 5) < 3e-3 with vp uncertain: a unit vector built from components that are v_unc off moves by <= 4 v_unc / |vp|
-    if (edge && std::fabs(rv - 3e-3) <= 5.0e-6 + 4.0 * v_unc / n2 + 1e-12) *edge |= 4;
     return round5_np(rv) < 3e-3;
 }
 
@@ -596,22 +480,13 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double *goal = &T.goal[3 * i];
     const double dis_goal = l3norm(pos, goal);
     const double k = 3.0 * T.turning_radius;
-    a.edge = 0;
     if (!a.is_use_dubins) {
         a.is_use_dubins = true;
         return true;
     }
     update_dubins(T, a, i, pos);
-    const double raw = norm_raw_for_edge3(pos, a.now_goal);
-    const double dis = round5_py(raw);
+    const double dis = l3norm(pos, a.now_goal);
     const double max_size = round5_py(6 * a.sampling_size);
-    {
-        // `dis < max_size`: the node may be off (node_unc) and so may the sampling size (the twin's: a path of another length)
-        double dq[3];
-        if (!node_unc(T, a, i, dq)) a.edge |= 2;
-        const double dss = a.plan.twin == 1 ? 12.0 * std::fabs(a.plan.ss2 - a.sampling_size) : 0.0;
-        if (near_bound(raw, 6 * a.sampling_size, dq[0] + dq[1] + dq[2] + dss + 5.0e-6)) a.edge |= 2;
-    }
     const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
     const double vA64[3] = {(double)vel[0], (double)vel[1], (double)vel[2]};
     const float nvA = std::sqrt((float)((double)(float)(vel[0] * vel[0]) + (double)(float)(vel[1] * vel[1]) + (double)(float)(vel[2] * vel[2])));
@@ -622,7 +497,7 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double deg100 = round5_np(100.0 * (PI / 180.0));
     const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
     const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
-    if (((is_parallel(vel, a.v_pref, &a.edge, a.v_unc) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
+    if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
         update_dubins(T, a, i, pos);
         if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
         else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
@@ -647,27 +522,10 @@ SCA_DHD static void track_adopt(AgentTrack &a, const Plan3D &P, const double *po
 // :329-338
 SCA_DHD static void track_finish(TrackView T, AgentTrack &a, int i, const double *pos, const double dif[3], double *V_des) {
     const double *goal = &T.goal[3 * i];
-    const double raw = norm_raw_for_edge(dif);
-    const double norm = round5_py(raw);                                 // l3norm(dif, [0, 0, 0])
+    const double zero[3] = {0, 0, 0};
+    const double norm = l3norm(dif, zero);
     double v[3];
     for (int q = 0; q < 3; q++) v[q] = dif[q] * T.pref_speed[i] / norm;
-    a.v_unc = 0.0;
-    if (!path_empty(a)) {
-        // dif points at the tracked node.  The truncation of :338 and the rounded norm of :332 with the node node_unc away:
-        // v = dif * pref_speed / norm moves by dq * ps / norm through dif and by |v| * dn / norm through the norm
-        double dq[3];
-        if (!node_unc(T, a, i, dq)) a.edge |= 8;
-        const double ps = T.pref_speed[i];
-        const double nn = norm > 1e-3 ? norm : 1e-3;
-        const double dn = dq[0] + dq[1] + dq[2];                            // what the norm can move by (<= |d node|)
-        for (int q = 0; q < 3; q++) {
-            const double u = (dq[q] * ps + std::fabs(v[q]) * dn) / nn;
-            if (near_trunc5_step(v[q], 100000.0 * u + 1e-9)) a.edge |= 8;
-            if (u > a.v_unc) a.v_unc = u;
-        }
-        // a rounded norm that flips moves every component by |v| * 1e-5 / norm: several truncation steps when the node is close
-        if (near_round5_tie(raw, 100000.0 * dn + 1e-9)) a.edge |= 16;
-    }
     if (l3norm(goal, pos) < 0.2) v[0] = v[1] = v[2] = 0.0;               // util.reached, bound 0.2
     for (int q = 0; q < 3; q++) { a.v_pref[q] = v[q]; V_des[q] = trunc5(v[q]); }
 }

@@ -300,75 +300,20 @@ int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const doubl
     return 0;
 }
 // diagnostics: the tracker record of one agent as 24 doubles (host tracker / device tracker): horizontal maneuver r_min, t, p,
-// length; vertical r_min, t, p, length; plan length, sampling size, b_unc, twin state, next, count, now_goal[3], v_pref[3], words
+// length; vertical r_min, t, p, length; plan length, sampling size, 0, 0, next, count, now_goal[3], v_pref[3], words
 static void track_dump(const sca_dubins::AgentTrack &a, double *o) {
     const sca_dubins::Plan3D &P = a.plan;
     o[0] = P.h.r_min; o[1] = P.h.t; o[2] = P.h.p; o[3] = P.h.length; o[4] = P.v.r_min; o[5] = P.v.t; o[6] = P.v.p; o[7] = P.v.length;
-    o[8] = P.length; o[9] = P.sampling_size; o[10] = P.b_unc; o[11] = (double)P.twin; o[12] = (double)a.next; o[13] = (double)P.count;
+    o[8] = P.length; o[9] = P.sampling_size; o[10] = 0.0; o[11] = 0.0; o[12] = (double)a.next; o[13] = (double)P.count;
     for (int q = 0; q < 3; q++) { o[14 + q] = a.now_goal[q]; o[17 + q] = a.v_pref[q]; }
     o[20] = P.mode[0] * 65536.0 + P.mode[1] * 256.0 + P.mode[2]; o[21] = P.mode[3] * 65536.0 + P.mode[4] * 256.0 + P.mode[5];
-    o[22] = (double)a.edge + 64.0 * P.iters; o[23] = (double)a.replans;
+    o[22] = 64.0 * P.iters; o[23] = (double)a.replans;
 }
 int sca_tracker_debug(void *tr, int agent, double *out24) {
     if (!tr || !out24) return SCA_ERR_ARG;
     auto *T = (sca_dubins::Tracker *)tr;
     if (agent < 0 || agent >= T->n) return SCA_ERR_ARG;
     track_dump(T->st[agent], out24);
-    return 0;
-}
-// diagnostics of the edge mark: the tracked node on the plan [0..2] and on its twin [3..5], node_unc [6..8], the twin's radii
-// and sampling size [9..11]
-int sca_tracker_debug_node(void *tr, int agent, double *out12) {
-    if (!tr || !out12) return SCA_ERR_ARG;
-    auto *T = (sca_dubins::Tracker *)tr;
-    if (agent < 0 || agent >= T->n) return SCA_ERR_ARG;
-    const sca_dubins::AgentTrack &a = T->st[agent];
-    for (int q = 0; q < 12; q++) out12[q] = 0.0;
-    if (a.next <= 0) return 0;
-    double s5[5];
-    a.plan.sample(a.next - 1, s5);
-    for (int q = 0; q < 3; q++) out12[q] = s5[q];
-    if (a.plan.twin == 1) { a.plan.sample_twin(a.next - 1, s5); for (int q = 0; q < 3; q++) out12[3 + q] = s5[q]; }
-    sca_dubins::node_unc(T->view(), a, agent, out12 + 6);
-    out12[9] = a.plan.h2.r_min; out12[10] = a.plan.v2.r_min; out12[11] = a.plan.ss2;
-    return 0;
-}
-int sca_tracker_edges(void *tr, uint8_t *edges) {
-    if (!tr || !edges) return SCA_ERR_ARG;
-    auto *T = (sca_dubins::Tracker *)tr;
-    for (int i = 0; i < T->n; i++) edges[i] = (uint8_t)T->st[i].edge;
-    return 0;
-}
-// Test hook (host tracker only): replace glibc's sin / cos / atan2 / acos by versions whose last bit differs in ~1/8 of the
-// calls (a deterministic function of the argument bits and `seed`, as another libm's would be) and pow(x, 2) by x * x -- the
-// kind of libm the device tracker runs on.  seed == 0 restores glibc.  tests/test_tracker.py uses it to check, without a GPU,
-// that every v_pref such a tracker gets wrong carries the edge mark.
-namespace {
-unsigned long long g_noise_seed = 0;
-inline double noisy(double r, double x, double y) {
-    if (!(r == r) || r == 0.0 || std::isinf(r)) return r;
-    unsigned long long a, b;
-    std::memcpy(&a, &x, 8); std::memcpy(&b, &y, 8);
-    unsigned long long h = (a ^ (b * 0x9E3779B97F4A7C15ull) ^ g_noise_seed) * 0xD6E8FEB86659FD93ull;
-    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
-    if ((h & 7) != 0) return r;
-    return std::nextafter(r, (h & 8) ? INFINITY : -INFINITY);
-}
-double n_sin(double x) { return noisy(std::sin(x), x, 1.0); }
-double n_cos(double x) { return noisy(std::cos(x), x, 2.0); }
-double n_acos(double x) { return noisy(std::acos(x), x, 3.0); }
-double n_atan2(double y, double x) { return noisy(std::atan2(y, x), y, x); }
-double n_pow(double x, double y) { return y == 2.0 ? x * x : std::pow(x, y); }
-}
-int sca_selftest_libm_noise(uint64_t seed) {
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (getenv("SCA_TIE_ULPS")) sca_dubins::g_tie_ulps = atof(getenv("SCA_TIE_ULPS"));
-    if (getenv("SCA_B_FACTOR")) sca_dubins::g_b_factor = atof(getenv("SCA_B_FACTOR"));
-    if (getenv("SCA_SHIFT_FACTOR")) sca_dubins::g_shift_factor = atof(getenv("SCA_SHIFT_FACTOR"));
-#endif
-    g_noise_seed = seed;
-    if (seed) { sca_dubins::h_sin = n_sin; sca_dubins::h_cos = n_cos; sca_dubins::h_acos = n_acos; sca_dubins::h_atan2 = n_atan2; sca_dubins::h_pow = n_pow; }
-    else { sca_dubins::h_sin = std::sin; sca_dubins::h_cos = std::cos; sca_dubins::h_acos = std::acos; sca_dubins::h_atan2 = std::atan2; sca_dubins::h_pow = std::pow; }
     return 0;
 }
 int sca_tracker_replans(void *tr, int32_t *replans) {
@@ -463,7 +408,6 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     for (int i = 0; i < n; i++) mode[i] = (pol[i] == SCA_POLICY_SCA || pol[i] == SCA_POLICY_RVO3D_DUBINS) ? 1 : 0;
     CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode.data(), n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemsetAsync(c->d.vpref_ext, 0, sizeof(double) * 3 * n, c->stream));
-    CHK(c, hipMemsetAsync(c->d.vpref_edge, 0, n, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     c->trk.parity = 0;
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
@@ -553,7 +497,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     r |= dalloc(c, &c->rec_new_own, N); d.rec_new = c->rec_new_own;
     r |= dalloc(c, &d.heading, 3 * N); r |= dalloc(c, &d.goal, 3 * N); r |= dalloc(c, &d.pref_speed, N);
     r |= dalloc(c, &d.vpref_ext, 3 * N); r |= dalloc(c, &d.total_dist, N); r |= dalloc(c, &d.max_run_dist, N);
-    r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.vpref_edge, N); r |= dalloc(c, &d.policy, N);
+    r |= dalloc(c, &d.step_num, N); r |= dalloc(c, &d.vpref_mode, N); r |= dalloc(c, &d.policy, N);
     r |= dalloc(c, &d.zaxis, N); r |= dalloc(c, &c->lp_list, N);
     r |= dalloc(c, &d.obs, M); r |= dalloc(c, &d.atree, 2 * N); r |= dalloc(c, &d.aperm, N);
     r |= dalloc(c, &d.obs_sorted, M); r |= dalloc(c, &d.awide, 2 * N); r |= dalloc(c, &d.owide, 2 * M);
@@ -629,7 +573,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->comm) { (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     (void)tracker_free(c);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
-                    d.step_num, d.vpref_mode, d.vpref_edge, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
+                    d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
                     d.done_count, d.agent_steps, c->tab, c->kd.kx, c->kd.ky, c->kd.kz, c->kd.mr,
                     c->kd.jobs[0], c->kd.jobs[1], c->kd.small, c->kd.counts, c->kd.nbox, c->kd.nge, c->kd.ps, c->kd.cbox, c->kd.chain, c->kd.chunks[0], c->kd.chunks[1], d.hist,
@@ -829,7 +773,6 @@ int sca_set_vpref(sca_ctx *c, const double *vpref, const uint8_t *mode) {
     ARG(c, vpref && mode && c->agents_set);
     CHK(c, hipMemcpyAsync(c->d.vpref_ext, vpref, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode, c->n, hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipMemsetAsync(c->d.vpref_edge, 0, c->n, c->stream));         // v_pref from outside: no device tracker, no edge
     CHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -58,7 +58,6 @@ struct DeviceView {
     double *max_run_dist;    // [n]
     int32_t *step_num;       // [n]
     uint8_t *vpref_mode;     // [n]
-    uint8_t *vpref_edge;     // [n] 1: the tracker's v_pref of this pass passed a rounding edge (SCA_ST_TRACKER_EDGE)
     uint8_t *policy;         // [n]
     uint8_t *zaxis;          // [n]
     // obstacles + trees
@@ -659,8 +658,8 @@ struct alignas(16) Prep {
     double nvA;            // |vA| as float32 norm (util.py:11)
     double rad1;           // second element of np.arange(0.5, ps + 0.03, ps - 0.5)
     unsigned vp_key;       // round5 numerator of |v_pref - v_pref| (= 0) << 10, without the index
-    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint, 8 v_pref came over a rounding
-                           // edge of the device tracker, 16 the straight-line v_pref sits on a rounding edge; bits 8..: get_phi
+    unsigned bits;         // 1 first_step, 2 bad pref speed, 4 v_pref passes the posture constraint, (8 unused),
+                           // 16 the straight-line v_pref sits on a rounding edge; bits 8..: get_phi
                            // numerator of v_pref
 };
 static_assert(sizeof(Prep) == 48, "Prep must be 48 bytes");
@@ -691,7 +690,6 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P,
     if (!candidate_speeds(ps, rad1)) { bits |= 2u; rad1 = ps; }
     r.rad1 = rad1;
     if (posture_ok(P, vA, r.nvA, pA.z, vpref)) bits |= 4u;
-    if (d.vpref_mode[agent] && d.vpref_edge[agent]) bits |= 8u;
     if (vedge) bits |= 16u;
     double kn;
     l3norm(vpref, vpref, &kn);
@@ -870,7 +868,7 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, 
     const V3 vA64 = to_v3(vA);
     const double rA = me.radius;
     const double ps = d.pref_speed[agent];
-    int st = (d.vpref_mode[agent] && d.vpref_edge[agent]) ? ST_TRACKER_EDGE : 0;
+    int st = 0;
     V3 vpref;
     bool vedge = false;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
@@ -1136,7 +1134,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
         pr.vp_key = 0;
         if (pol == POL_ORCA_LP || (pr.bits & 1u)) return;                            // no candidate sweep for these
     } else pr = ((const Prep *)d.prep)[agent];
-    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
@@ -1462,7 +1460,7 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const V3 vA64 = to_v3(vA);
     const Prep pr = pr_;
-    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 8u) ? ST_TRACKER_EDGE : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1;

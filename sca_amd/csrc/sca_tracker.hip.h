@@ -54,8 +54,7 @@ constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one
                                           // 512-thread workgroups of the kd build running beside the re-plans (k_kd_block 154 -> 99 us at c4)
 
 __device__ __forceinline__ bool track_active(const DeviceView &d, int agent) { return tracker_owns(d, agent); }   // mampenv.py:35
-__device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev &K, int agent, const double *V, int edge) {
-    d.vpref_edge[agent] = edge ? 1 : 0;
+__device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev &K, int agent, const double *V) {
     for (int q = 0; q < 3; q++) {
         double x = V[q];
         if (x != x) x = 0.0;                                             // what numpy.nan_to_num does on the host path
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
         return;
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, K, agent, V, a.edge);
+    track_store(d, K, agent, V);
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     double dif[3], V[3];
     sca_dubins::track_replan(T, a, agent, pos, heading, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, K, agent, V, a.edge);
+    track_store(d, K, agent, V);
 }
 
 // k_track + k_replan in ONE launch, one lane per agent of the shard: for passes in which nearly every tracked agent re-plans
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView
         sca_dubins::track_replan(T, a, agent, pos, heading, dif);
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, K, agent, V, a.edge);
+    track_store(d, K, agent, V);
 }
 
 // ---- four lanes per plan ---------------------------------------------------------------------------------------------------
@@ -253,30 +252,22 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
     int phase = 0, guard = 0;
-    bool have_twin = false;
-    for (;;) {
+    while (phase < 2 || ::fabs(step) > 1e-10) {
         double c;
         if (phase == 0) c = b;
         else if (phase == 1) { b *= 2.0; c = b; }
-        else if (phase == 2) {
-            if (::fabs(step) > 1e-10) { c = b + step; if (c < 1.0) c = 1.0; }
-            else if (P.b_unc > 0.0) { phase = 3; c = b + P.b_unc; }          // the twin's radius (Plan3D::twin), same call site
-            else break;
-        } else if (phase == 3 && b - P.b_unc >= 1.0) { phase = 4; c = b - P.b_unc; }
-        else break;
+        else { c = b + step; if (c < 1.0) c = 1.0; }
         const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv, sub, lane);
         if (phase < 2) {
             if (phase == 1 && ++guard > 200) return P;
             if (nf >= 2) { fbh = fch; fbv = fcv; phase = 2; }
             else phase = 1;
-        } else if (phase == 2) {
-            if (nf > 0 && c != b && length_tie(fcv.length, fbv.length)) note_tie(P, step);
+        } else {
             if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
             else step *= -0.1;
-        } else if (nf > 0) { have_twin = true; break; }
+        }
     }
     finish_plan(P, fbh, fbv, qi);
-    adopt_twin(P, have_twin, fch, fcv);
     return P;
 }
 
@@ -369,7 +360,6 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             double len = lenk[1], cn = nc[1];
 #pragma unroll
             for (int k = 2; k <= NODES; k++) { nf = node == k ? nfk[k] : nf; len = node == k ? lenk[k] : len; cn = node == k ? nc[k] : cn; }
-            if (nf > 0 && cn != b && length_tie(len, best_len)) note_tie(P, step);
             const bool acc = nf > 0 && len < best_len;                     // the same in every lane of the group
             if (acc) { b = cn; best_len = len; accepted = node; step *= 2.; node = 2 * node; }
             else { step *= -0.1; node = 2 * node + 1; }
@@ -381,15 +371,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             fetch_maneuver(fbv, fcv, src);
         }
     }
-    // the twin (Plan3D::twin): all quads evaluate the same radius
-    bool have_twin = false;
-    if (P.b_unc > 0.0) {
-        have_twin = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * (b + P.b_unc), fch, fcv, sub, lane) > 0;
-        if (!have_twin && b - P.b_unc >= 1.0)
-            have_twin = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * (b - P.b_unc), fch, fcv, sub, lane) > 0;
-    }
     finish_plan(P, fbh, fbv, qi);
-    adopt_twin(P, have_twin, fch, fcv);
     return P;
 }
 
@@ -416,7 +398,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     double dif[3], V[3];
     sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, K, agent, V, a.edge);
+    track_store(d, K, agent, V);
 }
 
 // The many-lanes-per-plan forms, ONE KERNEL EACH (round 2; they used to share one kernel that picked the form by the count:

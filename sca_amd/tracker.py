@@ -71,12 +71,6 @@ class DubinsTracker:
         self.L.sca_tracker_replans(self.h, _lib.ptr(r, C.c_int32))
         return r
 
-    def edges(self):
-        """Why the last vpref() of an agent may differ from another libm's (sca_tracker_edges; 0 = it cannot)."""
-        e = np.zeros(self.n, np.uint8)
-        self.L.sca_tracker_edges(self.h, _lib.ptr(e, C.c_uint8))
-        return e
-
     # MACAEnv(v_pref_fn=tracker): called once per step before the policy pass
     def __call__(self, env):
         if env._last_neighbors is not None:

@@ -1,14 +1,12 @@
 """The v_pref tracker on the device (sca_amd/csrc/sca_tracker.hip.h) against the golden v_pref of whole
 reference episodes and against the native host tracker.
 
-The device tracker is sca_dubins.hpp compiled for gfx950: the same statements as the (bit-exact) host tracker with the device
-library's sin / cos / atan2 / acos, whose last bit is not glibc's.  The planner's search (dubinsmaneuver3d.py:86-100) ends
-in comparisons of path lengths that differ by rounding noise, so the two can settle on horizontal radii ~1e-10 apart and the
-truncation of scaPolicy.py:338 (5 decimals) then flips in isolated components.  Tolerance, written here as the task
-requires: on the reference's recorded episodes every component within 1e-5 (one truncation step, the north-star bound), at
-most 0.5 % of the components different at all, re-plan decisions identical; on random scenes against the host tracker at most
-0.2 % different, none by more than 2e-4 (v = dif * pref_speed / l3norm(dif) divides by a norm rounded to 5 decimals, so a
-tracked node within a metre amplifies a flipped rounding to several 1e-5 steps), re-plan counts identical.
+The device tracker is sca_dubins.hpp compiled for gfx950: the same statements as the host tracker and -- since round 3 -- the
+same libm (sca_glibc_math.h: glibc's sin / cos / atan2 / acos / pow restated operation for operation; tests/test_gpu_glibc_math.py
+checks the device build against the host's bit for bit).  So everything here is EQUALITY: v_pref of every agent-step, every
+follow-or-re-plan decision, the velocities picked from them.  (Rounds 1-2 ran the device planner on the ROCm device library,
+one ulp away from glibc in a few per cent of the calls: 0.1 % of the agent-steps then got a v_pref one or two 5-decimal steps
+away, because the planner's radius search ends on comparisons of nearly equal path lengths.)
 """
 import numpy as np
 import pytest
@@ -17,7 +15,8 @@ from golden_util import load, static_inputs
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1.0e-5 * (1 + 1e-9)
+EPISODES = ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16', 'F4_mixed_takeoff16', 'F10_sca_exp3_map',
+            'F13_fuzz_track_00', 'F13_fuzz_track_01', 'F13_fuzz_track_02', 'F13_fuzz_track_03']
 
 
 def _solver_for(fx, st, in_pass):
@@ -30,71 +29,44 @@ def _solver_for(fx, st, in_pass):
     return sol
 
 
-@pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
-                                  'F4_mixed_takeoff16', 'F10_sca_exp3_map', 'F13_fuzz_track_00', 'F13_fuzz_track_01',
-                                  'F13_fuzz_track_02', 'F13_fuzz_track_03'])
+@pytest.mark.parametrize('name', EPISODES)
 def test_device_tracker_reproduces_reference_v_pref(name):
     """Open loop on the solver (states and agent.neighbors[0] come from the fixture), closed loop on the tracker's own
-    records: every compute_v_pref of the episode, all re-plans included."""
-    from sca_amd import tracker
+    records: every compute_v_pref of the episode, all re-plans included, bit for bit the reference's V_des."""
     fx = load(name)
     st = static_inputs(fx)
     n = len(st['radius'])
     ext = st['vpref_mode'].astype(bool)
     sol = _solver_for(fx, st, in_pass=False)
-    host = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=4)
     nb0 = np.full(n, -1.0)
-    total = differing = 0
-    worst = 0.0
+    total = 0
     for t in range(len(fx['step'])):
         called = fx['called'][t].astype(bool)
         active = called & ext
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], np.where(called, 0, 1).astype(np.uint8))
         got = sol.device_tracker_vpref(nb0)
         want = fx['vpref'][t]
-        d = np.abs(got[active] - want[active])
-        if d.size:
-            worst = max(worst, float(d.max()))
-            differing += int((d > 0).sum())
-            total += d.size
-        href = host.vpref(fx['pos'][t], fx['vel'][t], fx['heading'][t], active.astype(np.uint8))
-        assert np.array_equal(href[active], want[active])                  # the host tracker is the bit-exact one
-        host.note_neighbors(fx['nbr_valid'][t], fx['nbr_n'][t], fx['nbr_dsq'][t])
+        assert np.array_equal(got[active], want[active]), (name, t, float(np.abs(got[active] - want[active]).max()))
+        total += int(active.sum())
         v = fx['nbr_valid'][t].astype(bool)
         nb0[v] = np.where(fx['nbr_n'][t] > 0, fx['nbr_dsq'][t][:, 0], -1.0)[v]
-    assert worst <= TOL, (name, worst)
-    assert differing <= max(3, 0.005 * total), (name, differing, total)
-    # same follow-or-re-plan decisions as the reference made (its re-plans = the host tracker's, which match bit for bit)
-    assert np.array_equal(sol.device_tracker_replans()[ext], host.replans()[ext]), name
-    host.close()
+    assert total > 0
     sol.close()
 
 
-EDGE = 64                    # SCA_ST_TRACKER_EDGE
-
-
-@pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
-                                  'F4_mixed_takeoff16', 'F10_sca_exp3_map', 'F13_fuzz_track_00', 'F13_fuzz_track_01',
-                                  'F13_fuzz_track_02', 'F13_fuzz_track_03'])
+@pytest.mark.parametrize('name', EPISODES)
 def test_sca_as_shipped_velocity_parity_with_device_tracker(name):
     """SCA as the reference ships it (v_pref from the Dubins tracker, scaPolicy.py:32,264-338) with the tracker ON THE
-    DEVICE: new_velocity of every agent-step of the recorded episodes against the reference's action.  Open loop on the
-    states (they come from the fixture), closed loop on the tracker's records.  The bound, as measured (MI355X, round 2) and
-    asserted: the velocity is the reference's bit for bit except on isolated agent-steps (16 of 15 589 over the ten episodes,
-    <= 0.5 % asserted per episode), and there it is off by one or two steps of the 5-decimal grid (max |dv| 2e-5, asserted
-    <= 5e-5): in every one of them the solver's pick was the v_pref candidate itself or the same table candidate, so the
-    flipped truncation of v_pref shows through unamplified -- no case of another candidate being picked was seen.
-    EVERY such agent-step carries SCA_ST_TRACKER_EDGE.  The bit is conservative, not sharp: the reference's radius search
-    (dubinsmaneuver3d.py:86-100) ends on noise-level ties and, for level flight, where its vertical radius
-    1 / sqrt(1/Rmin^2 - 1/hr^2) is ill-conditioned, so in such scenes most agent-steps carry it (printed below)."""
+    DEVICE: new_velocity of every agent-step of the recorded episodes equals the reference's action bit for bit (15 589 tracked
+    agent-steps over the ten episodes; round 2: 16 of them off by up to 2e-5).  Open loop on the states (they come from the
+    fixture), closed loop on the tracker's records.  SCA_ST_TRACKER_EDGE is never set any more."""
     fx = load(name)
     st = static_inputs(fx)
     n = len(st['radius'])
     ext = st['vpref_mode'].astype(bool)
     sol = _solver_for(fx, st, in_pass=False)
     nb0 = np.full(n, -1.0)
-    steps = deviating = flagged = unflagged_dev = 0
-    worst = 0.0
+    steps = 0
     for t in range(len(fx['step'])):
         called = fx['called'][t].astype(bool)
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
@@ -102,23 +74,12 @@ def test_sca_as_shipped_velocity_parity_with_device_tracker(name):
         sol.device_tracker_vpref(nb0)                       # compute_v_pref of every tracked agent, on the device
         sol.policy_pass()                                   # the pass reads that v_pref (tracker not re-run: in_pass=False)
         a = sol.actions()
-        status = sol.diag()['status']
-        d = np.abs(a[:, :3].astype(np.float64) - fx['action'][t][:, :3].astype(np.float64)).max(axis=1)
-        dev = called & (d > 0)
-        edge = (status & EDGE) != 0
-        assert not (edge & ~ext).any()                      # only tracked agents can carry the bit
+        assert np.array_equal(a[called, :3], fx['action'][t][called, :3]), (name, t)
+        assert not (sol.diag()['status'] & 64).any()
         steps += int((called & ext).sum())
-        deviating += int(dev.sum())
-        flagged += int((edge & called).sum())
-        unflagged_dev += int((dev & ~edge).sum())
-        if dev.any():
-            worst = max(worst, float(d[dev].max()))
         v = fx['nbr_valid'][t].astype(bool)
         nb0[v] = np.where(fx['nbr_n'][t] > 0, fx['nbr_dsq'][t][:, 0], -1.0)[v]
-    print(f'{name}: {steps} tracked agent-steps, {deviating} with another velocity (max |dv| {worst:.3g}), {flagged} flagged')
-    assert unflagged_dev == 0, (name, unflagged_dev, deviating)
-    assert deviating <= max(2, 0.005 * steps), (name, deviating, steps)
-    assert worst <= 5e-5, (name, worst)
+    assert steps > 0
     sol.close()
 
 
@@ -182,10 +143,9 @@ def test_device_tracker_feeds_the_solver_what_the_oracle_expects():
     sol.close()
 
 
-def test_env_episode_with_device_tracker_matches_host_tracker_outcome():
-    """run_sca.py's default scene (16 drones on a circle, 8 obstacle spheres), whole episode: the device tracker's episode
-    ends like the host tracker's -- everybody at the goal, no collision, episode length within 3 % (isolated 1e-5 steps of
-    v_pref may pick another candidate somewhere, after which the two runs are different but equally valid episodes)."""
+def test_env_episode_with_device_tracker_equals_host_tracker_episode():
+    """run_sca.py's default scene (16 drones on a circle, 8 obstacle spheres), whole episode through the drop-in API: the
+    device tracker's episode IS the host tracker's -- same length, same final flags, the same positions at every step."""
     from sca_amd import env as E, scenarios, solver as S, tracker
     import math
 
@@ -200,22 +160,20 @@ def test_env_episode_with_device_tracker_matches_host_tracker_outcome():
         env = E.MACAEnv(v_pref_fn=fn, device_tracker=device)
         env.set_agents(agents, obstacles=obstacles)
         steps = 0
-        first = []
+        trail = []
         while steps < 2000:
             done = env.step({})
             steps += 1
-            if steps <= 30:
-                first.append(env.pos.copy())
+            trail.append(env.pos.copy())
             if done:
                 break
-        return steps, env.flags.copy(), np.array(first)
+        return steps, env.flags.copy(), np.array(trail)
 
     s_host, f_host, p_host = run(False)
     s_dev, f_dev, p_dev = run(True)
     assert (f_host & 1).all() and not (f_host & 6).any()
-    assert (f_dev & 1).all() and not (f_dev & 6).any()
-    assert abs(s_dev - s_host) <= max(3, 0.03 * s_host), (s_dev, s_host)
-    assert float(np.abs(p_dev - p_host).max()) <= 1e-4                    # the first 30 steps stay together
+    assert s_dev == s_host and np.array_equal(f_dev, f_host)
+    assert np.array_equal(p_dev, p_host)
 
 
 def test_kd_tail_launch_with_desynchronised_workgroups():
@@ -259,7 +217,8 @@ def test_kd_tail_launch_with_desynchronised_workgroups():
 
 def test_device_tracker_on_random_scenes_vs_host_tracker():
     """Fuzz: 30 random scenes (SCA / RVO3D+Dubins among other policies, take-off agents, pitched starts and goals), 25 steps
-    each; both trackers see the same states (the run follows the host tracker's v_pref)."""
+    each; both trackers see the same states (the run follows the host tracker's v_pref): every v_pref component equal, re-plan
+    counts equal."""
     from sca_amd import solver as S, tracker
     tot = diff = 0
     worst = 0.0
@@ -309,8 +268,7 @@ def test_device_tracker_on_random_scenes_vs_host_tracker():
         host.close()
         sol.close()
     assert tot > 100000
-    assert diff <= 0.002 * tot, (diff, tot)
-    assert worst <= 2e-4, worst
+    assert diff == 0 and worst == 0.0, (diff, tot, worst)
 
 
 def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
