@@ -190,7 +190,8 @@ int sca_agent_steps(sca_ctx *ctx, int64_t *count, int reset);
 int sca_selftest_l3norm(sca_ctx *ctx, int n, const double *a /*n*3*/, const double *b /*n*3*/, double *fast /*n*/, double *exact /*n*/);
 /* The tracker's libm (sca_amd/csrc/sca_glibc_math.h: glibc 2.35's sin / cos / atan2 / acos / pow(x, 2) restated operation for
  * operation, so that the device computes the reference's -- i.e. Python's math module's -- bits).  fn: 0 sin(a), 1 cos(a),
- * 2 acos(a), 3 atan2(a, b), 4 pow(a, 2); b may be NULL unless fn == 3.  sca_selftest_libm evaluates on the device,
+ * 2 acos(a), 3 atan2(a, b), 4 pow(a, 2) -- the branch-free forms the kernels call; 5 sin, 6 cos, 7 atan2, 8 pow as the literal
+ * restatements of glibc's control flow; 9 / 10 the sine / cosine of the fused sincos.  b may be NULL unless fn is 3 or 7.  sca_selftest_libm evaluates on the device,
  * sca_selftest_libm_host on the host (no GPU needed); tests demand both equal the running glibc bit for bit. */
 int sca_selftest_libm(sca_ctx *ctx, int fn, int n, const double *a, const double *b, double *out /*n*/);
 int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out /*n*/);

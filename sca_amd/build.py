@@ -37,7 +37,8 @@ def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get('SCA_BUILD_DEFS', '').split()            # experiments: extra -D flags
+    cmd = [hipcc()] + FLAGS + extra + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

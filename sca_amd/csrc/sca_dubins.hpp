@@ -51,7 +51,7 @@ SCA_DHD static inline double m_sin(double x) { return sca_gm::g_sin(x); }
 SCA_DHD static inline double m_cos(double x) { return sca_gm::g_cos(x); }
 SCA_DHD static inline double m_acos(double x) { return sca_gm::g_acos(x); }
 SCA_DHD static inline double m_atan2(double y, double x) { return sca_gm::g_atan2(y, x); }
-SCA_DHD static inline void m_sincos(double x, double &s, double &c) { s = sca_gm::g_sin(x); c = sca_gm::g_cos(x); }
+SCA_DHD static inline void m_sincos(double x, double &s, double &c) { sca_gm::g_sincos(x, s, c); }
 #else
 SCA_DHD static inline double m_pow(double x, double y) { return h_pow(x, y); }
 SCA_DHD static inline double m_sin(double x) { return h_sin(x); }
@@ -190,7 +190,7 @@ SCA_DHD static bool csc_word_uniform(int w, double alpha, double beta, double mb
     const double ya = (w == 0 || w == 2) ? -ca : ca;   // LSL(-,+) RSR(+,-) LSR(-,-) RSL(+,+)
     const double yb = (w == 1 || w == 2) ? -cb : cb;
     const double y = ya + yb;
-    p = std::sqrt(p2);
+    p = sca_gm::sqrt_(p2);
     const double A1 = m_atan2(y, x);
     double tmp;
     if (W_KNOWN && !cross) tmp = A1;
@@ -222,6 +222,48 @@ SCA_DHD static Frame2D frame2d(const double start[3], const double end[3]) {
     F.c_ab = m_cos(F.alpha - F.beta);
     return F;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The four CSC words of one 2-D plan at once, for the lane-per-plan kernels: csc_word_uniform<true> for w = 0 .. 3 with its six
+// arctangents taken out of the words and evaluated side by side through the branch-free form of sca_glibc_math.h -- one
+// straight-line block the scheduler can interleave, and ONE branch behind it for arguments outside that form's domain
+// (non-finite, denormal, beyond 2^+-500) instead of one inside every arctangent.  Same expressions, same values, same bits.
+SCA_DHD static void csc_words4(const Frame2D &F, double mbeta, double d, double t4[4], double p4[4], double q4[4], bool ok4[4]) {
+    const double cab2 = 2 * F.c_ab, d2 = d * d, dd = 2 * d;
+    bool dom = true;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const bool cross = w >= 2, rfirst = (w & 1) != 0;
+        const double u = rfirst ? -F.sa : F.sa;
+        const double v = (w == 0 || w == 3) ? -F.sb : F.sb;
+        const double S = u + v;
+        const double k2 = cross ? -2.0 : 2.0;
+        const double p2 = ((k2 + d2) + (cross ? cab2 : -cab2)) + (dd * S);
+        const double x = (d + u) + v;
+        const double ya = (w == 0 || w == 2) ? -F.ca : F.ca;
+        const double yb = (w == 1 || w == 2) ? -F.cb : F.cb;
+        const double y = ya + yb;
+        ok4[w] = !(p2 < 0);
+        p4[w] = sca_gm::sqrt_(p2);
+        double tmp = sca_gm::atan2_core(y, x, dom);
+        // LSL / RSR: their second arctangent is atan2(+0, p) = +0 and A1 - (+0) == A1; an infeasible word's is never read
+        if (cross) tmp = tmp - sca_gm::atan2_core(w == 2 ? -2.0 : 2.0, ok4[w] ? p4[w] : 1.0, dom);
+        const double ta = tmp - F.alpha;
+        t4[w] = mod2pi(rfirst ? -ta : ta);
+        const double qa = (w == 2 ? mbeta : F.beta) - tmp;
+        q4[w] = mod2pi((w == 1 || w == 2) ? -qa : qa);
+#ifndef SCA_WORDS_PER_GROUP
+#define SCA_WORDS_PER_GROUP 2
+#endif
+        // how many words the scheduler may interleave (all four: it runs out of registers and spills)
+        if (((w + 1) % SCA_WORDS_PER_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!dom) {                                                             // (cold) an argument outside the branch-free form's domain
+#pragma unroll
+        for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform<true>(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
+    }
+}
+#endif
+
 SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     Maneuver2D m;
     m.yaw = yaw;
@@ -235,8 +277,12 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     {
         const double mbeta = mod2pi(F.beta);
         double t4[4], p4[4], q4[4]; bool ok4[4];
+#if defined(SCA_V_WORDS) && SCA_V_WORDS == 1
+        csc_words4(F, mbeta, d, t4, p4, q4, ok4);
+#else
 #pragma unroll
         for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform<true>(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
+#endif
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const double cost = c * (std::fabs(t4[w]) + std::fabs(p4[w]) + std::fabs(q4[w]));
@@ -343,16 +389,51 @@ SCA_DHD static void finish_plan(Plan3D &P, const Maneuver2D &fbh, const Maneuver
 
 // try_to_construct (dubinsmaneuver3d.py:135-162); returns the number of maneuvers (0 or 2)
 // H = frame2d of the horizontal end points (qi[0,1,3] -> qf[0,1,3]), the same for every radius
-SCA_DHD static int try_to_construct(const Frame2D &H, const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
-                                    double hr, Maneuver2D &mh, Maneuver2D &mv) {
+// what try_to_construct computes from its arguments alone, the same for every candidate radius of a search: 1 / Rmin^2 of the
+// vertical curvature (:143) and the squared height difference of the vertical frame (dubins_path_planning :184) -- same
+// arguments, same functions, same bits as recomputing them per candidate
+struct SearchConst { double inv_rmin2, dz2; };
+SCA_DHD static SearchConst search_const(const double qi[5], const double qf[5], double Rmin) {
+    SearchConst K;
+    K.inv_rmin2 = 1.0 / m_pow(Rmin, 2.0);
+    K.dz2 = m_pow(qf[2] - qi[2], 2.0);
+    return K;
+}
+// frame2d for the vertical plane: start (0, z_i, pitch_i), end (len, z_f, pitch_f); dz2 = pow(z_f - z_i, 2) from SearchConst
+SCA_DHD static Frame2D frame2d_vertical(double len, double dz, double dz2, double spitch, double epitch) {
+    Frame2D F;
+    const double ex = len - 0.0;
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(SCA_V_FRAME) || SCA_V_FRAME == 1)
+    // the branch-free forms with one domain flag for the whole frame (see csc_words4)
+    bool dom = true;
+    F.D = sca_gm::sqrt_(sca_gm::pow2_core(ex, dom) + dz2);
+    const double theta = mod2pi(sca_gm::atan2_core(dz, ex, dom));
+    F.alpha = mod2pi(spitch - theta);
+    F.beta = mod2pi(epitch - theta);
+    sca_gm::sincos_core(F.alpha, F.sa, F.ca, dom);
+    sca_gm::sincos_core(F.beta, F.sb, F.cb, dom);
+    F.c_ab = sca_gm::cos_core(F.alpha - F.beta, dom);
+    if (dom) return F;
+#endif
+    F.D = std::sqrt(m_pow(ex, 2.0) + dz2);
+    const double theta2 = mod2pi(m_atan2(dz, ex));
+    F.alpha = mod2pi(spitch - theta2);
+    F.beta = mod2pi(epitch - theta2);
+    m_sincos(F.alpha, F.sa, F.ca);
+    m_sincos(F.beta, F.sb, F.cb);
+    F.c_ab = m_cos(F.alpha - F.beta);
+    return F;
+}
+SCA_DHD static int try_to_construct(const Frame2D &H, const SearchConst &K, const double qi[5], const double qf[5], double Rmin,
+                                    const double pitchlims[2], double hr, Maneuver2D &mh, Maneuver2D &mv) {
     // the vertical curvature first: when it fails (:146-147: a candidate clamped to Rmin, `c < 1 -> c = 1`, does every time) the
     // horizontal maneuver computed before it (:140) is never read by the caller, so it is not computed here
-    const double vc = std::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
+    (void)Rmin;
+    const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / m_pow(hr, 2.0));
     if (vc < 1e-5) return 0;
     mh = plan2d(H, qi[3], hr);
-    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
     const double vr = 1.0 / vc;
-    mv = plan2d(frame2d(qi3D, qf3D), qi3D[2], vr);
+    mv = plan2d(frame2d_vertical(mh.length, qf[2] - qi[2], K.dz2, qi[4], qf[4]), qi[4], vr);
     if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
     if (mv.mode[0] == 'R') { if (qi[4] - mv.t < pitchlims[0]) return 0; }
     else { if (qi[4] + mv.t > pitchlims[1]) return 0; }
@@ -366,12 +447,13 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
     Maneuver2D fbh, fbv, fch, fcv;
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const Frame2D H = frame2d(qi2D, qf2D);
-    int nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+    const SearchConst K = search_const(qi, qf, Rmin);
+    int nfb = try_to_construct(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
     int guard = 0;
     P.iters = 1;
     while (nfb < 2) {
         b *= 2.0;
-        nfb = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
+        nfb = try_to_construct(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);
         P.iters++;
         if (++guard > 200) return P;                                   // the reference would loop forever
     }
@@ -380,7 +462,7 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
         double c = b + step;
         if (c < 1.0) c = 1.0;
         P.iters++;
-        const int nfc = try_to_construct(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
+        const int nfc = try_to_construct(H, K, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv);
         if (nfc > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; continue; }
         step *= -0.1;
     }

@@ -1394,24 +1394,33 @@ int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, dou
     return 0;
 }
 
-// the restated glibc functions (sca_glibc_math.h): fn 0 sin(a), 1 cos(a), 2 acos(a), 3 atan2(a, b), 4 pow(a, 2)
+// the restated glibc functions (sca_glibc_math.h): fn 0 sin(a), 1 cos(a), 2 acos(a), 3 atan2(a, b), 4 pow(a, 2) in the branch-free
+// forms the kernels call; 5 sin, 6 cos, 7 atan2, 8 pow as the literal restatements (glibc's control flow); 9 / 10 the sine / cosine
+// of the fused sincos
 static double libm_eval_host(int fn, double a, double b) {
+    double s2, c2;
     switch (fn) {
     case 0: return sca_gm::g_sin(a);
     case 1: return sca_gm::g_cos(a);
     case 2: return sca_gm::g_acos(a);
     case 3: return sca_gm::g_atan2(a, b);
-    default: return sca_gm::g_pow2(a);
+    case 4: return sca_gm::g_pow2(a);
+    case 5: return sca_gm::g_sin_ref(a);
+    case 6: return sca_gm::g_cos_ref(a);
+    case 7: return sca_gm::g_atan2_ref(a, b);
+    case 8: return sca_gm::g_pow2_ref(a);
+    case 9: sca_gm::g_sincos(a, s2, c2); return s2;
+    default: sca_gm::g_sincos(a, s2, c2); return c2;
     }
 }
 int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out) {
-    if (fn < 0 || fn > 4 || n < 0 || !a || !out || (fn == 3 && !b)) return SCA_ERR_ARG;
+    if (fn < 0 || fn > 10 || n < 0 || !a || !out || ((fn == 3 || fn == 7) && !b)) return SCA_ERR_ARG;
     for (int i = 0; i < n; i++) out[i] = libm_eval_host(fn, a[i], b ? b[i] : 0.0);
     return 0;
 }
 int sca_selftest_libm(sca_ctx *c, int fn, int n, const double *a, const double *b, double *out) {
     if (!c) return SCA_ERR_ARG;
-    ARG(c, fn >= 0 && fn <= 4 && n > 0 && a && out && (fn != 3 || b));
+    ARG(c, fn >= 0 && fn <= 10 && n > 0 && a && out && ((fn != 3 && fn != 7) || b));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     for (double **p : {&da, &db, &dout}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
     CHK(c, hipMemcpyAsync(da, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));

@@ -413,17 +413,25 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_repla
     replan_group<LANES>(d, T, K, count);
 }
 
-// self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them)
+// self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them: 0-4 the
+// branch-free forms the kernels use, 5-8 the literal restatements, 9 / 10 the two results of the fused sincos)
 __global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, const double *b, int n, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double r;
+    double s2, c2;
     switch (fn) {
     case 0: r = sca_gm::g_sin(a[i]); break;
     case 1: r = sca_gm::g_cos(a[i]); break;
     case 2: r = sca_gm::g_acos(a[i]); break;
     case 3: r = sca_gm::g_atan2(a[i], b[i]); break;
-    default: r = sca_gm::g_pow2(a[i]); break;
+    case 4: r = sca_gm::g_pow2(a[i]); break;
+    case 5: r = sca_gm::g_sin_ref(a[i]); break;
+    case 6: r = sca_gm::g_cos_ref(a[i]); break;
+    case 7: r = sca_gm::g_atan2_ref(a[i], b[i]); break;
+    case 8: r = sca_gm::g_pow2_ref(a[i]); break;
+    case 9: sca_gm::g_sincos(a[i], s2, c2); r = s2; break;
+    default: sca_gm::g_sincos(a[i], s2, c2); r = c2; break;
     }
     out[i] = r;
 }

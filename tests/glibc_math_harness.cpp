@@ -20,6 +20,8 @@ static double (*volatile L_atan2)(double, double) = atan2;
 static double (*volatile L_pow)(double, double) = pow;
 
 static long total_bad = 0;
+static bool use_ref = false;
+static inline double my_atan2(double y, double x) { return use_ref ? sca_gm::g_atan2_ref(y, x) : sca_gm::g_atan2(y, x); }
 template <class F, class G, class A> static void run1(const char *name, long n, F f, G g, A arg) {
     long bad = 0; double first = 0;
     for (long i = 0; i < n; i++) { const double x = arg(); if (!same(f(x), g(x))) { if (!bad) first = x; bad++; } }
@@ -30,19 +32,23 @@ template <class F, class G, class A> static void run1(const char *name, long n, 
 }
 template <class A> static void run2(const char *name, long n, A arg) {
     long bad = 0; double fy = 0, fx = 0;
-    for (long i = 0; i < n; i++) { double y, x; arg(y, x); if (!same(sca_gm::g_atan2(y, x), L_atan2(y, x))) { if (!bad) { fy = y; fx = x; } bad++; } }
+    for (long i = 0; i < n; i++) { double y, x; arg(y, x); if (!same(my_atan2(y, x), L_atan2(y, x))) { if (!bad) { fy = y; fx = x; } bad++; } }
     printf("%-34s %10ld %8ld", name, n, bad);
-    if (bad) printf("   first atan2(%.17g, %.17g): mine %.17g glibc %.17g", fy, fx, sca_gm::g_atan2(fy, fx), L_atan2(fy, fx));
+    if (bad) printf("   first atan2(%.17g, %.17g): mine %.17g glibc %.17g", fy, fx, my_atan2(fy, fx), L_atan2(fy, fx));
     printf("\n");
     total_bad += bad;
 }
 
 int main(int argc, char **argv) {
     const long M = (long)(1e6 * (argc > 1 ? atof(argv[1]) : 1.0));
-    auto gs = [](double x) { return sca_gm::g_sin(x); };
-    auto gc = [](double x) { return sca_gm::g_cos(x); };
+    // argv[2] == "ref": the literal restatements (glibc's control flow); default: the branch-free forms the kernels use
+    const bool ref = argc > 2 && !strcmp(argv[2], "ref");
+    use_ref = ref;
+    auto gs = [ref](double x) { return ref ? sca_gm::g_sin_ref(x) : sca_gm::g_sin(x); };
+    auto gc = [ref](double x) { if (ref) return sca_gm::g_cos_ref(x); double s, c; sca_gm::g_sincos(x, s, c); const double c1 = sca_gm::g_cos(x);
+                                return sca_gm::bits(c) == sca_gm::bits(c1) && sca_gm::bits(s) == sca_gm::bits(sca_gm::g_sin(x)) ? c : NAN; };
     auto ga = [](double x) { return sca_gm::g_acos(x); };
-    auto gp = [](double x) { return sca_gm::g_pow2(x); };
+    auto gp = [ref](double x) { return ref ? sca_gm::g_pow2_ref(x) : sca_gm::g_pow2(x); };
     auto ls = [](double x) { return L_sin(x); };
     auto lc = [](double x) { return L_cos(x); };
     auto la = [](double x) { return L_acos(x); };

@@ -38,7 +38,7 @@ def test_device_libm_equals_host_libm_bit_for_bit():
                          mag(-60, 26), rng.choice(edges, n // 4) * (1 + rng.uniform(-1e-12, 1e-12, n // 4)) * rng.choice([-1.0, 1.0], n // 4),
                          rng.integers(0, 4000, n // 4) * 1.5707963267948966 + rng.uniform(-1e-9, 1e-9, n // 4),
                          [0.0, -0.0, 5e-324, 1e-300, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-10, 2.2250738585072014e-308]])
-    for fn in (0, 1):
+    for fn in (0, 1, 5, 6, 9, 10):
         d, h = _both(sol, fn, xs)
         bad = ~_same(d, h)
         assert not bad.any(), (fn, int(bad.sum()), xs[bad][:4], d[bad][:4], h[bad][:4])
@@ -52,9 +52,10 @@ def test_device_libm_equals_host_libm_bit_for_bit():
     # pow(x, 2)
     ps = np.concatenate([rng.uniform(-100, 100, 2 * n), rng.uniform(-2, 2, n), mag(-60, 60), mag(-359, 359), 1 + rng.uniform(-1e-6, 1e-6, n) * np.exp2(rng.uniform(-40, 0, n)),
                          [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 3.0]])
-    d, h = _both(sol, 4, ps)
-    bad = ~_same(d, h)
-    assert not bad.any(), (int(bad.sum()), ps[bad][:4], d[bad][:4], h[bad][:4])
+    for fn in (4, 8):
+        d, h = _both(sol, fn, ps)
+        bad = ~_same(d, h)
+        assert not bad.any(), (fn, int(bad.sum()), ps[bad][:4], d[bad][:4], h[bad][:4])
     # atan2: magnitudes over hundreds of decades, every sign combination, ratios at the table's break points, the constants the planner passes
     sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 1e308, -1e308, 2.2250738585072014e-308, 1e-160, 1e160, 2.0, 0.0625, 16.0])
     ys = [rng.uniform(-3, 3, 2 * n), rng.uniform(-1e5, 1e5, n), mag(-40, 40), mag(-1000, 1000), rng.choice([-2.0, 2.0, 0.0, -0.0], n), np.repeat(sp, len(sp))]
@@ -68,9 +69,10 @@ def test_device_libm_equals_host_libm_bit_for_bit():
     ys.append(x6 * np.exp2(rng.uniform(-70, 70, n)) * rng.choice([-1.0, 1.0], n))
     xq.append(x6)
     ya, xa = np.concatenate(ys), np.concatenate(xq)
-    d, h = _both(sol, 3, ya, xa)
-    bad = ~_same(d, h)
-    assert not bad.any(), (int(bad.sum()), ya[bad][:4], xa[bad][:4], d[bad][:4], h[bad][:4])
+    for fn in (3, 7):
+        d, h = _both(sol, fn, ya, xa)
+        bad = ~_same(d, h)
+        assert not bad.any(), (fn, int(bad.sum()), ya[bad][:4], xa[bad][:4], d[bad][:4], h[bad][:4])
     sol.close()
 
 

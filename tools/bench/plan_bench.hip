@@ -1,0 +1,62 @@
+// plan_bench.hip -- micro-benchmark of the 3-D Dubins planner's search (sca_dubins.hpp plan3d) on the device: one lane per plan,
+// the c4 circle's poses (40-km paths, level flight, headings a few degrees off the goal direction), workgroups of four
+// wavefronts as k_track_replan launches them.  Prints ms per launch, candidates per plan and a checksum of the lengths, so that
+// variants of the arithmetic (compile-time switches) can be compared for speed AND for identical results.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I sca_amd/csrc tools/bench/plan_bench.hip -o plan_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include "sca_dubins.hpp"
+
+#ifndef PB_BOUNDS
+#define PB_BOUNDS 2
+#endif
+__global__ __launch_bounds__(256, PB_BOUNDS) void k_plan(const double *q, int n, double *len, int *iters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double qi[5], qf[5];
+    for (int k = 0; k < 5; k++) { qi[k] = q[10 * i + k]; qf[k] = q[10 * i + 5 + k]; }
+    const double pl[2] = {-M_PI / 4, M_PI / 4};
+    const sca_dubins::Plan3D P = sca_dubins::plan3d(qi, qf, 1.5, pl);
+    len[i] = P.length + P.h.r_min * 1e-3 + P.v.t;
+    iters[i] = P.iters;
+}
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 96256;
+    const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    std::vector<double> q(10 * (size_t)n);
+    const double R = 1.25 * 100000 / (2 * M_PI);
+    unsigned s = 12345;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0 / 16777216.0); };
+    for (int i = 0; i < n; i++) {
+        const double th = 2 * M_PI * i / 100000.0;
+        double *p = &q[10 * (size_t)i];
+        // a few steps into the episode: 0.3 m along the chord, sideways offsets and heading changes of an avoidance manoeuvre
+        p[0] = R * cos(th) + 0.3 * cos(th + M_PI) + (rnd() - 0.5) * 0.2; p[1] = R * sin(th) + 0.3 * sin(th + M_PI) + (rnd() - 0.5) * 0.2; p[2] = 10.0 + (rnd() - 0.5) * 0.1;
+        p[3] = fmod(th + M_PI + (rnd() - 0.5) * 0.6, 2 * M_PI); p[4] = (rnd() - 0.5) * 0.3;
+        p[5] = -R * cos(th); p[6] = -R * sin(th); p[7] = 10.0; p[8] = fmod(th + M_PI, 2 * M_PI); p[9] = 0.0;
+    }
+    double *dq, *dl; int *di;
+    hipMalloc(&dq, q.size() * 8); hipMalloc(&dl, n * 8); hipMalloc(&di, n * 4);
+    hipMemcpy(dq, q.data(), q.size() * 8, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int r = 0; r < reps + 1; r++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_plan, dim3((n + 255) / 256), dim3(256), 0, 0, dq, n, dl, di);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms < best) best = ms;
+    }
+    std::vector<double> l(n); std::vector<int> it(n);
+    hipMemcpy(l.data(), dl, n * 8, hipMemcpyDeviceToHost); hipMemcpy(it.data(), di, n * 4, hipMemcpyDeviceToHost);
+    double sum = 0; long its = 0; int mx = 0; unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < n; i++) { sum += l[i]; its += it[i]; if (it[i] > mx) mx = it[i]; unsigned long long b; memcpy(&b, &l[i], 8); h = (h ^ b) * 1099511628211ull; }
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void *)k_plan);
+    printf("%-28s n %d  %.4f ms  candidates/plan %.1f (max %d)  hash %016llx  vgprs %d scratch %d\n", argc > 3 ? argv[3] : "", n, best, (double)its / n, mx, h,
+           fa.numRegs, (int)fa.localSizeBytes);
+    return 0;
+}
