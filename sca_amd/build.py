@@ -16,7 +16,8 @@ DEPS = ['sca_hip.hip', 'sca_kernels.hip.h', 'sca_kdbuild.hip.h', 'sca_tracker.hi
         'sca_glibc_tables.h', 'sca_core.h', os.path.join('..', '..', 'include', 'sca_hip.h')]
 # -ffp-contract=off: decisions must follow the reference's unfused arithmetic; fma() is explicit where numpy fuses.
 # -Xarch_host -mfma: the host tracker's libm (sca_glibc_math.h) is a chain of fused multiply-adds; without it every one is a libm call
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-builtin-pow', '-Xarch_host', '-mfma']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-builtin-pow', '-Xarch_host', '-mfma',
+         '-DSCA_GM_LDS_TABLES']   # the tracker kernels keep atan2's and sin / cos's lookup tables in LDS (sca_glibc_math.h)
 
 
 def hipcc():

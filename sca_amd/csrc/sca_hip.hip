@@ -364,7 +364,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass);
 static int tracker_free(sca_ctx *c) {
     if (!c->trk.st) { c->trk_on = false; return 0; }
     CHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->trk.st); (void)hipFree(c->trk.nbr0); (void)hipFree(c->trk.list); (void)hipFree(c->trk.count);
+    (void)hipFree(c->trk.st); (void)hipFree(c->trk.nbr0); (void)hipFree(c->trk.list); (void)hipFree(c->trk.count); (void)hipFree(c->trk.bcount);
     (void)hipFree(c->trk_goal_heading);
     if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
     if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
@@ -386,8 +386,10 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     const int n = c->n;
     CHK(c, hipMalloc((void **)&c->trk.st, sizeof(sca_dubins::AgentTrack) * n));
     CHK(c, hipMalloc((void **)&c->trk.nbr0, sizeof(double) * n));
-    CHK(c, hipMalloc((void **)&c->trk.list, sizeof(int32_t) * n));
+    CHK(c, hipMalloc((void **)&c->trk.list, sizeof(int32_t) * (size_t)n * TRK_BUCKETS));
     CHK(c, hipMalloc((void **)&c->trk.count, sizeof(int32_t) * 4));
+    CHK(c, hipMalloc((void **)&c->trk.bcount, sizeof(int32_t) * 4 * TRK_BUCKETS));
+    c->trk.n = n;
     CHK(c, hipMalloc((void **)&c->trk_goal_heading, sizeof(double) * 3 * n));
     CHK(c, hipStreamCreateWithFlags(&c->trk_stream, hipStreamNonBlocking));
     CHK(c, hipEventCreateWithFlags(&c->trk_fork, hipEventDisableTiming));
@@ -403,6 +405,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipMemcpyAsync(c->trk.nbr0, nb.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->trk_goal_heading, goal_heading, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemsetAsync(c->trk.count, 0, sizeof(int32_t) * 4, c->stream));
+    CHK(c, hipMemsetAsync(c->trk.bcount, 0, sizeof(int32_t) * 4 * TRK_BUCKETS, c->stream));
     CHK(c, hipMemsetAsync(c->d.nbr_valid, 0, n, c->stream));            // no policy pass of this agent set has left lists yet
     CHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) mode[i] = (pol[i] == SCA_POLICY_SCA || pol[i] == SCA_POLICY_RVO3D_DUBINS) ? 1 : 0;
@@ -425,7 +428,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_passes = 0;
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
-    c->trk_fuse = getenv("SCA_TRACKER_NOFUSE") == nullptr;
+    c->trk_fuse = getenv("SCA_TRACKER_FUSE") != nullptr;          // k_track_replan (no list, hence no ordering by expected length): opt-in since round 3
     c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : TRK_MID_MAX;
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
     c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;

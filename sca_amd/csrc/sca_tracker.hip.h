@@ -29,7 +29,10 @@ namespace sca {
 struct TrackDev {
     sca_dubins::AgentTrack *st;   // [n]
     double *nbr0;                 // [n] distSq of agent.neighbors[0] as the previous pass left it (-1: empty list)
-    int32_t *list;                // [n] agents that re-plan in this pass
+    int32_t *list;                // [TRK_BUCKETS][n] agents that re-plan in this pass, binned by how many candidate radii their PREVIOUS search
+                                  // tried (bucket b holds its members at list[b * n ..]): the lane-per-plan kernel takes them longest first
+    int32_t *bcount;              // [4][TRK_BUCKETS] members per bucket, the same ring over the passes as `count`
+    int n;                        // agents (the stride of the buckets)
     int32_t *count;               // [4] re-plans of the pass (= list length), a ring over the passes: pass p counts in slot p & 3 and
                                   // zeroes slot (p + 1) & 3; the host reads the previous pass's slot, which is final, without waiting
     int parity;                   // the slot of this pass
@@ -47,6 +50,26 @@ struct TrackDev {
 //   <= TRK_SPEC4_MAX / SPEC3 / SPEC2   k_replan_group<64 / 32 / 16>: the search 4 / 3 / 2 steps per round (below)
 //   <= TRK_MID_MAX    k_replan_group<4>: four lanes per plan, two wavefronts per SIMD (217 registers): 32 768 plans = 2048 wavefronts
 //   above             k_replan / k_track_replan: one lane per plan (0.44 ms up to 65 536 plans, 0.63 up to 131 072)
+// Re-plans ordered by expected length.  A search is sequential and takes 48 ... 114 candidate radii; a wavefront lasts as long as
+// its longest lane, and ~96 000 plans are 1500 wavefronts on 1024 SIMDs -- the SIMDs that hold two wavefronts run each at little
+// more than half speed, and the kernel lasts as long as the slowest of them.  With the plans in descending order of the number of
+// candidates their previous search took (the same agent one step later: correlation 0.9), the long searches are dispatched
+// first and sit alone on their SIMDs, the wavefronts that double up are the short ones, and the lanes of a wavefront end
+// together.  Measured on the planner alone (tools/bench/plan_bench.hip, 96 256 plans): 1.12 ms in arbitrary order, 0.76 ms in
+// descending order.  Buckets of eight candidates: bucket = clamp((iters - 40) / 8, 0, TRK_BUCKETS - 1), filled by k_track.
+constexpr int TRK_BUCKETS = 12;
+__device__ __forceinline__ int trk_bucket(int prev_iters) { const int b = (prev_iters - 40) >> 3; return b < 0 ? 0 : (b >= TRK_BUCKETS ? TRK_BUCKETS - 1 : b); }
+// the idx-th re-planning agent of the pass, longest expected search first
+__device__ __forceinline__ int trk_list_agent(const int32_t *list, const int32_t *bc, int n, int idx) {
+    int rem = idx;
+#pragma unroll
+    for (int b = TRK_BUCKETS - 1; b > 0; b--) {
+        const int c = bc[b];
+        if (rem < c) return list[(size_t)b * n + rem];
+        rem -= c;
+    }
+    return list[rem];
+}
 constexpr int TRK_MID_MAX = 32768;
 constexpr int TRK_REPLAN_LANES = 256;     // four wavefronts per workgroup = one per SIMD of a CU: the dispatcher then loads the SIMDs evenly
                                           // (65 536 plans as 1024 one-wave workgroups: 0.63 ms, some SIMDs drew two; as 256 of these: 0.44)
@@ -68,7 +91,9 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
 }
 
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.shard_begin + d.shard_count) return;
     double nb0 = K.nbr0[agent];
@@ -84,14 +109,24 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
     double dif[3], V[3];
     const bool replan = sca_dubins::track_decide(T, a, agent, pos, vel, nb0, dif);
     if (replan) {
-        // wave-aggregated append
-        const unsigned long long m = __ballot(1);
+        // wave-aggregated append to the bucket of the agent's previous search (a.plan still holds it)
         const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&K.count[K.parity], __popcll(m));
-        base = __shfl(base, leader);
-        K.list[base + __popcll(m & ((1ull << lane) - 1ull))] = agent;
+        const int mine = trk_bucket(a.plan.iters);
+        const unsigned long long all = __ballot(1);
+        if (lane == __ffsll((long long)all) - 1) atomicAdd(&K.count[K.parity], __popcll(all));
+        unsigned long long todo = all;
+        while (todo) {
+            const int b = __shfl(mine, __ffsll((long long)todo) - 1);
+            const unsigned long long m = __ballot(mine == b);
+            if (mine == b) {
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&K.bcount[K.parity * TRK_BUCKETS + b], __popcll(m));
+                base = __shfl(base, leader);
+                K.list[(size_t)b * K.n + base + __popcll(m & ((1ull << lane) - 1ull))] = agent;
+            }
+            todo &= ~m;
+        }
         return;
     }
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
@@ -99,10 +134,11 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = K.count[K.parity];
     if (idx >= count || count <= K.lo) return;                              // fewer re-plans: k_replan_few's / k_replan_mid's pass
-    const int agent = K.list[idx];
+    const int agent = trk_list_agent(K.list, K.bcount + K.parity * TRK_BUCKETS, K.n, idx);
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
@@ -117,6 +153,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
 // (the circle: 96 %), where compacting the re-planners into a list buys nothing and costs a launch on the pass's critical
 // path.  Lanes that follow their path finish early inside their wavefront.  Only counts the re-plans (no list).
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= d.shard_begin + d.shard_count) return;
@@ -381,7 +418,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid / LANES, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole groups leave together
-    const int agent = K.list[idx];
+    const int agent = trk_list_agent(K.list, K.bcount + K.parity * TRK_BUCKETS, K.n, idx);
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
@@ -408,6 +445,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
 constexpr int TRK_GROUP_THREADS = 256;
 template <int LANES>
 __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_replan_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int count = K.count[K.parity];
     if (count <= K.lo || count > K.hi) return;
     replan_group<LANES>(d, T, K, count);
@@ -416,6 +454,7 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_repla
 // self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them: 0-4 the
 // branch-free forms the kernels use, 5-8 the literal restatements, 9 / 10 the two results of the fused sincos)
 __global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, const double *b, int n, double *out) {
+    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double r;

@@ -272,9 +272,9 @@ def test_device_tracker_on_random_scenes_vs_host_tracker():
 
 
 def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
-    """k_track_replan (decision + re-plan in one launch, picked once >= 75 % of a large shard re-planned in a recent pass)
-    against k_track + k_replan (SCA_TRACKER_NOFUSE): whole resident episodes equal bit for bit, across the pass where the
-    library switches from one form to the other, and the re-plan counters agree."""
+    """k_track_replan (decision + re-plan in one launch; opt-in since round 3: SCA_TRACKER_FUSE) against k_track + the re-plan
+    kernel over the list ordered by expected search length (the default): whole resident episodes equal bit for bit, across
+    the pass where the library switches from one form to the other, and the re-plan counters agree."""
     from sca_amd import scenarios, solver as S
     n = 50000                                                             # ~42 000 re-plans per pass: the lane-per-plan range
     sc = scenarios.circle(n)
@@ -282,15 +282,15 @@ def test_fused_tracker_kernel_equals_track_plus_replan(monkeypatch):
     sols = []
     for nofuse in (True, False):
         if nofuse:
-            monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
+            monkeypatch.delenv('SCA_TRACKER_FUSE', raising=False)
         else:
-            monkeypatch.delenv('SCA_TRACKER_NOFUSE', raising=False)
+            monkeypatch.setenv('SCA_TRACKER_FUSE', '1')
         sol = S.BatchedSolver(max_agents=n)
         sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
         sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
                        scenarios.max_run_dist(sc['start'], sc['goal']))
         sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
-        sol.device_tracker_enable(sc['goal'][:, 3:6])                     # read SCA_TRACKER_NOFUSE
+        sol.device_tracker_enable(sc['goal'][:, 3:6])                     # reads SCA_TRACKER_FUSE
         sols.append(sol)
     plain, fused = sols
     seen_fused = False
@@ -331,7 +331,6 @@ def test_replan_kernel_ranges_give_the_same_episode(n, form, monkeypatch):
                 monkeypatch.setenv(k, v)
             else:
                 monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
         sol = S.BatchedSolver(max_agents=n)
         sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
         sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),

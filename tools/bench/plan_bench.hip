@@ -8,12 +8,15 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <string>
+#include <algorithm>
 #include "sca_dubins.hpp"
 
 #ifndef PB_BOUNDS
 #define PB_BOUNDS 2
 #endif
 __global__ __launch_bounds__(256, PB_BOUNDS) void k_plan(const double *q, int n, double *len, int *iters) {
+    sca_gm::lds_tables_load();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double qi[5], qf[5];
@@ -52,6 +55,36 @@ int main(int argc, char **argv) {
         if (r > 0 && ms < best) best = ms;
     }
     std::vector<double> l(n); std::vector<int> it(n);
+    if (argc > 4) {
+        // arrangement experiments: the plans re-ordered by their (now known) candidate counts; argv[4] = asc | desc | lpt | rand
+        hipMemcpy(it.data(), di, n * 4, hipMemcpyDeviceToHost);
+        std::vector<int> order(n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return it[a] < it[b]; });      // ascending
+        std::vector<int> perm;
+        const std::string mode = argv[4];
+        const int W = (n + 255) / 256, D = W > 256 ? W - 256 : 0;                  // workgroups, and how many of them double up a CU
+        if (mode == "asc") perm = order;
+        else if (mode == "desc") perm.assign(order.rbegin(), order.rend());
+        else if (mode == "rand") { perm = order; unsigned s2 = 99; for (int i = n - 1; i > 0; i--) { s2 = s2 * 1664525u + 1013904223u; std::swap(perm[i], perm[(s2 >> 4) % (i + 1)]); } }
+        else {                                                                      // lpt: [short half | long | short half]
+            const int nshort = std::min(n, 2 * D * 256), half = (nshort / 2 / 256) * 256;
+            for (int i = 0; i < half; i++) perm.push_back(order[i]);
+            for (int i = nshort; i < n; i++) perm.push_back(order[i]);
+            for (int i = half; i < nshort; i++) perm.push_back(order[i]);
+        }
+        std::vector<double> q2(q.size());
+        for (int i = 0; i < n; i++) memcpy(&q2[10 * (size_t)i], &q[10 * (size_t)perm[i]], 80);
+        hipMemcpy(dq, q2.data(), q2.size() * 8, hipMemcpyHostToDevice);
+        best = 1e9f;
+        for (int r = 0; r < reps + 1; r++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_plan, dim3((n + 255) / 256), dim3(256), 0, 0, dq, n, dl, di);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms < best) best = ms;
+        }
+    }
     hipMemcpy(l.data(), dl, n * 8, hipMemcpyDeviceToHost); hipMemcpy(it.data(), di, n * 4, hipMemcpyDeviceToHost);
     double sum = 0; long its = 0; int mx = 0; unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < n; i++) { sum += l[i]; its += it[i]; if (it[i] > mx) mx = it[i]; unsigned long long b; memcpy(&b, &l[i], 8); h = (h ^ b) * 1099511628211ull; }
