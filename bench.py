@@ -170,6 +170,22 @@ def roofline_of(leg, steps, tracked, wname):
     return k_replan, (None if leg['forms'] & 1 else k_solve)
 
 
+def leg_roofline(leg, steps, tracked, wname):
+    """the dominant kernel of a leg among the ones the library times with events (re-plan kernel, k_solve, neighbour query): its
+    algorithmic HBM rate against the 8 TB/s peak, and -- where a PMC capture of this workload exists -- its share of the chip's
+    VALU issue rate (all three are compute / latency kernels; the HBM fraction is reported as the task requires)"""
+    per_launch = leg['my_agent_steps'] / max(steps, 1)
+    cands = [('k_solve', leg['k_solve_ms'], BYTES_PER_AGENT_STEP, per_launch, 'agent-step'),
+             ('k_neighbors_kd / k_neighbors_kd4', leg['k1_ms'], 48 + 16 * 48, per_launch, 'agent-step (own record + 16 neighbour records)')]
+    if tracked and leg['replan_ms'] > 0:
+        cands.append(('re-plan kernel (k_replan / k_replan_group)', leg['replan_ms'], BYTES_PER_REPLAN, leg['my_plans'] / max(steps, 1), 're-plan'))
+    name, ms, bpu, units, uname = max(cands, key=lambda t: t[1])
+    gbs = bpu * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {'bound': 'hbm', 'kernel': name, 'kernel_ms': ms, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'bytes_per_unit': bpu, 'unit_name': uname, 'units_per_launch': units,
+            'traffic': measured_traffic(wname, name.split(' ')[0]), 'valu_issue_frac': valu_issue_frac(wname, per_launch, ms * 1e-3) if name == 'k_solve' else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,8 +200,10 @@ def main():
     ap.add_argument('--vpref', default=None, choices=['straight', 'dubins', 'dubins-device'],
                     help='SCA workloads: dubins-device (default) = the reference\'s Dubins tracker as kernels inside every step; '
                          'straight = the solver alone; dubins = the bit-exact host tracker every step (host-bound, 1 GPU)')
-    ap.add_argument('--exchange', default='inlib', choices=['inlib', 'torch'],
-                    help='N>1 GPUs: inlib = RCCL inside the library (one sca_run_steps call), torch = all_gather_into_tensor from Python')
+    ap.add_argument('--exchange', default='torch', choices=['inlib', 'torch'],
+                    help='N>1 GPUs: torch (default) = all_gather_into_tensor through torch.distributed between sca_step_begin / sca_step_end; '
+                         'inlib = RCCL inside the library (one sca_run_steps call per k steps; never run with more than one rank so far, '
+                         'hence opt-in)')
     ap.add_argument('--emulate-rank-of', type=int, default=0, metavar='G',
                     help='1 GPU only: time what ONE rank of G executes per step (neighbour structure over all N, the rest for the '
                          'middle shard of N/G; the other records are copied over where the all-gather would deliver them)')
@@ -245,29 +263,38 @@ def main():
     exchange = args.exchange if world > 1 and not share_gpu else ('torch' if world > 1 else 'none')
     stepper = None
     if exchange == 'inlib':
-        # the library's own RCCL communicator; if any rank cannot set it up (no librccl, init failure) every rank falls back
-        # to the collective issued through torch.distributed -- the ranks agree on that first
-        ok = 1
-        try:
-            box = [sol.comm_unique_id() if rank == 0 else None]
-        except Exception as e:                                  # noqa: BLE001 -- reported below, the fallback still measures
-            box, ok = [None], 0
-            print(f'[bench rank {rank}] sca_comm_unique_id failed: {e}', file=sys.stderr)
-        dist.broadcast_object_list(box, src=0, device=torch.device('cuda', local_rank))
-        if box[0] is None:
-            ok = 0
+        # The library's own RCCL communicator.  sca_comm_init is a collective (ncclCommInitRank): a rank that cannot load RCCL
+        # must say so BEFORE any rank enters it, or the others would wait inside it forever.  So: every rank probes (dlopen +
+        # symbols, no collective), the ranks agree (MIN), and only then the id travels and the communicators are made; a failure
+        # after that point (init error on some rank) is agreed on the same way and every rank falls back to torch.distributed.
+        dev = torch.device('cuda', local_rank)
+        flag = torch.tensor([1 if sol.comm_probe() else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+        if not ok and rank == 0:
+            print('[bench] librccl not loadable on some rank: exchange through torch.distributed', file=sys.stderr)
+        if ok:
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [sol.comm_unique_id()]
+                except Exception as e:                          # noqa: BLE001 -- reported, every rank then falls back
+                    print(f'[bench rank 0] sca_comm_unique_id failed: {e}', file=sys.stderr)
+            dist.broadcast_object_list(box, src=0, device=dev)
+            ok = 0 if box[0] is None else 1                     # the same on every rank: they all hold rank 0's answer
         if ok:
             try:
                 stepper = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0])
             except Exception as e:                              # noqa: BLE001
                 ok = 0
                 print(f'[bench rank {rank}] sca_comm_init failed: {e}', file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', local_rank))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if stepper is not None:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and stepper is not None:
                 sol.comm_destroy()
-            stepper, exchange = None, 'torch'
+                stepper = None
+        if stepper is None:
+            exchange = 'torch'
     if stepper is None:
         stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu, mode=mode)
 
@@ -322,6 +349,8 @@ def main():
             so_kd = extras['solver_only'] if args.nbr == 'kd' else g['solver_only']
             so_grid = g['solver_only'] if args.nbr == 'kd' else extras['solver_only']
             extras['scale_model']['solver_only'] = scale_model(sol, scene, S, timer, args.steps, args.warmup, False, so_kd, so_grid)['modes']
+        if tracked:
+            extras['value_parity'] = value_parity(S, scene, local_rank, mode=mode)
         if not args.no_extra_legs and wname == 'c4' and not args.agents:
             extras['extra_legs'] = extra_legs(S, timer, local_rank, args.steps, args.warmup)
 
@@ -394,7 +423,7 @@ def host_tracker_leg(sol, scene, S, timer, steps, warmup):
     total = sol.agent_steps(reset=True)
     kms = sol.kernel_ms()
     return dict(value=total / dt, ms_per_step=dt / steps * 1e3, agent_steps=total, my_agent_steps=total, plans=0, my_plans=0,
-                k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=0.0)
+                k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=0.0, forms=sol.pass_forms())
 
 
 def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
@@ -432,9 +461,52 @@ def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
     return out
 
 
+def value_parity(S, scene, device, steps=6, mode=0):
+    """SCA as shipped against the bit-exact path, on this workload's own scene: two solvers side by side from the start state --
+    A with the tracker on the device inside every resident step (what the timed leg runs), B fed by the native HOST tracker
+    (glibc's libm; pinned bit for bit to the reference's recorded v_pref, tests/test_tracker.py) -- compared after every step.
+    The velocities are the metric's v_new; B's are the reference's given its v_pref rule (max_abs_dv_solver_given_vpref = 0.0 says
+    so), hence max_abs_dv here is the value leg's max |v_new - v_ref| on the compared steps."""
+    from sca_amd import tracker as trk
+    sc, n = scene['sc'], scene['n']
+    ext = np.isin(scene['policy'], (0, 5))
+    a, b = make_solver(S, scene, device), make_solver(S, scene, device)
+    reset_state(a, scene); reset_state(b, scene)
+    a.device_tracker_enable(sc['goal'][:, 3:6], in_pass=True)
+    host = trk.DubinsTracker(sc['goal'][:, :3], sc['goal'][:, 3:6], scene['pref_speed'], scene['zaxis'])
+    agent_steps = deviating = vp_diff = 0
+    worst = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = b.get_state()
+        active = ((st['flags'] & 7) == 0)
+        hv = np.nan_to_num(host.vpref(st['pos'], st['vel'], st['heading'], (active & ext).astype(np.uint8)))
+        b.set_vpref(hv, ext.astype(np.uint8))
+        b.run_steps(1, mode)
+        host.note_nbr0(b.nbr0())
+        a.run_steps(1, mode)
+        a.synchronize(); b.synchronize()
+        va, vb = a.get_state()['vel'].astype(np.float64), b.get_state()['vel'].astype(np.float64)
+        d = np.abs(va - vb).max(axis=1)[active]
+        agent_steps += int(active.sum())
+        deviating += int((d > 0).sum())
+        worst = max(worst, float(d.max()) if d.size else 0.0)
+        pa, pb = np.nan_to_num(a.diag()['vpref']), np.nan_to_num(b.diag()['vpref'])
+        vp_diff += int((pa[active & ext] != pb[active & ext]).any(axis=1).sum())
+    ra, rb = a.device_tracker_replans()[ext], host.replans()[ext]
+    out = {'against': 'the native host tracker (bit-exact replica of scaPolicy.py:264-338 on glibc) feeding sca_set_vpref, same scene, from the start state',
+           'steps_compared': steps, 'agent_steps': agent_steps, 'deviating_agent_steps': deviating,
+           'deviating_frac': deviating / max(agent_steps, 1), 'max_abs_dv': worst, 'agent_steps_with_another_v_pref': vp_diff,
+           'flagged_frac': 0.0, 're_plan_counts_equal': bool(np.array_equal(ra, rb)), 're_plans_compared': int(ra.sum()),
+           'within_north_star_1e-5': worst <= 1e-5, 'seconds': round(time.perf_counter() - t0, 2)}
+    host.close(); a.close(); b.close()
+    return out
+
+
 def extra_legs(S, timer, device, steps, warmup):
     """the other BASELINE configs as short driver-timed legs: value (SCA workloads: as shipped, tracker on the device),
-    ms_per_step, and max |v_hip - v_oracle| of one policy pass on the state the leg ends in (kd mode: must be 0.0)"""
+    ms_per_step, the dominant kernel's roofline entry, max |v_hip - v_oracle| of one policy pass given the v_pref it used (kd mode:
+    must be 0.0) and, for SCA workloads, value_parity against the host-tracker run"""
     from sca_amd.distributed import ShardedStepper
     out = {}
     for name in ('c2', 'c3', 'c3lp', 'c5'):
@@ -450,7 +522,10 @@ def extra_legs(S, timer, device, steps, warmup):
         if tracked:
             leg2 = timed_leg(sol, scene, st, timer, steps, warmup, False)
             row['solver_only'] = {'value': leg2['value'], 'ms_per_step': leg2['ms_per_step']}
-        row['max_abs_dv'] = parity_sample(scene, sol, S, tracked, warmup)
+        row['max_abs_dv_solver_given_vpref'] = parity_sample(scene, sol, S, tracked, warmup)
+        row['roofline'] = leg_roofline(leg, steps, tracked, name)
+        if tracked:
+            row['value_parity'] = value_parity(S, scene, device)
         leg3 = timed_leg(sol, scene, ShardedStepper(sol, 0, 1, mode=1), timer, steps, warmup, tracked)
         row['grid_mode'] = {'value': leg3['value'], 'ms_per_step': leg3['ms_per_step']}
         out[name] = row
@@ -551,15 +626,48 @@ def cpu_baseline(scene, sol, S, tracked=False, warmup=20, mode=0):
     ref, v_all, reps_all, one_all = clock(cores, 8.0)
     _, v_one, reps_one, one_one = clock(1, 6.0)
     dv = float(np.abs(a[:, :3] - ref['action'][:, :3]).max())
-    return {'value': v_all, 'unit': 'agent-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps_all} policy passes over the {n}-agent state {sample_state} ({one_all:.2f} s each), OpenMP over agents; '
-                      f'v_pref handed over (the tracker is not part of the pass)',
-            'one_thread': {'value': v_one, 'cores': 1, 'sample': f'{reps_one} passes, {one_one:.2f} s each'},
-            'max_abs_dv_vs_hip': dv,
-            'reference_python': {'value': 35.9, 'unit': 'agent-steps/s', 'cores': 1, 'host': 'build container, 8 x Intel Xeon @ 2.10 GHz, '
-                                 'Python 3.10.12 / NumPy 2.2.6 (single-threaded by construction)',
-                                 'what': 'SCA policy-only rate of the reference itself, N=100 circle, 16 neighbours (BASELINE.md section 2; '
-                                         'c1 N=8: 52.6; ORCA3D 51.9; ORCA3D-LP 1811; RVO3D 100.7; S-RVO3D 84.7)'}}
+    out = {'value': v_all, 'unit': 'agent-steps/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{reps_all} policy passes over the {n}-agent state {sample_state} ({one_all:.2f} s each), OpenMP over agents; '
+                     f'v_pref handed over (policy_only: the tracker is not part of this number, see with_tracker)',
+           'one_thread': {'value': v_one, 'cores': 1, 'sample': f'{reps_one} passes, {one_one:.2f} s each'},
+           'policy_only': {'value': v_all, 'cores': cores, 'one_thread': v_one},
+           'max_abs_dv_vs_hip_solver_given_vpref': dv,
+           'reference_python': {'value': 35.9, 'unit': 'agent-steps/s', 'cores': 1, 'host': 'build container, 8 x Intel Xeon @ 2.10 GHz, '
+                                'Python 3.10.12 / NumPy 2.2.6 (single-threaded by construction)',
+                                'what': 'SCA policy-only rate of the reference itself, N=100 circle, 16 neighbours (BASELINE.md section 2; '
+                                        'c1 N=8: 52.6; ORCA3D 51.9; ORCA3D-LP 1811; RVO3D 100.7; S-RVO3D 84.7)'}}
+    if tracked:
+        # the same work as `value`: compute_v_pref of every active tracked agent (run_sca.py:250 -- AverageCost includes it) by the
+        # native host tracker on the same state, then the policy pass.  A fresh tracker on a mid-episode state plans for every agent
+        # (first call, scaPolicy.py:283-287) -- on the circle 97 % of the agents re-plan at every step anyway; elsewhere this is an
+        # upper bound of the tracker's share.
+        from sca_amd import tracker as trk
+        ext = np.isin(scene['policy'], (0, 5))
+        act = (((st['flags'] & 7) == 0) & ext).astype(np.uint8)
+
+        def clock_tracker(threads, budget):
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                tr = trk.DubinsTracker(sc['goal'][:, :3], sc['goal'][:, 3:6], scene['pref_speed'], scene['zaxis'], nthreads=threads)
+                t1 = time.perf_counter()
+                tr.vpref(st['pos'], st['vel'], st['heading'], act)
+                dt = time.perf_counter() - t1
+                tr.close()
+                reps += 1
+                if time.perf_counter() - t0 > budget or reps >= 20:
+                    return dt
+        trk_all, trk_one = clock_tracker(cores, 3.0), clock_tracker(1, 5.0)
+        pol_all, pol_one = active / v_all, active / v_one                  # seconds per policy pass
+        out['with_tracker'] = {'value': active / (pol_all + trk_all), 'cores': cores, 'one_thread': active / (pol_one + trk_one),
+                               'tracker_pass_s': trk_all, 'tracker_pass_s_one_thread': trk_one, 'policy_pass_s': pol_all,
+                               'tracked_agents': int(act.sum()),
+                               'what': 'host tracker pass (sca_tracker_vpref: every active SCA agent plans) + policy pass on the same state: '
+                                       'the CPU figure for the same work as `value`'}
+        out['value'] = out['with_tracker']['value']
+        out['one_thread']['value'] = out['with_tracker']['one_thread']
+        out['sample'] += '; `value` = with_tracker (tracker pass + policy pass), policy_only beside it'
+    return out
 
 
 if __name__ == '__main__':

@@ -150,9 +150,14 @@ int sca_use_own_stream(sca_ctx *ctx);
 /* RCCL inside the library (nothing in the reference: it is single-process).  One process per GPU; rank 0 calls
  * sca_comm_unique_id and hands the 128 bytes (an ncclUniqueId) to the other ranks by any means; every rank then calls
  * sca_comm_init after sca_set_agents.  From then on this rank owns agents [rank*n/nranks, (rank+1)*n/nranks) (n must divide),
+ * (sca_set_shard / sca_set_shard_emulation return SCA_ERR_STATE while the communicator exists),
  * and every step of sca_run_steps is: shard's policy pass + integrate -> ncclAllGather of the shard's moved 48-byte records
  * on the library's stream -> collision / goal flags, i.e. a multi-GPU episode is ONE host call per k steps.  librccl.so is
  * loaded with dlopen at the first call; SCA_ERR_UNSUPPORTED when it is missing. */
+/* 0 when librccl.so can be loaded and has every entry point the library uses, SCA_ERR_UNSUPPORTED otherwise.  No collective, no
+ * device work: ranks call it and AGREE on the result before any of them calls sca_comm_init, which blocks inside
+ * ncclCommInitRank until every rank has arrived. */
+int sca_comm_probe(void);
 int sca_comm_unique_id(void *id_out /*128 bytes*/);
 int sca_comm_init(sca_ctx *ctx, int rank, int nranks, const void *unique_id /*128 bytes*/);
 int sca_comm_destroy(sca_ctx *ctx);

@@ -54,6 +54,7 @@ SIGNATURES = {
     'sca_step_end': (C.c_int, [C.c_void_p]),
     'sca_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'sca_use_own_stream': (C.c_int, [C.c_void_p]),
+    'sca_comm_probe': (C.c_int, []),
     'sca_comm_unique_id': (C.c_int, [C.c_void_p]),
     'sca_comm_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'sca_comm_destroy': (C.c_int, [C.c_void_p]),

@@ -41,10 +41,11 @@ struct GridDev {
     double inv_cell;              // 1 / cell size; the cell is a little larger than neighborDist (see grid_inv_cell)
 };
 
-// Every object with distSq < rangeSq must sit in one of the 27 cells around the agent's.  distSq is rounded to 5 decimals
-// (util.py:100) and the cell index is floor(x * inv_cell) with two roundings, so the cell is made 1e-6 (relative) larger than
-// neighborDist: the slack (1e-5 m) is far above both.
-__host__ __device__ inline double grid_inv_cell(double neighbor_dist) { return 1.0 / (neighbor_dist * 1.000001); }
+// Every object with distSq < rangeSq must sit in one of the 27 cells around the agent's.  Membership is decided on distSq ROUNDED
+// to 5 decimals (util.py:100): round(d^2, 5) < nd^2 admits d^2 < nd^2 + 0.5e-5 when nd^2 is not on the 1e-5 grid, i.e.
+// d < sqrt(nd^2 + 1e-5) with room to spare -- for a small neighbor_dist that is relatively far beyond nd (nd = 0.1: 5e-4),
+// so the cell is derived from that bound, not from a relative slack; the factor covers the two roundings of floor(x * inv_cell).
+__host__ __device__ inline double grid_inv_cell(double neighbor_dist) { return 1.0 / (sqrt(neighbor_dist * neighbor_dist + 1.0e-5) * (1.0 + 1.0e-9)); }
 
 __device__ __forceinline__ long long grid_cell(double x, double inv_cell) { return (long long)floor(x * inv_cell); }
 __device__ __forceinline__ unsigned long long grid_key(long long cx, long long cy, long long cz) {

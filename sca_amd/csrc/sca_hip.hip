@@ -1036,7 +1036,18 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool tracked = c->trk_on && c->trk_in_pass;
     const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
     // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
-    const bool split = choose_solve_split(c, overlap, d.shard_count);
+    bool split = choose_solve_split(c, overlap, d.shard_count);
+    if (split && !c->d.sw_slot) {
+        // scratch of the two-launch solve (cones + survivor lists, ~2 KB per agent): all three buffers or none, and a pass that
+        // cannot have them runs the one-launch k_solve instead of failing
+        const size_t N = (size_t)c->max_n;
+        double *a = nullptr; uint16_t *b = nullptr; int32_t *e = nullptr;
+        const bool ok = hipMalloc((void **)&a, sizeof(double) * N * K_MAX * SLOTF) == hipSuccess &&
+                        hipMalloc((void **)&b, sizeof(uint16_t) * N * 512) == hipSuccess &&
+                        hipMalloc((void **)&e, sizeof(int32_t) * N) == hipSuccess;
+        if (ok) { c->d.sw_slot = a; c->d.sw_surv = b; c->d.sw_n = e; }
+        else { (void)hipGetLastError(); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (e) (void)hipFree(e); split = false; }
+    }
     c->forms = (split ? SCA_FORM_SOLVE_SPLIT : 0);
     if (split && lp_hi > lp_lo) c->d.lp_kernel = 1;                     // k_solve_pick4 carries no LP: its agents go to k_lp
     c->kd.skip_prep = overlap ? 1 : 0;
@@ -1102,12 +1113,6 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
     if (split) {
-        if (!c->d.sw_slot) {
-            const size_t N = (size_t)c->max_n;
-            CHK(c, hipMalloc((void **)&c->d.sw_slot, sizeof(double) * N * K_MAX * SLOTF));
-            CHK(c, hipMalloc((void **)&c->d.sw_surv, sizeof(uint16_t) * N * 512));
-            CHK(c, hipMalloc((void **)&c->d.sw_n, sizeof(int32_t) * N));
-        }
         hipLaunchKernelGGL(k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, ns, d, c->P);
     }
     if (overlap) {
@@ -1257,6 +1262,7 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
 }
 int sca_set_shard_emulation(sca_ctx *c, int on) {
     if (!c) return SCA_ERR_ARG;
+    if (c->comm && on) { c->err = "sca_set_shard_emulation with an active communicator: the exchange is real"; return SCA_ERR_STATE; }
     c->shard_emulation = on != 0;
     return 0;
 }
@@ -1273,6 +1279,9 @@ int sca_last_replan_ms(sca_ctx *c, float *replan_ms) {
 }
 
 // ---- RCCL inside the library (SURVEY.md 8b `sca_comm_init`, 8e) ---------------------------------------------------------
+int sca_comm_probe(void) {
+    return rccl_load() ? SCA_ERR_UNSUPPORTED : 0;
+}
 int sca_comm_unique_id(void *id_out) {
     if (!id_out) return SCA_ERR_ARG;
     if (rccl_load()) return SCA_ERR_UNSUPPORTED;
@@ -1530,6 +1539,8 @@ int sca_get_diag(sca_ctx *c, int32_t *diag, int32_t *status, double *vpref_used)
 int sca_set_shard(sca_ctx *c, int begin, int count) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, begin >= 0 && count >= 0 && begin + count <= c->n);
+    // with a communicator the shard IS rank * n / nranks: the in-place ncclAllGather of sca_run_steps relies on it
+    if (c->comm) { c->err = "sca_set_shard with an active communicator (the shard follows from rank / nranks; sca_comm_destroy first)"; return SCA_ERR_STATE; }
     c->d.shard_begin = begin; c->d.shard_count = count;
     return 0;
 }

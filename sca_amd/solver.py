@@ -268,6 +268,10 @@ class BatchedSolver:
         self._chk(self.L.sca_use_own_stream(self.ctx), 'sca_use_own_stream')
 
     # RCCL inside the library: run_steps then exchanges the shard's moved records itself, one host call per k steps
+    def comm_probe(self):
+        """True when the library can load RCCL (no collective: safe to call before the ranks agree on using it)."""
+        return self.L.sca_comm_probe() == 0
+
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
         rc = self.L.sca_comm_unique_id(buf)

@@ -1,0 +1,50 @@
+"""bench.py's own code paths on the GPU box: the JSON contract of a single-GPU run (value_parity, cpu_baseline incl. the tracker
+pass), the --vpref dubins leg (it died with a KeyError behind the timed run), and the script as the driver launches it
+for eight ranks, sharing GPU 0 through its test hook so that the first real SCALE run cannot die on plumbing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable] + args, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_json_line_small_swarm():
+    out = _run([os.path.join(ROOT, 'bench.py'), '--agents', '6000', '--steps', '5', '--warmup', '3'])
+    assert out['metric'] == 'agent_steps_per_sec' and out['n_gpus'] == 1 and out['dtype'] == 'f64' and out['vs_baseline'] is None
+    assert out['config']['agents'] == 6000 and out['config']['re_plans_timed'] > 0
+    r = out['roofline']
+    assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    vp = out['value_parity']                                    # SCA as shipped against the host-tracker run: identical
+    assert vp['deviating_agent_steps'] == 0 and vp['max_abs_dv'] == 0.0 and vp['re_plan_counts_equal'] and vp['agent_steps'] > 0
+    cpu = out['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['max_abs_dv_vs_hip_solver_given_vpref'] == 0.0
+    assert cpu['with_tracker']['value'] < cpu['policy_only']['value'] and cpu['value'] == cpu['with_tracker']['value']
+    assert 'solver_only' in out and 'grid_mode' in out and 'scale_model' in out
+
+
+def test_host_tracker_leg_prints_its_line():
+    out = _run([os.path.join(ROOT, 'bench.py'), '--workload', 'c2', '--vpref', 'dubins', '--steps', '4', '--warmup', '3', '--no-cpu-baseline'])
+    assert out['value'] > 0 and 'host' in out['config']['v_pref'] and out['config']['kernel_forms']
+
+
+def test_bench_script_eight_ranks_on_one_gpu():
+    """torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 with all ranks on GPU 0 (SCA_BENCH_SHARE_GPU: gloo group,
+    host-staged exchange): the launch line, the rendezvous, the strong-scaling shard arithmetic, the reductions and the one JSON
+    line are the ones the 8-GPU run uses."""
+    out = _run(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port',
+                '29551', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '3', '--agents', '8000'],
+               env={'SCA_BENCH_SHARE_GPU': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29551'}, timeout=1500)
+    assert out['n_gpus'] == 8 and out['scaling'] == 'strong' and out['config']['agents'] == 8000 and out['config']['agents_per_gpu'] == 1000
+    assert out['config']['agent_steps_timed'] == 8000 * 4 and out['value'] > 0
