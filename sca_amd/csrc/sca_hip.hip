@@ -214,6 +214,10 @@ struct sca_ctx {
     int trk_last_count = -1;            // -1: unknown
     unsigned trk_passes = 0;
     int forms = 0;                      // SCA_FORM_* of the last policy pass
+    int cus = 256, simds = 1024;         // the device's compute units / SIMDs (hipDeviceProp): every launch heuristic below is stated in
+                                        // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
+    int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
+    bool kd_force_ticket = false;
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
@@ -359,6 +363,8 @@ int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, co
     return 0;
 }
 
+// A threshold measured on the 256-CU part (1024 SIMDs), scaled to this device: they are all "so many wavefronts per SIMD".
+static inline int per_simd(const sca_ctx *c, long long at_1024_simds) { return (int)std::min<long long>(INT_MAX, at_1024_simds * c->simds / 1024); }
 // ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
 static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass);
 static int tracker_free(sca_ctx *c) {
@@ -429,10 +435,10 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
     c->trk_fuse = getenv("SCA_TRACKER_FUSE") != nullptr;          // k_track_replan (no list, hence no ordering by expected length): opt-in since round 3
-    c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : TRK_MID_MAX;
-    c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : TRK_SPEC2_MAX;
-    c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : TRK_SPEC3_MAX;
-    c->trk.spec4_max = getenv("SCA_TRK_SPEC4_MAX") ? atoi(getenv("SCA_TRK_SPEC4_MAX")) : TRK_SPEC4_MAX;
+    c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : per_simd(c, TRK_MID_MAX);
+    c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : per_simd(c, TRK_SPEC2_MAX);
+    c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : per_simd(c, TRK_SPEC3_MAX);
+    c->trk.spec4_max = getenv("SCA_TRK_SPEC4_MAX") ? atoi(getenv("SCA_TRK_SPEC4_MAX")) : per_simd(c, TRK_SPEC4_MAX);
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -484,12 +490,23 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SCA_KD_TICKET")) c->kd_force_ticket = std::atoi(e) != 0;
     int ndev = 0;
     CHK(c, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { c->err = "no HIP device: libsca_hip has no CPU path"; return SCA_ERR_HIP; }
     CHK(c, hipSetDevice(device));
     CHK(c, hipStreamCreateWithFlags(&c->stream_own, hipStreamNonBlocking));
     c->stream = c->stream_own;
+    {
+        hipDeviceProp_t prop;
+        CHK(c, hipGetDeviceProperties(&prop, device));
+        c->cus = std::max(1, prop.multiProcessorCount);
+        c->simds = 4 * c->cus;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_kd_lv_rank<false>, KD_LV_T, 0) == hipSuccess && per_cu > 0)
+            c->kd_rank_capacity = per_cu * c->cus;
+        else (void)hipGetLastError();
+    }
     for (auto &e : c->ev) CHK(c, hipEventCreate(&e));
     CHK(c, hipEventCreateWithFlags(&c->kd_ev, hipEventDisableTiming));
     CHK(c, hipHostMalloc((void **)&c->kd_host_counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3)));   // counts | nchunks
@@ -517,7 +534,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     d.kx = c->kd.kx; d.ky = c->kd.ky; d.kz = c->kd.kz;
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
-    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 4);   // counts | nchunks (one readback) | tail slot counter
+    r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 4); r |= dalloc(c, &c->kd.ticket, (size_t)KD_MAX_LEVELS + 1);   // counts | nchunks (one readback) | tail slot counter
     c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MIN + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
@@ -812,9 +829,8 @@ static int build_agent_tree(sca_ctx *c) {
 static int build_agent_tree_device(sca_ctx *c) {
     const int n = c->n;
     const DeviceView &d = c->d;
-    // the chained scan of a level pass waits on lower-numbered workgroups of the same launch: every chunk of a level must be
-    // resident at once (256 CUs x 4 workgroups of KD_LV_T threads x KD_CHUNK positions)
-    if (n > 256 * 4 * KD_CHUNK) { c->err = "device kd build is limited to 2097152 agents per context: use SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
+    // (no size limit: a level with more chunks than the chip holds at once takes its chunks by arrival, k_kd_lv_rank<true>; rounds
+    // 1-2 refused more than 256 CUs x 4 workgroups x KD_CHUNK = 2 097 152 agents, with the CU count as a literal)
     if (!c->perm_on_device) {
         CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->nbr_stream));
         c->perm_on_device = true;
@@ -854,7 +870,11 @@ static int build_agent_tree_device(sca_ctx *c) {
         levels = first_single + 1;
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
         for (int l = 0; l < first_single; l++) {
-            hipLaunchKernelGGL(k_kd_lv_rank, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
+            // chunk by arrival once a level can have more chunks than are resident at once (k_kd_lv_rank); SCA_KD_TICKET=1 forces it (tests)
+            if (grid > c->kd_rank_capacity || c->kd_force_ticket)
+                hipLaunchKernelGGL(k_kd_lv_rank<true>, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
+            else
+                hipLaunchKernelGGL(k_kd_lv_rank<false>, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
             hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T + 64), 0, c->nbr_stream, d, c->kd, l);   // + the bookkeeping wavefront
         }
         hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, first_single, ++c->kd_token);
@@ -1001,13 +1021,13 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
 // K3 form for this pass: one lane per agent (k_lp) once the shard has enough LP agents to fill the chip that way -- measured:
 // 100 000 agents 65 vs 106 us, 4096 agents 23 vs 12 us (a lane alone needs ~12 us for its 16 planes and the LP) --, else the
 // wave-per-agent form inside k_solve.  SCA_LP_FORM=lane|wave forces one (A/B measurements).
-constexpr int LP_LANE_MIN = 16384;
+constexpr int LP_LANE_MIN = 16384;              // one lane per LP agent once they fill the chip: 16 agents per SIMD
 static void choose_lp_form(sca_ctx *c, int &lo, int &hi) {
     const auto b = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin);
     const auto e = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin + c->d.shard_count);
     lo = (int)(b - c->h_lp_list.begin()); hi = (int)(e - c->h_lp_list.begin());
     const char *f = getenv("SCA_LP_FORM");
-    c->d.lp_kernel = (hi - lo >= LP_LANE_MIN) ? 1 : 0;
+    c->d.lp_kernel = (hi - lo >= per_simd(c, LP_LANE_MIN)) ? 1 : 0;
     if (f && f[0] == 'l') c->d.lp_kernel = hi > lo ? 1 : 0;
     if (f && f[0] == 'w') c->d.lp_kernel = 0;
 }
@@ -1023,8 +1043,9 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
     const int est = c->trk_last_count >= 0 ? c->trk_last_count : cnt;    // re-plans of a recent pass (all agents before the first readback)
     if (est <= c->trk.mid_max) return false;      // the many-lanes-per-plan forms: short re-plans, nothing to hide behind (measured equal
                                                   // with and without at 18 000 .. 30 000 agents)
-    const int rounds = (est + 65535) / 65536;
-    return rounds == 1 ? cnt <= 61440 : (rounds == 2 ? cnt <= 114688 : false);
+    const int per_round = 64 * c->simds;          // plans of the lane-per-plan kernel that are one wavefront per SIMD
+    const int rounds = (est + per_round - 1) / per_round;
+    return rounds == 1 ? cnt <= per_simd(c, 61440) : (rounds == 2 ? cnt <= per_simd(c, 114688) : false);
 }
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
@@ -1098,7 +1119,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     collide_reach(c, agent_reach, obs_reach);
     // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
     // below that the one-agent-per-wave form with its record stack has the shorter critical path (4096 random: 30 % faster)
-    const bool packed = c->k1_force < 0 ? cnt >= 6144 : c->k1_force != 0;
+    const bool packed = c->k1_force < 0 ? cnt >= per_simd(c, 6144) : c->k1_force != 0;   // four agents per wavefront once that still fills the SIMDs
     if (mode == SCA_NBR_GRID) {
         const int per_block = K1P_WAVES * K1P_APW;
         hipLaunchKernelGGL(k_neighbors_grid, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
@@ -1142,10 +1163,15 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
         hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
     if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)
-    // epilogue (one lane per agent) + the agents without any suitable candidate (rare; one wavefront each), one launch
+    // the agents without any suitable candidate (rare; one wavefront each), then the epilogue (one lane per agent)
     const int ablocks = (cnt + 255) / 256;
-    if (fuse_integrate) hipLaunchKernelGGL(k_action<true>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
-    else hipLaunchKernelGGL(k_action<false>, dim3(ablocks + FB_BLOCKS), dim3(256), 0, c->stream, d, c->P, ablocks);
+    if (fuse_integrate) {
+        hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
+    } else {
+        hipLaunchKernelGGL(k_fallback<false>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        hipLaunchKernelGGL(k_action<false>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
+    }
     CHK(c, hipGetLastError());
     if (fuse_integrate && c->d.hist) c->d.hist_row++;
     return 0;

@@ -57,6 +57,7 @@ struct KdScratch {
     unsigned long long *chain;// [chunk_cap] chained scan: (launch token << 32) | number of ">= split" members of the chunk
     KdChunkRec *chunks[2];    // [chunk_cap] per level parity: everything a workgroup of a level pass needs, in one 32-byte read
     int *nchunks;             // [KD_MAX_LEVELS + 1] workgroups with work per level
+    int *ticket;              // [KD_MAX_LEVELS + 1] arrival counters of k_kd_lv_rank<true> (chunk index by arrival, see there)
     int skip_prep;            // 1: k_kd_gather leaves the prologue of the tracker's agents to the tracker's kernels (v_pref is still being computed by
                               //    the tracker on another stream)
 };
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         else { s.small[0] = j; s.counts[KD_MAX_LEVELS] = 1; }
         for (int i = 1; i <= KD_MAX_LEVELS; i++) s.nchunks[i] = 0;
         s.counts[2 * KD_MAX_LEVELS + 3] = 0;                                 // table slots handed out by the tail launch
+        for (int i = 0; i <= KD_MAX_LEVELS; i++) s.ticket[i] = 0;
         s.nchunks[0] = d.n > s.wave_max ? (d.n + KD_CHUNK - 1) / KD_CHUNK : 0;
     }
     if (d.n > s.wave_max && p < (d.n + KD_CHUNK - 1) / KD_CHUNK) {                                    // the root's workgroups
@@ -266,11 +268,25 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
     }
 }
 
+// TICKET: which chunk a workgroup takes.  The chained scan makes a chunk wait for the chunks in front of it in its node.  With
+// chunk = blockIdx that is free of deadlock as long as the dispatcher starts workgroups in index order (per XCD, which is how
+// it behaves: the lowest unfinished chunk is then always running) -- and certainly while every chunk of a level is resident
+// at once.  A level with more chunks than the chip can hold at once (beyond ~2 million agents per rank) does not lean on that:
+// its workgroups take their chunk by ARRIVAL (one atomic per workgroup), so a chunk can only ever wait for workgroups that
+// already run.  The host picks the form per build from the occupancy the runtime reports (sca_hip.hip, kd_rank_capacity).
+template <bool TICKET>
 __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
     __shared__ KdRankLds SH;
-    const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
+    int blk = (int)blockIdx.x;
+    if (TICKET) {
+        __shared__ int tk;
+        if (threadIdx.x == 0) tk = atomicAdd(&s.ticket[level], 1);
+        __syncthreads();
+        blk = tk;
+    }
+    const KdChunk c = kd_find_chunk(s, level, blk);
     if (!c.valid) return;
-    kd_rank_part(s, level, token, c, SH, (int)blockIdx.x);
+    kd_rank_part(s, level, token, c, SH, blk);
 }
 
 // Level pass B: swaps (kdTree.py:108-111), node record and children (kdTree.py:112-122)

@@ -8,6 +8,7 @@
 //                    wave-uniform broadcasts, selection by packed integer keys and DPP wave minima.
 //                    k_solve_full finishes the rare agents without a suitable candidate (compute_without_suitV).
 //   k_action       : cartesian2spherical + float32 action row, one lane per agent; also update_velocitie
+//   k_fallback     : the agents without a suitable candidate (complete 513-candidate sweep, one wavefront each) + their epilogue
 //                    (mampenv.py:83-105) and the trajectory log when the state stays resident (sca_run_steps).
 //   k_collide_finish : check_agent_state + is_done (mampenv.py:51-80), eight agents per wavefront.
 //
@@ -1580,7 +1581,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, 
 // lane-transposed LDS array -- plane j, component c of lane l at [j][c][l]: every access is 64 consecutive doubles -- and
 // walks them with the scalar LP of sca_core.h through an accessor.  Same statements, same order: bit for bit the planes and
 // velocities of the wave-per-agent form.  Agents whose LP3 fails (planeFail < K) need LP4's projected planes: they go to
-// the fallback list and are finished, one wavefront each, by the second half of k_action (solve_one), like the agents
+// the fallback list and are finished, one wavefront each, by k_fallback (solve_one), like the agents
 // without a suitable candidate.
 struct LpPlanes { double v[K_MAX][6][64]; };                       // 48 KB per wavefront
 struct LpAccess {
@@ -1623,7 +1624,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t
     LpAccess pl; pl.S = &S; pl.lane = lane;
     V3 nv = v3(0, 0, 0);
     const int pf = lp3(pl, K, P.max_speed, vpref, false, nv);                       // :108
-    if (pf < K) {                                                                   // :110-111 linearProgram4: one wavefront, k_action
+    if (pf < K) {                                                                   // :110-111 linearProgram4: one wavefront, k_fallback
         const int slot = atomicAdd(d.fb_count, 1);
         d.fb_list[slot] = agent; d.is_fb[agent] = 1;
         return;
@@ -1677,26 +1678,29 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
     if (FUSE_INTEGRATE) integrate_agent(d, P, agent, me, actf);
 }
 
-// K2 epilogue and fallback in ONE launch.  Blocks [0, action_blocks): one LANE per agent (see above), skipping the agents
-// k_solve could not finish.  The remaining blocks: one wavefront per entry of the fallback list runs the complete sweep
-// (all 513 candidates in registers, incl. compute_without_suitV, scaPolicy.py:224-238) and then the same epilogue for that
-// agent.  The two halves never touch the same agent, so they need no order.
-constexpr int FB_BLOCKS = 1024;
+// K2 epilogue: one LANE per agent (see above), skipping the agents k_solve could not finish -- those are k_fallback's.
+// (One launch with the fallback sweep until round 3: the sweep keeps all 513 candidates in registers, so the kernel carried 252
+// VGPRs and the one-lane-per-agent epilogue ran at one wavefront per SIMD; alone it takes a quarter of that.)
 template <bool FUSE_INTEGRATE>
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action(DeviceView d, Params P, int action_blocks) {
+__global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
+    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (agent >= d.shard_begin + d.shard_count) return;
+    const int kind = d.is_fb[agent];
+    if (kind == 1) return;
+    action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
+}
+// The agents without any suitable candidate (rare): one wavefront per entry of the fallback list runs the complete sweep (all
+// 513 candidates in registers, incl. compute_without_suitV, scaPolicy.py:224-238) and then the same epilogue for that agent.
+// The list's length is on the device: a fixed grid strides over it (an empty list costs an empty launch).  k_action and
+// k_fallback never touch the same agent, so they need no order between them.
+constexpr int FB_BLOCKS = 256;
+template <bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Params P) {
     __shared__ SolveLds S;
-    if ((int)blockIdx.x < action_blocks) {
-        const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-        if (agent >= d.shard_begin + d.shard_count) return;
-        const int kind = d.is_fb[agent];
-        if (kind == 1) return;
-        action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
-        return;
-    }
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = *d.fb_count;
-    for (int i = ((int)blockIdx.x - action_blocks) * SOLVE_WAVES + wid; i < n; i += FB_BLOCKS * SOLVE_WAVES) {
+    for (int i = (int)blockIdx.x * SOLVE_WAVES + wid; i < n; i += FB_BLOCKS * SOLVE_WAVES) {
         const int agent = d.fb_list[i];
         solve_one(d, P, S, agent, lane, wid);
         __builtin_amdgcn_wave_barrier();
