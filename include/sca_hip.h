@@ -161,6 +161,31 @@ int sca_comm_probe(void);
 int sca_comm_unique_id(void *id_out /*128 bytes*/);
 int sca_comm_init(sca_ctx *ctx, int rank, int nranks, const void *unique_id /*128 bytes*/);
 int sca_comm_destroy(sca_ctx *ctx);
+/* Cell-owner partition of SCA_NBR_GRID with halo exchange (nothing in the reference: it is single-process).
+ * Space is cut into slabs of grid cells along `axis` (0 x, 1 y, 2 z); rank r owns the agents whose cell lies in its slab and
+ * holds copies of the agents in the one layer of cells on either side (the halo) -- everything the neighbour query
+ * (kdTree.py:124-156, agent.py:79-99 on the grid) and the collision check (mampenv.py:61-80) of its agents look at.  Per step
+ * it exchanges, with its two slab neighbours only, the old + moved records of the agents next to the cut and the private state
+ * (heading, v_pref, distances, tracker record) of agents that crossed it, instead of all N records.  Results equal a single
+ * rank's bit for bit (tests/test_gpu_partition.py).
+ *   sca_partition_init   after sca_set_agents + sca_set_state with the COMPLETE state on every rank.  cuts: nranks - 1 ascending
+ *                        coordinates along the axis, or NULL = equal shares of the agents as they stand; moved onto cell
+ *                        boundaries.  cap_halo / cap_mig: entries per message (0 = n / 4, n / 16); an overflow is reported
+ *                        by sca_partition_commit.  From then on the per-agent arrays of sca_get_* are meaningful for the owned
+ *                        agents only (sca_partition_owned).  sca_set_state (complete again) re-derives the ownership.
+ *   one step             sca_step_begin(SCA_NBR_GRID) -> sca_partition_pack(side 0 = lower neighbour, 1 = upper) into two DEVICE
+ *                        buffers of sca_partition_message_bytes() -> exchange (the buffer packed for side 0 is what the
+ *                        lower neighbour unpacks as ITS side 1) -> sca_partition_unpack(side, received buffer) ->
+ *                        sca_partition_commit (ownership moves; synchronises) -> sca_step_end.
+ *                        With one rank sca_run_steps does all of it. */
+int sca_partition_init(sca_ctx *ctx, int rank, int nranks, int axis, const double *cuts /*nranks-1, nullable*/, int cap_halo, int cap_mig);
+int sca_partition_disable(sca_ctx *ctx);
+int64_t sca_partition_message_bytes(sca_ctx *ctx);
+int sca_partition_pack(sca_ctx *ctx, int side, void *device_buf);
+int sca_partition_unpack(sca_ctx *ctx, int side, const void *device_buf);
+int sca_partition_commit(sca_ctx *ctx);
+int sca_partition_counts(sca_ctx *ctx, int *owned, int *halo);
+int sca_partition_owned(sca_ctx *ctx, int32_t *ids /*n*/, int *count);
 /* average device time of the kernels of the last sca_policy_pass / sca_run_steps, measured with HIP events */
 int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float *update_ms);
 

@@ -58,6 +58,14 @@ SIGNATURES = {
     'sca_comm_unique_id': (C.c_int, [C.c_void_p]),
     'sca_comm_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'sca_comm_destroy': (C.c_int, [C.c_void_p]),
+    'sca_partition_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_int]),
+    'sca_partition_disable': (C.c_int, [C.c_void_p]),
+    'sca_partition_message_bytes': (C.c_int64, [C.c_void_p]),
+    'sca_partition_pack': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'sca_partition_unpack': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'sca_partition_commit': (C.c_int, [C.c_void_p]),
+    'sca_partition_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'sca_partition_owned': (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_int)]),
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
     'sca_last_replan_ms': (C.c_int, [C.c_void_p, fp]),
     'sca_last_pass_forms': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

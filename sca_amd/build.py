@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIBDIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsca_hip.so')
 SOURCES = ['sca_hip.hip']
-DEPS = ['sca_hip.hip', 'sca_kernels.hip.h', 'sca_kdbuild.hip.h', 'sca_tracker.hip.h', 'sca_grid.hip.h', 'sca_dubins.hpp', 'sca_glibc_math.h',
+DEPS = ['sca_hip.hip', 'sca_kernels.hip.h', 'sca_kdbuild.hip.h', 'sca_tracker.hip.h', 'sca_grid.hip.h', 'sca_partition.hip.h', 'sca_dubins.hpp', 'sca_glibc_math.h',
         'sca_glibc_tables.h', 'sca_core.h', os.path.join('..', '..', 'include', 'sca_hip.h')]
 # -ffp-contract=off: decisions must follow the reference's unfused arithmetic; fma() is explicit where numpy fuses.
 # -Xarch_host -mfma: the host tracker's libm (sca_glibc_math.h) is a chain of fused multiply-adds; without it every one is a libm call

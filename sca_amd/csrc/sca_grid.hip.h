@@ -60,13 +60,15 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 256) d.done_count[i * 32] = 0;                                   // start of a step: K4's counters
     if (i == 0) { *d.fb_count = 0; *g.cursor = 0; }                          // ... an empty fallback list, no position handed out
-    if (i >= d.n) return;
-    const PubRec r = d.rec[i];
+    if (i >= present_count(d)) return;
+    const int a = present_agent(d, i);                                        // (bucket / slot are indexed by the position in the list)
+    const PubRec r = d.rec[a];
     const unsigned long long key = grid_key(grid_cell(r.px, g.inv_cell), grid_cell(r.py, g.inv_cell), grid_cell(r.pz, g.inv_cell));
     const int h = grid_bucket(key, g.hbits);
     g.bucket[i] = h;
     g.slot[i] = atomicAdd(&g.count[h], 1);
-    if (i >= d.shard_begin && i < d.shard_begin + d.shard_count && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, i))) prep_agent(d, P, (Prep *)d.prep, i);
+    const bool mine = d.present ? i < d.shard_count : shard_owns(d, a);
+    if (mine && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, a))) prep_agent(d, P, (Prep *)d.prep, a);
 }
 
 // GRID_ALLOC_PER buckets per lane: one atomic on the cursor per 2048 buckets (an atomic per 256 buckets, 1024 of them on one
@@ -109,11 +111,12 @@ __global__ __launch_bounds__(256) void k_grid_alloc(GridDev g) {
 
 __global__ __launch_bounds__(256) void k_grid_fill(DeviceView d, GridDev g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.n) return;
-    const PubRec r = d.rec[i];
+    if (i >= present_count(d)) return;
+    const int a = present_agent(d, i);
+    const PubRec r = d.rec[a];
     const int at = g.range[g.bucket[i]].x + g.slot[i];
     g.gx[at] = r.px; g.gy[at] = r.py; g.gz[at] = r.pz;
-    g.gid[at] = i;
+    g.gid[at] = a;
     g.gkey[at] = grid_key(grid_cell(r.px, g.inv_cell), grid_cell(r.py, g.inv_cell), grid_cell(r.pz, g.inv_cell));
 }
 
@@ -143,10 +146,9 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int grp = lane >> 4, gl = lane & 15, gshift = grp << 4;
-    const int end = d.shard_begin + d.shard_count;
-    const int agent_raw = d.shard_begin + (blockIdx.x * K1P_WAVES + wid) * K1P_APW + grp;
-    const bool exists = agent_raw < end;
-    const int agent = exists ? agent_raw : end - 1;                 // clamp: idle groups read a valid record, write nothing
+    const int idx = (blockIdx.x * K1P_WAVES + wid) * K1P_APW + grp;
+    const bool exists = idx < d.shard_count;
+    const int agent = shard_agent(d, exists ? idx : d.shard_count - 1);   // clamp: idle groups read a valid record, write nothing
     const PubRec me = d.rec[agent];
     int st = 0;
     const bool done = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35

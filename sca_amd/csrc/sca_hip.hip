@@ -17,6 +17,7 @@
 #include "sca_grid.hip.h"
 #include "sca_dubins.hpp"
 #include "sca_tracker.hip.h"
+#include "sca_partition.hip.h"
 
 using namespace sca;
 
@@ -214,6 +215,11 @@ struct sca_ctx {
     int trk_last_count = -1;            // -1: unknown
     unsigned trk_passes = 0;
     int forms = 0;                      // SCA_FORM_* of the last policy pass
+    // cell-owner partition of SCA_NBR_GRID (sca_partition.hip.h)
+    PartDev part{};
+    bool part_on = false;
+    int part_rank = 0, part_nranks = 1;
+    int part_counts[8] = {0};            // host copy of PartDev::counts after the last commit
     int cus = 256, simds = 1024;         // the device's compute units / SIMDs (hipDeviceProp): every launch heuristic below is stated in
                                         // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
     int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
@@ -367,6 +373,8 @@ int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, co
 static inline int per_simd(const sca_ctx *c, long long at_1024_simds) { return (int)std::min<long long>(INT_MAX, at_1024_simds * c->simds / 1024); }
 // ---- the same tracker on the device (sca_tracker.hip.h) ---------------------------------------------------------------
 static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass);
+static int part_free(sca_ctx *c);
+static int part_classify(sca_ctx *c);
 static int tracker_free(sca_ctx *c) {
     if (!c->trk.st) { c->trk_on = false; return 0; }
     CHK(c, hipStreamSynchronize(c->stream));
@@ -592,6 +600,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->stream_own) (void)hipStreamSynchronize(c->stream_own);
     if (c->comm) { (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     (void)tracker_free(c);
+    (void)part_free(c);
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
@@ -647,6 +656,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
         c->d.hist = nullptr; c->d.hist_cap = 0; c->d.hist_row = 0;
     }
     if (int r = tracker_free(c)) return r;                            // the tracker records belong to the old agent set
+    if (int r = part_free(c)) return r;                               // ... and so do the partition's lists
     if (c->comm && n % c->comm_nranks) { c->err = "agent count must be a multiple of the communicator's rank count"; return SCA_ERR_ARG; }
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
     if (c->comm) { c->d.shard_count = n / c->comm_nranks; c->d.shard_begin = c->comm_rank * c->d.shard_count; }
@@ -703,6 +713,7 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
     if (step_num) CHK(c, hipMemcpyAsync(c->d.step_num, step_num, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     c->state_set = true; c->state_fresh = true;
+    if (c->part_on) return part_classify(c);                              // a complete state again: ownership follows from it
     return 0;
 }
 
@@ -897,7 +908,7 @@ static int build_agent_tree_device(sca_ctx *c) {
 }
 // SCA_NBR_GRID: counting sort of all agents into cells of neighborDist (sca_grid.hip.h), three launches
 static int build_agent_grid_device(sca_ctx *c) {
-    const int n = c->n;
+    const int n = std::max(256, c->part_on ? c->d.n_present : c->n);      // k_grid_count's first 256 lanes also reset the step's counters
     const int H = 1 << c->grid.hbits;
     hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, c->d, c->grid, c->P);
     hipLaunchKernelGGL(k_grid_alloc, dim3((H + 256 * GRID_ALLOC_PER - 1) / (256 * GRID_ALLOC_PER)), dim3(256), 0, c->nbr_stream, c->grid);
@@ -972,7 +983,7 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     if (!c->trk_quad) { for (int i = 0; i < 4; i++) want[i] = false; want[4] = true; nwant = 1; }
     if (nwant == 0) { want[4] = true; nwant = 1; }
     const bool lane = want[4];
-    const bool fused = in_pass && lane && nwant == 1 && c->trk_fuse && (long long)lc * 4 >= (long long)cnt * 3;
+    const bool fused = in_pass && lane && nwant == 1 && c->trk_fuse && !c->part_on && (long long)lc * 4 >= (long long)cnt * 3;
     c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (nwant > (lane ? 1 : 0) ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
     if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
@@ -1023,6 +1034,12 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
 // wave-per-agent form inside k_solve.  SCA_LP_FORM=lane|wave forces one (A/B measurements).
 constexpr int LP_LANE_MIN = 16384;              // one lane per LP agent once they fill the chip: 16 agents per SIMD
 static void choose_lp_form(sca_ctx *c, int &lo, int &hi) {
+    if (c->part_on) {
+        // ownership is dynamic: the LP kernels walk all owned agents and skip the others (the share of LP agents decides the form)
+        lo = 0; hi = c->h_lp_list.empty() ? 0 : c->d.shard_count;
+        c->d.lp_kernel = ((long long)c->h_lp_list.size() / std::max(1, c->part_nranks) >= per_simd(c, LP_LANE_MIN)) ? 1 : 0;
+        return;
+    }
     const auto b = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin);
     const auto e = std::lower_bound(c->h_lp_list.begin(), c->h_lp_list.end(), c->d.shard_begin + c->d.shard_count);
     lo = (int)(b - c->h_lp_list.begin()); hi = (int)(e - c->h_lp_list.begin());
@@ -1052,6 +1069,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     int lp_lo = 0, lp_hi = 0;
     choose_lp_form(c, lp_lo, lp_hi);
     const DeviceView &d = c->d;
+    const int32_t *lp_ids = c->part_on ? d.own : c->lp_list;
     // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
     // v_pref) of the tracker's agents then moves from k_kd_gather to the tracker's kernels (track_store)
     const bool tracked = c->trk_on && c->trk_in_pass;
@@ -1157,11 +1175,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         if (!d.lp_kernel && lp_hi > lp_lo)                            // K3, one wavefront per LP agent (few of them)
             hipLaunchKernelGGL(k_solve_lpw, dim3((lp_hi - lp_lo + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P,
-                               c->lp_list, lp_lo, lp_hi);
+                               lp_ids, lp_lo, lp_hi);
     }
     if (d.lp_kernel) c->forms |= SCA_FORM_LP_LANE;
     if (d.lp_kernel)                                                  // K3: the LP agents of the shard, one lane each
-        hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, c->lp_list, lp_lo, lp_hi);
+        hipLaunchKernelGGL(k_lp, dim3((lp_hi - lp_lo + 63) / 64), dim3(64), 0, c->stream, d, c->P, lp_ids, lp_lo, lp_hi);
     if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)
     // the agents without any suitable candidate (rare; one wavefront each), then the epilogue (one lane per agent)
     const int ablocks = (cnt + 255) / 256;
@@ -1207,7 +1225,10 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
         hipLaunchKernelGGL(k_collide_finish, k4grid, dim3(K4_WAVES * 64), 0, c->stream, d, c->P, agent_reach, obs_reach,
                            c->state_fresh ? 1 : 0);
     c->state_fresh = false;
-    if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    if (c->part_on) {
+        const int halo = d.n_present - d.shard_count;
+        if (halo > 0) hipLaunchKernelGGL(k_goal_flags_others, dim3((halo + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+    } else if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[5], c->stream));
     CHK(c, hipGetLastError());
     std::swap(d.rec, d.rec_new);
@@ -1273,8 +1294,15 @@ static int exchange_moved_records(sca_ctx *c) {
 int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    if (c->part_on && c->part_nranks > 1) {
+        c->err = "cell-owner partition over several ranks: drive the step with sca_step_begin / sca_partition_pack / [exchange] / "
+                 "sca_partition_unpack / sca_partition_commit / sca_step_end (sca_amd.distributed.PartitionedStepper)";
+        return SCA_ERR_STATE;
+    }
+    if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     for (int s = 0; s < steps; s++) {
         if (int r = launch_policy(c, neighbor_mode, false, true)) return r;     // integrate fused into k_solve
+        if (c->part_on) { if (int r = sca_partition_commit(c)) return r; }     // (one rank: nobody to exchange with; the lists are rebuilt all the same)
         if (c->comm) { if (int r = exchange_moved_records(c)) return r; }
         else if (c->shard_emulation && c->d.shard_count < c->n) {
             // stand-in for the all-gather's arrivals: the other ranks' agents stand still (their records are copied over)
@@ -1321,6 +1349,7 @@ int sca_comm_init(sca_ctx *c, int rank, int nranks, const void *unique_id) {
     ARG(c, unique_id && nranks >= 1 && rank >= 0 && rank < nranks);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     if (c->comm) { c->err = "communicator already initialised (sca_comm_destroy first)"; return SCA_ERR_STATE; }
+    if (c->part_on) { c->err = "sca_comm_init with the cell-owner partition active"; return SCA_ERR_STATE; }
     if (c->n % nranks) { c->err = "agent count must be a multiple of the rank count"; return SCA_ERR_ARG; }
     if (const char *e = rccl_load()) { c->err = e; return SCA_ERR_UNSUPPORTED; }
     CHK(c, hipSetDevice(c->device));
@@ -1343,9 +1372,154 @@ int sca_comm_destroy(sca_ctx *c) {
     return 0;
 }
 
+// ---- cell-owner partition of SCA_NBR_GRID with halo exchange (sca_partition.hip.h) ---------------------
+static void part_view(sca_ctx *c) {
+    c->d.own = c->d.present = c->part.present[c->part.cur];
+    c->d.shard_begin = 0;
+    c->d.shard_count = c->part_counts[0];
+    c->d.n_present = c->part_counts[0] + c->part_counts[1];
+}
+static int part_free(sca_ctx *c) {
+    if (!c->part_on && !c->part.counts) return 0;
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (void *q : {(void *)c->part.present[0], (void *)c->part.present[1], (void *)c->part.halo_tmp, (void *)c->part.counts, (void *)c->part.emig})
+        if (q) (void)hipFree(q);
+    c->part = PartDev{};
+    c->part_on = false; c->part_rank = 0; c->part_nranks = 1;
+    c->d.own = c->d.present = nullptr; c->d.n_present = 0;
+    c->d.shard_begin = 0; c->d.shard_count = c->n;
+    return 0;
+}
+// lists being built -> current lists (after k_part_close): counts to the host, buffers swapped, accumulators cleared
+static int part_adopt(sca_ctx *c) {
+    CHK(c, hipMemcpyAsync(c->part_counts, c->part.counts, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (c->part_counts[4]) {
+        c->err = c->part_counts[4] & 4 ? "partition: owned + halo exceed the agent count (corrupt lists)"
+                                       : "partition: a halo / migration message overflowed its capacity (sca_partition_init caps)";
+        return SCA_ERR_STATE;
+    }
+    c->part.cur ^= 1;
+    c->part_counts[0] = c->part_counts[2]; c->part_counts[1] = c->part_counts[3];
+    const int z[4] = {c->part_counts[0], c->part_counts[1], 0, 0};
+    CHK(c, hipMemcpyAsync(c->part.counts, z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));                               // (z is on the stack)
+    part_view(c);
+    return 0;
+}
+static int part_classify(sca_ctx *c) {                                      // from records every rank holds completely
+    const int n = c->n;
+    CHK(c, hipMemsetAsync(c->part.counts, 0, sizeof(int) * 8, c->stream));
+    hipLaunchKernelGGL(k_part_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    hipLaunchKernelGGL(k_part_init_halo, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    hipLaunchKernelGGL(k_part_close, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    CHK(c, hipGetLastError());
+    return part_adopt(c);
+}
+int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double *cuts, int cap_halo, int cap_mig) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, nranks >= 1 && rank >= 0 && rank < nranks && axis >= 0 && axis <= 2 && cap_halo >= 0 && cap_mig >= 0);
+    if (!c->agents_set || !c->state_set) { c->err = "sca_set_agents and sca_set_state (the complete state, on every rank) first"; return SCA_ERR_STATE; }
+    if (c->comm) { c->err = "sca_partition_init with an active communicator (the all-gather mode)"; return SCA_ERR_STATE; }
+    if (int r = part_free(c)) return r;
+    const int n = c->n;
+    const double inv_cell = grid_inv_cell(c->P.neighbor_dist);
+    // the cuts: given (coordinates along the axis, nranks - 1 of them, ascending), or equal shares of the agents as they stand
+    // now; moved onto cell boundaries either way.  Identical on every rank: they all hold the same state.
+    std::vector<long long> cell_cut((size_t)nranks + 1);
+    cell_cut[0] = LLONG_MIN; cell_cut[nranks] = LLONG_MAX;
+    if (cuts) {
+        for (int r = 1; r < nranks; r++) cell_cut[r] = (long long)std::floor(cuts[r - 1] * inv_cell);
+    } else {
+        if (int r = fetch_records(c)) return r;
+        std::vector<long long> cells((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const PubRec &q = c->h_rec[i];
+            cells[i] = (long long)std::floor((axis == 0 ? q.px : (axis == 1 ? q.py : q.pz)) * inv_cell);
+        }
+        std::sort(cells.begin(), cells.end());
+        for (int r = 1; r < nranks; r++) cell_cut[r] = cells[(size_t)((long long)r * n / nranks)];
+    }
+    for (int r = 1; r < nranks; r++)
+        if (cell_cut[r] <= cell_cut[r - 1] && r > 1) { c->err = "partition: the cuts leave a rank without a layer of cells (too many ranks for this swarm along this axis)"; return SCA_ERR_ARG; }
+    PartDev &P = c->part;
+    for (int k = 0; k < 2; k++) CHK(c, hipMalloc((void **)&P.present[k], sizeof(int32_t) * n));
+    CHK(c, hipMalloc((void **)&P.halo_tmp, sizeof(int32_t) * n));
+    CHK(c, hipMalloc((void **)&P.counts, sizeof(int32_t) * 8));
+    CHK(c, hipMalloc((void **)&P.emig, n));
+    P.cur = 0; P.axis = axis; P.inv_cell = inv_cell;
+    P.lo_cell = cell_cut[rank]; P.hi_cell = cell_cut[rank + 1];
+    P.has_peer[0] = rank > 0; P.has_peer[1] = rank + 1 < nranks;
+    P.cap_halo = cap_halo > 0 ? cap_halo : std::max(1024, n / 4);
+    P.cap_mig = cap_mig > 0 ? cap_mig : std::max(256, n / 16);
+    P.trk_st = c->trk_on ? c->trk.st : nullptr;
+    P.trk_nbr0 = c->trk_on ? c->trk.nbr0 : nullptr;
+    c->part_on = true; c->part_rank = rank; c->part_nranks = nranks;
+    return part_classify(c);
+}
+int sca_partition_disable(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    return part_free(c);
+}
+int64_t sca_partition_message_bytes(sca_ctx *c) {
+    if (!c || !c->part_on) return 0;
+    return (int64_t)part_message_bytes(c->part.cap_halo, c->part.cap_mig);
+}
+int sca_partition_counts(sca_ctx *c, int *owned, int *halo) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
+    if (owned) *owned = c->part_counts[0];
+    if (halo) *halo = c->part_counts[1];
+    return 0;
+}
+int sca_partition_owned(sca_ctx *c, int32_t *ids, int *count) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, ids && count);
+    if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
+    *count = c->part_counts[0];
+    CHK(c, hipMemcpyAsync(ids, c->part.present[c->part.cur], sizeof(int32_t) * (size_t)*count, hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int sca_partition_pack(sca_ctx *c, int side, void *device_buf) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, (side == 0 || side == 1) && device_buf);
+    if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
+    PartHeader h{0, 0, c->part.cap_halo, c->part.cap_mig};
+    CHK(c, hipMemcpyAsync(device_buf, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));                               // (h is on the stack; 16 bytes)
+    c->part.trk_st = c->trk_on ? c->trk.st : nullptr;
+    c->part.trk_nbr0 = c->trk_on ? c->trk.nbr0 : nullptr;
+    const int cnt = c->d.shard_count;
+    if (c->part.has_peer[side] && cnt > 0)
+        hipLaunchKernelGGL(k_part_pack, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part, side, (uint8_t *)device_buf);
+    CHK(c, hipGetLastError());
+    return 0;
+}
+int sca_partition_unpack(sca_ctx *c, int side, const void *device_buf) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, (side == 0 || side == 1) && device_buf);
+    if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
+    if (!c->part.has_peer[side]) return 0;
+    const int lanes = std::max(c->part.cap_halo, c->part.cap_mig);
+    hipLaunchKernelGGL(k_part_unpack, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, c->d, c->part, (const uint8_t *)device_buf);
+    CHK(c, hipGetLastError());
+    return 0;
+}
+int sca_partition_commit(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
+    const int cnt = c->d.shard_count, n = c->n;
+    if (cnt > 0) hipLaunchKernelGGL(k_part_keep, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    hipLaunchKernelGGL(k_part_close, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    CHK(c, hipGetLastError());
+    return part_adopt(c);
+}
+
 int sca_step_begin(sca_ctx *c, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     return launch_policy(c, neighbor_mode, false, true);
 }
 int sca_step_end(sca_ctx *c) {
@@ -1566,6 +1740,7 @@ int sca_set_shard(sca_ctx *c, int begin, int count) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, begin >= 0 && count >= 0 && begin + count <= c->n);
     // with a communicator the shard IS rank * n / nranks: the in-place ncclAllGather of sca_run_steps relies on it
+    if (c->part_on) { c->err = "sca_set_shard with the cell-owner partition active (sca_partition_disable first)"; return SCA_ERR_STATE; }
     if (c->comm) { c->err = "sca_set_shard with an active communicator (the shard follows from rank / nranks; sca_comm_destroy first)"; return SCA_ERR_STATE; }
     c->d.shard_begin = begin; c->d.shard_count = count;
     return 0;

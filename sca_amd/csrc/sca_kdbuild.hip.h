@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
         mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
-        if (id >= d.shard_begin && id < d.shard_begin + d.shard_count && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
+        if (shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
     }
     if (d.n > s.wave_max) {
 #pragma unroll

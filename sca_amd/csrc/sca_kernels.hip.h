@@ -100,6 +100,12 @@ struct DeviceView {
     HistRow *hist;
     int hist_cap, hist_row;
     int n, m, shard_begin, shard_count;
+    // Whose agents are this rank's: ids [shard_begin, shard_begin + shard_count) -- or, with the cell-owner partition of
+    // SCA_NBR_GRID (sca_partition.hip.h), the first shard_count entries of `present` (own == present); the entries behind them,
+    // up to n_present, are the halo copies.  Null: the contiguous range, and every agent is present.
+    const int32_t *own;
+    const int32_t *present;
+    int n_present;
     int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
     // k_solve in two launches (k_solve_sweep / k_solve_pick4, see solve_fast): what the first leaves for the second
     double *sw_slot;         // [n][SLOTF][K_MAX] cones / planes of the agent's neighbours, component-major (neighbour j's component q at
@@ -109,6 +115,12 @@ struct DeviceView {
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
                              // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
 };
+
+// the i-th agent of this rank (i < shard_count) / the i-th agent whose record this rank holds (i < present_count(d))
+__device__ __forceinline__ int shard_agent(const DeviceView &d, int i) { return d.own ? d.own[i] : d.shard_begin + i; }
+__device__ __forceinline__ bool shard_owns(const DeviceView &d, int agent) { return agent >= d.shard_begin && agent < d.shard_begin + d.shard_count; }
+__device__ __forceinline__ int present_count(const DeviceView &d) { return d.present ? d.n_present : d.n; }
+__device__ __forceinline__ int present_agent(const DeviceView &d, int i) { return d.present ? d.present[i] : i; }
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
@@ -1392,8 +1404,8 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 8) void k_solve(DeviceView d, Par
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
-    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast<0, 1>(d, P, S, agent, lane, wid);
+    const int idx = blockIdx.x * SOLVE_WAVES + wid;
+    if (idx < d.shard_count) solve_fast<0, 1>(d, P, S, shard_agent(d, idx), lane, wid);
 }
 // K3, wave-per-agent form: the ORCA3D-Official agents of the shard (positions [lo, hi) of the sorted list of their ids) when
 // they are too few for k_lp to fill the chip
@@ -1402,15 +1414,15 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_lpw(DeviceView d, Pa
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int idx = lo + blockIdx.x * SOLVE_WAVES + wid;
-    if (idx < hi) solve_fast<0, 2>(d, P, S, list[idx], lane, wid);
+    if (idx < hi && d.policy[list[idx]] == POL_ORCA_LP) solve_fast<0, 2>(d, P, S, list[idx], lane, wid);   // (partition mode hands over all owned agents)
 }
 // the first half of k_solve for passes whose v_pref arrives late (solve_fast); the second is k_solve_pick4
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, Params P) {
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int agent = d.shard_begin + blockIdx.x * SOLVE_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) solve_fast<1, 1>(d, P, S, agent, lane, wid);
+    const int idx = blockIdx.x * SOLVE_WAVES + wid;
+    if (idx < d.shard_count) solve_fast<1, 1>(d, P, S, shard_agent(d, idx), lane, wid);
 }
 
 
@@ -1570,8 +1582,8 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = lane >> 4;
-    const int agent = d.shard_begin + (blockIdx.x * SOLVE_WAVES + wid) * PICK_APW + row;
-    if (agent < d.shard_begin + d.shard_count) solve_pick4(d, P, S.pk[wid][row], agent, lane & 15, row);   // whole rows leave together
+    const int idx = (blockIdx.x * SOLVE_WAVES + wid) * PICK_APW + row;
+    if (idx < d.shard_count) solve_pick4(d, P, S.pk[wid][row], shard_agent(d, idx), lane & 15, row);   // whole rows leave together
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1599,6 +1611,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t
     const int at = lo + blockIdx.x * 64 + lane;
     if (at >= hi) return;
     const int agent = list[at];
+    if (d.policy[agent] != POL_ORCA_LP) return;                                     // (partition mode hands over all owned agents)
     const PubRec me = d.rec[agent];
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) return;          // mampenv.py:35 (k_solve wrote the bookkeeping)
     const Prep pr = ((const Prep *)d.prep)[agent];
@@ -1683,8 +1696,9 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
 // VGPRs and the one-lane-per-agent epilogue ran at one wavefront per SIMD; alone it takes a quarter of that.)
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.shard_begin + d.shard_count) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.shard_count) return;
+    const int agent = shard_agent(d, idx);
     const int kind = d.is_fb[agent];
     if (kind == 1) return;
     action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
@@ -1710,8 +1724,9 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Par
 }
 
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.shard_begin + d.shard_count) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.shard_count) return;
+    const int agent = shard_agent(d, idx);
     float act[7];
     for (int k = 0; k < 7; k++) act[k] = d.action[(size_t)agent * 8 + k];
     integrate_agent(d, P, agent, d.rec[agent], act);
@@ -1782,10 +1797,9 @@ __device__ __forceinline__ void collide_finish_body(const DeviceView &d, const P
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane & (NEAR_MAX - 1), grp = lane / NEAR_MAX;
-    const int end = d.shard_begin + d.shard_count;
-    const int agent_raw = d.shard_begin + (blockIdx.x * K4_WAVES + wid) * K4_APW + grp;
-    const bool exists = agent_raw < end;
-    const int agent = exists ? agent_raw : end - 1;
+    const int idx = (blockIdx.x * K4_WAVES + wid) * K4_APW + grp;
+    const bool exists = idx < d.shard_count;
+    const int agent = shard_agent(d, exists ? idx : d.shard_count - 1);
     PubRec me_old;
     const CollideCtx c = collide_ctx(d, agent, me_old);
     const int near_n = d.near_n[agent];
@@ -1848,9 +1862,15 @@ __global__ __launch_bounds__(256) void k_nbr0(DeviceView d, double *out) {
 // multi-GPU only: agents of other shards arrived by all-gather with the flags their owner published one step ago;
 // replicate the at-goal test for them -- the only flag of another agent the policy reads (scaPolicy.py:53).
 __global__ __launch_bounds__(256) void k_goal_flags_others(DeviceView d, Params P) {
-    const int agent = blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.n) return;
-    if (agent >= d.shard_begin && agent < d.shard_begin + d.shard_count) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int agent;
+    if (d.present) {                                                     // partition mode: the halo copies, behind the owned agents
+        if (d.shard_count + i >= d.n_present) return;
+        agent = d.present[d.shard_count + i];
+    } else {
+        agent = i;
+        if (agent >= d.n || shard_owns(d, agent)) return;
+    }
     const PubRec r = d.rec_new[agent];
     const V3 g = v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]);
     if (l3norm(v3(r.px, r.py, r.pz), g) <= P.near_goal_threshold) d.rec_new[agent].flags = r.flags | FLAG_AT_GOAL;

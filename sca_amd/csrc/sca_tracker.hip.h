@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.shard_begin + d.shard_count) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.shard_count) return;
+    const int agent = shard_agent(d, idx);
     double nb0 = K.nbr0[agent];
     if (K.nbr0_from_lists && d.nbr_valid[agent]) {                       // lists of the previous pass (agent.py:79-99)
         nb0 = d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0;
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
-    const int agent = d.shard_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (agent >= d.shard_begin + d.shard_count) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.shard_count) return;
+    const int agent = shard_agent(d, idx);
     const double nb0 = K.nbr0[agent];                                    // saved by the previous pass's epilogue
     if (!track_active(d, agent)) return;
     const PubRec r = d.rec[agent];

@@ -96,3 +96,81 @@ class ShardedStepper:
 
     def sync(self):
         self.sol.synchronize()
+
+
+class PartitionedStepper:
+    """SCA_NBR_GRID with the cell-owner partition (sca_partition_*): slabs of grid cells along one axis, one
+    per rank; a step exchanges, with the two slab neighbours only, the records of the agents next to the cut and the agents
+    that crossed it -- point to point (isend / irecv: RCCL on GPUs; gloo with host staging when ranks share a GPU in tests).
+
+    Every rank must hold the complete state when this is constructed (sca_set_state); afterwards a rank's per-agent arrays are
+    meaningful for `owned()` only."""
+
+    def __init__(self, solver, rank, world, torch_mod, dist_mod, axis=0, cuts=None, staged=False, cap_halo=0, cap_mig=0):
+        self.sol, self.rank, self.world = solver, int(rank), int(world)
+        self.torch, self.dist, self.staged = torch_mod, dist_mod, staged
+        solver.partition_init(self.rank, self.world, axis, cuts, cap_halo, cap_mig)
+        nbytes = solver.partition_message_bytes()
+        dev = torch_mod.device('cuda', torch_mod.cuda.current_device())
+        self.out = [torch_mod.zeros(nbytes, dtype=torch_mod.uint8, device=dev) for _ in range(2)]     # to the lower / upper neighbour
+        self.inb = [torch_mod.zeros(nbytes, dtype=torch_mod.uint8, device=dev) for _ in range(2)]     # from the lower / upper neighbour
+        self._stream = None
+        if not staged and self.world > 1:
+            torch_mod.cuda.synchronize()
+            self._stream = torch_mod.cuda.Stream(device=dev)      # the library's kernels and the transfers on ONE stream
+            solver.set_stream(self._stream.cuda_stream)
+
+    def owned(self):
+        return self.sol.partition_owned()
+
+    def _peers(self):
+        return [(0, self.rank - 1) if self.rank > 0 else None, (1, self.rank + 1) if self.rank + 1 < self.world else None]
+
+    def _exchange(self):
+        t, d = self.torch, self.dist
+        if self.world == 1:
+            return
+        if self.staged:
+            self.sol.synchronize()
+            send = [self.out[s].cpu() for s in (0, 1)]
+            recv = [t.empty_like(send[0]) for _ in (0, 1)]
+            ops = []
+            for pr in self._peers():
+                if pr is None:
+                    continue
+                side, peer = pr
+                ops.append(d.P2POp(d.isend, send[side], peer))
+                ops.append(d.P2POp(d.irecv, recv[side], peer))
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+            for pr in self._peers():
+                if pr is not None:
+                    self.inb[pr[0]].copy_(recv[pr[0]])
+            t.cuda.synchronize()
+            return
+        with t.cuda.stream(self._stream):
+            ops = []
+            for pr in self._peers():
+                if pr is None:
+                    continue
+                side, peer = pr
+                ops.append(d.P2POp(d.isend, self.out[side], peer))
+                ops.append(d.P2POp(d.irecv, self.inb[side], peer))
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+
+    def run(self, steps):
+        from .solver import NBR_GRID
+        sol = self.sol
+        for _ in range(int(steps)):
+            sol.step_begin(NBR_GRID)
+            for side in (0, 1):
+                sol.partition_pack(side, self.out[side].data_ptr())
+            self._exchange()
+            for side in (0, 1):
+                sol.partition_unpack(side, self.inb[side].data_ptr())
+            sol.partition_commit()
+            sol.step_end()
+
+    def sync(self):
+        self.sol.synchronize()

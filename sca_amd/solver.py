@@ -267,6 +267,37 @@ class BatchedSolver:
     def use_own_stream(self):
         self._chk(self.L.sca_use_own_stream(self.ctx), 'sca_use_own_stream')
 
+    # ---- cell-owner partition of SCA_NBR_GRID with halo exchange (sca_partition_*) ---------------------------
+    def partition_init(self, rank, nranks, axis=0, cuts=None, cap_halo=0, cap_mig=0):
+        c = None if cuts is None else _lib.ptr(_lib.as_d(cuts), C.c_double)
+        self._chk(self.L.sca_partition_init(self.ctx, int(rank), int(nranks), int(axis), c, int(cap_halo), int(cap_mig)), 'sca_partition_init')
+
+    def partition_disable(self):
+        self._chk(self.L.sca_partition_disable(self.ctx), 'sca_partition_disable')
+
+    def partition_message_bytes(self):
+        return int(self.L.sca_partition_message_bytes(self.ctx))
+
+    def partition_pack(self, side, device_ptr):
+        self._chk(self.L.sca_partition_pack(self.ctx, int(side), C.c_void_p(device_ptr)), 'sca_partition_pack')
+
+    def partition_unpack(self, side, device_ptr):
+        self._chk(self.L.sca_partition_unpack(self.ctx, int(side), C.c_void_p(device_ptr)), 'sca_partition_unpack')
+
+    def partition_commit(self):
+        self._chk(self.L.sca_partition_commit(self.ctx), 'sca_partition_commit')
+
+    def partition_counts(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.L.sca_partition_counts(self.ctx, C.byref(a), C.byref(b)), 'sca_partition_counts')
+        return a.value, b.value
+
+    def partition_owned(self):
+        ids = np.zeros(self.n, np.int32)
+        k = C.c_int(0)
+        self._chk(self.L.sca_partition_owned(self.ctx, _lib.ptr(ids, C.c_int32), C.byref(k)), 'sca_partition_owned')
+        return ids[:k.value].copy()
+
     # RCCL inside the library: run_steps then exchanges the shard's moved records itself, one host call per k steps
     def comm_probe(self):
         """True when the library can load RCCL (no collective: safe to call before the ranks agree on using it)."""
