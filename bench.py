@@ -204,6 +204,9 @@ def main():
                     help='N>1 GPUs: torch (default) = all_gather_into_tensor through torch.distributed between sca_step_begin / sca_step_end; '
                          'inlib = RCCL inside the library (one sca_run_steps call per k steps; never run with more than one rank so far, '
                          'hence opt-in)')
+    ap.add_argument('--partition', action='store_true',
+                    help='N>1 GPUs, with --nbr grid: cell-owner partition with halo exchange (sca_partition_*: a rank holds its slab of grid '
+                         'cells + a one-cell halo and talks to its two slab neighbours) instead of the all-gather of all N records')
     ap.add_argument('--emulate-rank-of', type=int, default=0, metavar='G',
                     help='1 GPU only: time what ONE rank of G executes per step (neighbour structure over all N, the rest for the '
                          'middle shard of N/G; the other records are copied over where the all-gather would deliver them)')
@@ -295,6 +298,17 @@ def main():
                 stepper = None
         if stepper is None:
             exchange = 'torch'
+    if args.partition and args.emulate_rank_of > 1:
+        pass                                                    # (handled below: one rank of G alone)
+    elif args.partition:
+        if world < 2 or args.nbr != 'grid':
+            raise SystemExit('--partition needs --gpus N > 1 and --nbr grid')
+        from sca_amd.distributed import PartitionedStepper
+        if stepper is not None:
+            sol.comm_destroy()
+        stepper = PartitionedStepper(sol, rank, world, torch, dist, axis=0, staged=share_gpu)
+        stepper.begin, stepper.count = 0, n                    # (re-plan statistics: over all rows; a rank's rows only change while it owns them)
+        exchange = 'partition'
     if stepper is None:
         stepper = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=share_gpu, mode=mode)
 
@@ -303,10 +317,16 @@ def main():
         if world > 1 or n % args.emulate_rank_of:
             raise SystemExit('--emulate-rank-of G needs --gpus 1 and G | N')
         G = args.emulate_rank_of
-        sol.set_shard_emulation(True)
-        sol.set_shard((G // 2) * (n // G), n // G)
-        stepper.begin, stepper.count = (G // 2) * (n // G), n // G
-        emulated = {'rank_of': G, 'agents_solved': n // G}
+        if args.partition:
+            from sca_amd.distributed import PartitionedStepper
+            stepper = PartitionedStepper(sol, G // 2, G, torch, None, axis=0, emulate=True)
+            stepper.begin, stepper.count = 0, n
+            emulated = {'rank_of': G, 'agents_solved': sol.partition_counts()[0], 'mode': 'cell-owner partition'}
+        else:
+            sol.set_shard_emulation(True)
+            sol.set_shard((G // 2) * (n // G), n // G)
+            stepper.begin, stepper.count = (G // 2) * (n // G), n // G
+            emulated = {'rank_of': G, 'agents_solved': n // G}
         args.no_extra = True
         args.no_cpu_baseline = True
     if vpref == 'dubins':
@@ -368,9 +388,11 @@ def main():
                                   'dubins': 'native Dubins tracker on the host every step (end-to-end SCA, bit-exact, host-bound)',
                                   'dubins-device': 'SCA as shipped: Dubins tracker + 3-D Dubins planner on the device inside every step '
                                                    '(k_track, k_replan / k_replan_group / k_track_replan)'}[vpref],
-                       'parallelism': (f'{n} agents sharded over {world} GPUs, one all-gather of 48-B records per step '
-                                       + ('by the library\'s RCCL communicator inside sca_run_steps' if exchange == 'inlib'
-                                          else 'through torch.distributed')) if world > 1 else 'single GPU',
+                       'parallelism': ((f'{n} agents in {world} slabs of grid cells (cell-owner partition): per step a rank exchanges the records next '
+                                        'to its cuts and the agents that crossed them with its two slab neighbours (isend / irecv)') if exchange == 'partition' else
+                                       (f'{n} agents sharded over {world} GPUs, one all-gather of 48-B records per step '
+                                        + ('by the library\'s RCCL communicator inside sca_run_steps' if exchange == 'inlib'
+                                           else 'through torch.distributed'))) if world > 1 else 'single GPU',
                        'agent_steps_timed': main_leg['agent_steps'], 're_plans_timed': main_leg['plans']},
             'roofline': roof,
         }
@@ -454,6 +476,24 @@ def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
         out['modes'][name] = rows
     sol.set_shard_emulation(False)
     sol.set_shard(0, n)
+    # the same rank with the cell-owner partition of SCA_NBR_GRID (sca_partition_*): it holds and bins its slab + a one-cell halo
+    # instead of all N records; its two point-to-point messages are assumed to cost what the all-gather is assumed to cost
+    import torch
+    from sca_amd.distributed import PartitionedStepper
+    rows = []
+    for G in (2, 4, 8):
+        reset_state(sol, scene)
+        st = PartitionedStepper(sol, G // 2, G, torch, None, axis=0, emulate=True)
+        st.begin, st.count = 0, n
+        leg = timed_leg(sol, scene, st, timer, steps, warmup, tracked)
+        owned, halo = sol.partition_counts()
+        rows.append({'G': G, 'ms_rank_step': leg['ms_per_step'], 'ms_1gpu_step': full_ms['grid'], 'agents_owned': owned,
+                     'predicted_speedup': full_ms['grid'] / (leg['ms_per_step'] + ALLGATHER_MS_ASSUMED),
+                     'predicted_speedup_without_exchange': full_ms['grid'] / leg['ms_per_step']})
+        sol.partition_disable()
+        sol.set_shard_emulation(False)
+    out['modes']['grid_partition'] = rows
+    reset_state(sol, scene)
     # the headline row the judge asked for: G = 8, the mode with the better prediction
     best = max(((r['predicted_speedup'], m, r) for m, rows in out['modes'].items() for r in rows if r['G'] == 8), default=None)
     if best:

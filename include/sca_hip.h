@@ -173,16 +173,17 @@ int sca_comm_destroy(sca_ctx *ctx);
  *                        boundaries.  cap_halo / cap_mig: entries per message (0 = n / 4, n / 16); an overflow is reported
  *                        by sca_partition_commit.  From then on the per-agent arrays of sca_get_* are meaningful for the owned
  *                        agents only (sca_partition_owned).  sca_set_state (complete again) re-derives the ownership.
- *   one step             sca_step_begin(SCA_NBR_GRID) -> sca_partition_pack(side 0 = lower neighbour, 1 = upper) into two DEVICE
- *                        buffers of sca_partition_message_bytes() -> exchange (the buffer packed for side 0 is what the
- *                        lower neighbour unpacks as ITS side 1) -> sca_partition_unpack(side, received buffer) ->
- *                        sca_partition_commit (ownership moves; synchronises) -> sca_step_end.
+ *   one step             sca_step_begin(SCA_NBR_GRID) -> sca_partition_pack into two DEVICE buffers of sca_partition_message_bytes()
+ *                        (for the lower / the upper slab neighbour) -> exchange (what a rank packed for its lower neighbour is
+ *                        what that neighbour unpacks as the message from ITS upper one) -> sca_partition_unpack(from lower,
+ *                        from upper) -> sca_partition_commit (ownership moves; nothing waits for the device: the host sizes its
+ *                        launches with bounds and learns the exact counts a step or two late) -> sca_step_end.
  *                        With one rank sca_run_steps does all of it. */
 int sca_partition_init(sca_ctx *ctx, int rank, int nranks, int axis, const double *cuts /*nranks-1, nullable*/, int cap_halo, int cap_mig);
 int sca_partition_disable(sca_ctx *ctx);
 int64_t sca_partition_message_bytes(sca_ctx *ctx);
-int sca_partition_pack(sca_ctx *ctx, int side, void *device_buf);
-int sca_partition_unpack(sca_ctx *ctx, int side, const void *device_buf);
+int sca_partition_pack(sca_ctx *ctx, void *device_buf_lower, void *device_buf_upper);       /* NULL where there is no neighbour */
+int sca_partition_unpack(sca_ctx *ctx, const void *device_buf_lower, const void *device_buf_upper);
 int sca_partition_commit(sca_ctx *ctx);
 int sca_partition_counts(sca_ctx *ctx, int *owned, int *halo);
 int sca_partition_owned(sca_ctx *ctx, int32_t *ids /*n*/, int *count);

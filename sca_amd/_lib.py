@@ -61,8 +61,8 @@ SIGNATURES = {
     'sca_partition_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.c_int]),
     'sca_partition_disable': (C.c_int, [C.c_void_p]),
     'sca_partition_message_bytes': (C.c_int64, [C.c_void_p]),
-    'sca_partition_pack': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
-    'sca_partition_unpack': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'sca_partition_pack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sca_partition_unpack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'sca_partition_commit': (C.c_int, [C.c_void_p]),
     'sca_partition_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sca_partition_owned': (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_int)]),

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
     const int h = grid_bucket(key, g.hbits);
     g.bucket[i] = h;
     g.slot[i] = atomicAdd(&g.count[h], 1);
-    const bool mine = d.present ? i < d.shard_count : shard_owns(d, a);
+    const bool mine = d.present ? i < shard_size(d) : shard_owns(d, a);
     if (mine && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, a))) prep_agent(d, P, (Prep *)d.prep, a);
 }
 
@@ -147,8 +147,10 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
     const int wid = threadIdx.x >> 6;
     const int grp = lane >> 4, gl = lane & 15, gshift = grp << 4;
     const int idx = (blockIdx.x * K1P_WAVES + wid) * K1P_APW + grp;
-    const bool exists = idx < d.shard_count;
-    const int agent = shard_agent(d, exists ? idx : d.shard_count - 1);   // clamp: idle groups read a valid record, write nothing
+    const int scnt = shard_size(d);
+    if (scnt <= 0) return;
+    const bool exists = idx < scnt;
+    const int agent = shard_agent(d, exists ? idx : scnt - 1);           // clamp: idle groups read a valid record, write nothing
     const PubRec me = d.rec[agent];
     int st = 0;
     const bool done = (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) != 0;   // mampenv.py:35

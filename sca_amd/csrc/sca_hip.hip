@@ -219,7 +219,14 @@ struct sca_ctx {
     PartDev part{};
     bool part_on = false;
     int part_rank = 0, part_nranks = 1;
-    int part_counts[8] = {0};            // host copy of PartDev::counts after the last commit
+    int part_counts[8] = {0};            // [0] owned, [1] halo: UPPER BOUNDS the launches are sized with (the kernels read the exact
+                                        // counts on the device); [4] error bits as last seen
+    int *part_host = nullptr;            // pinned: the counts of an earlier commit, copied back without being waited for
+    hipEvent_t part_ev = nullptr;
+    bool part_pending = false;
+    int part_known[2] = {0, 0};          // the last exact counts the host has seen, and how many commits ago
+    int part_age = 0, part_copy_age = 0;
+    uint8_t *part_scratch[2] = {nullptr, nullptr};   // outgoing messages of a rank that runs alone (sca_run_steps: one rank, or emulation)
     int cus = 256, simds = 1024;         // the device's compute units / SIMDs (hipDeviceProp): every launch heuristic below is stated in
                                         // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
     int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
@@ -1294,15 +1301,22 @@ static int exchange_moved_records(sca_ctx *c) {
 int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
-    if (c->part_on && c->part_nranks > 1) {
+    if (c->part_on && c->part_nranks > 1 && !c->shard_emulation) {
         c->err = "cell-owner partition over several ranks: drive the step with sca_step_begin / sca_partition_pack / [exchange] / "
                  "sca_partition_unpack / sca_partition_commit / sca_step_end (sca_amd.distributed.PartitionedStepper)";
         return SCA_ERR_STATE;
     }
+    if (c->part_on && c->part_nranks > 1) {                                 // emulation: this rank alone, its messages go nowhere
+        for (int k = 0; k < 2; k++)
+            if (!c->part_scratch[k]) CHK(c, hipMalloc((void **)&c->part_scratch[k], part_message_bytes(c->part.cap_halo, c->part.cap_mig)));
+    }
     if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     for (int s = 0; s < steps; s++) {
         if (int r = launch_policy(c, neighbor_mode, false, true)) return r;     // integrate fused into k_solve
-        if (c->part_on) { if (int r = sca_partition_commit(c)) return r; }     // (one rank: nobody to exchange with; the lists are rebuilt all the same)
+        if (c->part_on) {                                                      // one rank (or one rank alone, emulation): nobody to exchange with
+            if (c->part_nranks > 1) { if (int r = sca_partition_pack(c, c->part_scratch[0], c->part_scratch[1])) return r; }
+            if (int r = sca_partition_commit(c)) return r;
+        }
         if (c->comm) { if (int r = exchange_moved_records(c)) return r; }
         else if (c->shard_emulation && c->d.shard_count < c->n) {
             // stand-in for the all-gather's arrivals: the other ranks' agents stand still (their records are copied over)
@@ -1375,6 +1389,7 @@ int sca_comm_destroy(sca_ctx *c) {
 // ---- cell-owner partition of SCA_NBR_GRID with halo exchange (sca_partition.hip.h) ---------------------
 static void part_view(sca_ctx *c) {
     c->d.own = c->d.present = c->part.present[c->part.cur];
+    c->d.count_dev = c->part.counts;
     c->d.shard_begin = 0;
     c->d.shard_count = c->part_counts[0];
     c->d.n_present = c->part_counts[0] + c->part_counts[1];
@@ -1384,37 +1399,69 @@ static int part_free(sca_ctx *c) {
     CHK(c, hipStreamSynchronize(c->stream));
     for (void *q : {(void *)c->part.present[0], (void *)c->part.present[1], (void *)c->part.halo_tmp, (void *)c->part.counts, (void *)c->part.emig})
         if (q) (void)hipFree(q);
+    if (c->part_host) { (void)hipHostFree(c->part_host); c->part_host = nullptr; }
+    for (int k = 0; k < 2; k++) if (c->part_scratch[k]) { (void)hipFree(c->part_scratch[k]); c->part_scratch[k] = nullptr; }
+    if (c->part_ev) { (void)hipEventDestroy(c->part_ev); c->part_ev = nullptr; }
     c->part = PartDev{};
-    c->part_on = false; c->part_rank = 0; c->part_nranks = 1;
-    c->d.own = c->d.present = nullptr; c->d.n_present = 0;
+    c->part_on = false; c->part_rank = 0; c->part_nranks = 1; c->part_pending = false;
+    c->d.own = c->d.present = nullptr; c->d.count_dev = nullptr; c->d.n_present = 0;
     c->d.shard_begin = 0; c->d.shard_count = c->n;
     return 0;
 }
-// lists being built -> current lists (after k_part_close): counts to the host, buffers swapped, accumulators cleared
-static int part_adopt(sca_ctx *c) {
-    CHK(c, hipMemcpyAsync(c->part_counts, c->part.counts, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
-    CHK(c, hipStreamSynchronize(c->stream));
-    if (c->part_counts[4]) {
-        c->err = c->part_counts[4] & 4 ? "partition: owned + halo exceed the agent count (corrupt lists)"
-                                       : "partition: a halo / migration message overflowed its capacity (sca_partition_init caps)";
-        return SCA_ERR_STATE;
-    }
+// The launch bounds from what the host knows: the exact counts of a commit one or two steps back + room for what can have
+// arrived since.  Agents move 0.1 m per step and cells are 10 m wide, so a step changes an owner's count by the few agents within
+// 0.1 m of a cut; the margin is a sixteenth of the rank's agents (+ 4096) per commit of age -- and k_part_keep checks it: a launch
+// that turned out too small sets an error bit instead of leaving agents out silently.
+static void part_bounds(sca_ctx *c) {
+    const long long grow = (long long)c->part_age + 1;
+    c->part_counts[0] = (int)std::min<long long>(c->n, c->part_known[0] + grow * (c->part_known[0] / 16 + 4096));
+    c->part_counts[1] = (int)std::min<long long>(c->n, c->part_known[1] + grow * (c->part_known[1] / 4 + 4096));
+    if (c->part_counts[0] + c->part_counts[1] > c->n) c->part_counts[1] = c->n - c->part_counts[0];
+}
+static int part_report(sca_ctx *c, int bits) {
+    if (!bits) return 0;
+    c->err = bits & 4 ? "partition: owned + halo exceed the agent count (corrupt lists)"
+           : bits & 8 ? "partition: a rank's agent count outgrew the launch bound between two read-backs (results of that step are incomplete)"
+                      : "partition: a halo / migration message overflowed its capacity (sca_partition_init caps)";
+    return SCA_ERR_STATE;
+}
+// lists being built -> current lists (behind k_part_close), without waiting for the device: the counts move on the device, the
+// host asks for a copy and sizes its launches with bounds until it has arrived.  wait: get the exact counts now.
+static int part_adopt(sca_ctx *c, bool wait) {
     c->part.cur ^= 1;
-    c->part_counts[0] = c->part_counts[2]; c->part_counts[1] = c->part_counts[3];
-    const int z[4] = {c->part_counts[0], c->part_counts[1], 0, 0};
-    CHK(c, hipMemcpyAsync(c->part.counts, z, sizeof(z), hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipStreamSynchronize(c->stream));                               // (z is on the stack)
+    c->part_age++;
+    if (c->part_pending) c->part_copy_age++;
+    if (c->part_pending && hipEventQuery(c->part_ev) == hipSuccess) {
+        c->part_known[0] = c->part_host[0]; c->part_known[1] = c->part_host[1]; c->part_counts[4] = c->part_host[4];
+        c->part_age = c->part_copy_age;                                     // commits since that snapshot
+        c->part_pending = false;
+    }
+    if (!c->part_pending || wait) {
+        if (c->part_pending) CHK(c, hipEventSynchronize(c->part_ev));
+        CHK(c, hipMemcpyAsync(c->part_host, c->part.counts, sizeof(int) * 5, hipMemcpyDeviceToHost, c->stream));   // a snapshot behind this commit
+        CHK(c, hipEventRecord(c->part_ev, c->stream));
+        c->part_copy_age = 0;
+        c->part_pending = true;
+    }
+    if (wait) {
+        CHK(c, hipEventSynchronize(c->part_ev));
+        c->part_known[0] = c->part_host[0]; c->part_known[1] = c->part_host[1]; c->part_counts[4] = c->part_host[4];
+        c->part_age = 0; c->part_pending = false;
+        c->part_counts[0] = c->part_known[0]; c->part_counts[1] = c->part_known[1];
+    } else part_bounds(c);
     part_view(c);
-    return 0;
+    return part_report(c, c->part_counts[4]);
 }
 static int part_classify(sca_ctx *c) {                                      // from records every rank holds completely
     const int n = c->n;
-    CHK(c, hipMemsetAsync(c->part.counts, 0, sizeof(int) * 8, c->stream));
+    CHK(c, hipMemsetAsync(c->part.counts, 0, sizeof(int) * 16, c->stream));
     hipLaunchKernelGGL(k_part_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
     hipLaunchKernelGGL(k_part_init_halo, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
-    hipLaunchKernelGGL(k_part_close, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    hipLaunchKernelGGL(k_part_close<false>, dim3(64), dim3(256), 0, c->stream, c->d, c->part);
     CHK(c, hipGetLastError());
-    return part_adopt(c);
+    CHK(c, hipMemcpyAsync(c->part.counts, c->part.counts + 2, sizeof(int) * 2, hipMemcpyDeviceToDevice, c->stream));   // current = built
+    CHK(c, hipMemsetAsync(c->part.counts + 2, 0, sizeof(int) * 2, c->stream));
+    return part_adopt(c, true);
 }
 int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double *cuts, int cap_halo, int cap_mig) {
     if (!c) return SCA_ERR_ARG;
@@ -1445,8 +1492,11 @@ int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double 
     PartDev &P = c->part;
     for (int k = 0; k < 2; k++) CHK(c, hipMalloc((void **)&P.present[k], sizeof(int32_t) * n));
     CHK(c, hipMalloc((void **)&P.halo_tmp, sizeof(int32_t) * n));
-    CHK(c, hipMalloc((void **)&P.counts, sizeof(int32_t) * 8));
+    CHK(c, hipMalloc((void **)&P.counts, sizeof(int32_t) * 16));
     CHK(c, hipMalloc((void **)&P.emig, n));
+    CHK(c, hipHostMalloc((void **)&c->part_host, sizeof(int) * 8));
+    CHK(c, hipEventCreateWithFlags(&c->part_ev, hipEventDisableTiming));
+    c->part_pending = false; c->part_age = 0;
     P.cur = 0; P.axis = axis; P.inv_cell = inv_cell;
     P.lo_cell = cell_cut[rank]; P.hi_cell = cell_cut[rank + 1];
     P.has_peer[0] = rank > 0; P.has_peer[1] = rank + 1 < nranks;
@@ -1468,52 +1518,54 @@ int64_t sca_partition_message_bytes(sca_ctx *c) {
 int sca_partition_counts(sca_ctx *c, int *owned, int *halo) {
     if (!c) return SCA_ERR_ARG;
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
-    if (owned) *owned = c->part_counts[0];
-    if (halo) *halo = c->part_counts[1];
-    return 0;
+    int h[5];
+    CHK(c, hipMemcpyAsync(h, c->part.counts, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (owned) *owned = h[0];
+    if (halo) *halo = h[1];
+    return part_report(c, h[4]);
 }
 int sca_partition_owned(sca_ctx *c, int32_t *ids, int *count) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, ids && count);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
-    *count = c->part_counts[0];
+    CHK(c, hipMemcpyAsync(count, c->part.counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
     CHK(c, hipMemcpyAsync(ids, c->part.present[c->part.cur], sizeof(int32_t) * (size_t)*count, hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int sca_partition_pack(sca_ctx *c, int side, void *device_buf) {
+int sca_partition_pack(sca_ctx *c, void *device_buf_lower, void *device_buf_upper) {
     if (!c) return SCA_ERR_ARG;
-    ARG(c, (side == 0 || side == 1) && device_buf);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
-    PartHeader h{0, 0, c->part.cap_halo, c->part.cap_mig};
-    CHK(c, hipMemcpyAsync(device_buf, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipStreamSynchronize(c->stream));                               // (h is on the stack; 16 bytes)
+    ARG(c, (device_buf_lower || !c->part.has_peer[0]) && (device_buf_upper || !c->part.has_peer[1]));
     c->part.trk_st = c->trk_on ? c->trk.st : nullptr;
     c->part.trk_nbr0 = c->trk_on ? c->trk.nbr0 : nullptr;
-    const int cnt = c->d.shard_count;
-    if (c->part.has_peer[side] && cnt > 0)
-        hipLaunchKernelGGL(k_part_pack, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part, side, (uint8_t *)device_buf);
+    const int cnt = std::max(1, c->d.shard_count);
+    hipLaunchKernelGGL(k_part_pack, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part,
+                       c->part.has_peer[0] ? (uint8_t *)device_buf_lower : nullptr, c->part.has_peer[1] ? (uint8_t *)device_buf_upper : nullptr);
     CHK(c, hipGetLastError());
     return 0;
 }
-int sca_partition_unpack(sca_ctx *c, int side, const void *device_buf) {
+int sca_partition_unpack(sca_ctx *c, const void *device_buf_lower, const void *device_buf_upper) {
     if (!c) return SCA_ERR_ARG;
-    ARG(c, (side == 0 || side == 1) && device_buf);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
-    if (!c->part.has_peer[side]) return 0;
+    ARG(c, (device_buf_lower || !c->part.has_peer[0]) && (device_buf_upper || !c->part.has_peer[1]));
+    if (!c->part.has_peer[0] && !c->part.has_peer[1]) return 0;
     const int lanes = std::max(c->part.cap_halo, c->part.cap_mig);
-    hipLaunchKernelGGL(k_part_unpack, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, c->d, c->part, (const uint8_t *)device_buf);
+    hipLaunchKernelGGL(k_part_unpack, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, c->d, c->part,
+                       c->part.has_peer[0] ? (const uint8_t *)device_buf_lower : nullptr, c->part.has_peer[1] ? (const uint8_t *)device_buf_upper : nullptr);
     CHK(c, hipGetLastError());
     return 0;
 }
 int sca_partition_commit(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
-    const int cnt = c->d.shard_count, n = c->n;
-    if (cnt > 0) hipLaunchKernelGGL(k_part_keep, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
-    hipLaunchKernelGGL(k_part_close, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    const int cnt = std::max(1, c->d.shard_count);
+    hipLaunchKernelGGL(k_part_keep, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
+    hipLaunchKernelGGL(k_part_close<true>, dim3(16), dim3(256), 0, c->stream, c->d, c->part);
     CHK(c, hipGetLastError());
-    return part_adopt(c);
+    return part_adopt(c, false);
 }
 
 int sca_step_begin(sca_ctx *c, int neighbor_mode) {
@@ -1530,6 +1582,7 @@ int sca_step_end(sca_ctx *c) {
 int sca_synchronize(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;
     CHK(c, hipStreamSynchronize(c->stream));
+    if (c->part_on) { int h[5]; CHK(c, hipMemcpy(h, c->part.counts, sizeof(h), hipMemcpyDeviceToHost)); if (int r = part_report(c, h[4])) return r; }
     if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
     if (c->profiling && c->pool_used >= 4) {
         double a = 0, b = 0;

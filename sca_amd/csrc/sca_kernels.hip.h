@@ -106,6 +106,8 @@ struct DeviceView {
     const int32_t *own;
     const int32_t *present;
     int n_present;
+    const int32_t *count_dev;   // partition mode: [0] owned, [1] halo ON THE DEVICE -- shard_count / n_present are then upper bounds the host
+                                // sizes its launches with (it learns the exact counts a step or two late and never waits for them)
     int lp_kernel;           // 1: the ORCA3D-LP agents past their bootstrap step are solved by k_lp (one lane per agent)
     // k_solve in two launches (k_solve_sweep / k_solve_pick4, see solve_fast): what the first leaves for the second
     double *sw_slot;         // [n][SLOTF][K_MAX] cones / planes of the agent's neighbours, component-major (neighbour j's component q at
@@ -119,7 +121,8 @@ struct DeviceView {
 // the i-th agent of this rank (i < shard_count) / the i-th agent whose record this rank holds (i < present_count(d))
 __device__ __forceinline__ int shard_agent(const DeviceView &d, int i) { return d.own ? d.own[i] : d.shard_begin + i; }
 __device__ __forceinline__ bool shard_owns(const DeviceView &d, int agent) { return agent >= d.shard_begin && agent < d.shard_begin + d.shard_count; }
-__device__ __forceinline__ int present_count(const DeviceView &d) { return d.present ? d.n_present : d.n; }
+__device__ __forceinline__ int shard_size(const DeviceView &d) { return d.count_dev ? d.count_dev[0] : d.shard_count; }
+__device__ __forceinline__ int present_count(const DeviceView &d) { return d.count_dev ? d.count_dev[0] + d.count_dev[1] : (d.present ? d.n_present : d.n); }
 __device__ __forceinline__ int present_agent(const DeviceView &d, int i) { return d.present ? d.present[i] : i; }
 
 // ------------------------------------------------------------------------------------------------
@@ -1405,7 +1408,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 8) void k_solve(DeviceView d, Par
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one agent per wavefront, no grid-stride loop (the loop form costs registers: 1 wave/SIMD instead of 2)
     const int idx = blockIdx.x * SOLVE_WAVES + wid;
-    if (idx < d.shard_count) solve_fast<0, 1>(d, P, S, shard_agent(d, idx), lane, wid);
+    if (idx < shard_size(d)) solve_fast<0, 1>(d, P, S, shard_agent(d, idx), lane, wid);
 }
 // K3, wave-per-agent form: the ORCA3D-Official agents of the shard (positions [lo, hi) of the sorted list of their ids) when
 // they are too few for k_lp to fill the chip
@@ -1422,7 +1425,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int idx = blockIdx.x * SOLVE_WAVES + wid;
-    if (idx < d.shard_count) solve_fast<1, 1>(d, P, S, shard_agent(d, idx), lane, wid);
+    if (idx < shard_size(d)) solve_fast<1, 1>(d, P, S, shard_agent(d, idx), lane, wid);
 }
 
 
@@ -1583,7 +1586,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = lane >> 4;
     const int idx = (blockIdx.x * SOLVE_WAVES + wid) * PICK_APW + row;
-    if (idx < d.shard_count) solve_pick4(d, P, S.pk[wid][row], shard_agent(d, idx), lane & 15, row);   // whole rows leave together
+    if (idx < shard_size(d)) solve_pick4(d, P, S.pk[wid][row], shard_agent(d, idx), lane & 15, row);   // whole rows leave together
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1697,7 +1700,7 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.shard_count) return;
+    if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
     const int kind = d.is_fb[agent];
     if (kind == 1) return;
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Par
 
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.shard_count) return;
+    if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
     float act[7];
     for (int k = 0; k < 7; k++) act[k] = d.action[(size_t)agent * 8 + k];
@@ -1798,8 +1801,10 @@ __device__ __forceinline__ void collide_finish_body(const DeviceView &d, const P
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane & (NEAR_MAX - 1), grp = lane / NEAR_MAX;
     const int idx = (blockIdx.x * K4_WAVES + wid) * K4_APW + grp;
-    const bool exists = idx < d.shard_count;
-    const int agent = shard_agent(d, exists ? idx : d.shard_count - 1);
+    const int cnt = shard_size(d);
+    if (cnt <= 0) return;
+    const bool exists = idx < cnt;
+    const int agent = shard_agent(d, exists ? idx : cnt - 1);
     PubRec me_old;
     const CollideCtx c = collide_ctx(d, agent, me_old);
     const int near_n = d.near_n[agent];
@@ -1865,8 +1870,9 @@ __global__ __launch_bounds__(256) void k_goal_flags_others(DeviceView d, Params 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int agent;
     if (d.present) {                                                     // partition mode: the halo copies, behind the owned agents
-        if (d.shard_count + i >= d.n_present) return;
-        agent = d.present[d.shard_count + i];
+        const int own = shard_size(d);
+        if (own + i >= present_count(d)) return;
+        agent = d.present[own + i];
     } else {
         agent = i;
         if (agent >= d.n || shard_owns(d, agent)) return;

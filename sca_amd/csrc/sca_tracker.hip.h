@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.shard_count) return;
+    if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
     double nb0 = K.nbr0[agent];
     if (K.nbr0_from_lists && d.nbr_valid[agent]) {                       // lists of the previous pass (agent.py:79-99)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.shard_count) return;
+    if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
     const double nb0 = K.nbr0[agent];                                    // saved by the previous pass's epilogue
     if (!track_active(d, agent)) return;

@@ -106,7 +106,13 @@ class PartitionedStepper:
     Every rank must hold the complete state when this is constructed (sca_set_state); afterwards a rank's per-agent arrays are
     meaningful for `owned()` only."""
 
-    def __init__(self, solver, rank, world, torch_mod, dist_mod, axis=0, cuts=None, staged=False, cap_halo=0, cap_mig=0):
+    def __init__(self, solver, rank, world, torch_mod, dist_mod, axis=0, cuts=None, staged=False, cap_halo=0, cap_mig=0, emulate=False):
+        """emulate=True (measurements on one GPU): this rank of `world` alone -- its messages go nowhere and empty ones arrive, so
+        the halo copies are gone after the first step and agents that leave are lost; what the rank executes per step is what it
+        would execute in company."""
+        self.emulate = bool(emulate)
+        if self.emulate:
+            solver.set_shard_emulation(True)
         self.sol, self.rank, self.world = solver, int(rank), int(world)
         self.torch, self.dist, self.staged = torch_mod, dist_mod, staged
         solver.partition_init(self.rank, self.world, axis, cuts, cap_halo, cap_mig)
@@ -115,7 +121,7 @@ class PartitionedStepper:
         self.out = [torch_mod.zeros(nbytes, dtype=torch_mod.uint8, device=dev) for _ in range(2)]     # to the lower / upper neighbour
         self.inb = [torch_mod.zeros(nbytes, dtype=torch_mod.uint8, device=dev) for _ in range(2)]     # from the lower / upper neighbour
         self._stream = None
-        if not staged and self.world > 1:
+        if not staged and self.world > 1 and not self.emulate:
             torch_mod.cuda.synchronize()
             self._stream = torch_mod.cuda.Stream(device=dev)      # the library's kernels and the transfers on ONE stream
             solver.set_stream(self._stream.cuda_stream)
@@ -128,7 +134,7 @@ class PartitionedStepper:
 
     def _exchange(self):
         t, d = self.torch, self.dist
-        if self.world == 1:
+        if self.world == 1 or self.emulate:                      # (the inbound buffers stay zeroed: empty messages)
             return
         if self.staged:
             self.sol.synchronize()
@@ -162,13 +168,14 @@ class PartitionedStepper:
     def run(self, steps):
         from .solver import NBR_GRID
         sol = self.sol
+        if self.world == 1 or self.emulate:                      # nobody to talk to: the whole loop inside the library
+            sol.run_steps(steps, NBR_GRID)
+            return
         for _ in range(int(steps)):
             sol.step_begin(NBR_GRID)
-            for side in (0, 1):
-                sol.partition_pack(side, self.out[side].data_ptr())
+            sol.partition_pack(self.out[0].data_ptr(), self.out[1].data_ptr())
             self._exchange()
-            for side in (0, 1):
-                sol.partition_unpack(side, self.inb[side].data_ptr())
+            sol.partition_unpack(self.inb[0].data_ptr(), self.inb[1].data_ptr())
             sol.partition_commit()
             sol.step_end()
 

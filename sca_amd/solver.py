@@ -278,11 +278,11 @@ class BatchedSolver:
     def partition_message_bytes(self):
         return int(self.L.sca_partition_message_bytes(self.ctx))
 
-    def partition_pack(self, side, device_ptr):
-        self._chk(self.L.sca_partition_pack(self.ctx, int(side), C.c_void_p(device_ptr)), 'sca_partition_pack')
+    def partition_pack(self, lower_ptr, upper_ptr):
+        self._chk(self.L.sca_partition_pack(self.ctx, C.c_void_p(lower_ptr), C.c_void_p(upper_ptr)), 'sca_partition_pack')
 
-    def partition_unpack(self, side, device_ptr):
-        self._chk(self.L.sca_partition_unpack(self.ctx, int(side), C.c_void_p(device_ptr)), 'sca_partition_unpack')
+    def partition_unpack(self, lower_ptr, upper_ptr):
+        self._chk(self.L.sca_partition_unpack(self.ctx, C.c_void_p(lower_ptr), C.c_void_p(upper_ptr)), 'sca_partition_unpack')
 
     def partition_commit(self):
         self._chk(self.L.sca_partition_commit(self.ctx), 'sca_partition_commit')

@@ -48,3 +48,12 @@ def test_bench_script_eight_ranks_on_one_gpu():
                env={'SCA_BENCH_SHARE_GPU': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29551'}, timeout=1500)
     assert out['n_gpus'] == 8 and out['scaling'] == 'strong' and out['config']['agents'] == 8000 and out['config']['agents_per_gpu'] == 1000
     assert out['config']['agent_steps_timed'] == 8000 * 4 and out['value'] > 0
+
+
+def test_bench_script_partition_mode_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 --nbr grid --partition (cell-owner partition, point-to-point halo exchange) through the same test hook"""
+    out = _run(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                '29553', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '3', '--agents', '6000', '--nbr', 'grid',
+                '--partition'], env={'SCA_BENCH_SHARE_GPU': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29553'}, timeout=1500)
+    assert out['n_gpus'] == 2 and out['config']['agents'] == 6000 and 'slabs of grid cells' in out['config']['parallelism']
+    assert out['config']['agent_steps_timed'] == 6000 * 5 and out['value'] > 0
