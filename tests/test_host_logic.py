@@ -90,18 +90,20 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def test_two_rank_sharded_stepping_matches_single_process(tmp_path):
-    """world_size 2 over gloo: each rank steps its half with the checker backend, exchanges the moved 48-byte records
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_stepping_over_gloo_matches_single_process(tmp_path, world):
+    """world_size 2 and 8 over gloo: each rank steps its shard with the checker backend, exchanges the moved 48-byte records
     with all_gather_into_tensor exactly as the GPU path does, and must land on the single-process result bit for bit."""
     import subprocess
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29531', str(script), ROOT],
-                       env=env, capture_output=True, text=True, timeout=600)
+    port = str(29531 + world)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, OMP_NUM_THREADS='1' if world > 2 else '2')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+                        '--master-addr', '127.0.0.1', '--master-port', port, str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count('OK') == 2, r.stdout[-2000:]
+    assert r.stdout.count('OK') == world, r.stdout[-2000:]
 
 
 def test_binvox_map_to_obstacles_matches_reference():
