@@ -73,11 +73,12 @@ SCA_DHD static inline double fma3(const double *a, const double *b) { return std
 // unless that lies within 2^-53 ulp of a rounding midpoint, and even then its floor is the same unless the midpoint sits
 // just below an integer -- no such input exists at a rate that matters (< 1e-30 per call).  No branch: a guarded form that fell
 // back to the division for a whole wavefront cost 68 spilled registers and 15 % of the kernel (measured, round 2).
+// (t / 2 is never formed: scalings by two are exact, so q0 = t * (fl(1/pi) / 2), the residual against 2 pi is twice the one
+// against pi, and the halved reciprocal takes it back: the same q1 bit for bit, one multiplication less)
 SCA_DHD static inline double mod2pi(double t) {
-    const double x = t * 0.5;                                            // exact
-    const double q0 = x * 0.3183098861837907;
-    const double r = std::fma(-q0, PI, x);
-    const double q1 = std::fma(r, 0.3183098861837907, q0);
+    const double q0 = t * 0.15915494309189535;
+    const double r = std::fma(-q0, 2.0 * PI, t);
+    const double q1 = std::fma(r, 0.15915494309189535, q0);
     return t - 2.0 * PI * std::floor(q1);
 }
 #else
@@ -470,6 +471,368 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
     return P;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(SCA_PLAN_LEAN) || SCA_PLAN_LEAN == 1)
+// ---- the lane-per-plan search, lean (device) --------------------------------------------------------------------------------
+// plan3d above, for the kernels that give a plan one lane: the SAME candidates in the same order with the same verdicts, but
+//   * a candidate is evaluated for what the search reads of it -- feasible or not, and the length -- and the winning radius is
+//     constructed once more at the end for its maneuvers (the evaluation is a pure function of the radius): the four Maneuver2D
+//     the literal loop carries (best / candidate x horizontal / vertical: 48 registers) are gone from the loop, which is what
+//     lets the scheduler keep the four words of a 2-D plan in flight together instead of spilling;
+//   * when every lane of the wavefront is FAR -- both 2-D problems with d = D / radius >= 36 (paths of more than 36 turning
+//     radii; the benchmark circle's are 10^4) -- a candidate is one straight-line block: every arctangent of a far problem is
+//     glibc's case (i) with a quotient below 1/16 (|y| <= 2 against x >= d - 2, or 2 against p >= sqrt(d^2 - 4 d - 4)), i.e. the
+//     polynomial piece and nothing else (atan_far: the same operations on the same values as sca_gm::atan2_core takes for such
+//     arguments); every word is feasible (p^2 > 0); both CCC words are infeasible (their |tmp| > 1).  Anything else -- a lane
+//     that is not far, a quotient below 2^-56 (glibc's early return), a non-finite value -- sends the whole wavefront's
+//     candidate through try_to_construct above.
+namespace lean {
+using sca_gm::fma_;
+#if defined(SCA_LEAN_STATS)
+#define SCA_LEAN_STAT(i) atomicAdd(&::g_lean_stats[i], 1ull)
+#else
+#define SCA_LEAN_STAT(i) ((void)0)
+#endif
+#if defined(SCA_LEAN_TIMING)
+#define SCA_LEAN_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#define SCA_LEAN_TACC(i, a, b) if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 || true) { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_)) atomicAdd(&::g_lean_stats[i], (b) - (a)); }
+#else
+#define SCA_LEAN_T(v) ((void)0)
+#define SCA_LEAN_TACC(i, a, b) ((void)0)
+#endif
+// sqrt for finite x >= 2^-767, x > 0 (sca_gm::sqrt_ without its select for +-0 / inf)
+SCA_DHD static inline double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y, h0 = y * 0.5;
+    const double r0 = fma_(-h0, s0, 0.5);
+    const double s1 = fma_(s0, r0, s0), h1 = fma_(h0, r0, h0);
+    const double d0 = fma_(-s1, s1, x);
+    const double s2 = fma_(d0, h1, s1);
+    const double d1 = fma_(-s2, s2, x);
+    return fma_(d1, h1, s2);
+}
+// atan_far_n below: atan2(y, x) for 2^-400 < x < 2^100, 16 |y| < x -- case (i) of e_atan2.c with u < 1/16: the polynomial piece
+SCA_DHD static inline bool far_d(double d) { return d >= 7.0 && d < 1.2676506002282294e30; }
+// ---- lock-step forms -----------------------------------------------------------------------------------------------------
+// A dependent fp64 fma on gfx950 returns after ~13 cycles while the SIMD could issue one every 4 (measured: a chain of fmas
+// 5.7 ns per link, four interleaved chains 2.05 ns per fma, scratch/mb2/ilp.hip) -- and the compiler's scheduler, which believes
+// the latency is the issue time, leaves Horner chains and Newton steps back to back.  So the N independent evaluations a 2-D
+// problem consists of (four words: four square roots, six arctangents, eight mod2pi) are written as rows: statement k of
+// all N evaluations, then statement k + 1 of all N ...  Same operations on the same values; only the order in the instruction
+// stream differs.  SCA_LEAN_ROW (optional) pins the rows with scheduling barriers.
+#if defined(SCA_LEAN_SB)
+#define SCA_LEAN_ROW() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCA_LEAN_ROW() ((void)0)
+#endif
+#define SCA_ROW(N, ...) { _Pragma("unroll") for (int k = 0; k < (N); k++) { __VA_ARGS__; } SCA_LEAN_ROW(); }
+template <int N> SCA_DHD static inline void sqrt_pos_n(const double (&x)[N], double (&out)[N]) {
+    double y[N], s[N], h[N], r[N], d[N];
+    SCA_ROW(N, y[k] = __builtin_amdgcn_rsq(x[k]))
+    SCA_ROW(N, s[k] = x[k] * y[k]; h[k] = y[k] * 0.5)
+    SCA_ROW(N, r[k] = fma_(-h[k], s[k], 0.5))
+    SCA_ROW(N, s[k] = fma_(s[k], r[k], s[k]); h[k] = fma_(h[k], r[k], h[k]))
+    SCA_ROW(N, d[k] = fma_(-s[k], s[k], x[k]))
+    SCA_ROW(N, s[k] = fma_(d[k], h[k], s[k]))
+    SCA_ROW(N, d[k] = fma_(-s[k], s[k], x[k]))
+    SCA_ROW(N, out[k] = fma_(d[k], h[k], s[k]))
+}
+// atan_far for N argument pairs (see atan_far: recip_of / div_by twice, the polynomial, the tail).  kmin: the running minimum of
+// hiword(u) - 1 (unsigned) over the first NK pairs -- a quotient 0 < u < 2^-56 (where glibc leaves this piece) shows as a key below
+// 0x3c6fffff, u == 0 (glibc's piece for y == 0 too) wraps to the top: one comparison per candidate instead of two per arctangent
+template <int N, int NK> SCA_DHD static inline void atan_far_n(const double (&y)[N], const double (&x)[N], double (&out)[N], uint32_t &kmin) {
+    using namespace sca_gm;                                              // (the table macros name its arrays)
+    double ay[N], r[N], e[N], u[N], v0[N], vv[N], w[N], q[N], du[N], vs[N], ps[N], uv[N];
+    SCA_ROW(N, ay[k] = sca_gm::fabs_(y[k]); r[k] = __builtin_amdgcn_rcp(x[k]))
+    SCA_ROW(N, e[k] = fma_(-x[k], r[k], 1.0))
+    SCA_ROW(N, r[k] = fma_(e[k], r[k], r[k]))
+    SCA_ROW(N, e[k] = fma_(-x[k], r[k], 1.0))
+    SCA_ROW(N, r[k] = fma_(e[k], r[k], r[k]))
+    SCA_ROW(N, u[k] = ay[k] * r[k])
+    SCA_ROW(N, e[k] = fma_(-x[k], u[k], ay[k]))
+    SCA_ROW(N, u[k] = fma_(e[k], r[k], u[k]))
+    // from here two chains per pair: the quotient's low part (du) and the polynomial in u^2
+    SCA_ROW(N, v0[k] = x[k] * u[k]; vs[k] = u[k] * u[k])
+    SCA_ROW(N, vv[k] = fma_(x[k], u[k], -v0[k]); w[k] = ay[k] - v0[k]; ps[k] = sca_gm::fma_k(vs[k], sca_gm::dbl(0x3fb375f08b31cbceull), sca_gm::dbl(0xbfb7458022b13c25ull)); uv[k] = u[k] * vs[k])
+    SCA_ROW(N, w[k] = w[k] - vv[k]; ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0x3fbc71c6e5129a3bull)))
+    SCA_ROW(N, q[k] = w[k] * r[k]; ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0xbfc24924923f7603ull)))
+    SCA_ROW(N, e[k] = fma_(-x[k], q[k], w[k]); ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0x3fc99999999997fdull)))
+    SCA_ROW(N, du[k] = fma_(e[k], r[k], q[k]); ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0xbfd5555555555555ull)))
+    SCA_ROW(N, e[k] = fma_(uv[k], ps[k], du[k]))
+    SCA_ROW(N, e[k] = u[k] + e[k])
+    // u >= 1/16 in some lane: the table piece (cij) for everybody, selected per pair
+    bool small[N], all_small = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) { small[k] = u[k] < 0.0625; all_small = all_small && small[k]; }
+    if (sca_gm::any_lane(!all_small)) {
+        // (in groups of at most three pairs: seven coefficients per pair are 14 registers each)
+        const double two52 = sca_gm::dbl(0x4330000000000000ull);
+        constexpr int G = N > 3 ? 3 : N;
+#pragma unroll
+        for (int g = 0; g < N; g += G) {
+            double c0[G], c1[G], c2[G], c3[G], c4[G], c5[G], c6[G], t3[G], v[G], p3[G], bb[G], dv[G], ww[G]; int idx[G];
+            SCA_ROW(G, t3[k] = fma_(u[g + k], 256.0, two52))
+            SCA_ROW(G, idx[k] = (int)(t3[k] - two52) - 16; idx[k] = idx[k] < 0 ? 0 : (idx[k] > 240 ? 240 : idx[k]))
+            SCA_ROW(G, const uint64_t *c = SCA_GM_ATAN_TAB + 7 * idx[k]; c0[k] = tab(c, 0); c1[k] = tab(c, 1); c2[k] = tab(c, 2);
+                       c3[k] = tab(c, 3); c4[k] = tab(c, 4); c5[k] = tab(c, 5); c6[k] = tab(c, 6))
+            SCA_ROW(G, t3[k] = u[g + k] - c0[k])
+            SCA_ROW(G, v[k] = t3[k] + du[g + k])
+            SCA_ROW(G, p3[k] = fma_(v[k], c6[k], c5[k]); bb[k] = v[k] - t3[k])
+            SCA_ROW(G, p3[k] = fma_(v[k], p3[k], c4[k]); dv[k] = t3[k] - (v[k] - bb[k]); bb[k] = du[g + k] - bb[k])
+            SCA_ROW(G, p3[k] = fma_(v[k], p3[k], c3[k]); dv[k] = dv[k] + bb[k]; ww[k] = v[k] * v[k])
+            SCA_ROW(G, ww[k] = ww[k] * p3[k])
+            SCA_ROW(G, ww[k] = fma_(dv[k], c2[k], ww[k]))
+            SCA_ROW(G, ww[k] = fma_(v[k], c2[k], ww[k]))
+            SCA_ROW(G, e[g + k] = small[g + k] ? e[g + k] : ww[k] + c1[k])
+        }
+    }
+    SCA_ROW(N, out[k] = sca_gm::copysign_(e[k], y[k]))
+#pragma unroll
+    for (int k = 0; k < NK; k++) { const uint32_t key = (uint32_t)sca_gm::hiword(u[k]) - 1u; kmin = key < kmin ? key : kmin; }
+}
+SCA_DHD static inline bool keys_odd(uint32_t kmin) { return kmin < 0x3c6fffffu; }
+// mod2pi for N arguments: the device form above with its exact scalings by two folded into the constants (x = t / 2 is never
+// formed: q0 = t * fl(1 / 2 pi), the residual against 2 pi is twice the residual against pi, and half of fl(1 / pi) takes it back)
+template <int N> SCA_DHD static inline void mod2pi_n(const double (&t)[N], double (&out)[N]) {
+    double q[N], r[N];
+    SCA_ROW(N, q[k] = t[k] * 0.15915494309189535)
+    SCA_ROW(N, r[k] = std::fma(-q[k], 2.0 * PI, t[k]))
+    SCA_ROW(N, q[k] = std::fma(r[k], 0.15915494309189535, q[k]))
+    SCA_ROW(N, q[k] = std::floor(q[k]))
+    SCA_ROW(N, q[k] = 2.0 * PI * q[k])
+    SCA_ROW(N, out[k] = t[k] - q[k])
+}
+// the four CSC words of a far 2-D problem: the shortest word's cost, its first segment and whether it starts with a right turn
+template <bool WINNER>
+SCA_DHD static inline double words_far(const Frame2D &F, double mbeta, double d, double c, uint32_t &kmin, double &bt, bool &bright) {
+    const double cab2 = 2 * F.c_ab, d2 = d * d, dd = 2 * d;
+    double p2[4], y6[6], x6[6], p[4], A[6];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const bool cross = w >= 2, rfirst = (w & 1) != 0;
+        const double u = rfirst ? -F.sa : F.sa;                // LSL(+,-) RSR(-,+) LSR(+,+) RSL(-,-)
+        const double v = (w == 0 || w == 3) ? -F.sb : F.sb;
+        const double S = u + v;
+        const double k2 = cross ? -2.0 : 2.0;
+        p2[w] = ((k2 + d2) + (cross ? cab2 : -cab2)) + (dd * S);
+        x6[w] = (d + u) + v;
+        const double ya = (w == 0 || w == 2) ? -F.ca : F.ca;
+        const double yb = (w == 1 || w == 2) ? -F.cb : F.cb;
+        y6[w] = ya + yb;
+    }
+    SCA_LEAN_ROW();
+    sqrt_pos_n<4>(p2, p);
+    y6[4] = -2.0; x6[4] = p[2];                                 // LSR's and RSL's second arctangent
+    y6[5] = 2.0; x6[5] = p[3];
+    atan_far_n<6, 4>(y6, x6, A, kmin);                          // (the quotients 2 / p of the last two cannot be tiny)
+    double arg[8], m[8];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const bool rfirst = (w & 1) != 0;
+        const double tmp = w >= 2 ? A[w] - A[w + 2] : A[w];     // LSL / RSR: their second arctangent is atan2(+0, p) = +0
+        const double ta = tmp - F.alpha;
+        arg[w] = rfirst ? -ta : ta;
+        const double qa = (w == 2 ? mbeta : F.beta) - tmp;
+        arg[4 + w] = (w == 1 || w == 2) ? -qa : qa;
+    }
+    SCA_LEAN_ROW();
+    mod2pi_n<8>(arg, m);
+    double cost[4];
+    SCA_ROW(4, cost[k] = std::fabs(m[k]) + std::fabs(p[k]))
+    SCA_ROW(4, cost[k] = cost[k] + std::fabs(m[4 + k]))
+    SCA_ROW(4, cost[k] = c * cost[k])
+    double bcost = INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (WINNER) {
+            const bool lt = bcost > cost[w];
+            bcost = lt ? cost[w] : bcost; bt = lt ? m[w] : bt; bright = lt ? (w & 1) != 0 : bright;
+        } else bcost = sca_gm::min_(bcost, cost[w]);
+    }
+    return bcost;
+}
+// sin and cos of three arguments below 105414350 in magnitude, in rows: sca_gm::sincos_bf<3> statement for statement (one do_sin
+// and one do_cos per argument; see there), with ONE wavefront-uniform decision for all three -- whether any do_sin argument
+// needs the table piece -- instead of two inside every call.  sn[2] is computed and not used by the caller (cos(alpha - beta)).
+SCA_DHD static inline void sincos3(const double (&x)[3], double (&sn)[3], double (&cs)[3]) {
+    using namespace sca_gm;
+    constexpr int N = 3;
+    const double hp0 = dbl(0x3ff921fb54442d18ull), hp1 = dbl(0x3c91a62633145c07ull);
+    const double toint = dbl(0x4338000000000000ull), big = dbl(0x42c8000000000000ull);
+    const double mp1 = dbl(0x3ff921fb58000000ull), mp2 = dbl(0xbe4dde973c000000ull);
+    const double pp3 = dbl(0xbc8cb3b398000000ull), pp4 = dbl(0xbacd747f23e32ed7ull);
+    int32_t hx[N]; bool r1[N], r2[N]; uint32_t n[N];
+    double t[N], xn[N], y[N], t2[N], d1[N], a3[N], d2[N], da3[N], tt[N], a2[N], da2[N], aS[N], dS[N], aC[N], dC[N], S[N], C[N];
+    SCA_ROW(N, hx[k] = hiword(x[k]) & 0x7fffffff; r1[k] = hx[k] < 0x3feb6000; r2[k] = hx[k] < 0x400368fd)
+    // reduce_sincos (range 3) and the range-2 arguments
+    SCA_ROW(N, t[k] = fma_(x[k], dbl(0x3fe45f306dc9c883ull), toint); tt[k] = hp0 - fabs_(x[k]))
+    SCA_ROW(N, xn[k] = t[k] - toint; n[k] = loword(t[k]); a2[k] = tt[k] + hp1)
+    SCA_ROW(N, y[k] = fma_(-xn[k], mp1, x[k]); da2[k] = (tt[k] - a2[k]) + hp1)
+    SCA_ROW(N, y[k] = fma_(-xn[k], mp2, y[k]))
+    SCA_ROW(N, t2[k] = fma_(-xn[k], pp3, y[k]))
+    SCA_ROW(N, d1[k] = fma_(-pp3, xn[k], y[k] - t2[k]); a3[k] = fma_(-xn[k], pp4, t2[k]))
+    SCA_ROW(N, d2[k] = fma_(-xn[k], pp4, t2[k] - a3[k]))
+    SCA_ROW(N, da3[k] = d1[k] + d2[k])
+    SCA_ROW(N, aS[k] = sel(r1[k], x[k], sel(r2[k], a2[k], a3[k])); dS[k] = sel(r1[k], 0.0, sel(r2[k], da2[k], da3[k]));
+               aC[k] = sel(r1[k], x[k], sel(r2[k], tt[k], a3[k])); dC[k] = sel(r1[k], 0.0, sel(r2[k], hp1, da3[k])))
+    // do_cos of (aC, dC): the table piece
+    {
+        double db[N], aa[N], u[N], xx[N], xr[N], p[N], s[N], q[N], c[N], cor[N]; int ki[N];
+        SCA_ROW(N, db[k] = flip(dC[k], aC[k] < 0); aa[k] = fabs_(aC[k]))
+        SCA_ROW(N, u[k] = aa[k] + big)
+        SCA_ROW(N, xr[k] = (aa[k] - (u[k] - big)) + db[k]; ki[k] = (int)(loword(u[k]) << 2); ki[k] = ki[k] < 0 ? 0 : (ki[k] > 436 ? 436 : ki[k]))
+        SCA_ROW(N, xx[k] = xr[k] * xr[k])
+        SCA_ROW(N, p[k] = fma_k(xx[k], dbl(0x3f811110e829872full), dbl(0xbfc5555555555515ull)); q[k] = fma_k(xx[k], dbl(0x3f56c16bedd9e239ull), dbl(0xbfa5555555555535ull)); s[k] = xr[k] * xx[k])
+        SCA_ROW(N, s[k] = fma_(s[k], p[k], xr[k]); q[k] = fma_k(xx[k], q[k], 0.5))
+        SCA_ROW(N, c[k] = xx[k] * q[k])
+        SCA_ROW(N, cor[k] = fma_(-s[k], tab(SCA_GM_SINCOS_TAB, ki[k] + 1), tab(SCA_GM_SINCOS_TAB, ki[k] + 3)))
+        SCA_ROW(N, cor[k] = fma_(-c[k], tab(SCA_GM_SINCOS_TAB, ki[k] + 2), cor[k]))
+        SCA_ROW(N, cor[k] = fma_(-s[k], tab(SCA_GM_SINCOS_TAB, ki[k]), cor[k]))
+        SCA_ROW(N, C[k] = tab(SCA_GM_SINCOS_TAB, ki[k] + 2) + cor[k])
+    }
+    // do_sin of (aS, dS): TAYLOR_SIN, and the table piece when some lane's argument is 0.126 or more
+    bool tay[N];
+    {
+        double xxt[N], pt[N], w[N];
+        SCA_ROW(N, tay[k] = fabs_(aS[k]) < 0.126; xxt[k] = aS[k] * aS[k])
+        SCA_ROW(N, pt[k] = fma_k(xxt[k], dbl(0xbe5addffc2fcdf59ull), dbl(0x3ec71de27b9a7ed9ull)))
+        SCA_ROW(N, pt[k] = fma_k(xxt[k], pt[k], dbl(0xbf2a01a019db08b8ull)))
+        SCA_ROW(N, pt[k] = fma_k(xxt[k], pt[k], dbl(0x3f81111111110eceull)))
+        SCA_ROW(N, pt[k] = fma_k(xxt[k], pt[k], dbl(0xbfc5555555555555ull)))
+        SCA_ROW(N, w[k] = fma_(pt[k], aS[k], -(dS[k] * 0.5)))
+        SCA_ROW(N, w[k] = fma_(xxt[k], w[k], dS[k]))
+        SCA_ROW(N, S[k] = w[k] + aS[k])
+    }
+    if (any_lane(!(tay[0] && tay[1] && tay[2]))) {
+        double db[N], aa[N], u[N], xx[N], xr[N], p[N], s[N], q[N], c[N], cor[N]; int ki[N];
+        SCA_ROW(N, db[k] = flip(dS[k], aS[k] <= 0); aa[k] = fabs_(aS[k]))
+        SCA_ROW(N, u[k] = aa[k] + big)
+        SCA_ROW(N, xr[k] = aa[k] - (u[k] - big); ki[k] = (int)(loword(u[k]) << 2); ki[k] = ki[k] < 0 ? 0 : (ki[k] > 436 ? 436 : ki[k]))
+        SCA_ROW(N, xx[k] = xr[k] * xr[k])
+        SCA_ROW(N, p[k] = fma_k(xx[k], dbl(0x3f811110e829872full), dbl(0xbfc5555555555515ull)); q[k] = fma_k(xx[k], dbl(0x3f56c16bedd9e239ull), dbl(0xbfa5555555555535ull)); s[k] = xr[k] * xx[k])
+        SCA_ROW(N, s[k] = fma_(s[k], p[k], db[k]); q[k] = fma_k(xx[k], q[k], 0.5))
+        SCA_ROW(N, s[k] = xr[k] + s[k]; c[k] = xx[k] * q[k])
+        SCA_ROW(N, c[k] = fma_(xr[k], db[k], c[k]))
+        SCA_ROW(N, cor[k] = fma_(s[k], tab(SCA_GM_SINCOS_TAB, ki[k] + 3), tab(SCA_GM_SINCOS_TAB, ki[k] + 1)))
+        SCA_ROW(N, cor[k] = fma_(-c[k], tab(SCA_GM_SINCOS_TAB, ki[k]), cor[k]))
+        SCA_ROW(N, cor[k] = fma_(s[k], tab(SCA_GM_SINCOS_TAB, ki[k] + 2), cor[k]))
+        SCA_ROW(N, S[k] = sel(tay[k], S[k], copysign_(tab(SCA_GM_SINCOS_TAB, ki[k]) + cor[k], aS[k])))
+    }
+    // sin: r1 do_sin; r2 copysign(do_cos, x); r3 (n & 1 ? do_cos : do_sin), negated when n & 2.  cos: r1 do_cos; r2 do_sin; r3 with n + 1.
+    // |x| < 2^-26: sin(x) = x; |x| < 2^-27: cos(x) = 1
+    SCA_ROW(N, const bool odd = (n[k] & 1) != 0; const uint32_t m = n[k] + 1;
+               const double s3 = flip(sel(odd, C[k], S[k]), (n[k] & 2) != 0), c3 = flip(sel((m & 1) != 0, C[k], S[k]), (m & 2) != 0);
+               const double sv = sel(r1[k], S[k], sel(r2[k], copysign_(C[k], x[k]), s3)), cv = sel(r1[k], C[k], sel(r2[k], S[k], c3));
+               sn[k] = hx[k] < 0x3e500000 ? x[k] : sv; cs[k] = hx[k] < 0x3e400000 ? 1.0 : cv)
+}
+// a candidate by the literal construction: a function of its own (called, cold) so that the search loop's code stays small
+#if defined(SCA_LEAN_GENERAL_INLINE)
+SCA_DHD static inline
+#else
+SCA_DHD static __attribute__((noinline))
+#endif
+bool candidate_general(const Frame2D &H, const SearchConst &K, const double qi[5], const double qf[5], double Rmin,
+                       const double pitchlims[2], double hr, double &len) {
+    Maneuver2D mh, mv;
+    const int n = try_to_construct(H, K, qi, qf, Rmin, pitchlims, hr, mh, mv);
+    len = mv.length;
+    return n > 0;
+}
+// one candidate radius: feasible?  len = the 3-D path's length.  (try_to_construct + what the search reads of its result)
+#if defined(SCA_LEAN_CAND_NOINLINE)
+SCA_DHD static __attribute__((noinline))
+#else
+SCA_DHD static inline
+#endif
+bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst &K, const double qi[5], const double qf[5], double Rmin,
+               const double pitchlims[2], double hr, double &len) {
+#if defined(SCA_LEAN_WAVEITERS)
+    { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_)) atomicAdd(&::g_wave_iters[threadIdx.x >> 6], 1); }
+#endif
+    const double dH = H.D / hr;                                                       // (plan2d)
+    if (fast_ok && !sca_gm::any_lane(!far_d(dH))) {
+        uint32_t kmin = 0xffffffffu;
+        SCA_LEAN_T(t0);
+        const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / sca_gm::g_pow2_main(hr));    // (hr = Rmin c: inside pow2's main range, plan3d_lean checks Rmin)
+        const bool flat = vc < 1e-5;                                                  // :146-147 (a lane that leaves here computes on, unread)
+        SCA_LEAN_T(t1);
+        double dummy_t = 0.0; bool dummy_r = false;
+        const double lenH = words_far<false>(H, mbetaH, dH, hr, kmin, dummy_t, dummy_r);
+        SCA_LEAN_T(t2);
+        const double vr = 1.0 / (flat ? 1.0 : vc);
+        // frame2d_vertical
+        const double dz = qf[2] - qi[2];
+        Frame2D F;
+        F.D = sqrt_pos(sca_gm::g_pow2_main(lenH) + K.dz2);                            // (36 hr <= lenH < 2^100 when nothing below objects)
+        const bool far_theta = lenH > std::fabs(dz) && lenH < 1.2676506002282294e30;
+        const double y1[1] = {dz}, x1[1] = {lenH};
+        double th[1];
+        atan_far_n<1, 1>(y1, x1, th, kmin);
+        const double theta = mod2pi(th[0]);
+        F.alpha = mod2pi(qi[4] - theta);
+        F.beta = mod2pi(qf[4] - theta);
+        SCA_LEAN_T(t3);
+        const double x3[3] = {F.alpha, F.beta, F.alpha - F.beta};
+        double s3[3], c3[3];
+        sincos3(x3, s3, c3);
+        F.sa = s3[0]; F.ca = c3[0]; F.sb = s3[1]; F.cb = c3[1]; F.c_ab = c3[2];
+        const double dV = F.D / vr;
+        SCA_LEAN_T(t4);
+        double t = 0.0; bool right = false;
+        const double lenV = words_far<true>(F, mod2pi(F.beta), dV, vr, kmin, t, right);
+        const bool ok = !flat && !(right ? (qi[4] - t < pitchlims[0]) : (qi[4] + t > pitchlims[1]));
+        SCA_LEAN_T(t5);
+        SCA_LEAN_TACC(0, t0, t1); SCA_LEAN_TACC(1, t1, t2); SCA_LEAN_TACC(2, t2, t3); SCA_LEAN_TACC(3, t3, t4); SCA_LEAN_TACC(4, t4, t5); SCA_LEAN_TACC(5, 0ull, 1ull);
+        if (!sca_gm::any_lane(!flat && (keys_odd(kmin) || !far_theta || !far_d(dV)))) { SCA_LEAN_STAT(0); len = lenV; return ok; }
+        SCA_LEAN_STAT(1);
+    }
+    SCA_LEAN_STAT(2);
+    return candidate_general(H, K, qi, qf, Rmin, pitchlims, hr, len);
+}
+}  // namespace lean
+SCA_DHD static Plan3D plan3d_lean(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2]) {
+    Plan3D P;
+#if defined(SCA_LEAN_TIMING)
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
+    const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
+    const Frame2D H = frame2d(qi2D, qf2D);
+    const double mbetaH = mod2pi(H.beta);
+    const SearchConst K = search_const(qi, qf, Rmin);
+    // the lean form squares Rmin c without pow's range checks: c <= 2^201 (the doubling stage's guard), so
+    const bool fast_ok = !sca_gm::any_lane(!(Rmin >= 1e-40 && Rmin <= 1e40));
+    double b = 1.0, best = 0.0;
+    bool fb = lean::candidate(fast_ok, H, mbetaH, K, qi, qf, Rmin, pitchlims, Rmin * b, best);
+    int guard = 0;
+    P.iters = 1;
+    while (!fb) {
+        b *= 2.0;
+        fb = lean::candidate(fast_ok, H, mbetaH, K, qi, qf, Rmin, pitchlims, Rmin * b, best);
+        P.iters++;
+        if (++guard > 200) return P;
+    }
+    double step = 0.1;
+    while (std::fabs(step) > 1e-10) {
+        double c = b + step;
+        if (c < 1.0) c = 1.0;
+        P.iters++;
+        double lc;
+        const bool fc = lean::candidate(fast_ok, H, mbetaH, K, qi, qf, Rmin, pitchlims, Rmin * c, lc);
+        if (fc && lc < best) { b = c; best = lc; step *= 2.; continue; }
+        step *= -0.1;
+    }
+#if defined(SCA_LEAN_TIMING)
+    { const unsigned long long tl = __builtin_readcyclecounter(); atomicMax(&::g_lean_stats[6], tl - t_begin); if ((threadIdx.x & 63) == 0) atomicAdd(&::g_lean_stats[7], tl - t_begin); }
+#endif
+    Maneuver2D fbh, fbv;
+    try_to_construct(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv);      // the winner's maneuvers (the candidate evaluated again)
+    finish_plan(P, fbh, fbv, qi);
+    return P;
+}
+#define SCA_PLAN3D_LANE plan3d_lean
+#else
+#define SCA_PLAN3D_LANE plan3d
+#endif
+
 // ---- the tracker (scaPolicy.py:243-338) ------------------------------------------------------------------------------
 struct AgentTrack {
     bool is_use_dubins = false;
@@ -520,7 +883,7 @@ SCA_DHD static void compute_dubins(TrackView T, AgentTrack &a, int i, const doub
     double qi[5], qf[5];
     dubins_endpoints(T, i, pos, heading, qi, qf);
     const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    adopt_plan(a, plan3d(qi, qf, T.turning_radius, pl));
+    adopt_plan(a, SCA_PLAN3D_LANE(qi, qf, T.turning_radius, pl));
 }
 SCA_DHD static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
 SCA_DHD static bool path_pop(AgentTrack &a, double out[3]) {

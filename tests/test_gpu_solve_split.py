@@ -131,9 +131,10 @@ def test_split_beside_the_replans_equals_one_launch(S, monkeypatch, n):
 
 
 def test_forms_the_library_picks_by_itself(S):
-    """No switches: a large tracked shard on the circle (nearly every agent re-plans every step) gets the fused tracker kernel and
-    the split solve once the first re-plan count has come back; a small one keeps k_track + k_replan_few and the one-launch
-    k_solve; without the tracker nothing is split."""
+    """No switches: a large tracked shard on the circle (nearly every agent re-plans every step) gets the lane-per-plan re-plan
+    kernel behind k_track (the fused k_track_replan is opt-in since round 3: SCA_TRACKER_FUSE) and the split solve once the
+    first re-plan count has come back; a small one keeps k_track + k_replan_few and the one-launch k_solve; without the tracker
+    nothing is split."""
     from sca_amd import scenarios
 
     def run(n, tracker, steps):
@@ -153,7 +154,7 @@ def test_forms_the_library_picks_by_itself(S):
         return f
 
     big = run(60000, True, 16)
-    assert big & S.FORM_SOLVE_SPLIT and big & S.FORM_TRACK_FUSED and big & S.FORM_REPLAN_LANE and not big & S.FORM_REPLAN_FEW, big
+    assert big & S.FORM_SOLVE_SPLIT and big & S.FORM_REPLAN_LANE and not big & (S.FORM_REPLAN_FEW | S.FORM_TRACK_FUSED), big
     small = run(3000, True, 16)
     assert small & S.FORM_REPLAN_FEW and not small & (S.FORM_SOLVE_SPLIT | S.FORM_TRACK_FUSED | S.FORM_REPLAN_LANE), small
     assert run(60000, False, 3) == 0
@@ -161,7 +162,7 @@ def test_forms_the_library_picks_by_itself(S):
 
 def test_long_tracked_episode_all_forms_against_the_plain_ones(S, monkeypatch):
     """A soak for the stream choreography: 240 resident steps of a 60 000-agent tracked shard with everything the library
-    picks by itself (split solve on two streams, k_track_replan, count readbacks, form switches as the re-plan count moves)
+    can pick (split solve on two streams, k_track_replan switched on, count readbacks, form switches as the re-plan count moves)
     against the same episode with the plain forms (k_track + k_replan, one-launch k_solve), compared every 20 steps."""
     from sca_amd import scenarios
     n = 60000
@@ -170,9 +171,9 @@ def test_long_tracked_episode_all_forms_against_the_plain_ones(S, monkeypatch):
     sols = []
     for plain in (True, False):
         if plain:
-            monkeypatch.setenv('SCA_SOLVE_SPLIT', '0'); monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1')
-        else:
-            monkeypatch.delenv('SCA_SOLVE_SPLIT', raising=False); monkeypatch.delenv('SCA_TRACKER_NOFUSE', raising=False)
+            monkeypatch.setenv('SCA_SOLVE_SPLIT', '0'); monkeypatch.setenv('SCA_TRACKER_NOFUSE', '1'); monkeypatch.delenv('SCA_TRACKER_FUSE', raising=False)
+        else:                                          # (the fused tracker kernel is opt-in since round 3: covered here)
+            monkeypatch.delenv('SCA_SOLVE_SPLIT', raising=False); monkeypatch.delenv('SCA_TRACKER_NOFUSE', raising=False); monkeypatch.setenv('SCA_TRACKER_FUSE', '1')
         sol = S.BatchedSolver(max_agents=n)
         sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
         sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], policy, S.zaxis_flags(sc['start'], sc['goal']),

@@ -10,21 +10,36 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#if defined(SCA_LEAN_STATS) || defined(SCA_LEAN_TIMING)
+__device__ unsigned long long g_lean_stats[8];
+#endif
+#if defined(SCA_LEAN_WAVEITERS)
+__shared__ int g_wave_iters[4];
+#endif
 #include "sca_dubins.hpp"
 
 #ifndef PB_BOUNDS
 #define PB_BOUNDS 2
 #endif
 __global__ __launch_bounds__(256, PB_BOUNDS) void k_plan(const double *q, int n, double *len, int *iters) {
+#if defined(SCA_LEAN_WAVEITERS)
+    if (threadIdx.x < 4) g_wave_iters[threadIdx.x] = 0;
+    const unsigned long long tb = __builtin_readcyclecounter();
+#endif
     sca_gm::lds_tables_load();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double qi[5], qf[5];
     for (int k = 0; k < 5; k++) { qi[k] = q[10 * i + k]; qf[k] = q[10 * i + 5 + k]; }
     const double pl[2] = {-M_PI / 4, M_PI / 4};
-    const sca_dubins::Plan3D P = sca_dubins::plan3d(qi, qf, 1.5, pl);
+    const sca_dubins::Plan3D P = sca_dubins::SCA_PLAN3D_LANE(qi, qf, 1.5, pl);
     len[i] = P.length + P.h.r_min * 1e-3 + P.v.t;
     iters[i] = P.iters;
+#if defined(SCA_LEAN_WAVEITERS)
+    const unsigned long long te = __builtin_readcyclecounter();
+    len[i] = (double)(te - tb);                     // (the checksum is void in this build)
+    iters[i] = g_wave_iters[threadIdx.x >> 6];
+#endif
 }
 
 int main(int argc, char **argv) {
@@ -86,10 +101,27 @@ int main(int argc, char **argv) {
         }
     }
     hipMemcpy(l.data(), dl, n * 8, hipMemcpyDeviceToHost); hipMemcpy(it.data(), di, n * 4, hipMemcpyDeviceToHost);
+#if defined(SCA_LEAN_WAVEITERS)
+    { double cy = 0, itw = 0, mxc = 0, mxi = 0; int nw = 0;
+      for (int i = 0; i < n; i += 64) { double c = 0; for (int k = i; k < i + 64 && k < n; k++) c = std::max(c, l[k]); cy += c; itw += it[i]; mxc = std::max(mxc, c); mxi = std::max(mxi, (double)it[i]); nw++; }
+      printf("  waves %d: mean %.0f cycles, %.1f wave-iterations (%.0f cycles each); max %.0f cycles, max %.0f iterations\n", nw, cy / nw, itw / nw, cy / itw, mxc, mxi); }
+#endif
     double sum = 0; long its = 0; int mx = 0; unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < n; i++) { sum += l[i]; its += it[i]; if (it[i] > mx) mx = it[i]; unsigned long long b; memcpy(&b, &l[i], 8); h = (h ^ b) * 1099511628211ull; }
     hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void *)k_plan);
     printf("%-28s n %d  %.4f ms  candidates/plan %.1f (max %d)  hash %016llx  vgprs %d scratch %d\n", argc > 3 ? argv[3] : "", n, best, (double)its / n, mx, h,
            fa.numRegs, (int)fa.localSizeBytes);
+#if defined(SCA_LEAN_TIMING)
+    { unsigned long long st[8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_lean_stats), sizeof st);
+    const double it = (double)st[5];
+    printf("  wave-candidates %.0f; cycles per candidate: vc %.0f  H words %.0f  V frame-a %.0f  V sincos %.0f  V words %.0f\n", it, st[0] / it, st[1] / it, st[2] / it, st[3] / it, st[4] / it);
+    printf("  search loop per lane: max %llu cycles, lane-0 sum %llu cycles (launches included: all)\n", st[6], st[7]); }
+#endif
+#if defined(SCA_LEAN_STATS)
+    unsigned long long st[8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_lean_stats), sizeof st);
+    printf("  lean stats: fast %llu  fast-then-general %llu  general %llu | odd %llu !dom %llu !far_theta %llu !far_dV %llu\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+#endif
     return 0;
 }
