@@ -282,6 +282,13 @@ int sca_device_tracker_debug(sca_ctx *ctx, int agent, double *out24);
  * (dubinsmaneuver2d.py:33-109) as one sign-parametrised instruction stream; this compares it with the literal words on the
  * given frames (alpha, beta in [0, 2 pi), d >= 0) and counts results that are not bit-identical (must be 0) */
 int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, const double *d, int64_t *mismatches);
+/* host self-test (no GPU needed): the device's lane-per-plan kernels run the 3-D planner's search in a lean form (a candidate
+ * radius evaluated for feasibility and length only; far problems through a straight-line block; sca_dubins.hpp, plan3d_lean);
+ * this runs that form, compiled for the host, and the literal planner (dubinsmaneuver3d.py:34-113) on n poses q[n][10] =
+ * (qi[5], qf[5]) and counts plans that are not bit-identical (must be 0); the other two outputs (nullable) say how many
+ * candidates took the lean block and how many the literal construction */
+int sca_selftest_plan3d_lean(int n, const double *q, double turning_radius, double pitch_lo, double pitch_hi, int64_t *mismatches,
+                             int64_t *lean_candidates, int64_t *literal_candidates);
 
 /* host-only helpers (no GPU needed) ----------------------------------------------------------------- */
 /* unit Fibonacci directions of scaPolicy.py:195-200 (SoA [3][num_N]) and the get_phi numerators */

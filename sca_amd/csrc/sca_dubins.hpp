@@ -471,8 +471,8 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
     return P;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && (!defined(SCA_PLAN_LEAN) || SCA_PLAN_LEAN == 1)
-// ---- the lane-per-plan search, lean (device) --------------------------------------------------------------------------------
+#if !defined(SCA_PLAN_LEAN) || SCA_PLAN_LEAN == 1
+// ---- the lane-per-plan search, lean (device; compiled for the host as well, where tests compare it with plan3d) --------------------------------------------------------------------------------
 // plan3d above, for the kernels that give a plan one lane: the SAME candidates in the same order with the same verdicts, but
 //   * a candidate is evaluated for what the search reads of it -- feasible or not, and the length -- and the winning radius is
 //     constructed once more at the end for its maneuvers (the evaluation is a pure function of the radius): the four Maneuver2D
@@ -487,6 +487,20 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
 //     candidate through try_to_construct above.
 namespace lean {
 using sca_gm::fma_;
+static long long g_host_fast = 0, g_host_literal = 0;      // candidates by the lean block / by try_to_construct (host self-test only)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define SCA_LEAN_HOST_COUNT(x) (++(x))
+#else
+#define SCA_LEAN_HOST_COUNT(x) ((void)0)
+#endif
+// does any lane of the wavefront say so?  (host: the one caller)
+SCA_DHD static inline bool any_says(bool b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(b) != 0;
+#else
+    return b;
+#endif
+}
 #if defined(SCA_LEAN_STATS)
 #define SCA_LEAN_STAT(i) atomicAdd(&::g_lean_stats[i], 1ull)
 #else
@@ -501,6 +515,7 @@ using sca_gm::fma_;
 #endif
 // sqrt for finite x >= 2^-767, x > 0 (sca_gm::sqrt_ without its select for +-0 / inf)
 SCA_DHD static inline double sqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(x);
     const double s0 = x * y, h0 = y * 0.5;
     const double r0 = fma_(-h0, s0, 0.5);
@@ -509,6 +524,9 @@ SCA_DHD static inline double sqrt_pos(double x) {
     const double s2 = fma_(d0, h1, s1);
     const double d1 = fma_(-s2, s2, x);
     return fma_(d1, h1, s2);
+#else
+    return std::sqrt(x);
+#endif
 }
 // atan_far_n below: atan2(y, x) for 2^-400 < x < 2^100, 16 |y| < x -- case (i) of e_atan2.c with u < 1/16: the polynomial piece
 SCA_DHD static inline bool far_d(double d) { return d >= 7.0 && d < 1.2676506002282294e30; }
@@ -526,6 +544,7 @@ SCA_DHD static inline bool far_d(double d) { return d >= 7.0 && d < 1.2676506002
 #endif
 #define SCA_ROW(N, ...) { _Pragma("unroll") for (int k = 0; k < (N); k++) { __VA_ARGS__; } SCA_LEAN_ROW(); }
 template <int N> SCA_DHD static inline void sqrt_pos_n(const double (&x)[N], double (&out)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
     double y[N], s[N], h[N], r[N], d[N];
     SCA_ROW(N, y[k] = __builtin_amdgcn_rsq(x[k]))
     SCA_ROW(N, s[k] = x[k] * y[k]; h[k] = y[k] * 0.5)
@@ -535,13 +554,18 @@ template <int N> SCA_DHD static inline void sqrt_pos_n(const double (&x)[N], dou
     SCA_ROW(N, s[k] = fma_(d[k], h[k], s[k]))
     SCA_ROW(N, d[k] = fma_(-s[k], s[k], x[k]))
     SCA_ROW(N, out[k] = fma_(d[k], h[k], s[k]))
+#else
+    SCA_ROW(N, out[k] = std::sqrt(x[k]))
+#endif
 }
 // atan_far for N argument pairs (see atan_far: recip_of / div_by twice, the polynomial, the tail).  kmin: the running minimum of
-// hiword(u) - 1 (unsigned) over the first NK pairs -- a quotient 0 < u < 2^-56 (where glibc leaves this piece) shows as a key below
-// 0x3c6fffff, u == 0 (glibc's piece for y == 0 too) wraps to the top: one comparison per candidate instead of two per arctangent
+// hiword(u) - 1 (unsigned) over the first NK pairs -- a quotient 0 < u < 2^-1000 shows as a key below 0x016fffff, u == 0 (y == 0)
+// wraps to the top: one comparison per candidate
 template <int N, int NK> SCA_DHD static inline void atan_far_n(const double (&y)[N], const double (&x)[N], double (&out)[N], uint32_t &kmin) {
     using namespace sca_gm;                                              // (the table macros name its arrays)
-    double ay[N], r[N], e[N], u[N], v0[N], vv[N], w[N], q[N], du[N], vs[N], ps[N], uv[N];
+    double ay[N], e[N], u[N], v0[N], vv[N], w[N], du[N], vs[N], ps[N], uv[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r[N], q[N];
     SCA_ROW(N, ay[k] = sca_gm::fabs_(y[k]); r[k] = __builtin_amdgcn_rcp(x[k]))
     SCA_ROW(N, e[k] = fma_(-x[k], r[k], 1.0))
     SCA_ROW(N, r[k] = fma_(e[k], r[k], r[k]))
@@ -557,13 +581,19 @@ template <int N, int NK> SCA_DHD static inline void atan_far_n(const double (&y)
     SCA_ROW(N, q[k] = w[k] * r[k]; ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0xbfc24924923f7603ull)))
     SCA_ROW(N, e[k] = fma_(-x[k], q[k], w[k]); ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0x3fc99999999997fdull)))
     SCA_ROW(N, du[k] = fma_(e[k], r[k], q[k]); ps[k] = sca_gm::fma_k(vs[k], ps[k], sca_gm::dbl(0xbfd5555555555555ull)))
+#else
+    // host: the two quotients by the machine's division (what the device's reciprocal-and-correction sequences round to)
+    SCA_ROW(N, ay[k] = sca_gm::fabs_(y[k]); u[k] = ay[k] / x[k])
+    SCA_ROW(N, v0[k] = x[k] * u[k]; vs[k] = u[k] * u[k]; uv[k] = u[k] * vs[k])
+    SCA_ROW(N, vv[k] = fma_(x[k], u[k], -v0[k]); w[k] = (ay[k] - v0[k]) - vv[k]; du[k] = w[k] / x[k]; ps[k] = sca_gm::atan_poly_k(vs[k]))
+#endif
     SCA_ROW(N, e[k] = fma_(uv[k], ps[k], du[k]))
     SCA_ROW(N, e[k] = u[k] + e[k])
     // u >= 1/16 in some lane: the table piece (cij) for everybody, selected per pair
     bool small[N], all_small = true;
 #pragma unroll
     for (int k = 0; k < N; k++) { small[k] = u[k] < 0.0625; all_small = all_small && small[k]; }
-    if (sca_gm::any_lane(!all_small)) {
+    if (lean::any_says(!all_small)) {
         // (in groups of at most three pairs: seven coefficients per pair are 14 registers each)
         const double two52 = sca_gm::dbl(0x4330000000000000ull);
         constexpr int G = N > 3 ? 3 : N;
@@ -585,11 +615,19 @@ template <int N, int NK> SCA_DHD static inline void atan_far_n(const double (&y)
             SCA_ROW(G, e[g + k] = small[g + k] ? e[g + k] : ww[k] + c1[k])
         }
     }
-    SCA_ROW(N, out[k] = sca_gm::copysign_(e[k], y[k]))
+    // glibc's early return for exponent fields 57 or more apart (e_atan2.c: `de < -57`, x > 0): the quotient itself.  Only the
+    // first NK pairs can be that lopsided (the others are 2 / p)
 #pragma unroll
-    for (int k = 0; k < NK; k++) { const uint32_t key = (uint32_t)sca_gm::hiword(u[k]) - 1u; kmin = key < kmin ? key : kmin; }
+    for (int k = 0; k < NK; k++) {
+        const int32_t de = (hiword(ay[k]) & 0x7ff00000) - (hiword(x[k]) & 0x7ff00000);
+        e[k] = de < (int32_t)0xfc700001 ? u[k] : e[k];
+        const uint32_t key = (uint32_t)hiword(u[k]) - 1u;
+        kmin = key < kmin ? key : kmin;
+    }
+    SCA_ROW(N, out[k] = sca_gm::copysign_(e[k], y[k]))
 }
-SCA_DHD static inline bool keys_odd(uint32_t kmin) { return kmin < 0x3c6fffffu; }
+// (the lean division has no scaling for quotients near the bottom of the exponent range: 0 < u < 2^-1000 goes the literal way)
+SCA_DHD static inline bool keys_odd(uint32_t kmin) { return kmin < 0x016fffffu; }
 // mod2pi for N arguments: the device form above with its exact scalings by two folded into the constants (x = t / 2 is never
 // formed: q0 = t * fl(1 / 2 pi), the residual against 2 pi is twice the residual against pi, and half of fl(1 / pi) takes it back)
 template <int N> SCA_DHD static inline void mod2pi_n(const double (&t)[N], double (&out)[N]) {
@@ -650,12 +688,11 @@ SCA_DHD static inline double words_far(const Frame2D &F, double mbeta, double d,
     }
     return bcost;
 }
-// sin and cos of three arguments below 105414350 in magnitude, in rows: sca_gm::sincos_bf<3> statement for statement (one do_sin
+// sin and cos of N (three: the lane-per-plan search; one: a lane of the quad search) arguments below 105414350 in magnitude, in rows: sca_gm::sincos_bf<3> statement for statement (one do_sin
 // and one do_cos per argument; see there), with ONE wavefront-uniform decision for all three -- whether any do_sin argument
 // needs the table piece -- instead of two inside every call.  sn[2] is computed and not used by the caller (cos(alpha - beta)).
-SCA_DHD static inline void sincos3(const double (&x)[3], double (&sn)[3], double (&cs)[3]) {
+template <int N> SCA_DHD static inline void sincos_n(const double (&x)[N], double (&sn)[N], double (&cs)[N]) {
     using namespace sca_gm;
-    constexpr int N = 3;
     const double hp0 = dbl(0x3ff921fb54442d18ull), hp1 = dbl(0x3c91a62633145c07ull);
     const double toint = dbl(0x4338000000000000ull), big = dbl(0x42c8000000000000ull);
     const double mp1 = dbl(0x3ff921fb58000000ull), mp2 = dbl(0xbe4dde973c000000ull);
@@ -702,7 +739,10 @@ SCA_DHD static inline void sincos3(const double (&x)[3], double (&sn)[3], double
         SCA_ROW(N, w[k] = fma_(xxt[k], w[k], dS[k]))
         SCA_ROW(N, S[k] = w[k] + aS[k])
     }
-    if (any_lane(!(tay[0] && tay[1] && tay[2]))) {
+    bool all_tay = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) all_tay = all_tay && tay[k];
+    if (lean::any_says(!all_tay)) {
         double db[N], aa[N], u[N], xx[N], xr[N], p[N], s[N], q[N], c[N], cor[N]; int ki[N];
         SCA_ROW(N, db[k] = flip(dS[k], aS[k] <= 0); aa[k] = fabs_(aS[k]))
         SCA_ROW(N, u[k] = aa[k] + big)
@@ -749,7 +789,7 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
     { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_)) atomicAdd(&::g_wave_iters[threadIdx.x >> 6], 1); }
 #endif
     const double dH = H.D / hr;                                                       // (plan2d)
-    if (fast_ok && !sca_gm::any_lane(!far_d(dH))) {
+    if (fast_ok && !lean::any_says(!far_d(dH))) {
         uint32_t kmin = 0xffffffffu;
         SCA_LEAN_T(t0);
         const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / sca_gm::g_pow2_main(hr));    // (hr = Rmin c: inside pow2's main range, plan3d_lean checks Rmin)
@@ -773,7 +813,7 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
         SCA_LEAN_T(t3);
         const double x3[3] = {F.alpha, F.beta, F.alpha - F.beta};
         double s3[3], c3[3];
-        sincos3(x3, s3, c3);
+        sincos_n<3>(x3, s3, c3);
         F.sa = s3[0]; F.ca = c3[0]; F.sb = s3[1]; F.cb = c3[1]; F.c_ab = c3[2];
         const double dV = F.D / vr;
         SCA_LEAN_T(t4);
@@ -782,10 +822,11 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
         const bool ok = !flat && !(right ? (qi[4] - t < pitchlims[0]) : (qi[4] + t > pitchlims[1]));
         SCA_LEAN_T(t5);
         SCA_LEAN_TACC(0, t0, t1); SCA_LEAN_TACC(1, t1, t2); SCA_LEAN_TACC(2, t2, t3); SCA_LEAN_TACC(3, t3, t4); SCA_LEAN_TACC(4, t4, t5); SCA_LEAN_TACC(5, 0ull, 1ull);
-        if (!sca_gm::any_lane(!flat && (keys_odd(kmin) || !far_theta || !far_d(dV)))) { SCA_LEAN_STAT(0); len = lenV; return ok; }
+        if (!lean::any_says(!flat && (keys_odd(kmin) || !far_theta || !far_d(dV)))) { SCA_LEAN_STAT(0); SCA_LEAN_HOST_COUNT(g_host_fast); len = lenV; return ok; }
         SCA_LEAN_STAT(1);
     }
     SCA_LEAN_STAT(2);
+    SCA_LEAN_HOST_COUNT(g_host_literal);
     return candidate_general(H, K, qi, qf, Rmin, pitchlims, hr, len);
 }
 }  // namespace lean
@@ -799,7 +840,7 @@ SCA_DHD static Plan3D plan3d_lean(const double qi[5], const double qf[5], double
     const double mbetaH = mod2pi(H.beta);
     const SearchConst K = search_const(qi, qf, Rmin);
     // the lean form squares Rmin c without pow's range checks: c <= 2^201 (the doubling stage's guard), so
-    const bool fast_ok = !sca_gm::any_lane(!(Rmin >= 1e-40 && Rmin <= 1e40));
+    const bool fast_ok = !lean::any_says(!(Rmin >= 1e-40 && Rmin <= 1e40));
     double b = 1.0, best = 0.0;
     bool fb = lean::candidate(fast_ok, H, mbetaH, K, qi, qf, Rmin, pitchlims, Rmin * b, best);
     int guard = 0;
@@ -828,7 +869,9 @@ SCA_DHD static Plan3D plan3d_lean(const double qi[5], const double qf[5], double
     finish_plan(P, fbh, fbv, qi);
     return P;
 }
-#define SCA_PLAN3D_LANE plan3d_lean
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(SCA_PLAN_LEAN) || SCA_PLAN_LEAN == 1)
+#define SCA_PLAN3D_LANE plan3d_lean            // the device's lane-per-plan kernels
 #else
 #define SCA_PLAN3D_LANE plan3d
 #endif

@@ -353,6 +353,32 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
     return 0;
 }
 
+// host self-test: the lean search of the device's lane-per-plan kernels (sca_dubins.hpp, plan3d_lean, compiled for the host)
+// against the literal plan3d on the given poses, bit for bit
+int sca_selftest_plan3d_lean(int n, const double *q, double turning_radius, double pitch_lo, double pitch_hi, int64_t *mismatches,
+                             int64_t *lean_candidates, int64_t *literal_candidates) {
+    if (n < 0 || !q || !mismatches) return SCA_ERR_ARG;
+    const double pl[2] = {pitch_lo, pitch_hi};
+    auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0 || (a != a && b != b); };
+    int64_t bad = 0;
+    sca_dubins::lean::g_host_fast = sca_dubins::lean::g_host_literal = 0;
+    for (int i = 0; i < n; i++) {
+        const double *qi = q + 10 * (size_t)i, *qf = qi + 5;
+        const sca_dubins::Plan3D A = sca_dubins::plan3d(qi, qf, turning_radius, pl), B = sca_dubins::plan3d_lean(qi, qf, turning_radius, pl);
+        bool ok = A.ok == B.ok && A.iters == B.iters && A.count == B.count && same(A.length, B.length) && same(A.sampling_size, B.sampling_size) &&
+                  std::memcmp(A.mode, B.mode, 7) == 0;
+        const sca_dubins::Maneuver2D *ma[2] = {&A.h, &A.v}, *mb[2] = {&B.h, &B.v};
+        for (int k = 0; k < 2 && ok && A.ok; k++)
+            ok = same(ma[k]->r_min, mb[k]->r_min) && same(ma[k]->t, mb[k]->t) && same(ma[k]->p, mb[k]->p) && same(ma[k]->length, mb[k]->length) &&
+                 same(ma[k]->yaw, mb[k]->yaw);
+        if (!ok) bad++;
+    }
+    *mismatches = bad;
+    if (lean_candidates) *lean_candidates = sca_dubins::lean::g_host_fast;
+    if (literal_candidates) *literal_candidates = sca_dubins::lean::g_host_literal;
+    return 0;
+}
+
 // host self-test: the sign-parametrised CSC word of the device's four-lane planner against the literal word(), bit for bit
 int sca_selftest_dubins_words(int n, const double *alpha, const double *beta, const double *d, int64_t *mismatches) {
     if (n < 0 || !alpha || !beta || !d || !mismatches) return SCA_ERR_ARG;

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
+    // (the next pass may be k_track's again: it appends to the bucket counts of that parity)
+    if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
@@ -280,33 +282,128 @@ __device__ __forceinline__ int try_to_construct_quad(const QuadFrame &H, const d
     return 2;
 }
 
+// ---- the quad search, lean (round 3) ------------------------------------------------------------------------------------------
+// What sca_dubins::lean::candidate is to the lane-per-plan search, for a quad: a candidate is evaluated for what the search reads
+// of it (feasible?, length); when every lane of the wavefront is far (d >= 7 in both planes) lane `sub` evaluates word `sub`
+// with the lean pieces -- case (i) arctangents in rows (the word's own and, for LSR / RSL, the one of 2 / p; LSL / RSR run
+// atan2(+0, p) = +0 through the same instructions), sqrt without its special cases, one sin / cos pair per lane for the
+// vertical frame -- and the costs meet through DPP broadcasts.  Anything else goes through try_to_construct_quad.  The
+// winner's maneuvers are constructed once at the end of the search (try_to_construct_quad on the accepted radius).
+struct QuadWordSigns { bool cross, rfirst, negv, negya, negyb, negq, usemb; double y2; };
+__device__ __forceinline__ QuadWordSigns quad_word_signs(int sub) {
+    QuadWordSigns g;
+    g.cross = sub >= 2; g.rfirst = (sub & 1) != 0; g.negv = sub == 0 || sub == 3; g.negya = sub == 0 || sub == 2;
+    g.negyb = sub == 1 || sub == 2; g.negq = g.negyb; g.usemb = sub == 2;
+    g.y2 = sub == 2 ? -2.0 : (sub == 3 ? 2.0 : 0.0);                     // LSL / RSR: atan2(+0, p)
+    return g;
+}
+// word `sub` of a far 2-D problem: cost, first segment; kmin as in lean::atan_far_n
+__device__ __forceinline__ double quad_word_far(const sca_dubins::Frame2D &F, double mbeta, double d, double c, const QuadWordSigns &g,
+                                                uint32_t &kmin, double &t_out) {
+    using namespace sca_dubins;
+    using sca_gm::flip;
+    const double cab2 = 2 * F.c_ab, d2 = d * d, dd = 2 * d;
+    const double u = flip(F.sa, g.rfirst), v = flip(F.sb, g.negv);
+    const double S = u + v;
+    const double k2 = g.cross ? -2.0 : 2.0;
+    const double p2[1] = {((k2 + d2) + flip(cab2, !g.cross)) + (dd * S)};
+    double p[1];
+    lean::sqrt_pos_n<1>(p2, p);
+    const double y[2] = {flip(F.ca, g.negya) + flip(F.cb, g.negyb), g.y2}, x[2] = {(d + u) + v, p[0]};
+    double A[2];
+    lean::atan_far_n<2, 1>(y, x, A, kmin);
+    const double tmp = A[0] - A[1];                                       // (A[1] = +0 for LSL / RSR: A[0] - (+0) == A[0])
+    const double ta = tmp - F.alpha, qa = (g.usemb ? mbeta : F.beta) - tmp;
+    const double arg[2] = {flip(ta, g.rfirst), flip(qa, g.negq)};
+    double m[2];
+    lean::mod2pi_n<2>(arg, m);
+    t_out = m[0];
+    return c * (::fabs(m[0]) + ::fabs(p[0]) + ::fabs(m[1]));
+}
+// returns feasible?; len = the path's length.  All four lanes of the quad return the same.
+__device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, const sca_dubins::SearchConst &K, const double qi[5], const double qf[5],
+                                          double Rmin, const double pitchlims[2], double hr, int sub, int lane, const QuadWordSigns &g, double &len) {
+    using namespace sca_dubins;
+    const double dH = H.F.D / hr;
+    if (fast_ok && !sca_dubins::lean::any_says(!lean::far_d(dH))) {
+        uint32_t kmin = 0xffffffffu;
+        const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / sca_gm::g_pow2_main(hr));
+        const bool flat = vc < 1e-5;
+        double tw;
+        const double costH = quad_word_far(H.F, H.mbeta, dH, hr, g, kmin, tw);
+        const double lenH = sca_gm::min_(sca_gm::min_(quad_bcast_d<0>(costH), quad_bcast_d<1>(costH)), sca_gm::min_(quad_bcast_d<2>(costH), quad_bcast_d<3>(costH)));
+        const double vr = 1.0 / (flat ? 1.0 : vc);
+        const double dz = qf[2] - qi[2];
+        Frame2D F;
+        F.D = lean::sqrt_pos(sca_gm::g_pow2_main(lenH) + K.dz2);
+        const bool far_theta = lenH > ::fabs(dz) && lenH < 1.2676506002282294e30;
+        const double y1[1] = {dz}, x1[1] = {lenH};
+        double th[1];
+        lean::atan_far_n<1, 1>(y1, x1, th, kmin);
+        const double theta = mod2pi(th[0]);
+        F.alpha = mod2pi(qi[4] - theta);
+        F.beta = mod2pi(qf[4] - theta);
+        const double a1[1] = {sub == 0 ? F.alpha : (sub == 1 ? F.beta : F.alpha - F.beta)};
+        double s1[1], c1[1];
+        lean::sincos_n<1>(a1, s1, c1);
+        F.sa = quad_bcast_d<0>(s1[0]); F.ca = quad_bcast_d<0>(c1[0]);
+        F.sb = quad_bcast_d<1>(s1[0]); F.cb = quad_bcast_d<1>(c1[0]);
+        F.c_ab = quad_bcast_d<2>(c1[0]);
+        const double dV = F.D / vr;
+        const double costV = quad_word_far(F, mod2pi(F.beta), dV, vr, g, kmin, tw);
+        // the reference's first-minimum rule over the words in planner order
+        const double c0 = quad_bcast_d<0>(costV), c1v = quad_bcast_d<1>(costV), c2 = quad_bcast_d<2>(costV), c3 = quad_bcast_d<3>(costV);
+        const double t0 = quad_bcast_d<0>(tw), t1 = quad_bcast_d<1>(tw), t2 = quad_bcast_d<2>(tw), t3 = quad_bcast_d<3>(tw);
+        double bc = c0, bt = t0; bool right = false;
+        { const bool lt = bc > c1v; bc = lt ? c1v : bc; bt = lt ? t1 : bt; right = lt ? true : right; }
+        { const bool lt = bc > c2; bc = lt ? c2 : bc; bt = lt ? t2 : bt; right = lt ? false : right; }
+        { const bool lt = bc > c3; bc = lt ? c3 : bc; bt = lt ? t3 : bt; right = lt ? true : right; }
+        const bool ok = !flat && !(right ? (qi[4] - bt < pitchlims[0]) : (qi[4] + bt > pitchlims[1]));
+        // (kmin differs between the lanes of a quad: any lane's objection sends the whole wavefront the literal way)
+        if (!sca_dubins::lean::any_says(!flat && (lean::keys_odd(kmin) || !far_theta || !lean::far_d(dV)))) { len = bc; return ok; }
+    }
+    Maneuver2D mh, mv;
+    const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, hr, mh, mv, sub, lane);
+    len = mv.length;
+    return nf > 0;
+}
+
 // plan3d (sca_dubins.hpp) with the quad planner; the reference's three stages (first try, doubling, local search) are
 // phases 0, 1, 2 of one loop so that the planner is inlined once
 __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
                                                           int sub, int lane) {
     using namespace sca_dubins;
     Plan3D P;
-    double b = 1.0, step = 0.1;
-    Maneuver2D fbh, fbv, fch, fcv;
+    double b = 1.0, step = 0.1, best = 0.0;
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
+    const SearchConst K = search_const(qi, qf, Rmin);
+    const QuadWordSigns g = quad_word_signs(sub);
+    const bool fast_ok = !sca_dubins::lean::any_says(!(Rmin >= 1e-40 && Rmin <= 1e40));
     int phase = 0, guard = 0;
+    P.iters = 0;
     while (phase < 2 || ::fabs(step) > 1e-10) {
         double c;
         if (phase == 0) c = b;
         else if (phase == 1) { b *= 2.0; c = b; }
         else { c = b + step; if (c < 1.0) c = 1.0; }
-        const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * c, fch, fcv, sub, lane);
+        double lc;
+        const bool fc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * c, sub, lane, g, lc);
+        P.iters++;
         if (phase < 2) {
             if (phase == 1 && ++guard > 200) return P;
-            if (nf >= 2) { fbh = fch; fbv = fcv; phase = 2; }
+            if (fc) { best = lc; phase = 2; }
             else phase = 1;
         } else {
-            if (nf > 0 && fcv.length < fbv.length) { b = c; fbh = fch; fbv = fcv; step *= 2.; }
+            if (fc && lc < best) { b = c; best = lc; step *= 2.; }
             else step *= -0.1;
         }
     }
+    Maneuver2D fbh, fbv;
+    try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
+    const int it = P.iters;
     finish_plan(P, fbh, fbv, qi);
+    P.iters = it;
     return P;
 }
 
@@ -322,20 +419,6 @@ constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass:
 constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: three steps per round, 32 lanes per plan (2048 wavefronts)
 constexpr int TRK_SPEC4_MAX = 1280;        // <= this many: four steps per round, a whole wavefront per plan
 
-__device__ __forceinline__ void fetch_maneuver(sca_dubins::Maneuver2D &dst, const sca_dubins::Maneuver2D &mine, int src) {
-    const double r = lane_fetch_d(mine.r_min, src);
-    const double t = lane_fetch_d(mine.t, src);
-    const double p = lane_fetch_d(mine.p, src);
-    const double l = lane_fetch_d(mine.length, src);
-    const int packed = (int)(unsigned char)mine.mode[0] | ((int)(unsigned char)mine.mode[1] << 8) | ((int)(unsigned char)mine.mode[2] << 16) |
-                       ((int)mine.ok << 24);
-    const int m = __shfl(packed, src);
-    dst.yaw = mine.yaw;                                                    // the same start yaw for every candidate
-    dst.r_min = r; dst.t = t; dst.p = p; dst.length = l;
-    dst.mode[0] = (char)(m & 255); dst.mode[1] = (char)((m >> 8) & 255); dst.mode[2] = (char)((m >> 16) & 255);
-    dst.ok = ((m >> 24) & 1) != 0;
-}
-
 template <int D>
 __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
                                                           int sub, int lane) {
@@ -343,16 +426,20 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     constexpr int NODES = (1 << D) - 1, LANES = 4 << D;
     Plan3D P;
     const int quad = (lane & (LANES - 1)) >> 2, base = lane & ~(LANES - 1);
-    Maneuver2D fbh, fbv, fch, fcv;
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
     const QuadFrame H = frame2d_quad(qi2D, qf2D, sub);
+    const SearchConst K = search_const(qi, qf, Rmin);
+    const QuadWordSigns g = quad_word_signs(sub);
+    const bool fast_ok = !sca_dubins::lean::any_says(!(Rmin >= 1e-40 && Rmin <= 1e40));
     // first try and doubling (:74-78): rare beyond the first candidate, all quads evaluate the same radius
-    double b = 1.0;
-    int nfb = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);
+    double b = 1.0, best_len = 0.0;
+    bool fb = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * b, sub, lane, g, best_len);
     int guard = 0;
-    while (nfb < 2) {
+    P.iters = 1;
+    while (!fb) {
         b *= 2.0;
-        nfb = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);
+        fb = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * b, sub, lane, g, best_len);
+        P.iters++;
         if (++guard > 200) return P;
     }
     double step = 0.1;
@@ -373,26 +460,24 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         double myc = nc[1];
 #pragma unroll
         for (int k = 2; k <= NODES; k++) myc = quad == k - 1 ? nc[k] : myc;
-        const int nfc = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * myc, fch, fcv, sub, lane);
+        double mylen;
+        const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
         // Every node's verdict inputs (feasible?, length) into every lane FIRST -- independent cross-lane reads, and for a whole
         // wavefront per plan plain v_readlane of a fixed lane -- then the walk along the sequential loop's path is register
-        // arithmetic; the two maneuvers of the last accepted node are fetched once per round (the walk only needs lengths).
-        // Before, every depth step waited for three dependent ds_bpermute round trips and an accept for eighteen more:
-        // more than half of a round (c2: k_replan_few 121 -> 93 us).
+        // arithmetic (the walk only needs lengths; the maneuvers of the radius it ends on are constructed after the search).
         int nfk[NODES + 1];
         double lenk[NODES + 1];
 #pragma unroll
         for (int k = 1; k <= NODES; k++) {
             if constexpr (LANES == 64) {
                 nfk[k] = __builtin_amdgcn_readlane(nfc, 4 * (k - 1));
-                lenk[k] = readlane_f64(fcv.length, 4 * (k - 1));
+                lenk[k] = readlane_f64(mylen, 4 * (k - 1));
             } else {
                 nfk[k] = __shfl(nfc, base + 4 * (k - 1));
-                lenk[k] = lane_fetch_d(fcv.length, base + 4 * (k - 1));
+                lenk[k] = lane_fetch_d(mylen, base + 4 * (k - 1));
             }
         }
-        int node = 1, accepted = 0;
-        double best_len = fbv.length;
+        int node = 1;
 #pragma unroll
         for (int depth = 0; depth < D; depth++) {
             int nf = nfk[1];
@@ -400,17 +485,17 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
 #pragma unroll
             for (int k = 2; k <= NODES; k++) { nf = node == k ? nfk[k] : nf; len = node == k ? lenk[k] : len; cn = node == k ? nc[k] : cn; }
             const bool acc = nf > 0 && len < best_len;                     // the same in every lane of the group
-            if (acc) { b = cn; best_len = len; accepted = node; step *= 2.; node = 2 * node; }
+            P.iters++;
+            if (acc) { b = cn; best_len = len; step *= 2.; node = 2 * node; }
             else { step *= -0.1; node = 2 * node + 1; }
             if (!(::fabs(step) > 1e-10)) break;
         }
-        if (accepted) {                                                    // whole groups take this branch together
-            const int src = base + 4 * (accepted - 1);
-            fetch_maneuver(fbh, fch, src);
-            fetch_maneuver(fbv, fcv, src);
-        }
     }
+    Maneuver2D fbh, fbv;
+    try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
+    const int it = P.iters;
     finish_plan(P, fbh, fbv, qi);
+    P.iters = it;
     return P;
 }
 

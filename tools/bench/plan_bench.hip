@@ -10,6 +10,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <map>
 #if defined(SCA_LEAN_STATS) || defined(SCA_LEAN_TIMING)
 __device__ unsigned long long g_lean_stats[8];
 #endif
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(256, PB_BOUNDS) void k_plan(const double *q, int n,
 #if defined(SCA_LEAN_WAVEITERS)
     if (threadIdx.x < 4) g_wave_iters[threadIdx.x] = 0;
     const unsigned long long tb = __builtin_readcyclecounter();
+    const unsigned long long wb = wall_clock64();
 #endif
     sca_gm::lds_tables_load();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,19 +39,28 @@ __global__ __launch_bounds__(256, PB_BOUNDS) void k_plan(const double *q, int n,
     iters[i] = P.iters;
 #if defined(SCA_LEAN_WAVEITERS)
     const unsigned long long te = __builtin_readcyclecounter();
-    len[i] = (double)(te - tb);                     // (the checksum is void in this build)
+    const int ln = threadIdx.x & 63;                // (the checksum is void in this build)
+    len[i] = ln == 0 ? (double)(te - tb) : ln == 3 ? (double)(wall_clock64() - wb) : ln == 4 ? (double)wb : (ln == 1 ? (double)tb : (double)(__builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 24)));
     iters[i] = g_wave_iters[threadIdx.x >> 6];
 #endif
 }
 
 int main(int argc, char **argv) {
-    const int n = argc > 1 ? atoi(argv[1]) : 96256;
+    // argv[1]: the number of synthetic plans, or a file of n x 10 doubles (qi[5], qf[5]: recorded poses, scratch/dump_c4.py)
+    int n = argc > 1 ? atoi(argv[1]) : 96256;
     const int reps = argc > 2 ? atoi(argv[2]) : 5;
-    std::vector<double> q(10 * (size_t)n);
+    std::vector<double> q;
+    FILE *pf = (argc > 1 && n == 0) ? fopen(argv[1], "rb") : nullptr;
+    if (pf) {
+        fseek(pf, 0, SEEK_END); n = (int)(ftell(pf) / 80); fseek(pf, 0, SEEK_SET);
+        q.resize(10 * (size_t)n);
+        if (fread(q.data(), 80, n, pf) != (size_t)n) return 1;
+        fclose(pf);
+    } else q.resize(10 * (size_t)n);
     const double R = 1.25 * 100000 / (2 * M_PI);
     unsigned s = 12345;
     auto rnd = [&] { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0 / 16777216.0); };
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n && !pf; i++) {
         const double th = 2 * M_PI * i / 100000.0;
         double *p = &q[10 * (size_t)i];
         // a few steps into the episode: 0.3 m along the chord, sideways offsets and heading changes of an avoidance manoeuvre
@@ -82,7 +93,11 @@ int main(int argc, char **argv) {
         if (mode == "asc") perm = order;
         else if (mode == "desc") perm.assign(order.rbegin(), order.rend());
         else if (mode == "rand") { perm = order; unsigned s2 = 99; for (int i = n - 1; i > 0; i--) { s2 = s2 * 1664525u + 1013904223u; std::swap(perm[i], perm[(s2 >> 4) % (i + 1)]); } }
-        else {                                                                      // lpt: [short half | long | short half]
+        else if (mode == "fold") {                                                  // longest first; the workgroups of the second round shortest first
+            const int first = std::min(n, 256 * 256);
+            for (int i = 0; i < first; i++) perm.push_back(order[n - 1 - i]);
+            for (int i = 0; i < n - first; i++) perm.push_back(order[i]);
+        } else {                                                                      // lpt: [short half | long | short half]
             const int nshort = std::min(n, 2 * D * 256), half = (nshort / 2 / 256) * 256;
             for (int i = 0; i < half; i++) perm.push_back(order[i]);
             for (int i = nshort; i < n; i++) perm.push_back(order[i]);
@@ -102,9 +117,32 @@ int main(int argc, char **argv) {
     }
     hipMemcpy(l.data(), dl, n * 8, hipMemcpyDeviceToHost); hipMemcpy(it.data(), di, n * 4, hipMemcpyDeviceToHost);
 #if defined(SCA_LEAN_WAVEITERS)
-    { double cy = 0, itw = 0, mxc = 0, mxi = 0; int nw = 0;
-      for (int i = 0; i < n; i += 64) { double c = 0; for (int k = i; k < i + 64 && k < n; k++) c = std::max(c, l[k]); cy += c; itw += it[i]; mxc = std::max(mxc, c); mxi = std::max(mxi, (double)it[i]); nw++; }
-      printf("  waves %d: mean %.0f cycles, %.1f wave-iterations (%.0f cycles each); max %.0f cycles, max %.0f iterations\n", nw, cy / nw, itw / nw, cy / itw, mxc, mxi); }
+    {   // per wavefront: lane 0 holds the cycles, lane 1 the start (cycles since the first wave's start), lane 2 the hardware id
+        struct W { double cyc, start; unsigned hw; int iters; };
+        std::vector<W> w;
+        double t0 = 1e300;
+        for (int i = 0; i + 2 < n; i += 64) t0 = std::min(t0, l[i + 1]);
+        for (int i = 0; i + 2 < n; i += 64) w.push_back({l[i], l[i + 1] - t0, (unsigned)l[i + 2], it[i]});
+        { double c = 0, wl = 0, w0 = 1e300, w1 = 0; for (int i = 0; i + 4 < n; i += 64) { c += l[i]; wl += l[i + 3]; w0 = std::min(w0, l[i + 4]); w1 = std::max(w1, l[i + 4] + l[i + 3]); }
+          printf("  core clock while the waves ran: %.3f GHz (cycles / 100-MHz ticks); first wave start to last wave end %.1f us\n", c / wl * 0.1, (w1 - w0) * 0.01); }
+        double cy = 0, itw = 0, mxc = 0; for (auto &x : w) { cy += x.cyc; itw += x.iters; mxc = std::max(mxc, x.start + x.cyc); }
+        printf("  waves %zu: mean %.0f cycles, %.1f wave-iterations (%.0f cycles each); last wave ends at %.0f cycles\n", w.size(), cy / w.size(), itw / w.size(), cy / itw, mxc);
+        std::map<unsigned, std::vector<int>> by;                                   // SIMD -> its waves
+        for (size_t k = 0; k < w.size(); k++) by[w[k].hw & 0xfffffff0u] .push_back((int)k);
+        int lone = 0, pair = 0, more = 0; double cl = 0, il = 0, cp = 0, ip = 0;
+        for (auto &kv : by) { if (kv.second.size() == 1) lone++; else if (kv.second.size() == 2) pair++; else more++;
+            for (int k : kv.second) { if (kv.second.size() == 1) { cl += w[k].cyc; il += w[k].iters; } else { cp += w[k].cyc; ip += w[k].iters; } } }
+        printf("  SIMDs with 1 / 2 / more waves: %d / %d / %d; cycles per iteration alone %.0f, sharing %.0f\n", lone, pair, more, cl / std::max(il, 1.0), cp / std::max(ip, 1.0));
+        // wall-clock view (100-MHz ticks are global; the cycle counters of different XCDs are not aligned)
+        std::vector<double> ws, wd; double w0 = 1e300;
+        for (int i = 0; i + 4 < n; i += 64) { ws.push_back(l[i + 4]); wd.push_back(l[i + 3]); w0 = std::min(w0, l[i + 4]); }
+        int late[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t k = 0; k < ws.size(); k++) { const double us = (ws[k] - w0) * 0.01; late[us < 5 ? 0 : us < 50 ? 1 : us < 200 ? 2 : us < 400 ? 3 : us < 600 ? 4 : 5]++; }
+        printf("  wave starts: <5 us %d, <50 us %d, <200 us %d, <400 us %d, <600 us %d, later %d\n", late[0], late[1], late[2], late[3], late[4], late[5]);
+        std::vector<int> ord(ws.size()); for (size_t k = 0; k < ws.size(); k++) ord[k] = (int)k;
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ws[a] + wd[a] > ws[b] + wd[b]; });
+        for (int k = 0; k < 10; k++) { const int j = ord[k]; printf("    wave %4d (block %d): start %.1f us, runs %.1f us, %d iterations (%.2f us each)\n", j, j / 4, (ws[j] - w0) * 0.01, wd[j] * 0.01, w[j].iters, wd[j] * 0.01 / w[j].iters); }
+    }
 #endif
     double sum = 0; long its = 0; int mx = 0; unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < n; i++) { sum += l[i]; its += it[i]; if (it[i] > mx) mx = it[i]; unsigned long long b; memcpy(&b, &l[i], 8); h = (h ^ b) * 1099511628211ull; }
