@@ -38,7 +38,9 @@ def _solver(scene):
     return sol
 
 
-@pytest.mark.parametrize('kind,n,steps', [('circle', 1024, 60), ('takeoff', 16384, 40), ('circle', 100000, 12)])
+# (the 160-agent circle runs to the end of the episode: path lengths from 21 turning radii down to arrival -- the lean search's
+# far block, its table pieces, the literal way for near problems, and the hand-over between them)
+@pytest.mark.parametrize('kind,n,steps', [('circle', 1024, 60), ('takeoff', 16384, 40), ('circle', 100000, 12), ('circle', 160, 800)])
 def test_value_leg_equals_host_tracker_run(kind, n, steps):
     from sca_amd import tracker
     scene = _scene(kind, n)
