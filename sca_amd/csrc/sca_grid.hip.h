@@ -57,6 +57,7 @@ __device__ __forceinline__ int grid_bucket(unsigned long long key, int hbits) {
 }
 
 __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Params P) {
+    SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 256) d.done_count[i * 32] = 0;                                   // start of a step: K4's counters
     if (i == 0) { *d.fb_count = 0; *g.cursor = 0; }                          // ... an empty fallback list, no position handed out
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
 // address at N = 100 000, cost 13 us of the kernel's 14: the same-address rate is ~12 ns per atomic)
 constexpr int GRID_ALLOC_PER = 8;
 __global__ __launch_bounds__(256) void k_grid_alloc(GridDev g) {
+    SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     __shared__ int wtot[4];
     __shared__ int base_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_grid_alloc(GridDev g) {
 }
 
 __global__ __launch_bounds__(256) void k_grid_fill(DeviceView d, GridDev g) {
+    SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= present_count(d)) return;
     const int a = present_agent(d, i);

@@ -23,6 +23,19 @@
 #include "sca_kernels.hip.h"
 
 namespace sca {
+// The kd build is a chain of ~17 short dependent launches; in a tracked pass it runs beside the re-plan kernel, whose wavefronts are
+// older and dense in VALU work, and the SIMD's arbiter serves the oldest wavefront first: the build's wavefronts got the issue
+// slots that were left (k_kd_block 124 us against 33 alone, a level pass 18.5 against 9.1).  With s_setprio they go first on the
+// SIMDs they share -- a few thousand instructions each -- and the re-plan kernel does not get measurably longer: k_kd_block 56 us,
+// level pass 11.6, c4 step 0.759 -> 0.743 ms.  (SCA_KD_PRIO=0 at build time switches it off.)
+#ifndef SCA_KD_PRIO
+#define SCA_KD_PRIO 3
+#endif
+#if SCA_KD_PRIO > 0
+#define SCA_KD_SETPRIO() __builtin_amdgcn_s_setprio(SCA_KD_PRIO)
+#else
+#define SCA_KD_SETPRIO() ((void)0)
+#endif
 
 // A node of <= wave_max members (KdScratch::wave_max, chosen per build) is finished, whole subtree, by ONE WORKGROUP in LDS
 // (k_kd_block).  The host picks it between these bounds so that the node sizes of a level (n / 2^k, within a few per cent)
@@ -78,6 +91,7 @@ __device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 
 // Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
 __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Params P) {
+    SCA_KD_SETPRIO();
     __shared__ double red[4][6];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -276,6 +290,7 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
 // already run.  The host picks the form per build from the occupancy the runtime reports (sca_hip.hip, kd_rank_capacity).
 template <bool TICKET>
 __global__ __launch_bounds__(KD_LV_T) void k_kd_lv_rank(KdScratch s, int level, unsigned token) {
+    SCA_KD_SETPRIO();
     __shared__ KdRankLds SH;
     int blk = (int)blockIdx.x;
     if (TICKET) {
@@ -395,6 +410,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
 }
 
 __global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+    SCA_KD_SETPRIO();
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
     kd_swap_part(d, s, level, c);
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScr
 // changed since -- a node with many chunks, more levels -- it is slower, never wrong: the statistics only set the speed.
 constexpr int KD_TAIL_STACK = 2 * KD_MAX_LEVELS;
 __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScratch s, int level, unsigned token) {
+    SCA_KD_SETPRIO();
     __shared__ KdRankLds SH;
     __shared__ KdTailOut out;
     __shared__ KdChunkRec stack[KD_TAIL_STACK];
@@ -529,6 +546,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 
 template <int KBM, int KBT>
 __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+    SCA_KD_SETPRIO();
     static_assert(KBM == 2 * KBT, "k_kd_block is written for two consecutive positions per thread");
     constexpr int KB_SWROW = KbLds<KBM, KBT>::SWROW, KB_MAX = KBM, KB_T = KBT, KB_E = 2;
     __shared__ KbLds<KBM, KBT> S;
