@@ -145,6 +145,7 @@ __device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long 
 // reference builds no list (scaPolicy.py:34): K4 then never needs a tree.
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
                                                                   double obs_reach, double max_radius) {
+    SCA_K1_SETPRIO();
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;

@@ -509,18 +509,21 @@ constexpr int K1P_G = 16;
 constexpr int K1P_APW = 4;
 
 
-__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
-                                                                 double max_radius) {
-    // In a tracked pass K1 runs beside the re-plan kernel, whose wavefronts are older and therefore served first by the SIMD's
-    // arbiter: 293 us there against 90 alone, and the neighbour branch (K0 -> K1 -> k_solve_sweep) ended last.  With issue priority
-    // it takes what it needs (the re-plan kernel's longest wavefronts mostly sit alone on their SIMDs): c4 0.740 -> 0.718 ms.
-    // k_solve_sweep gets none: with it the re-plans end 90 us later (measured: 0.775 ms).  (SCA_K1_PRIO=0 switches it off.)
+// In a tracked pass K1 runs beside the re-plan kernel, whose wavefronts are older and therefore served first by the SIMD's
+// arbiter: 293 us there against 90 alone, and the neighbour branch (K0 -> K1 -> k_solve_sweep) ended last.  With issue priority
+// it takes what it needs (the re-plan kernel's longest wavefronts mostly sit alone on their SIMDs): c4 0.740 -> 0.718 ms.
+// k_solve_sweep gets none: with it the re-plans end 90 us later (measured: 0.775 ms).  (SCA_K1_PRIO=0 switches it off.)
 #ifndef SCA_K1_PRIO
 #define SCA_K1_PRIO 3
 #endif
 #if SCA_K1_PRIO > 0
-    __builtin_amdgcn_s_setprio(SCA_K1_PRIO);
+#define SCA_K1_SETPRIO() __builtin_amdgcn_s_setprio(SCA_K1_PRIO)
+#else
+#define SCA_K1_SETPRIO() ((void)0)
 #endif
+__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
+                                                                 double max_radius) {
+    SCA_K1_SETPRIO();
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
