@@ -91,47 +91,56 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
 }
 
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    // the re-plan list: per workgroup the lanes count themselves into their buckets in LDS, ONE vector atomic fetches the
+    // workgroup's offsets in all twelve buckets, and the lanes write their slots.  (Until the end of round 3 every wavefront
+    // fetched its offsets itself, one bucket after the other: ~5000 dependent same-address atomics per pass, which is what
+    // k_track's 52 us at c4 were made of -- it executes 1400 instructions per wavefront.)
+    __shared__ int s_cnt[TRK_BUCKETS], s_base[TRK_BUCKETS];
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
+    if (threadIdx.x < TRK_BUCKETS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= shard_size(d)) return;
-    const int agent = shard_agent(d, idx);
-    double nb0 = K.nbr0[agent];
-    if (K.nbr0_from_lists && d.nbr_valid[agent]) {                       // lists of the previous pass (agent.py:79-99)
-        nb0 = d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0;
-        K.nbr0[agent] = nb0;
-    }
-    if (!track_active(d, agent)) return;
-    const PubRec r = d.rec[agent];
-    const double pos[3] = {r.px, r.py, r.pz};
-    const float vel[3] = {r.vx, r.vy, r.vz};
-    sca_dubins::AgentTrack &a = K.st[agent];
-    double dif[3], V[3];
-    const bool replan = sca_dubins::track_decide(T, a, agent, pos, vel, nb0, dif);
-    if (replan) {
-        // wave-aggregated append to the bucket of the agent's previous search (a.plan still holds it)
-        const int lane = threadIdx.x & 63;
-        const int mine = trk_bucket(a.plan.iters);
-        const unsigned long long all = __ballot(1);
-        if (lane == __ffsll((long long)all) - 1) atomicAdd(&K.count[K.parity], __popcll(all));
-        unsigned long long todo = all;
-        while (todo) {
-            const int b = __shfl(mine, __ffsll((long long)todo) - 1);
-            const unsigned long long m = __ballot(mine == b);
-            if (mine == b) {
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&K.bcount[K.parity * TRK_BUCKETS + b], __popcll(m));
-                base = __shfl(base, leader);
-                K.list[(size_t)b * K.n + base + __popcll(m & ((1ull << lane) - 1ull))] = agent;
-            }
-            todo &= ~m;
+    const bool in_shard = idx < shard_size(d);
+    const int agent = in_shard ? shard_agent(d, idx) : 0;
+    bool active = false, replan = false;
+    int mine = 0, my_rank = 0;
+    double pos[3] = {0, 0, 0}, dif[3] = {0, 0, 0};
+    if (in_shard) {
+        double nb0 = K.nbr0[agent];
+        if (K.nbr0_from_lists && d.nbr_valid[agent]) {                   // lists of the previous pass (agent.py:79-99)
+            nb0 = d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0;
+            K.nbr0[agent] = nb0;
         }
-        return;
+        active = track_active(d, agent);
+        if (active) {
+            const PubRec r = d.rec[agent];
+            pos[0] = r.px; pos[1] = r.py; pos[2] = r.pz;
+            const float vel[3] = {r.vx, r.vy, r.vz};
+            sca_dubins::AgentTrack &a = K.st[agent];
+            replan = sca_dubins::track_decide(T, a, agent, pos, vel, nb0, dif);
+            if (replan) {
+                mine = trk_bucket(a.plan.iters);                         // the bucket of the agent's previous search (a.plan still holds it)
+                my_rank = atomicAdd(&s_cnt[mine], 1);
+            } else {
+                double V[3];
+                sca_dubins::track_finish(T, a, agent, pos, dif, V);
+                track_store(d, K, agent, V);
+            }
+        }
     }
-    sca_dubins::track_finish(T, a, agent, pos, dif, V);
-    track_store(d, K, agent, V);
+    __syncthreads();
+    if (threadIdx.x < TRK_BUCKETS) {
+        const int c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = c > 0 ? atomicAdd(&K.bcount[K.parity * TRK_BUCKETS + threadIdx.x], c) : 0;
+    } else if (threadIdx.x == 64) {
+        int total = 0;
+        for (int b = 0; b < TRK_BUCKETS; b++) total += s_cnt[b];
+        if (total > 0) atomicAdd(&K.count[K.parity], total);
+    }
+    __syncthreads();
+    if (replan) K.list[(size_t)mine * K.n + s_base[mine] + my_rank] = agent;
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
