@@ -163,8 +163,9 @@ def roofline_of(leg, steps, tracked, wname):
                 'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if leg['forms'] & 2 else
                                                     'k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
                                     / VALU_PEAK_WAVE_INSTS) or None,
-                'note': 'a sequential fp64 search per plan (~68 candidate radii x 13 arctangents on the restated glibc libm): pure compute, '
-                        'bound by the latency of one wavefront\'s dependent instruction stream; the HBM fraction is reported as required'}
+                'note': 'a sequential fp64 search per plan (~69 candidate radii, each two 2-D Dubins problems on the restated glibc libm, lean form): '
+                        'pure compute -- the kernel lasts as long as its longest search (~119 candidates x 4.5 us per wavefront) and the pass as a '
+                        'whole issues VALU work without a gap between k_track and the join (DESIGN.md section 5); the HBM fraction is reported as required'}
     # a split pass: the timed [solve] interval is k_solve_pick4 only (k_solve_sweep runs beside the re-plans); k_solve's own
     # roofline entry then comes from the solver_only leg, where it is one kernel
     return k_replan, (None if leg['forms'] & 1 else k_solve)
