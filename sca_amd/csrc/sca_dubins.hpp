@@ -478,13 +478,14 @@ SCA_DHD static Plan3D plan3d(const double qi[5], const double qf[5], double Rmin
 //     constructed once more at the end for its maneuvers (the evaluation is a pure function of the radius): the four Maneuver2D
 //     the literal loop carries (best / candidate x horizontal / vertical: 48 registers) are gone from the loop, which is what
 //     lets the scheduler keep the four words of a 2-D plan in flight together instead of spilling;
-//   * when every lane of the wavefront is FAR -- both 2-D problems with d = D / radius >= 36 (paths of more than 36 turning
-//     radii; the benchmark circle's are 10^4) -- a candidate is one straight-line block: every arctangent of a far problem is
-//     glibc's case (i) with a quotient below 1/16 (|y| <= 2 against x >= d - 2, or 2 against p >= sqrt(d^2 - 4 d - 4)), i.e. the
-//     polynomial piece and nothing else (atan_far: the same operations on the same values as sca_gm::atan2_core takes for such
-//     arguments); every word is feasible (p^2 > 0); both CCC words are infeasible (their |tmp| > 1).  Anything else -- a lane
-//     that is not far, a quotient below 2^-56 (glibc's early return), a non-finite value -- sends the whole wavefront's
-//     candidate through try_to_construct above.
+//   * when every lane of the wavefront is FAR -- both 2-D problems with d = D / radius >= 7 (the benchmark circle's d are 10^4, and
+//     26 for its large-radius plans) -- a candidate is one straight-line block.  For d >= 7 every arctangent is glibc's case (i)
+//     (|y| <= 2 against x >= d - 2 >= 5, or 2 against p >= sqrt(d^2 - 4 d - 4) > 4): the polynomial piece when the quotient is
+//     below 1/16, else the table piece, decided per row group with a ballot and selected per lane (atan_far_n: the same
+//     operations on the same values as sca_gm::atan2_core takes for such arguments, incl. glibc's early return for exponents 57
+//     or more apart); every word is feasible (p^2 >= 17); both CCC words are infeasible (their tmp <= -1.6).  Anything else -- a
+//     lane that is not far, a quotient below 2^-1000 (the lean division has no scaling), a non-finite value -- sends the whole
+//     wavefront's candidate through try_to_construct above (a called function, cold).
 namespace lean {
 using sca_gm::fma_;
 static long long g_host_fast = 0, g_host_literal = 0;      // candidates by the lean block / by try_to_construct (host self-test only)
