@@ -274,17 +274,38 @@ __device__ __forceinline__ sca_dubins::Maneuver2D plan2d_quad(const QuadFrame &Q
     return m;
 }
 
-__device__ __forceinline__ int try_to_construct_quad(const QuadFrame &H, const double qi[5], const double qf[5], double Rmin,
+// frame2d_quad for the vertical plane: start (0, z_i, pitch_i), end (len, z_f, pitch_f); dz^2 = pow(z_f - z_i, 2) is the same for
+// every candidate of a search and comes from SearchConst (same argument, same function, same bits: sca_dubins::frame2d_vertical)
+__device__ __forceinline__ QuadFrame frame2d_quad_vertical(double len, double dz, double dz2, double spitch, double epitch, int sub) {
+    using namespace sca_dubins;
+    QuadFrame Q;
+    const double ex = len - 0.0;
+    Q.F.D = ::sqrt(m_pow(ex, 2.0) + dz2);
+    const double theta = mod2pi(m_atan2(dz, ex));
+    Q.F.alpha = mod2pi(spitch - theta);
+    Q.F.beta = mod2pi(epitch - theta);
+    const double arg = sub == 0 ? Q.F.alpha : (sub == 1 ? Q.F.beta : Q.F.alpha - Q.F.beta);
+    double sn, cs;
+    m_sincos(arg, sn, cs);
+    Q.F.sa = quad_bcast_d<0>(sn);
+    Q.F.ca = quad_bcast_d<0>(cs);
+    Q.F.sb = quad_bcast_d<1>(sn);
+    Q.F.cb = quad_bcast_d<1>(cs);
+    Q.F.c_ab = quad_bcast_d<2>(cs);
+    Q.mbeta = mod2pi(Q.F.beta);
+    return Q;
+}
+__device__ __forceinline__ int try_to_construct_quad(const QuadFrame &H, const sca_dubins::SearchConst &K, const double qi[5], const double qf[5], double Rmin,
                                                      const double pitchlims[2], double hr, sca_dubins::Maneuver2D &mh,
                                                      sca_dubins::Maneuver2D &mv, int sub, int lane) {
     using namespace sca_dubins;
-    const double vc = ::sqrt(1.0 / m_pow(Rmin, 2.0) - 1.0 / m_pow(hr, 2.0));
+    (void)Rmin;
+    const double vc = ::sqrt(K.inv_rmin2 - 1.0 / m_pow(hr, 2.0));          // (1 / Rmin^2 once per search: SearchConst)
     if (vc < 1e-5) return 0;                                             // see try_to_construct: mh would not be read
     mh = plan2d_quad(H, qi[3], hr, sub, lane);
-    const double qi3D[3] = {0.0, qi[2], qi[4]}, qf3D[3] = {mh.length, qf[2], qf[4]};
     const double vr = 1.0 / vc;
-    const QuadFrame V = frame2d_quad(qi3D, qf3D, sub);
-    mv = plan2d_quad(V, qi3D[2], vr, sub, lane);
+    const QuadFrame V = frame2d_quad_vertical(mh.length, qf[2] - qi[2], K.dz2, qi[4], qf[4], sub);
+    mv = plan2d_quad(V, qi[4], vr, sub, lane);
     if (mv.mode[0] == 'R' && mv.mode[1] == 'L' && mv.mode[2] == 'R') return 0;
     if (mv.mode[0] == 'R') { if (qi[4] - mv.t < pitchlims[0]) return 0; }
     else { if (qi[4] + mv.t > pitchlims[1]) return 0; }
@@ -372,7 +393,7 @@ __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, cons
         if (!sca_dubins::lean::any_says(!flat && (lean::keys_odd(kmin) || !far_theta || !lean::far_d(dV)))) { len = bc; return ok; }
     }
     Maneuver2D mh, mv;
-    const int nf = try_to_construct_quad(H, qi, qf, Rmin, pitchlims, hr, mh, mv, sub, lane);
+    const int nf = try_to_construct_quad(H, K, qi, qf, Rmin, pitchlims, hr, mh, mv, sub, lane);
     len = mv.length;
     return nf > 0;
 }
@@ -409,7 +430,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
         }
     }
     Maneuver2D fbh, fbv;
-    try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
+    try_to_construct_quad(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
     const int it = P.iters;
     finish_plan(P, fbh, fbv, qi);
     P.iters = it;
@@ -501,7 +522,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         }
     }
     Maneuver2D fbh, fbv;
-    try_to_construct_quad(H, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
+    try_to_construct_quad(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
     const int it = P.iters;
     finish_plan(P, fbh, fbv, qi);
     P.iters = it;
