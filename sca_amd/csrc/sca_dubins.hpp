@@ -682,10 +682,12 @@ SCA_DHD static inline double words_far(const Frame2D &F, double mbeta, double d,
     double bcost = INFINITY;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        if (WINNER) {
-            const bool lt = bcost > cost[w];
-            bcost = lt ? cost[w] : bcost; bt = lt ? m[w] : bt; bright = lt ? (w & 1) != 0 : bright;
-        } else bcost = sca_gm::min_(bcost, cost[w]);
+        bcost = sca_gm::min_(bcost, cost[w]);
+    }
+    if (WINNER) {                                              // the first word that attains the minimum (`if bcost > cost` in planner order)
+        const bool e0 = cost[0] == bcost, e1 = cost[1] == bcost, e2 = cost[2] == bcost;
+        bt = e0 ? m[0] : (e1 ? m[1] : (e2 ? m[2] : m[3]));
+        bright = e0 ? false : (e1 ? true : (e2 ? false : true));
     }
     return bcost;
 }
