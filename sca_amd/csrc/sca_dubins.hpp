@@ -791,6 +791,10 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
 #if defined(SCA_LEAN_WAVEITERS)
     { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_)) atomicAdd(&::g_wave_iters[threadIdx.x >> 6], 1); }
 #endif
+    // the radius Rmin itself (every search's first candidate, and every candidate the search clamps to c = 1): the vertical
+    // curvature is sqrt(x - x) = 0 for a finite Rmin, i.e. try_to_construct leaves at :146-147 -- when that holds for the whole
+    // wavefront nothing is evaluated
+    if (fast_ok && !lean::any_says(hr != Rmin)) { len = 0.0; return false; }
     const double dH = H.D / hr;                                                       // (plan2d)
     if (fast_ok && !lean::any_says(!far_d(dH))) {
         uint32_t kmin = 0xffffffffu;
@@ -859,6 +863,11 @@ SCA_DHD static Plan3D plan3d_lean(const double qi[5], const double qf[5], double
         double c = b + step;
         if (c < 1.0) c = 1.0;
         P.iters++;
+#if !defined(SCA_LEAN_NO_CLAMP_SKIP)
+        // a candidate clamped to c = 1 is the radius Rmin itself: never feasible (see lean::candidate), so the lane takes the
+        // verdict without an evaluation and goes on to its next candidate within the same trip of the wavefront's loop
+        if (fast_ok && Rmin * c == Rmin) { step *= -0.1; continue; }
+#endif
         double lc;
         const bool fc = lean::candidate(fast_ok, H, mbetaH, K, qi, qf, Rmin, pitchlims, Rmin * c, lc);
         if (fc && lc < best) { b = c; best = lc; step *= 2.; continue; }

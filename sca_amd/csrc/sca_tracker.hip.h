@@ -354,6 +354,7 @@ __device__ __forceinline__ double quad_word_far(const sca_dubins::Frame2D &F, do
 __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, const sca_dubins::SearchConst &K, const double qi[5], const double qf[5],
                                           double Rmin, const double pitchlims[2], double hr, int sub, int lane, const QuadWordSigns &g, double &len) {
     using namespace sca_dubins;
+    if (fast_ok && !sca_dubins::lean::any_says(hr != Rmin)) { len = 0.0; return false; }      // (see lean::candidate: the radius Rmin itself)
     const double dH = H.F.D / hr;
     if (fast_ok && !sca_dubins::lean::any_says(!lean::far_d(dH))) {
         uint32_t kmin = 0xffffffffu;
