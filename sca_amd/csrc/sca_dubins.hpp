@@ -223,48 +223,6 @@ SCA_DHD static Frame2D frame2d(const double start[3], const double end[3]) {
     F.c_ab = m_cos(F.alpha - F.beta);
     return F;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-// The four CSC words of one 2-D plan at once, for the lane-per-plan kernels: csc_word_uniform<true> for w = 0 .. 3 with its six
-// arctangents taken out of the words and evaluated side by side through the branch-free form of sca_glibc_math.h -- one
-// straight-line block the scheduler can interleave, and ONE branch behind it for arguments outside that form's domain
-// (non-finite, denormal, beyond 2^+-500) instead of one inside every arctangent.  Same expressions, same values, same bits.
-SCA_DHD static void csc_words4(const Frame2D &F, double mbeta, double d, double t4[4], double p4[4], double q4[4], bool ok4[4]) {
-    const double cab2 = 2 * F.c_ab, d2 = d * d, dd = 2 * d;
-    bool dom = true;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const bool cross = w >= 2, rfirst = (w & 1) != 0;
-        const double u = rfirst ? -F.sa : F.sa;
-        const double v = (w == 0 || w == 3) ? -F.sb : F.sb;
-        const double S = u + v;
-        const double k2 = cross ? -2.0 : 2.0;
-        const double p2 = ((k2 + d2) + (cross ? cab2 : -cab2)) + (dd * S);
-        const double x = (d + u) + v;
-        const double ya = (w == 0 || w == 2) ? -F.ca : F.ca;
-        const double yb = (w == 1 || w == 2) ? -F.cb : F.cb;
-        const double y = ya + yb;
-        ok4[w] = !(p2 < 0);
-        p4[w] = sca_gm::sqrt_(p2);
-        double tmp = sca_gm::atan2_core(y, x, dom);
-        // LSL / RSR: their second arctangent is atan2(+0, p) = +0 and A1 - (+0) == A1; an infeasible word's is never read
-        if (cross) tmp = tmp - sca_gm::atan2_core(w == 2 ? -2.0 : 2.0, ok4[w] ? p4[w] : 1.0, dom);
-        const double ta = tmp - F.alpha;
-        t4[w] = mod2pi(rfirst ? -ta : ta);
-        const double qa = (w == 2 ? mbeta : F.beta) - tmp;
-        q4[w] = mod2pi((w == 1 || w == 2) ? -qa : qa);
-#ifndef SCA_WORDS_PER_GROUP
-#define SCA_WORDS_PER_GROUP 2
-#endif
-        // how many words the scheduler may interleave (all four: it runs out of registers and spills)
-        if (((w + 1) % SCA_WORDS_PER_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!dom) {                                                             // (cold) an argument outside the branch-free form's domain
-#pragma unroll
-        for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform<true>(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
-    }
-}
-#endif
-
 SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     Maneuver2D m;
     m.yaw = yaw;
@@ -278,12 +236,8 @@ SCA_DHD static Maneuver2D plan2d(const Frame2D &F, double yaw, double c) {
     {
         const double mbeta = mod2pi(F.beta);
         double t4[4], p4[4], q4[4]; bool ok4[4];
-#if defined(SCA_V_WORDS) && SCA_V_WORDS == 1
-        csc_words4(F, mbeta, d, t4, p4, q4, ok4);
-#else
 #pragma unroll
         for (int w = 0; w < 4; w++) ok4[w] = csc_word_uniform<true>(w, F.alpha, F.beta, mbeta, d, F.sa, F.sb, F.ca, F.cb, F.c_ab, t4[w], p4[w], q4[w]);
-#endif
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const double cost = c * (std::fabs(t4[w]) + std::fabs(p4[w]) + std::fabs(q4[w]));
@@ -404,8 +358,8 @@ SCA_DHD static SearchConst search_const(const double qi[5], const double qf[5], 
 SCA_DHD static Frame2D frame2d_vertical(double len, double dz, double dz2, double spitch, double epitch) {
     Frame2D F;
     const double ex = len - 0.0;
-#if defined(__HIP_DEVICE_COMPILE__) && (!defined(SCA_V_FRAME) || SCA_V_FRAME == 1)
-    // the branch-free forms with one domain flag for the whole frame (see csc_words4)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the branch-free forms with one domain flag for the whole frame
     bool dom = true;
     F.D = sca_gm::sqrt_(sca_gm::pow2_core(ex, dom) + dz2);
     const double theta = mod2pi(sca_gm::atan2_core(dz, ex, dom));
