@@ -93,7 +93,25 @@ int main(int argc, char **argv) {
         if (mode == "asc") perm = order;
         else if (mode == "desc") perm.assign(order.rbegin(), order.rend());
         else if (mode == "rand") { perm = order; unsigned s2 = 99; for (int i = n - 1; i > 0; i--) { s2 = s2 * 1664525u + 1013904223u; std::swap(perm[i], perm[(s2 >> 4) % (i + 1)]); } }
-        else if (mode == "fold") {                                                  // longest first; the workgroups of the second round shortest first
+        else if (mode.rfind("keys:", 0) == 0) {                                     // the library's order: buckets of the PREVIOUS search's length (file of n int32), longest first
+            std::vector<int> key(n);
+            FILE *kf = fopen(mode.c_str() + 5, "rb");
+            if (!kf || fread(key.data(), 4, n, kf) != (size_t)n) { printf("no keys\n"); return 1; }
+            fclose(kf);
+            const int bw = getenv("PB_BW") ? atoi(getenv("PB_BW")) : 8, nb = 96 / bw;      // bucket width (the library: 8 -> 12 buckets from 40 up)
+            auto bucket = [&](int it) { const int b = (it - 40) / bw; return it < 40 ? 0 : (b >= nb ? nb - 1 : b); };
+            for (int b = nb - 1; b >= 0; b--) for (int i = 0; i < n; i++) if (bucket(key[i]) == b) perm.push_back(i);
+        } else if (mode.rfind("groups:", 0) == 0 || mode == "groups_true") {       // wavefront-sized groups of consecutive plans (spatially coherent), the groups longest first
+            std::vector<int> key(n);
+            if (mode == "groups_true") key = it;
+            else { FILE *kf = fopen(mode.c_str() + 7, "rb"); if (!kf || fread(key.data(), 4, n, kf) != (size_t)n) { printf("no keys\n"); return 1; } fclose(kf); }
+            const int G = getenv("PB_GROUP") ? atoi(getenv("PB_GROUP")) : 64, ng = (n + G - 1) / G;
+            std::vector<int> gk(ng, 0), go(ng);
+            for (int i = 0; i < n; i++) gk[i / G] = std::max(gk[i / G], key[i]);
+            for (int g = 0; g < ng; g++) go[g] = g;
+            std::stable_sort(go.begin(), go.end(), [&](int a, int b) { return gk[a] > gk[b]; });
+            for (int g : go) for (int i = g * G; i < std::min(n, (g + 1) * G); i++) perm.push_back(i);
+        } else if (mode == "fold") {                                                  // longest first; the workgroups of the second round shortest first
             const int first = std::min(n, 256 * 256);
             for (int i = 0; i < first; i++) perm.push_back(order[n - 1 - i]);
             for (int i = 0; i < n - first; i++) perm.push_back(order[i]);
