@@ -187,6 +187,26 @@ def leg_roofline(leg, steps, tracked, wname):
             'traffic': measured_traffic(wname, name.split(' ')[0]), 'valu_issue_frac': valu_issue_frac(wname, per_launch, ms * 1e-3) if name == 'k_solve' else None}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` as a CHILD process, relay its output (rank 0's one JSON line) and return its exit code.  This
+    process never imports torch.cuda nor touches the GPU, and nothing is exec'ed: the ranks are ordinary children."""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] WORLD_SIZE unset: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -220,6 +240,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
+        if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+            raise SystemExit(self_launch(args.gpus))            # `python bench.py --gpus N`: start the N ranks as a child job
         raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` '
                          f'(WORLD_SIZE={world}): one rank per GPU')
     import torch
@@ -397,6 +419,10 @@ def main():
                        'agent_steps_timed': main_leg['agent_steps'], 're_plans_timed': main_leg['plans']},
             'roofline': roof,
         }
+        # how many ranks the process group itself reported (not what --gpus asked for), and what carried the exchange
+        out['rccl_ranks_seen'] = dist.get_world_size() if dist is not None else 1
+        out['process_group'] = {'backend': dist.get_backend() if dist is not None else None, 'exchange': exchange,
+                                'ranks_sharing_gpu0_test_hook': share_gpu}
         FORMS = {1: 'k_solve_sweep + k_solve_pick4', 2: 'k_track_replan', 4: 'lane-per-plan re-plan kernel', 8: 'k_replan_group (4 .. 64 lanes per plan)', 16: 'k_lp'}
         out['config']['kernel_forms'] = [v for k, v in FORMS.items() if main_leg['forms'] & k] or ['k_solve']
         if roof2 is None and tracked and 'solver_only' in extras:

@@ -57,3 +57,28 @@ def test_bench_script_partition_mode_two_ranks_on_one_gpu():
                 '--partition'], env={'SCA_BENCH_SHARE_GPU': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29553'}, timeout=1500)
     assert out['n_gpus'] == 2 and out['config']['agents'] == 6000 and 'slabs of grid cells' in out['config']['parallelism']
     assert out['config']['agent_steps_timed'] == 6000 * 5 and out['value'] > 0
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the command shape the driver's 1-GPU record shows -- must start its own
+    torch.distributed.run job as a child, relay rank 0's line and say how many ranks the process group reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['SCA_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3', '--agents', '6000'],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks_seen'] == 2 and out['process_group']['backend'] == 'gloo'
+    assert out['config']['agent_steps_timed'] == 6000 * 4 and out['value'] > 0
+
+
+def test_bench_self_launch_partition_variant():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['SCA_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3', '--agents', '6000',
+                        '--nbr', 'grid', '--partition'], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['rccl_ranks_seen'] == 2 and out['process_group']['exchange'] == 'partition'

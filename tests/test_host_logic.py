@@ -163,7 +163,23 @@ def test_scenario_generators_match_reference_fixtures():
 
 
 
-def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
+def test_bench_refuses_a_gpu_count_that_contradicts_its_launcher():
+    """launched BY a launcher (WORLD_SIZE set) with another --gpus: refuse; without a launcher bench.py starts the ranks itself
+    (tests/test_gpu_bench.py::test_bench_self_launches_two_ranks)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1'],
                        env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and 'torch.distributed.run' in (r.stdout + r.stderr)
+
+
+def test_bench_self_launch_starts_torch_distributed_run_as_a_child_and_returns_its_code():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's command shape): the ranks are started as a child job.  No GPU
+    here, so both ranks stop at "bench.py needs a GPU" -- what is checked is the plumbing: the launch line, that each rank got
+    WORLD_SIZE = 2 (it passed the --gpus check) and that the parent returns the job's non-zero code without touching a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--agents', '64'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    both = r.stdout + r.stderr
+    assert 'launching' in both and '--nproc-per-node 2' in both
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and ('needs a GPU' in both or 'No HIP GPUs' in both or 'ProcessGroupNCCL' in both or 'NCCL' in both or 'CUDA' in both), both[-3000:]
