@@ -256,6 +256,15 @@ int sca_tracker_replans(void *tracker, int32_t *replans /*n*/);
 int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pitch_min, double pitch_max, double *length,
                     char *mode7, int32_t *n_samples, double *samples /*nullable, cap*5*/, int cap);
 
+/* What the tracker's bit-for-bit claim is conditional on.  Host and device tracker compute sin / cos / atan2 / acos / x ** 2 with a
+ * restatement of ONE libm build -- GNU C Library 2.35, x86-64, the FMA variants (sca_amd/csrc/sca_glibc_math.h), the libm under the
+ * Python that recorded tests/golden/.  math.sin & co. of a reference run on another host are THAT host's libm; if it is another
+ * build the reference itself prints other last bits there, and this library keeps printing 2.35's.  sca_libm_check compares the
+ * restatement with the running libm on a fixed set of 5 x 4096 arguments: returns 0 when they agree, 1 when they do not
+ * (mismatches[5], nullable: sin, cos, atan2, acos, pow(x, 2)).  sca_tracker_create prints one note on stderr in the second case
+ * (SCA_QUIET silences it) and sca_device_tracker_enable leaves the condition in sca_last_error; behaviour never changes. */
+int sca_libm_check(int64_t *mismatches);
+
 /* The same tracker on the device: one lane per agent for the tracking, tracker records resident in HBM, the re-planning
  * agents of a step compacted into kernels of their own -- one lane up to one wavefront per plan, by how many a step has
  * (sca_amd/csrc/sca_tracker.hip.h).  Same statements as the host tracker AND the same libm (sca_glibc_math.h: glibc's sin / cos /

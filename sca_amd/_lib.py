@@ -90,6 +90,7 @@ SIGNATURES = {
     'sca_device_tracker_replans': (C.c_int, [C.c_void_p, ip]),
     'sca_selftest_dubins_words': (C.c_int, [C.c_int, dp, dp, dp, C.POINTER(C.c_int64)]),
     'sca_selftest_plan3d_lean': (C.c_int, [C.c_int, dp, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'sca_libm_check': (C.c_int, [C.POINTER(C.c_int64)]),
     'sca_dubins_plan': (C.c_int, [dp, dp, C.c_double, C.c_double, C.c_double, dp, C.c_char_p, ip, dp, C.c_int]),
     'sca_candidate_table': (C.c_int, [C.c_int, dp, dp]),
     'sca_kd_build_host': (C.c_int, [C.c_int, dp, ip, dp]),

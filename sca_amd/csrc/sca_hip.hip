@@ -289,11 +289,63 @@ int sca_kd_build_host(int n, const double *pos, int32_t *perm, double *tree_out)
     return 0;
 }
 
+// ---- what the tracker's parity claim is conditional on ----------------------------------------------------------------------
+// The tracker (host and device) computes sin / cos / atan2 / acos / x ** 2 with a restatement of ONE libm build: GNU C Library
+// 2.35, x86-64, the FMA variants its ifunc resolvers pick on AVX2 machines (sca_glibc_math.h) -- the libm the golden fixtures were
+// recorded with.  A Python reference run on THIS host calls THIS host's libm; where that is another build (another glibc, a CPU
+// without FMA, aarch64) the reference itself would print other last bits than the fixtures, and the library would keep printing
+// 2.35's.  sca_libm_check compares the two on a fixed argument set (5 x 4096 points over the ranges a flight path produces) so
+// that the condition is visible at run time: 0 = this host's libm gives the restated bits, 1 = it does not (mismatch counts per
+// function in mismatches[5]: sin, cos, atan2, acos, pow(x, 2)).  Informational: nothing in the library changes its behaviour.
+static double (*volatile p_sin)(double) = std::sin;
+static double (*volatile p_cos)(double) = std::cos;
+static double (*volatile p_atan2)(double, double) = std::atan2;
+static int g_libm_state = -1;                   // -1 unknown, 0 equal, 1 different
+static int64_t g_libm_bad[5] = {0, 0, 0, 0, 0};
+static int libm_check_run() {
+    if (g_libm_state >= 0) return g_libm_state;
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto u01 = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+    auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0 || (a != a && b != b); };
+    int64_t bad[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4096; i++) {
+        const int k = i & 7;
+        // angles: fractions of a turn, many turns (path angles are un-reduced sums), tiny, next to multiples of pi / 2
+        double a = k < 3 ? (u01() - 0.5) * 4.0 * M_PI : k < 5 ? (u01() - 0.5) * 2000.0 : k == 5 ? (u01() - 0.5) * std::ldexp(1.0, -(int)(u01() * 60))
+                 : (double)(int)(u01() * 64 - 32) * M_PI_2 + (u01() - 0.5) * 1e-6;
+        if (!same(sca_gm::g_sin(a), p_sin(a))) bad[0]++;
+        if (!same(sca_gm::g_cos(a), p_cos(a))) bad[1]++;
+        // arctangents: both components over fourteen decades, every quadrant, quotients on both sides of 1/16 and of 1
+        const double y = (u01() - 0.5) * std::pow(10.0, u01() * 14 - 9), x = (u01() - 0.5) * std::pow(10.0, u01() * 14 - 9);
+        if (!same(sca_gm::g_atan2(y, x), p_atan2(y, x))) bad[2]++;
+        const double cth = k < 6 ? u01() * 2.0 - 1.0 : (k == 6 ? 1.0 - u01() * 1e-9 : -1.0 + u01() * 1e-9);
+        if (!same(sca_gm::g_acos(cth), p_acos(cth))) bad[3]++;
+        const double b = (u01() - 0.5) * std::pow(10.0, u01() * 12 - 6);
+        if (!same(sca_gm::g_pow2(b), p_pow(b, 2.0))) bad[4]++;
+    }
+    int64_t total = 0;
+    for (int q = 0; q < 5; q++) { g_libm_bad[q] = bad[q]; total += bad[q]; }
+    g_libm_state = total ? 1 : 0;
+    if (g_libm_state && !getenv("SCA_QUIET"))
+        fprintf(stderr, "[libsca_hip] note: this host's libm differs from the restated glibc 2.35 x86-64 FMA build in %lld of 20480 test "
+                        "arguments (sin %lld, cos %lld, atan2 %lld, acos %lld, pow(x,2) %lld): the Dubins tracker reproduces the bits of THAT "
+                        "libm (the one the golden vectors were recorded with); a Python reference run on this host would differ from both "
+                        "in the last bit of some path lengths.\n",
+                (long long)total, (long long)bad[0], (long long)bad[1], (long long)bad[2], (long long)bad[3], (long long)bad[4]);
+    return g_libm_state;
+}
+int sca_libm_check(int64_t *mismatches /*5, nullable*/) {
+    const int r = libm_check_run();
+    if (mismatches) for (int q = 0; q < 5; q++) mismatches[q] = g_libm_bad[q];
+    return r;
+}
+
 // ---- native v_pref tracker (host only, no GPU needed): scaPolicy.py:264-338 + dubinsmaneuver2d/3d.py ----------------
 void *sca_tracker_create(int n, const double *goal, const double *goal_heading, const double *pref_speed,
                          const uint8_t *zaxis, double turning_radius, double pitch_min, double pitch_max,
                          double neighbor_dist) {
     if (n <= 0 || !goal || !goal_heading || !pref_speed) return nullptr;
+    (void)libm_check_run();                                              // one note on stderr when this host's libm is another build
     auto *T = new sca_dubins::Tracker();
     T->n = n;
     T->goal.assign(goal, goal + 3 * (size_t)n);
@@ -470,6 +522,9 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
                               (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4})
             (void)hipFuncGetAttributes(&fa, f);
     }
+    if (libm_check_run())                                                // informational (the call succeeds): sca_last_error carries the condition
+        c->err = "note: this host's libm is not the restated glibc 2.35 x86-64 FMA build (sca_libm_check): the tracker reproduces that "
+                 "build's bits, a Python reference run on this host would not";
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
     c->d.trk_nbr0 = c->trk_in_pass ? c->trk.nbr0 : nullptr;
     c->trk_passes = 0;
@@ -1259,8 +1314,11 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
                            c->state_fresh ? 1 : 0);
     c->state_fresh = false;
     if (c->part_on) {
-        const int halo = d.n_present - d.shard_count;
-        if (halo > 0) hipLaunchKernelGGL(k_goal_flags_others, dim3((halo + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+        // sized with the whole present bound: d.shard_count and d.n_present are the host's UPPER bounds (part_bounds clamps the halo
+        // bound to n - owned bound, i.e. to 0 for small swarms), so their difference says nothing about the halo count -- the kernel
+        // reads the exact counts and returns beyond them (halo copies that arrived at their goal kept flying for their
+        // neighbours on this rank for one step)
+        hipLaunchKernelGGL(k_goal_flags_others, dim3((std::max(1, d.n_present) + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     } else if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[5], c->stream));
     CHK(c, hipGetLastError());
@@ -1344,7 +1402,7 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
             if (int r = sca_partition_commit(c)) return r;
         }
         if (c->comm) { if (int r = exchange_moved_records(c)) return r; }
-        else if (c->shard_emulation && c->d.shard_count < c->n) {
+        else if (c->shard_emulation && !c->part_on && c->d.shard_count < c->n) {      // (partition: the halo copies stand still by themselves)
             // stand-in for the all-gather's arrivals: the other ranks' agents stand still (their records are copied over)
             const int b = c->d.shard_begin, e = b + c->d.shard_count;
             if (b > 0) CHK(c, hipMemcpyAsync(c->d.rec_new, c->d.rec, sizeof(PubRec) * (size_t)b, hipMemcpyDeviceToDevice, c->stream));
@@ -1513,13 +1571,19 @@ int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double 
         std::sort(cells.begin(), cells.end());
         for (int r = 1; r < nranks; r++) cell_cut[r] = cells[(size_t)((long long)r * n / nranks)];
     }
-    for (int r = 1; r < nranks; r++)
-        if (cell_cut[r] <= cell_cut[r - 1] && r > 1) { c->err = "partition: the cuts leave a rank without a layer of cells (too many ranks for this swarm along this axis)"; return SCA_ERR_ARG; }
+    // an INTERIOR rank needs two layers of cells: with one, an agent that migrates into it lands in a cell that is the next rank's
+    // halo layer as well, and that rank hears of it one step late (only the sender's two slab neighbours get messages)
+    for (int r = 2; r < nranks; r++)
+        if (cell_cut[r] - cell_cut[r - 1] < 2) { c->err = "partition: the cuts leave an interior rank fewer than two layers of cells (too many ranks for this swarm along this axis)"; return SCA_ERR_ARG; }
+    if (nranks > 1 && cell_cut[1] == LLONG_MIN) { c->err = "partition: bad cut"; return SCA_ERR_ARG; }
     PartDev &P = c->part;
     for (int k = 0; k < 2; k++) CHK(c, hipMalloc((void **)&P.present[k], sizeof(int32_t) * n));
     CHK(c, hipMalloc((void **)&P.halo_tmp, sizeof(int32_t) * n));
     CHK(c, hipMalloc((void **)&P.counts, sizeof(int32_t) * 16));
     CHK(c, hipMalloc((void **)&P.emig, n));
+    for (int k = 0; k < 2; k++) CHK(c, hipMemsetAsync(P.present[k], 0, sizeof(int32_t) * n, c->stream));   // entries beyond the exact counts are
+    CHK(c, hipMemsetAsync(P.halo_tmp, 0, sizeof(int32_t) * n, c->stream));                                  // never meant to be read; if a bound
+    CHK(c, hipMemsetAsync(P.emig, 0, n, c->stream));                                                        // slips, the read is agent 0, not garbage
     CHK(c, hipHostMalloc((void **)&c->part_host, sizeof(int) * 8));
     CHK(c, hipEventCreateWithFlags(&c->part_ev, hipEventDisableTiming));
     c->part_pending = false; c->part_age = 0;

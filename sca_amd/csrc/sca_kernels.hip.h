@@ -1430,7 +1430,8 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_lpw(DeviceView d, Pa
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int idx = lo + blockIdx.x * SOLVE_WAVES + wid;
-    if (idx < hi && d.policy[list[idx]] == POL_ORCA_LP) solve_fast<0, 2>(d, P, S, list[idx], lane, wid);   // (partition mode hands over all owned agents)
+    // (partition mode hands over all owned agents: `hi` is then the host's bound and the exact count is on the device)
+    if (idx < hi && !(d.count_dev && idx >= shard_size(d)) && d.policy[list[idx]] == POL_ORCA_LP) solve_fast<0, 2>(d, P, S, list[idx], lane, wid);
 }
 // the first half of k_solve for passes whose v_pref arrives late (solve_fast); the second is k_solve_pick4
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, Params P) {
@@ -1629,6 +1630,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t
     const int lane = threadIdx.x;
     const int at = lo + blockIdx.x * 64 + lane;
     if (at >= hi) return;
+    if (d.count_dev && at >= shard_size(d)) return;                                 // partition mode: `hi` is the host's bound, the list the owned agents
     const int agent = list[at];
     if (d.policy[agent] != POL_ORCA_LP) return;                                     // (partition mode hands over all owned agents)
     const PubRec me = d.rec[agent];

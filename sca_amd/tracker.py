@@ -95,3 +95,12 @@ def dubins_plan(qi, qf, rmin=1.5, pitchlims=(-math.pi / 4, math.pi / 4), max_sam
     if rc != 0:
         raise RuntimeError(f'sca_dubins_plan rc={rc}')
     return length.value, mode.value.decode(), samples[:min(ns.value, max_samples)], ns.value
+
+
+def libm_check():
+    """(matches, mismatches[5]) -- does this host's libm give the bits of the restated glibc 2.35 x86-64 FMA build the tracker
+    computes with (sca_libm_check)?  False means: a Python reference run on THIS host would differ from the golden vectors, and
+    from this library, in the last bit of some path lengths."""
+    bad = (C.c_int64 * 5)()
+    r = _lib.lib().sca_libm_check(bad)
+    return r == 0, list(bad)

@@ -9,6 +9,7 @@ import ctypes as C
 import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -67,3 +68,32 @@ def test_library_build_equals_python_math():
     assert same(_host(3, y, x), [math.atan2(p, q) for p, q in zip(y, x)])
     assert same(_host(4, x), [float(v) ** 2 for v in x])
     assert same(_host(4, x), [math.pow(v, 2) for v in x])
+
+
+def test_libm_check_says_what_the_parity_claim_is_conditional_on(tmp_path):
+    """sca_libm_check: equal to the running libm on the recorded build -- and, with a libm whose sine is off by one ulp preloaded
+    in front of it (what another glibc build looks like from here), it says so: return 1, the sine's count, one note on stderr from
+    sca_tracker_create.  Nothing else changes: the tracker keeps computing the restated build's bits."""
+    from sca_amd import tracker
+    ok, bad = tracker.libm_check()
+    if _glibc_is_the_recorded_one():
+        assert ok and bad == [0, 0, 0, 0, 0]
+    shim = tmp_path / 'offsin.c'
+    shim.write_text('#define _GNU_SOURCE\n#include <dlfcn.h>\n#include <math.h>\n'
+                    'double sin(double x) { static double (*real)(double); if (!real) real = (double (*)(double))dlsym(RTLD_NEXT, "sin");\n'
+                    '  double r = real(x); return nextafter(r, 10.0); }\n')
+    so = tmp_path / 'liboffsin.so'
+    subprocess.check_call(['gcc', '-O1', '-shared', '-fPIC', '-fno-builtin', str(shim), '-o', str(so), '-ldl', '-lm'])
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'import numpy as np\n'
+            'from sca_amd import tracker\n'
+            'ok, bad = tracker.libm_check(); print("CHECK", ok, bad)\n'
+            'tr = tracker.DubinsTracker(np.zeros((1, 3)), np.zeros((1, 3)), 1.0, nthreads=1); tr.close()\n'
+            'l, mode, _, n = tracker.dubins_plan([0.0, 0.0, 3.0, -1.5707963267948966, 0.0], [0.0, 0.0, 13.0, 1.5707963267948966, 0.0], 1.5)\n'
+            'print("PLAN", mode, repr(l))\n' % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LD_PRELOAD=str(so)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('CHECK')][0]
+    assert 'False' in line and '[4096, 0, 0, 0, 0]' in line, line
+    assert "this host's libm differs from the restated glibc 2.35" in r.stderr
+    assert 'PLAN RLRLSR 16.442132978487617' in r.stdout        # the __main__ instance of dubinsmaneuver3d.py: still the recorded bits

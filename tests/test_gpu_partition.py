@@ -20,6 +20,13 @@ def _scene(n, kind):
     if kind == 'cube':                                          # every policy, dense enough for collisions and arrivals
         sc = scenarios.random_cube(n, seed=3)
         pol = (np.arange(n) % 5).astype(np.uint8)
+    elif kind == 'arrive':                                      # short trips: most agents reach their goal within 60 steps, many of them
+        sc = scenarios.random_cube(n, seed=11)                  # next to a cut -- as halo copies of the rank across it (the
+        rng = np.random.default_rng(12)                         # at-goal flag of a halo copy must be set in the step it arrives)
+        sc['goal'] = sc['goal'].copy()
+        sc['goal'][:, :3] = sc['start'][:, :3] + rng.normal(0.0, 1.6, (n, 3))
+        pol = np.where(np.arange(n) % 3 == 0, 1, np.arange(n) % 5).astype(np.uint8)      # RVO3D / S-RVO3D / ORCA: straight-line v_pref
+        pol[pol == 0] = 2
     else:
         sc = scenarios.circle(n)
         pol = np.where(np.arange(n) % 7 == 3, 2, 0).astype(np.uint8)
@@ -100,6 +107,11 @@ for block in range(steps // 10):
     moved_total = len(own0 ^ set(own.tolist()))
 t = torch.tensor([moved_total]); dist.all_reduce(t)
 print('RANK', rank, 'owned', len(st.owned()), 'halo', sol.partition_counts()[1], 'changed owner (both ranks)', int(t.item()), 'OK' if ok else 'MISMATCH', flush=True)
+if kind == 'arrive':
+    arrived = int((ref.get_state()['flags'] & 1).sum())
+    print('RANK', rank, 'arrived', arrived, flush=True)
+    if arrived < n // 4:
+        print('RANK', rank, 'too few arrivals: the test does not test the at-goal flag of halo copies', flush=True); ok = False
 if int(os.environ.get('SCA_TEST_NEED_MIGRATION', '1')) and int(t.item()) == 0:
     print('RANK', rank, 'no agent crossed a cut: the test does not test migration', flush=True); ok = False
 dist.destroy_process_group()
@@ -108,13 +120,14 @@ sys.exit(0 if ok else 1)
 
 
 @pytest.mark.parametrize('world,n,kind,track,axis,steps', [(2, 3000, 'cube', False, 0, 60), (2, 3000, 'cube', True, 1, 60),
-                                                          (3, 4000, 'cube', True, 2, 40), (2, 20000, 'circle', True, 0, 30)])
+                                                          (3, 4000, 'cube', True, 2, 40), (2, 20000, 'circle', True, 0, 30),
+                                                          (2, 6000, 'arrive', False, 0, 60), (3, 6000, 'arrive', False, 1, 60)])
 def test_partitioned_ranks_match_single_rank(tmp_path, world, n, kind, track, axis, steps):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    port = str(29560 + world + axis)
+    port = str(29560 + world + axis + (10 if kind == 'arrive' else 0))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, SCA_TEST_N=str(n), SCA_TEST_STEPS=str(steps), SCA_TEST_SCENE=kind,
-               SCA_TEST_TRACK=str(int(track)), SCA_TEST_AXIS=str(axis), SCA_TEST_NEED_MIGRATION='0' if kind == 'circle' else '1')
+               SCA_TEST_TRACK=str(int(track)), SCA_TEST_AXIS=str(axis), SCA_TEST_NEED_MIGRATION='0' if kind in ('circle', 'arrive') else '1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
                         '--master-port', port, str(script), ROOT], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]

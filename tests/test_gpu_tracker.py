@@ -348,3 +348,45 @@ def test_replan_kernel_ranges_give_the_same_episode(n, form, monkeypatch):
         assert np.array_equal(a.diag()['vpref'], b.diag()['vpref'], equal_nan=True), (form, t)
     assert np.array_equal(a.device_tracker_replans(), b.device_tracker_replans())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('form', ['spec4', 'spec3', 'spec2', 'quad', 'lane'])
+@pytest.mark.parametrize('family', ['c4', 'c2', 'c5', 'all'])
+def test_device_planner_long_range_kats(family, form, monkeypatch):
+    """tests/golden/F7b_dubins_kat_long.npz -- the REFERENCE's planner on c4 (4.7 .. 39.8 km), c2 (61 .. 412 m) and c5 (11 .. 17 m)
+    poses -- through every re-plan kernel: k_replan_group<64 / 32 / 16 / 4> and the lane-per-plan k_replan (the c4 family alone fills
+    its wavefront with far plans: the lean search's straight-line block; `all` mixes far and near lanes: the literal way).  Length,
+    word, both radii, t / p of both maneuvers, sampling size and sample count of the record each kernel leaves: the reference's bits."""
+    import ctypes as C
+    from sca_amd import _lib, solver as S
+    from test_dubins_kat_long import load_kats, words_of
+    k = load_kats()
+    sel = np.flatnonzero(np.char.startswith(k['family'], family.encode())) if family != 'all' else np.arange(len(k['length']))
+    n = len(sel)
+    env = {'spec4': None, 'spec3': ('0', None, None, None), 'spec2': ('0', '0', None, None), 'quad': ('0', '0', '0', None),
+           'lane': ('0', '0', '0', '1')}[form]
+    for key, v in zip(('SCA_TRK_SPEC4_MAX', 'SCA_TRK_SPEC3_MAX', 'SCA_TRK_SPEC2_MAX', 'SCA_TRK_MID_MAX'), env or (None,) * 4):
+        if v is None:
+            monkeypatch.delenv(key, raising=False)
+        else:
+            monkeypatch.setenv(key, v)
+    qi, qf = k['qi'][sel], k['qf'][sel]
+    sol = S.BatchedSolver(max_agents=n)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    start6 = np.concatenate([qi, np.zeros((n, 1))], 1)
+    goal6 = np.concatenate([qf, np.zeros((n, 1))], 1)
+    sol.set_agents(np.full(n, 0.5), np.ones(n), qf[:, :3], np.zeros(n, np.uint8), S.zaxis_flags(start6, goal6), np.full(n, 1e9))
+    sol.set_state(qi[:, :3], np.zeros((n, 3), np.float32), start6[:, 3:6], np.zeros(n, np.uint8))
+    sol.device_tracker_enable(goal6[:, 3:6], in_pass=False)
+    sol.device_tracker_vpref(np.full(n, -1.0))                  # the first compute_v_pref of every agent: a plan each
+    assert np.array_equal(sol.device_tracker_replans(), np.ones(n, np.int32))
+    want_form = {'lane': S.FORM_REPLAN_LANE}.get(form, S.FORM_REPLAN_FEW)
+    assert sol.pass_forms() & want_form, (form, sol.pass_forms())
+    o = np.zeros(24)
+    for j, i in enumerate(sel):
+        assert sol.L.sca_device_tracker_debug(sol.ctx, j, _lib.ptr(o, C.c_double)) == 0
+        assert o[8] == k['length'][i] and words_of(o) == k['mode'][i], (family, form, i, o[8], k['length'][i], words_of(o), k['mode'][i])
+        assert o[0] == k['radii'][i, 0] and o[4] == k['radii'][i, 1], (family, form, i)
+        assert o[1] == k['tpq'][i, 0] and o[2] == k['tpq'][i, 1] and o[5] == k['tpq'][i, 3] and o[6] == k['tpq'][i, 4], (family, form, i)
+        assert o[9] == k['sampling'][i] and int(o[13]) == k['n'][i], (family, form, i)
+    sol.close()

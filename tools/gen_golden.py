@@ -649,6 +649,13 @@ def main():
             obs14 = [(list(map(float, rng.uniform(-side, side, 3) * np.array([1, 1, 0.5]) + np.array([0, 0, side / 2]))),
                       float(rng.choice([0.3, 1.0]))) for _ in range(4)]
             run_env_episode(agent_mod, env_mod, classes, nm, pos, goal, pol, obs14, 20, radius=rad, pref_speed=psp, outdir=od)
+    # F15: BASELINE config 2 itself -- N = 1024 circle, rad = 1.25 N / 2 pi (the arc spacing bench.py and SURVEY 8d use), SCA with
+    # its Dubins tracker, steps 0-3 stepped by the reference (about ten minutes of Python: ~2000 Dubins plans of 412 m)
+    if want('F15_sca_circle1024'):
+        pos, goal = rs.set_circle_pos((0, 0), 1.25 * 1024 / (2.0 * math.pi), 1024)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        run_env_episode(agent_mod, env_mod, classes, 'F15_sca_circle1024', pos, goal, [POL_SCA] * 1024, [], 4, outdir=od)
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
