@@ -17,8 +17,9 @@
 // The host launches the re-plan kernels a recent pass's count makes possible (launch_tracker); the device-side count of the
 // pass decides which of them, and which form inside k_replan_few, does the work.
 //
-// The arithmetic is sca_dubins.hpp compiled for gfx950: same statements as the host tracker, the device library's
-// sin / cos / atan2 / acos instead of glibc's.  State: one AgentTrack record per agent, resident in HBM.
+// The arithmetic is sca_dubins.hpp compiled for gfx950: same statements as the host tracker and the same libm -- glibc 2.35's
+// sin / cos / atan2 / acos / pow restated operation for operation (sca_glibc_math.h), so every plan and every v_pref equals the
+// host tracker's bit for bit.  State: one AgentTrack record per agent, resident in HBM.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sca_dubins.hpp"

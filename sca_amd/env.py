@@ -17,7 +17,7 @@ Differences that matter:
     per-agent stateful planner outside the kernel boundary.  The native restatement is sca_amd.tracker.DubinsTracker:
     pass it as MACAEnv(v_pref_fn=tracker) (any `v_pref_fn(env) -> [N,3]` works; bit-exact, host-bound), or use
     MACAEnv(device_tracker=True): the same tracker as kernels inside every pass (state stays in HBM; equal to the host
-    tracker up to isolated 1e-5 steps); without either the straight-line rule of rvo3dPolicy.py:182-196
+    tracker bit for bit -- same statements, same restated glibc libm); without either the straight-line rule of rvo3dPolicy.py:182-196
     is used and `env.dubins_tracker` is False;
   * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
 There is no CPU path: constructing the env without a GPU raises.

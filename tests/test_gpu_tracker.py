@@ -16,7 +16,8 @@ from golden_util import load, static_inputs
 pytestmark = pytest.mark.gpu
 
 EPISODES = ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16', 'F4_mixed_takeoff16', 'F10_sca_exp3_map',
-            'F13_fuzz_track_00', 'F13_fuzz_track_01', 'F13_fuzz_track_02', 'F13_fuzz_track_03']
+            'F13_fuzz_track_00', 'F13_fuzz_track_01', 'F13_fuzz_track_02', 'F13_fuzz_track_03',
+            'F15_sca_circle1024']             # BASELINE config 2 itself, steps 0-3 stepped by the reference (2038 plans of 412 m)
 
 
 def _solver_for(fx, st, in_pass):

@@ -26,7 +26,7 @@ def test_dubins_planner_kats():
 
 @pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
                                   'F4_mixed_takeoff16', 'F10_sca_exp3_map', 'F13_fuzz_track_00', 'F13_fuzz_track_01',
-                                  'F13_fuzz_track_02', 'F13_fuzz_track_03'])
+                                  'F13_fuzz_track_02', 'F13_fuzz_track_03', 'F15_sca_circle1024'])
 def test_tracker_reproduces_reference_v_pref(name):
     """Open loop on the solver (states come from the fixture), closed loop on the tracker's own state: every
     compute_v_pref of the episode, including all re-plans, must return the reference's V_des bit for bit."""
