@@ -45,6 +45,15 @@ BYTES_PER_AGENT_STEP = 48 + 32 + 16 * 48 + 32
 # (~480) + v_pref (24) written
 BYTES_PER_REPLAN = 48 + 24 + 48 + 480 + 24
 ALLGATHER_MS_ASSUMED = 0.030     # scale_model: one in-place ncclAllGather of N x 48 B over xGMI, latency bound (not measurable on one GPU)
+TRACK_OVERLAP_MS = 0.020         # scale_model, tracked legs: the rank's k_track (19-31 us, profiles/r03_b_*) needs only the rank's own moved
+                                 # records, so an exchange issued right behind the integrate stage can run beside it
+
+
+def allgather_ms_model(n_agents, G):
+    """MODELLED, not measured: an all-gather of n_agents x 48 B among G fully connected GPUs, every peer's shard over its own xGMI
+    link (7 x ~153 GB/s per GPU, MI355X_MICROARCH.md) at 80 % of the link rate, plus 20 us of launch / synchronisation latency"""
+    shard_bytes = 48.0 * n_agents / G
+    return 0.020 + shard_bytes / (0.8 * 153e9) * 1e3
 
 WORKLOADS = {
     'c2': dict(kind='circle', n=1024, policy='sca', desc='c2: circle N=1024, SCA policy'),
@@ -234,6 +243,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='value leg only: no solver_only / grid_mode / scale_model / extra_legs')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the c2 / c3 / c3lp / c5 legs')
+    ap.add_argument('--no-weak-model', action='store_true', help='skip scale_model.weak (one rank of 2 / 8 at N = G x 100000, timed on this GPU)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -392,6 +402,9 @@ def main():
             so_kd = extras['solver_only'] if args.nbr == 'kd' else g['solver_only']
             so_grid = g['solver_only'] if args.nbr == 'kd' else extras['solver_only']
             extras['scale_model']['solver_only'] = scale_model(sol, scene, S, timer, args.steps, args.warmup, False, so_kd, so_grid)['modes']
+        if wname == 'c4' and not args.agents and not args.no_weak_model:
+            full = {'kd': (main_leg if args.nbr == 'kd' else g)['ms_per_step'], 'grid': (g if args.nbr == 'kd' else main_leg)['ms_per_step']}
+            extras['scale_model']['weak'] = weak_scale_model(S, timer, local_rank, w, n, max(10, args.steps // 2), max(5, args.warmup // 2), tracked, full)
         if tracked:
             extras['value_parity'] = value_parity(S, scene, local_rank, mode=mode)
         if not args.no_extra_legs and wname == 'c4' and not args.agents:
@@ -483,6 +496,10 @@ def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
     from sca_amd.distributed import ShardedStepper
     n = scene['n']
     out = {'allgather_ms_assumed': ALLGATHER_MS_ASSUMED,
+           'modelled': 'ms_rank_step is MEASURED on this GPU (one rank of G executing alone, the other ranks\' records copied over); the exchange '
+                       'time and every predicted_* figure are MODELLED (no run with more than one GPU has happened); '
+                       'predicted_speedup charges the all-gather serially, predicted_speedup_exchange_overlapped lets it run beside the '
+                       'rank\'s next k_track (%.0f us, tracked legs only)' % (TRACK_OVERLAP_MS * 1e3),
            'method': 'sca_set_shard + sca_set_shard_emulation on one GPU, same leg as `value` (v_pref, steps, warm-up)', 'modes': {}}
     full_ms = {'kd': leg_kd['ms_per_step'], 'grid': leg_grid['ms_per_step']}
     sol.set_shard_emulation(True)
@@ -497,8 +514,10 @@ def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
             st.begin, st.count = (G // 2) * cnt, cnt
             leg = timed_leg(sol, scene, st, timer, steps, warmup, tracked)
             rank_ms = leg['ms_per_step']
+            hidden = TRACK_OVERLAP_MS if tracked else 0.0
             rows.append({'G': G, 'ms_rank_step': rank_ms, 'ms_1gpu_step': full_ms[name],
                          'predicted_speedup': full_ms[name] / (rank_ms + ALLGATHER_MS_ASSUMED),
+                         'predicted_speedup_exchange_overlapped': full_ms[name] / (rank_ms + max(0.0, ALLGATHER_MS_ASSUMED - hidden)),
                          'predicted_speedup_without_exchange': full_ms[name] / rank_ms})
         out['modes'][name] = rows
     sol.set_shard_emulation(False)
@@ -525,6 +544,48 @@ def scale_model(sol, scene, S, timer, steps, warmup, tracked, leg_kd, leg_grid):
     best = max(((r['predicted_speedup'], m, r) for m, rows in out['modes'].items() for r in rows if r['G'] == 8), default=None)
     if best:
         out.update({'G': 8, 'mode': best[1], 'ms_rank_step': best[2]['ms_rank_step'], 'predicted_speedup': best[0]})
+    return out
+
+
+def weak_scale_model(S, timer, device, w, per_gpu, steps, warmup, tracked, full_ms):
+    """WEAK scaling, the regime DESIGN.md section 6 argues the hardware wants: `per_gpu` agents on every GPU, N = G x per_gpu in total.
+    What ONE rank of G then executes per step is timed on this GPU exactly as in scale_model (the replicated kd-tree / grid over all N
+    agents, everything else for its per_gpu agents; with the cell-owner partition only its slab + halo); the exchange is MODELLED
+    (allgather_ms_model).  efficiency = t(1 GPU, per_gpu agents) / (rank step + exchange): 1.0 = perfect weak scaling."""
+    import torch
+    from sca_amd.distributed import PartitionedStepper, ShardedStepper
+    out = {'agents_per_gpu': per_gpu, 'modelled': 'rank step MEASURED on one GPU, exchange MODELLED (allgather_ms_model); no multi-GPU run has happened',
+           'rows': []}
+    for G in (2, 8):
+        scene = build_scene(w, G * per_gpu)
+        n = scene['n']
+        sol = make_solver(S, scene, device)
+        ag = allgather_ms_model(n, G)
+        row = {'G': G, 'agents': n, 'allgather_ms_modelled': ag}
+        sol.set_shard_emulation(True)
+        for name in ('kd', 'grid'):
+            sol.set_shard((G // 2) * per_gpu, per_gpu)
+            st = ShardedStepper(sol, 0, 1, mode=NBR[name])
+            st.begin, st.count = (G // 2) * per_gpu, per_gpu
+            leg = timed_leg(sol, scene, st, timer, steps, warmup, tracked)
+            row[name] = {'ms_rank_step': leg['ms_per_step'], 'ms_1gpu_step': full_ms[name],
+                         'weak_efficiency': full_ms[name] / (leg['ms_per_step'] + ag),
+                         'agent_steps_per_s_predicted': n / ((leg['ms_per_step'] + ag) * 1e-3)}
+        sol.set_shard_emulation(False)
+        sol.set_shard(0, n)
+        reset_state(sol, scene)
+        st = PartitionedStepper(sol, G // 2, G, torch, None, axis=0, emulate=True)
+        st.begin, st.count = 0, n
+        leg = timed_leg(sol, scene, st, timer, steps, warmup, tracked)
+        owned, halo = sol.partition_counts()
+        p2p = 0.020 + 2 * 104.0 * max(halo, 1) / (0.8 * 153e9) * 1e3      # two halo messages of 104-B entries to the slab neighbours
+        row['grid_partition'] = {'ms_rank_step': leg['ms_per_step'], 'agents_owned': owned, 'halo': halo, 'exchange_ms_modelled': p2p,
+                                 'ms_1gpu_step': full_ms['grid'], 'weak_efficiency': full_ms['grid'] / (leg['ms_per_step'] + p2p),
+                                 'agent_steps_per_s_predicted': n / ((leg['ms_per_step'] + p2p) * 1e-3)}
+        sol.partition_disable()
+        sol.set_shard_emulation(False)
+        sol.close()
+        out['rows'].append(row)
     return out
 
 

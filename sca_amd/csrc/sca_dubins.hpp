@@ -765,6 +765,9 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
         Frame2D F;
         F.D = sqrt_pos(sca_gm::g_pow2_main(lenH) + K.dz2);                            // (36 hr <= lenH < 2^100 when nothing below objects)
         const bool far_theta = lenH > std::fabs(dz) && lenH < 1.2676506002282294e30;
+        // near in the vertical plane (vr grows without bound towards Rmin): known here, before the vertical frame's trigonometry and
+        // words -- the literal way at once instead of after a whole evaluation that would be thrown away (round 4)
+        if (!lean::any_says(!flat && !far_d(F.D / vr))) {
         const double y1[1] = {dz}, x1[1] = {lenH};
         double th[1];
         atan_far_n<1, 1>(y1, x1, th, kmin);
@@ -784,6 +787,7 @@ bool candidate(bool fast_ok, const Frame2D &H, double mbetaH, const SearchConst 
         SCA_LEAN_T(t5);
         SCA_LEAN_TACC(0, t0, t1); SCA_LEAN_TACC(1, t1, t2); SCA_LEAN_TACC(2, t2, t3); SCA_LEAN_TACC(3, t3, t4); SCA_LEAN_TACC(4, t4, t5); SCA_LEAN_TACC(5, 0ull, 1ull);
         if (!lean::any_says(!flat && (keys_odd(kmin) || !far_theta || !far_d(dV)))) { SCA_LEAN_STAT(0); SCA_LEAN_HOST_COUNT(g_host_fast); len = lenV; return ok; }
+        }
         SCA_LEAN_STAT(1);
     }
     SCA_LEAN_STAT(2);

@@ -231,6 +231,7 @@ struct sca_ctx {
                                         // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
     int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
     bool kd_force_ticket = false;
+    int kd_wave_cap = KD_WAVE_CAP;      // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536)
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
@@ -587,6 +588,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TICKET")) c->kd_force_ticket = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SCA_KD_WAVE_CAP")) c->kd_wave_cap = std::min(KD_WAVE_CAP, std::max(2 * KD_WAVE_FLOOR, std::atoi(e)));
     int ndev = 0;
     CHK(c, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { c->err = "no HIP device: libsca_hip has no CPU path"; return SCA_ERR_HIP; }
@@ -631,7 +633,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->kd.job_cap = (int)(N / 64 + 64);
     r |= dalloc(c, &c->kd.jobs[0], (size_t)c->kd.job_cap); r |= dalloc(c, &c->kd.jobs[1], (size_t)c->kd.job_cap);
     r |= dalloc(c, &c->kd.small, N); r |= dalloc(c, &c->kd.counts, (size_t)2 * KD_MAX_LEVELS + 4); r |= dalloc(c, &c->kd.ticket, (size_t)KD_MAX_LEVELS + 1);   // counts | nchunks (one readback) | tail slot counter
-    c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_MIN + 8);
+    c->kd.chunk_cap = (int)(N / KD_CHUNK + N / KD_WAVE_FLOOR + 8);
     r |= dalloc(c, &c->kd.nbox, (size_t)2 * c->kd.job_cap * 6); r |= dalloc(c, &c->kd.nge, (size_t)2 * c->kd.job_cap);
     r |= dalloc(c, &c->kd.ps, N);
     r |= dalloc(c, &c->kd.cbox, (size_t)2 * c->kd.job_cap * 12); r |= dalloc(c, &c->kd.chain, (size_t)c->kd.chunk_cap);
@@ -936,11 +938,12 @@ static int build_agent_tree_device(sca_ctx *c) {
     }
     // size of the subtrees handed to k_kd_block: 1.25 x the average node size of the first level that fits (n / 2^k), so that
     // the nodes of that level -- all within a few per cent of the average -- are on one side of it
-    int wave_max = n <= 1024 ? 1024 : KD_WAVE_CAP;          // a tree that fits one workgroup: the smaller one if it can
-    if (n > KD_WAVE_CAP) {
+    const int cap = c->kd_wave_cap;
+    int wave_max = (n <= 1024 && cap >= 1024) ? 1024 : cap; // a tree that fits one workgroup: the smaller one if it can
+    if (n > cap) {
         double sz = (double)n;
-        while (sz > KD_WAVE_CAP / 1.25) sz *= 0.5;
-        wave_max = std::min(KD_WAVE_CAP, std::max(KD_WAVE_MIN + 1, (int)std::ceil(1.25 * sz)));
+        while (sz > cap / 1.25) sz *= 0.5;
+        wave_max = std::min(cap, std::max(cap / 2 + 1, (int)std::ceil(1.25 * sz)));
     }
     c->kd.wave_max = wave_max;
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, d, c->kd, c->P);
@@ -967,7 +970,7 @@ static int build_agent_tree_device(sca_ctx *c) {
         if (c->kd_single_hint > 0 && !c->kd_nohint) first_single = c->kd_single_hint - 1;
         first_single = std::min(first_single, KD_MAX_LEVELS - 2);
         levels = first_single + 1;
-        const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / KD_WAVE_MIN + 8);   // >= chunks of any level of n agents
+        const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / (wave_max / 2 + 1) + 8);   // >= chunks of any level of n agents (a node of the level passes has > wave_max members... its children > 0)
         for (int l = 0; l < first_single; l++) {
             // chunk by arrival once a level can have more chunks than are resident at once (k_kd_lv_rank); SCA_KD_TICKET=1 forces it (tests)
             if (grid > c->kd_rank_capacity || c->kd_force_ticket)
@@ -980,7 +983,12 @@ static int build_agent_tree_device(sca_ctx *c) {
     }
 
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
-    if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->nbr_stream, d, c->kd, levels);
+    // one workgroup per subtree, in LDS: the smallest form that holds wave_max members (two positions per thread)
+    if (wave_max <= 256) hipLaunchKernelGGL((k_kd_block<256, 128>), dim3(sgrid), dim3(128), 0, c->nbr_stream, d, c->kd, levels);
+    else if (wave_max <= 512) hipLaunchKernelGGL((k_kd_block<512, 256>), dim3(sgrid), dim3(256), 0, c->nbr_stream, d, c->kd, levels);
+    else if (wave_max <= 768) hipLaunchKernelGGL((k_kd_block<768, 384>), dim3(sgrid), dim3(384), 0, c->nbr_stream, d, c->kd, levels);
+    else if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->nbr_stream, d, c->kd, levels);
+    else if (wave_max <= 1280) hipLaunchKernelGGL((k_kd_block<1280, 640>), dim3(sgrid), dim3(640), 0, c->nbr_stream, d, c->kd, levels);
     else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->nbr_stream, d, c->kd, levels);
     CHK(c, hipGetLastError());
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every

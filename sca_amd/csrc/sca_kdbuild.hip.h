@@ -41,7 +41,8 @@ namespace sca {
 // (k_kd_block).  The host picks it between these bounds so that the node sizes of a level (n / 2^k, within a few per cent)
 // do not straddle it: with a fixed 1024 the 4096- and 16384-agent trees needed a whole level pass for the half of their
 // ~1024-member nodes that were a little larger.
-constexpr int KD_WAVE_MIN = 768, KD_WAVE_CAP = 1536;
+constexpr int KD_WAVE_MIN = 768, KD_WAVE_CAP = 1536;   // the defaults; SCA_KD_WAVE_CAP picks a smaller workgroup form (sca_ctx::kd_wave_cap)
+constexpr int KD_WAVE_FLOOR = 128;                     // tables are sized for subtrees handed over at this size or above
 constexpr int KD_MAX_LEVELS = 40;
 constexpr int KD_CHUNK = 2048;         // positions per workgroup in the level passes over larger nodes
 

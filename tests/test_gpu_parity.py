@@ -214,18 +214,29 @@ def test_resident_steps_match_stepwise_oracle(S, oracle):
     sol.close()
 
 
-@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 200, 257, 300, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 5000, 40000])
-def test_device_kd_build_matches_host_replica(S, n):
+@pytest.mark.parametrize('cap', ['default', '1024', '768', '512', '256'])
+@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 127, 128, 129, 200, 257, 300, 1000, 1024, 1025, 1500, 1536, 2048, 2049, 3000, 5000, 40000])
+def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
     """K0: the kd-tree built on the device (nodes, boxes, permutation) against the sequential host replica of
-    kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent)."""
+    kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent).  `cap`: the largest subtree one
+    workgroup finishes in LDS (SCA_KD_WAVE_CAP; k_kd_block<1536 / 1024 / 768 / 512 / 256>): more, smaller subtrees on more
+    CUs against more level passes above them -- the same tree whatever the cut."""
     import ctypes as C
     from sca_amd import _lib
     L = _lib.lib()
+    if cap != 'default':
+        if n in (1, 7, 10, 11, 64, 127, 200, 1024, 2049):
+            pytest.skip('the smaller caps are exercised on a subset of the sizes')
+        monkeypatch.setenv('SCA_KD_WAVE_CAP', cap)
     rng = np.random.default_rng(n)
     pos = rng.uniform(-60, 60, (n, 3))
     if n >= 64:
         pos[: n // 4] = np.round(pos[: n // 4], 0)            # duplicates and ties on split planes
         pos[n // 4: n // 3, 2] = 10.0                          # a flat slab (degenerate axis)
+    if n in (300, 1500, 3000):                                 # a geometric progression along x: every split peels one point off
+        k = min(n // 2, 400)                                   # (subtrees hundreds of levels deep, one queued leaf per level)
+        pos[-k:, 0] = 100.0 + 2.0 ** (-np.arange(k, dtype=np.float64) / 8.0) * 50.0
+        pos[-k:, 1:] = 0.0
     sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
     sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
     sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), np.zeros((n, 3)), np.full(n, 1, np.uint8))
