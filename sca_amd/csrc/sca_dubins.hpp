@@ -551,7 +551,8 @@ template <int N, int NK> SCA_DHD static inline void atan_far_n(const double (&y)
     if (lean::any_says(!all_small)) {
         // (in groups of at most three pairs: seven coefficients per pair are 14 registers each)
         const double two52 = sca_gm::dbl(0x4330000000000000ull);
-        constexpr int G = N > 3 ? 3 : N;
+        constexpr int G = N <= 3 ? N : (N % 3 == 0 ? 3 : 2);          // a divisor of N (instantiated: N = 1, 2, 6)
+        static_assert(N % G == 0, "the groups must tile the pairs (N = 4 with groups of three read two pairs that do not exist)");
 #pragma unroll
         for (int g = 0; g < N; g += G) {
             double c0[G], c1[G], c2[G], c3[G], c4[G], c5[G], c6[G], t3[G], v[G], p3[G], bb[G], dv[G], ww[G]; int idx[G];

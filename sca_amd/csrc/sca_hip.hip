@@ -231,7 +231,7 @@ struct sca_ctx {
                                         // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
     int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
     bool kd_force_ticket = false;
-    int kd_wave_cap = KD_WAVE_CAP;      // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536)
+    int kd_wave_cap = 0;                // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536); 0: chosen per pass
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
@@ -938,7 +938,11 @@ static int build_agent_tree_device(sca_ctx *c) {
     }
     // size of the subtrees handed to k_kd_block: 1.25 x the average node size of the first level that fits (n / 2^k), so that
     // the nodes of that level -- all within a few per cent of the average -- are on one side of it
-    const int cap = c->kd_wave_cap;
+    // Subtrees of up to 1536 members (one workgroup of 12 wavefronts each) when the build has the chip to itself; up to 1024 when it
+    // runs beside the tracker's re-plans (a side stream): twice as many, smaller workgroups spread over twice as many CUs, each
+    // competing with fewer re-plan wavefronts -- measured at c5 (N = 16 384, 16 subtrees of ~1024 against 32 of ~512): step 0.284
+    // -> 0.268 ms; c3 (no tracker, 4 against 8 subtrees) the other way round: 0.127 against 0.129
+    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : (c->nbr_stream != c->stream ? 1024 : KD_WAVE_CAP);
     int wave_max = (n <= 1024 && cap >= 1024) ? 1024 : cap; // a tree that fits one workgroup: the smaller one if it can
     if (n > cap) {
         double sz = (double)n;

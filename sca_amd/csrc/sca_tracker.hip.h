@@ -352,28 +352,31 @@ __device__ __forceinline__ double quad_word_far(const sca_dubins::Frame2D &F, do
     return c * (::fabs(m[0]) + ::fabs(p[0]) + ::fabs(m[1]));
 }
 // returns feasible?; len = the path's length.  All four lanes of the quad return the same.
+// Round 4: the lean pieces are taken PER PLANE.  Round 3 took the lean form only for candidates that were far in both planes and
+// otherwise evaluated the whole candidate the literal way -- after having evaluated it the lean way first: c2 / c5 search their last
+// ~40 candidates at d_V = D_V / vr < 7 (vr grows without bound as the radius approaches Rmin) and ran 12 % / 20 % SLOWER than a
+// build without any lean form.  Now:
+//   (i)   a bound first: the horizontal path is at most D_H + (4 pi + 3) hr long (two arcs of less than a turn, a straight of at most
+//         d + 3 radii), hence d_V <= sqrt((D_H + 16 hr)^2 + dz^2) * vc; below 7 for some lane: no attempt at the far vertical block;
+//   (ii)  d_V itself as soon as the horizontal length is known, before the vertical frame's arctangent, sin / cos and words;
+//   (iii) far in the horizontal plane but near in the vertical one (the end of every search on paths of a few hundred metres: c2): the
+//         lean horizontal length IS plan2d's (same words, same first-minimum), so only the vertical maneuver goes the literal way --
+//         frame2d_quad_vertical + plan2d_quad on that length, then try_to_construct's three tests (dubinsmaneuver3d.py:152-161).
+// All of it only chooses between evaluations that return the same bits.  (Also measured: the vertical frame by the lean pieces in
+// (iii) -- it does not depend on d_V -- takes k_replan_group<64> from 156 to 147 us at c2 but from 253 to 261 registers, i.e. to one
+// wavefront per SIMD: c5, whose ~1100 re-plans per step need a second wavefront on some SIMDs, 108 -> 129 us.  Not taken.)
 __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, const sca_dubins::SearchConst &K, const double qi[5], const double qf[5],
                                           double Rmin, const double pitchlims[2], double hr, int sub, int lane, const QuadWordSigns &g, double &len) {
     using namespace sca_dubins;
     if (fast_ok && !sca_dubins::lean::any_says(hr != Rmin)) { len = 0.0; return false; }      // (see lean::candidate: the radius Rmin itself)
     const double dH = H.F.D / hr;
-    // The far block pays only when it is also FAR IN THE VERTICAL PLANE for every candidate of the wavefront; a wavefront that finds out
-    // at the end evaluates the candidate twice (measured, round 4: c2 / c5 search their last ~40 candidates at d_V = D_V / vr < 7 --
-    // vr grows without bound as the radius approaches Rmin -- and ran 12 % / 20 % SLOWER than a build without the far block).  So:
-    // (i) a bound first: the horizontal path is at most D_H + (4 pi + 3) hr long (two arcs of less than a turn and a straight of at
-    //     most d + 3 radii), hence d_V <= sqrt((D_H + 16 hr)^2 + dz^2) * vc; below 7 for some lane: the literal way at once;
-    // (ii) d_V itself as soon as the horizontal length is known, before the vertical frame's arctangent, sin / cos and words.
-    // Both only choose between two evaluations that return the same bits.
-    const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / sca_gm::g_pow2_main(hr));
-    const bool flat = vc < 1e-5;
-    const double dz = qf[2] - qi[2];
-    bool try_far = fast_ok && !sca_dubins::lean::any_says(!lean::far_d(dH));
-    if (try_far) {
+    if (fast_ok && !sca_dubins::lean::any_says(!lean::far_d(dH))) {
+        const double vc = sca_gm::sqrt_(K.inv_rmin2 - 1.0 / sca_gm::g_pow2_main(hr));
+        const bool flat = vc < 1e-5;
+        const double dz = qf[2] - qi[2];
         const double reach = H.F.D + 16.0 * hr;
         const double dV_ub = ::sqrt(reach * reach + dz * dz) * vc;
-        try_far = !sca_dubins::lean::any_says(!flat && dV_ub < 7.0);
-    }
-    if (try_far) {
+        const bool try_far_v = !sca_dubins::lean::any_says(!flat && dV_ub < 7.0);
         uint32_t kmin = 0xffffffffu;
         double tw;
         const double costH = quad_word_far(H.F, H.mbeta, dH, hr, g, kmin, tw);
@@ -382,31 +385,40 @@ __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, cons
         Frame2D F;
         F.D = lean::sqrt_pos(sca_gm::g_pow2_main(lenH) + K.dz2);
         const bool far_theta = lenH > ::fabs(dz) && lenH < 1.2676506002282294e30;
-        if (!sca_dubins::lean::any_says(!flat && !lean::far_d(F.D / vr))) {
-        const double y1[1] = {dz}, x1[1] = {lenH};
-        double th[1];
-        lean::atan_far_n<1, 1>(y1, x1, th, kmin);
-        const double theta = mod2pi(th[0]);
-        F.alpha = mod2pi(qi[4] - theta);
-        F.beta = mod2pi(qf[4] - theta);
-        const double a1[1] = {sub == 0 ? F.alpha : (sub == 1 ? F.beta : F.alpha - F.beta)};
-        double s1[1], c1[1];
-        lean::sincos_n<1>(a1, s1, c1);
-        F.sa = quad_bcast_d<0>(s1[0]); F.ca = quad_bcast_d<0>(c1[0]);
-        F.sb = quad_bcast_d<1>(s1[0]); F.cb = quad_bcast_d<1>(c1[0]);
-        F.c_ab = quad_bcast_d<2>(c1[0]);
-        const double dV = F.D / vr;
-        const double costV = quad_word_far(F, mod2pi(F.beta), dV, vr, g, kmin, tw);
-        // the reference's first-minimum rule over the words in planner order
-        const double c0 = quad_bcast_d<0>(costV), c1v = quad_bcast_d<1>(costV), c2 = quad_bcast_d<2>(costV), c3 = quad_bcast_d<3>(costV);
-        const double t0 = quad_bcast_d<0>(tw), t1 = quad_bcast_d<1>(tw), t2 = quad_bcast_d<2>(tw), t3 = quad_bcast_d<3>(tw);
-        double bc = c0, bt = t0; bool right = false;
-        { const bool lt = bc > c1v; bc = lt ? c1v : bc; bt = lt ? t1 : bt; right = lt ? true : right; }
-        { const bool lt = bc > c2; bc = lt ? c2 : bc; bt = lt ? t2 : bt; right = lt ? false : right; }
-        { const bool lt = bc > c3; bc = lt ? c3 : bc; bt = lt ? t3 : bt; right = lt ? true : right; }
-        const bool ok = !flat && !(right ? (qi[4] - bt < pitchlims[0]) : (qi[4] + bt > pitchlims[1]));
-        // (kmin differs between the lanes of a quad: any lane's objection sends the whole wavefront the literal way)
-        if (!sca_dubins::lean::any_says(!flat && (lean::keys_odd(kmin) || !far_theta || !lean::far_d(dV)))) { len = bc; return ok; }
+        if (try_far_v && !sca_dubins::lean::any_says(!flat && !lean::far_d(F.D / vr))) {
+            const double y1[1] = {dz}, x1[1] = {lenH};
+            double th[1];
+            lean::atan_far_n<1, 1>(y1, x1, th, kmin);
+            const double theta = mod2pi(th[0]);
+            F.alpha = mod2pi(qi[4] - theta);
+            F.beta = mod2pi(qf[4] - theta);
+            const double a1[1] = {sub == 0 ? F.alpha : (sub == 1 ? F.beta : F.alpha - F.beta)};
+            double s1[1], c1[1];
+            lean::sincos_n<1>(a1, s1, c1);
+            F.sa = quad_bcast_d<0>(s1[0]); F.ca = quad_bcast_d<0>(c1[0]);
+            F.sb = quad_bcast_d<1>(s1[0]); F.cb = quad_bcast_d<1>(c1[0]);
+            F.c_ab = quad_bcast_d<2>(c1[0]);
+            const double dV = F.D / vr;
+            const double costV = quad_word_far(F, mod2pi(F.beta), dV, vr, g, kmin, tw);
+            // the reference's first-minimum rule over the words in planner order
+            const double c0 = quad_bcast_d<0>(costV), c1v = quad_bcast_d<1>(costV), c2 = quad_bcast_d<2>(costV), c3 = quad_bcast_d<3>(costV);
+            const double t0 = quad_bcast_d<0>(tw), t1 = quad_bcast_d<1>(tw), t2 = quad_bcast_d<2>(tw), t3 = quad_bcast_d<3>(tw);
+            double bc = c0, bt = t0; bool right = false;
+            { const bool lt = bc > c1v; bc = lt ? c1v : bc; bt = lt ? t1 : bt; right = lt ? true : right; }
+            { const bool lt = bc > c2; bc = lt ? c2 : bc; bt = lt ? t2 : bt; right = lt ? false : right; }
+            { const bool lt = bc > c3; bc = lt ? c3 : bc; bt = lt ? t3 : bt; right = lt ? true : right; }
+            const bool ok = !flat && !(right ? (qi[4] - bt < pitchlims[0]) : (qi[4] + bt > pitchlims[1]));
+            // (kmin differs between the lanes of a quad: any lane's objection sends the whole wavefront the literal way)
+            if (!sca_dubins::lean::any_says(!flat && (lean::keys_odd(kmin) || !far_theta || !lean::far_d(dV)))) { len = bc; return ok; }
+        }
+        if (!sca_dubins::lean::any_says(!flat && lean::keys_odd(kmin))) {                       // (iii)
+            const QuadFrame V = frame2d_quad_vertical(lenH, dz, K.dz2, qi[4], qf[4], sub);
+            const Maneuver2D mv2 = plan2d_quad(V, qi[4], vr, sub, lane);
+            bool okv = !flat && !(mv2.mode[0] == 'R' && mv2.mode[1] == 'L' && mv2.mode[2] == 'R');
+            if (mv2.mode[0] == 'R') okv = okv && !(qi[4] - mv2.t < pitchlims[0]);
+            else okv = okv && !(qi[4] + mv2.t > pitchlims[1]);
+            len = mv2.length;
+            return okv;
         }
     }
     Maneuver2D mh, mv;
