@@ -687,7 +687,7 @@ VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4      # SIMDs x clock / cycles per wav
 
 
 def _pmc(wname):
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f).get(wname)
