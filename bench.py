@@ -406,7 +406,7 @@ def main():
             full = {'kd': (main_leg if args.nbr == 'kd' else g)['ms_per_step'], 'grid': (g if args.nbr == 'kd' else main_leg)['ms_per_step']}
             extras['scale_model']['weak'] = weak_scale_model(S, timer, local_rank, w, n, max(10, args.steps // 2), max(5, args.warmup // 2), tracked, full)
         if tracked:
-            extras['value_parity'] = value_parity(S, scene, local_rank, mode=mode)
+            extras['value_parity'] = value_parity(S, scene, local_rank, steps=12, mode=mode)
         if not args.no_extra_legs and wname == 'c4' and not args.agents:
             extras['extra_legs'] = extra_legs(S, timer, local_rank, args.steps, args.warmup)
 
@@ -653,7 +653,7 @@ def extra_legs(S, timer, device, steps, warmup):
         row['max_abs_dv_solver_given_vpref'] = parity_sample(scene, sol, S, tracked, warmup)
         row['roofline'] = leg_roofline(leg, steps, tracked, name)
         if tracked:
-            row['value_parity'] = value_parity(S, scene, device)
+            row['value_parity'] = value_parity(S, scene, device, steps=30)
         leg3 = timed_leg(sol, scene, ShardedStepper(sol, 0, 1, mode=1), timer, steps, warmup, tracked)
         row['grid_mode'] = {'value': leg3['value'], 'ms_per_step': leg3['ms_per_step']}
         out[name] = row
