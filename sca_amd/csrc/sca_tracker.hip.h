@@ -362,9 +362,11 @@ __device__ __forceinline__ double quad_word_far(const sca_dubins::Frame2D &F, do
 //   (iii) far in the horizontal plane but near in the vertical one (the end of every search on paths of a few hundred metres: c2): the
 //         lean horizontal length IS plan2d's (same words, same first-minimum), so only the vertical maneuver goes the literal way --
 //         frame2d_quad_vertical + plan2d_quad on that length, then try_to_construct's three tests (dubinsmaneuver3d.py:152-161).
-// All of it only chooses between evaluations that return the same bits.  (Also measured: the vertical frame by the lean pieces in
-// (iii) -- it does not depend on d_V -- takes k_replan_group<64> from 156 to 147 us at c2 but from 253 to 261 registers, i.e. to one
-// wavefront per SIMD: c5, whose ~1100 re-plans per step need a second wavefront on some SIMDs, 108 -> 129 us.  Not taken.)
+//         The vertical FRAME is lean in (iii) as well (it does not depend on d_V): k_replan_group<64> 156 -> 146 us at c2.  The
+//         64-lane kernel sits at 256 registers with it (one build of this form needed 261, i.e. one wavefront per SIMD: c5 108 ->
+//         129 us), which is why TRK_SPEC4_MAX is 1024 now: a wavefront per plan only while every plan gets a SIMD of its own; 1025 ..
+//         1280 plans take the 32-lane form (measured equal at c5, whose count sits there).  The 32- / 16- / 4-lane kernels: 245 / 233 / 230.
+// All of it only chooses between evaluations that return the same bits.
 __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, const sca_dubins::SearchConst &K, const double qi[5], const double qf[5],
                                           double Rmin, const double pitchlims[2], double hr, int sub, int lane, const QuadWordSigns &g, double &len) {
     using namespace sca_dubins;
@@ -385,7 +387,9 @@ __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, cons
         Frame2D F;
         F.D = lean::sqrt_pos(sca_gm::g_pow2_main(lenH) + K.dz2);
         const bool far_theta = lenH > ::fabs(dz) && lenH < 1.2676506002282294e30;
-        if (try_far_v && !sca_dubins::lean::any_says(!flat && !lean::far_d(F.D / vr))) {
+        // the vertical frame by the lean pieces whenever the path is longer than it is high (theta = atan2(dz, lenH) is then a case-(i)
+        // arctangent): it does not care how near the end points are in units of the vertical radius -- only the words do
+        if (!sca_dubins::lean::any_says(!flat && !far_theta)) {
             const double y1[1] = {dz}, x1[1] = {lenH};
             double th[1];
             lean::atan_far_n<1, 1>(y1, x1, th, kmin);
@@ -399,26 +403,28 @@ __device__ __forceinline__ bool cand_quad(bool fast_ok, const QuadFrame &H, cons
             F.sb = quad_bcast_d<1>(s1[0]); F.cb = quad_bcast_d<1>(c1[0]);
             F.c_ab = quad_bcast_d<2>(c1[0]);
             const double dV = F.D / vr;
-            const double costV = quad_word_far(F, mod2pi(F.beta), dV, vr, g, kmin, tw);
-            // the reference's first-minimum rule over the words in planner order
-            const double c0 = quad_bcast_d<0>(costV), c1v = quad_bcast_d<1>(costV), c2 = quad_bcast_d<2>(costV), c3 = quad_bcast_d<3>(costV);
-            const double t0 = quad_bcast_d<0>(tw), t1 = quad_bcast_d<1>(tw), t2 = quad_bcast_d<2>(tw), t3 = quad_bcast_d<3>(tw);
-            double bc = c0, bt = t0; bool right = false;
-            { const bool lt = bc > c1v; bc = lt ? c1v : bc; bt = lt ? t1 : bt; right = lt ? true : right; }
-            { const bool lt = bc > c2; bc = lt ? c2 : bc; bt = lt ? t2 : bt; right = lt ? false : right; }
-            { const bool lt = bc > c3; bc = lt ? c3 : bc; bt = lt ? t3 : bt; right = lt ? true : right; }
-            const bool ok = !flat && !(right ? (qi[4] - bt < pitchlims[0]) : (qi[4] + bt > pitchlims[1]));
-            // (kmin differs between the lanes of a quad: any lane's objection sends the whole wavefront the literal way)
-            if (!sca_dubins::lean::any_says(!flat && (lean::keys_odd(kmin) || !far_theta || !lean::far_d(dV)))) { len = bc; return ok; }
-        }
-        if (!sca_dubins::lean::any_says(!flat && lean::keys_odd(kmin))) {                       // (iii)
-            const QuadFrame V = frame2d_quad_vertical(lenH, dz, K.dz2, qi[4], qf[4], sub);
-            const Maneuver2D mv2 = plan2d_quad(V, qi[4], vr, sub, lane);
-            bool okv = !flat && !(mv2.mode[0] == 'R' && mv2.mode[1] == 'L' && mv2.mode[2] == 'R');
-            if (mv2.mode[0] == 'R') okv = okv && !(qi[4] - mv2.t < pitchlims[0]);
-            else okv = okv && !(qi[4] + mv2.t > pitchlims[1]);
-            len = mv2.length;
-            return okv;
+            const double mbetaV = mod2pi(F.beta);
+            if (try_far_v && !sca_dubins::lean::any_says(!flat && !lean::far_d(dV))) {
+                const double costV = quad_word_far(F, mbetaV, dV, vr, g, kmin, tw);
+                // the reference's first-minimum rule over the words in planner order
+                const double c0 = quad_bcast_d<0>(costV), c1v = quad_bcast_d<1>(costV), c2 = quad_bcast_d<2>(costV), c3 = quad_bcast_d<3>(costV);
+                const double t0 = quad_bcast_d<0>(tw), t1 = quad_bcast_d<1>(tw), t2 = quad_bcast_d<2>(tw), t3 = quad_bcast_d<3>(tw);
+                double bc = c0, bt = t0; bool right = false;
+                { const bool lt = bc > c1v; bc = lt ? c1v : bc; bt = lt ? t1 : bt; right = lt ? true : right; }
+                { const bool lt = bc > c2; bc = lt ? c2 : bc; bt = lt ? t2 : bt; right = lt ? false : right; }
+                { const bool lt = bc > c3; bc = lt ? c3 : bc; bt = lt ? t3 : bt; right = lt ? true : right; }
+                const bool ok = !flat && !(right ? (qi[4] - bt < pitchlims[0]) : (qi[4] + bt > pitchlims[1]));
+                // (kmin differs between the lanes of a quad: any lane's objection sends the whole wavefront the literal way)
+                if (!sca_dubins::lean::any_says(!flat && lean::keys_odd(kmin))) { len = bc; return ok; }
+            } else if (!sca_dubins::lean::any_says(!flat && lean::keys_odd(kmin))) {                // (iii)
+                QuadFrame V; V.F = F; V.mbeta = mbetaV;
+                const Maneuver2D mv2 = plan2d_quad(V, qi[4], vr, sub, lane);
+                bool okv = !flat && !(mv2.mode[0] == 'R' && mv2.mode[1] == 'L' && mv2.mode[2] == 'R');
+                if (mv2.mode[0] == 'R') okv = okv && !(qi[4] - mv2.t < pitchlims[0]);
+                else okv = okv && !(qi[4] + mv2.t > pitchlims[1]);
+                len = mv2.length;
+                return okv;
+            }
         }
     }
     Maneuver2D mh, mv;
@@ -476,7 +482,7 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
 // path: used while a pass has so few re-plans that most SIMDs would idle anyway.
 constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass: two steps per round, 16 lanes per plan (2048 wavefronts: two per SIMD)
 constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: three steps per round, 32 lanes per plan (2048 wavefronts)
-constexpr int TRK_SPEC4_MAX = 1280;        // <= this many: four steps per round, a whole wavefront per plan
+constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: four steps per round, a whole wavefront per plan -- and a SIMD per wavefront (the kernel sits at the 256-register edge)
 
 template <int D>
 __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
