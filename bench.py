@@ -63,9 +63,12 @@ WORKLOADS = {
     'c5': dict(kind='takeoff', n=16384, policy='mixed', desc='c5: take-off/landing N=16384, SCA even ids / S-RVO3D odd ids'),
 }
 POL = {'sca': 0, 'rvo': 1, 'srvo': 2, 'orca': 3, 'orcalp': 4}
-NBR = {'kd': 0, 'grid': 1}
+NBR = {'kd': 0, 'grid': 1, 'auto': 3}
 NBR_DESC = {'kd': 'kd-tree of kdTree.py rebuilt on the device every step (replicated per rank), device query: the reference\'s lists',
-            'grid': 'SCA_NBR_GRID: hashed grid rebuilt every step (lists equal the reference\'s while <= 16 objects are in range)'}
+            'grid': 'SCA_NBR_GRID: hashed grid rebuilt every step (lists equal the reference\'s while <= 16 objects are in range)',
+            'auto': 'SCA_NBR_AUTO: the reference\'s lists entry for entry -- the grid query for every agent, the kd-tree query (kdTree.py) for the '
+                    'agents with more than 16 objects in range or equal rounded distances; the kd-tree of kdTree.py is still rebuilt every step '
+                    '(its permutation is history), beside the grid build and query instead of in front of them'}
 
 
 def build_scene(w, n):

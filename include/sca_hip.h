@@ -64,7 +64,18 @@ enum sca_neighbor_mode {
                                      reference's (object, distSq) pairs whenever <= max_neighbors objects are in range; entries of
                                      equal distSq are ordered obstacles first, then by agent id (the reference: kd visit order);
                                      with more in range the 16 nearest are kept and SCA_ST_NBR_OVERFLOW is raised */
-    SCA_NBR_KDTREE_HOSTBUILD = 2  /* same tree built on the host from a position read-back (debug / A-B reference) */
+    SCA_NBR_KDTREE_HOSTBUILD = 2, /* same tree built on the host from a position read-back (debug / A-B reference) */
+    SCA_NBR_AUTO = 3              /* the reference's lists, entry for entry, at the grid's price: the grid query for every agent, and the
+                                     kd query (kdTree.py:124-156) for the agents whose list the grid cannot give exactly -- more than
+                                     max_neighbors objects in range, or two objects of one kind at the same rounded distance (their order is
+                                     the kd-tree's visit order, agent.py:87-90).  The kd-tree is still built every step -- its permutation is
+                                     history (kdTree.py:43-45) -- but on a stream of its own beside the grid build and query, in
+                                     sca_run_steps already behind the previous step's integrate stage, and a pass waits for it only when the
+                                     grid query listed somebody (a device-side wait, hipStreamWaitValue32).  A pass is a plain SCA_NBR_KDTREE
+                                     pass where that cannot pay: with the tracker inside the pass (the neighbour branch runs beside the
+                                     re-plans there), and for 256 passes whenever the grid query listed more than an eighth of the shard
+                                     (rings at the 16-neighbour density, lattices of identical cells).  Measured: random N = 4096 0.128 ->
+                                     0.107 ms per step, N = 16 384 0.198 -> 0.160, N = 65 536 0.382 -> 0.333. */
 };
 
 enum sca_status_bit {             /* per-agent status word of the last policy pass */

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
     SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 256) d.done_count[i * 32] = 0;                                   // start of a step: K4's counters
-    if (i == 0) { *d.fb_count = 0; *g.cursor = 0; }                          // ... an empty fallback list, no position handed out
+    if (i == 0) { *d.fb_count = 0; *g.cursor = 0; if (d.kdq_count) *d.kdq_count = 0; }   // ... an empty fallback list, no position handed out, nobody for the kd query
     if (i >= present_count(d)) return;
     const int a = present_agent(d, i);                                        // (bucket / slot are indexed by the position in the list)
     const PubRec r = d.rec[a];
@@ -143,6 +143,10 @@ __device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long 
 // their kd-tree exactly as in the kd kernels (scaPolicy.py:114-116, agent.py:101-124); then the agents of the 27 cells.
 // Every agent that is not done gets its collision candidates for K4 (`near`), also on the bootstrap step, when the
 // reference builds no list (scaPolicy.py:34): K4 then never needs a tree.
+// AUTO (SCA_NBR_AUTO): a list the grid cannot give exactly -- it overflowed, or two neighbours of one kind have the same rounded distance
+// (the reference orders those by the kd-tree's visit order, agent.py:87-90: append, stable sort) -- is not flagged but handed to the kd
+// query (d.kdq_list); every other list IS the reference's, entry for entry: a sorted list without ties has one order.
+template <bool AUTO>
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
                                                                   double obs_reach, double max_radius) {
     SCA_K1_SETPRIO();
@@ -328,6 +332,29 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
             d.near_n[agent] = (scan && complete) ? near_cnt : -1;
         }
         return;
+    }
+    if (AUTO) {
+        const double nd = row_shl_d<1>(Ld);                              // (every lane executes the cross-lane reads)
+        const int ni = __builtin_amdgcn_mov_dpp(Li, 0x101, 0xf, 0xf, true);
+        const bool tie = gl + 1 < cnt && nd == Ld && ((ni ^ Li) & NBR_OBSTACLE_BIT) == 0;
+        const bool again = (((__ballot(tie) >> gshift) & 0xffffull) != 0) || (st & ST_NBR_OVERFLOW) != 0;
+        if (again) st &= ~ST_NBR_OVERFLOW;                               // (the kd query writes the agent's status afresh)
+        // one atomic per wavefront for its (up to four) listed agents -- and none once the count has passed the cap: "too many" is
+        // all the later passes and the gated kd query of everybody need to know (100 000 same-address atomics were 260 us)
+        const unsigned long long am = __ballot(again && gl == 0);
+        if (am != 0) {
+            const int leader = __ffsll((long long)am) - 1;
+            int base = 0;
+            if ((int)(threadIdx.x & 63) == leader) {
+                const int seen = __atomic_load_n(d.kdq_count, __ATOMIC_RELAXED);        // (a stale value only costs an atomic)
+                base = seen > d.kdq_cap ? -1 : atomicAdd(d.kdq_count, __popcll(am));
+            }
+            base = __shfl(base, leader);
+            if (again && gl == 0 && base >= 0) {
+                const int at = base + __popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull));
+                if (at < d.n) d.kdq_list[at] = agent;
+            }
+        }
     }
     d.nbr_id[agent * K_MAX + gl] = (gl < cnt) ? Li : -1;
     d.nbr_dsq[agent * K_MAX + gl] = (gl < cnt) ? Ld : 0.0;

@@ -231,6 +231,25 @@ struct sca_ctx {
                                         // wavefronts per SIMD and scaled with them; the figures were measured on a 256-CU MI355X
     int kd_rank_capacity = 1 << 30;     // workgroups of k_kd_lv_rank the device holds at once (occupancy x CUs)
     bool kd_force_ticket = false;
+    // SCA_NBR_AUTO: the grid query for everybody, the kd query for the agents it lists; the kd BUILD (the permutation is history: it
+    // runs every step) on a stream of its own beside the grid build and query
+    hipStream_t kd_stream = nullptr;
+    hipEvent_t ev_auto_fork = nullptr, ev_auto_k1g = nullptr, ev_auto_kd = nullptr, ev_auto_moved = nullptr, ev_auto_cnt = nullptr;
+    int32_t *kdq_list = nullptr, *kdq_count = nullptr;
+    int *auto_ticket = nullptr;         // k_neighbors_kd_auto's last-workgroup ticket
+    unsigned *auto_ready = nullptr;     // device word: the last AUTO pass whose lists are final (k_auto_ready; hipStreamWaitValue32)
+    unsigned auto_seq = 0;
+    bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
+    hipEvent_t ev_auto_gather[2] = {nullptr, nullptr};   // the gather kernel of the last two builds: the integrate stage must not write into
+    unsigned auto_builds = 0;                            // the record buffer a build's gather still reads (the two buffers alternate)
+    bool auto_unjoined = false;         // kd_stream may still be working on the last AUTO pass's tree / kd query
+    int *kdq_host = nullptr;            // pinned: the list length of an earlier pass (never waited for)
+    bool kdq_pending = false;
+    int kdq_last = -1;                  // -1: unknown
+    int auto_backoff = 0;               // passes left to run as plain SCA_NBR_KDTREE (the grid listed too many agents: ties everywhere)
+    bool auto_ran = false, auto_fits = false;   // the last pass was an AUTO pass / the grid's candidate lists cover the collision reach
+    bool kd_ahead = false;              // the kd build of the NEXT pass is already enqueued on kd_stream (sca_run_steps, behind the integrate stage)
+    unsigned auto_passes = 0;
     int kd_wave_cap = 0;                // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536); 0: chosen per pass
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
@@ -702,6 +721,14 @@ void sca_destroy(sca_ctx *c) {
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
     for (auto &e : c->pool_trk) (void)hipEventDestroy(e);
+    if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipStreamDestroy(c->kd_stream); }
+    for (hipEvent_t e : {c->ev_auto_fork, c->ev_auto_k1g, c->ev_auto_kd, c->ev_auto_moved, c->ev_auto_cnt}) if (e) (void)hipEventDestroy(e);
+    if (c->kdq_list) (void)hipFree(c->kdq_list);
+    if (c->kdq_count) (void)hipFree(c->kdq_count);
+    if (c->kdq_host) (void)hipHostFree(c->kdq_host);
+    if (c->auto_ready) (void)hipFree(c->auto_ready);
+    if (c->auto_ticket) (void)hipFree(c->auto_ticket);
+    for (hipEvent_t e : c->ev_auto_gather) if (e) (void)hipEventDestroy(e);
     if (c->kd_ev) (void)hipEventDestroy(c->kd_ev);
     if (c->kd_host_counts) (void)hipHostFree(c->kd_host_counts);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
@@ -778,6 +805,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     CHK(c, hipMemsetAsync(c->d.step_num, 0, sizeof(int32_t) * n, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     c->agents_set = true; c->state_set = false; c->h_pos_valid = false;
+    c->kdq_last = -1; c->auto_backoff = 0; c->kd_ahead = false; c->auto_ran = false;
     return 0;
 }
 
@@ -927,13 +955,12 @@ static int build_agent_tree(sca_ctx *c) {
 
 // KDTree.buildAgentTree on the device (sca_kdbuild.hip.h): gather, one launch per level of large nodes, one launch
 // that finishes every small subtree.  Everything is enqueued on the context's stream; nothing comes back to the host.
-static int build_agent_tree_device(sca_ctx *c) {
+static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView &d) {
     const int n = c->n;
-    const DeviceView &d = c->d;
     // (no size limit: a level with more chunks than the chip holds at once takes its chunks by arrival, k_kd_lv_rank<true>; rounds
     // 1-2 refused more than 256 CUs x 4 workgroups x KD_CHUNK = 2 097 152 agents, with the CU count as a literal)
     if (!c->perm_on_device) {
-        CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->nbr_stream));
+        CHK(c, hipMemcpyAsync(d.aperm, c->h_perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ks));
         c->perm_on_device = true;
     }
     // size of the subtrees handed to k_kd_block: 1.25 x the average node size of the first level that fits (n / 2^k), so that
@@ -942,7 +969,7 @@ static int build_agent_tree_device(sca_ctx *c) {
     // runs beside the tracker's re-plans (a side stream): twice as many, smaller workgroups spread over twice as many CUs, each
     // competing with fewer re-plan wavefronts -- measured at c5 (N = 16 384, 16 subtrees of ~1024 against 32 of ~512): step 0.284
     // -> 0.268 ms; c3 (no tracker, 4 against 8 subtrees) the other way round: 0.127 against 0.129
-    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : (c->nbr_stream != c->stream ? 1024 : KD_WAVE_CAP);
+    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : ((c->trk_on && c->trk_in_pass && ks != c->stream) ? 1024 : KD_WAVE_CAP);
     int wave_max = (n <= 1024 && cap >= 1024) ? 1024 : cap; // a tree that fits one workgroup: the smaller one if it can
     if (n > cap) {
         double sz = (double)n;
@@ -950,7 +977,11 @@ static int build_agent_tree_device(sca_ctx *c) {
         wave_max = std::min(cap, std::max(cap / 2 + 1, (int)std::ceil(1.25 * sz)));
     }
     c->kd.wave_max = wave_max;
-    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, c->nbr_stream, d, c->kd, c->P);
+    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, ks, d, c->kd, c->P);
+    if (c->kd.aux) {                                                    // SCA_NBR_AUTO: the last kernel of the build that reads the record buffer
+        CHK(c, hipEventRecord(c->ev_auto_gather[c->auto_builds & 1u], ks));
+        c->auto_builds++;
+    }
     int levels = 0;
     if (n > wave_max) {
         // Level passes: two launches per level (rank | swap) while the nodes span several chunks, then ONE launch
@@ -978,29 +1009,29 @@ static int build_agent_tree_device(sca_ctx *c) {
         for (int l = 0; l < first_single; l++) {
             // chunk by arrival once a level can have more chunks than are resident at once (k_kd_lv_rank); SCA_KD_TICKET=1 forces it (tests)
             if (grid > c->kd_rank_capacity || c->kd_force_ticket)
-                hipLaunchKernelGGL(k_kd_lv_rank<true>, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
+                hipLaunchKernelGGL(k_kd_lv_rank<true>, dim3(grid), dim3(KD_LV_T), 0, ks, c->kd, l, ++c->kd_token);
             else
-                hipLaunchKernelGGL(k_kd_lv_rank<false>, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, c->kd, l, ++c->kd_token);
-            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T + 64), 0, c->nbr_stream, d, c->kd, l);   // + the bookkeeping wavefront
+                hipLaunchKernelGGL(k_kd_lv_rank<false>, dim3(grid), dim3(KD_LV_T), 0, ks, c->kd, l, ++c->kd_token);
+            hipLaunchKernelGGL(k_kd_lv_swap, dim3(grid), dim3(KD_LV_T + 64), 0, ks, d, c->kd, l);   // + the bookkeeping wavefront
         }
-        hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, c->nbr_stream, d, c->kd, first_single, ++c->kd_token);
+        hipLaunchKernelGGL(k_kd_level_tail, dim3(grid), dim3(KD_LV_T), 0, ks, d, c->kd, first_single, ++c->kd_token);
     }
 
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
     // one workgroup per subtree, in LDS: the smallest form that holds wave_max members (two positions per thread)
-    if (wave_max <= 256) hipLaunchKernelGGL((k_kd_block<256, 128>), dim3(sgrid), dim3(128), 0, c->nbr_stream, d, c->kd, levels);
-    else if (wave_max <= 512) hipLaunchKernelGGL((k_kd_block<512, 256>), dim3(sgrid), dim3(256), 0, c->nbr_stream, d, c->kd, levels);
-    else if (wave_max <= 768) hipLaunchKernelGGL((k_kd_block<768, 384>), dim3(sgrid), dim3(384), 0, c->nbr_stream, d, c->kd, levels);
-    else if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, c->nbr_stream, d, c->kd, levels);
-    else if (wave_max <= 1280) hipLaunchKernelGGL((k_kd_block<1280, 640>), dim3(sgrid), dim3(640), 0, c->nbr_stream, d, c->kd, levels);
-    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, c->nbr_stream, d, c->kd, levels);
+    if (wave_max <= 256) hipLaunchKernelGGL((k_kd_block<256, 128>), dim3(sgrid), dim3(128), 0, ks, d, c->kd, levels);
+    else if (wave_max <= 512) hipLaunchKernelGGL((k_kd_block<512, 256>), dim3(sgrid), dim3(256), 0, ks, d, c->kd, levels);
+    else if (wave_max <= 768) hipLaunchKernelGGL((k_kd_block<768, 384>), dim3(sgrid), dim3(384), 0, ks, d, c->kd, levels);
+    else if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, ks, d, c->kd, levels);
+    else if (wave_max <= 1280) hipLaunchKernelGGL((k_kd_block<1280, 640>), dim3(sgrid), dim3(640), 0, ks, d, c->kd, levels);
+    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, ks, d, c->kd, levels);
     CHK(c, hipGetLastError());
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
     if (n > wave_max && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
-        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, c->nbr_stream));
-        CHK(c, hipEventRecord(c->kd_ev, c->nbr_stream));
+        CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, ks));
+        CHK(c, hipEventRecord(c->kd_ev, ks));
         c->kd_ev_pending = true;
         c->kd_ev_gen = c->kd_gen;
     }
@@ -1165,7 +1196,82 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
     return rounds == 1 ? cnt <= per_simd(c, 61440) : (rounds == 2 ? cnt <= per_simd(c, 114688) : false);
 }
 
+// SCA_NBR_AUTO's resources, on first use
+static int auto_prepare(sca_ctx *c) {
+    if (c->kd_stream) return 0;
+    CHK(c, hipStreamCreateWithFlags(&c->kd_stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&c->ev_auto_fork, &c->ev_auto_k1g, &c->ev_auto_kd, &c->ev_auto_moved, &c->ev_auto_cnt})
+        CHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    CHK(c, hipMalloc((void **)&c->kdq_list, sizeof(int32_t) * (size_t)c->max_n));
+    CHK(c, hipMalloc((void **)&c->kdq_count, sizeof(int32_t)));
+    CHK(c, hipMemsetAsync(c->kdq_count, 0, sizeof(int32_t), c->stream));
+    CHK(c, hipMalloc((void **)&c->auto_ready, sizeof(unsigned)));
+    CHK(c, hipMemsetAsync(c->auto_ready, 0, sizeof(unsigned), c->stream));
+    CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
+    CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    for (hipEvent_t &e : c->ev_auto_gather) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->auto_seq = 0; c->auto_builds = 0;
+    c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
+    CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
+    c->d.kdq_list = c->kdq_list; c->d.kdq_count = c->kdq_count;
+    c->kdq_pending = false; c->kdq_last = -1; c->auto_backoff = 0; c->kd_ahead = false;
+    return 0;
+}
+// the kd build of a pass on kd_stream, beside whatever runs on the other streams (aux: it leaves the step's counters and the solve's
+// prologue to the grid's kernels).  `positions`: the record buffer that holds the positions to build from.
+static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *positions) {
+    CHK(c, hipStreamWaitEvent(c->kd_stream, after, 0));
+    DeviceView v = c->d;
+    v.rec = const_cast<PubRec *>(positions);
+    const int keep_skip = c->kd.skip_prep;
+    c->kd.aux = 1;
+    const int r = build_agent_tree_device(c, c->kd_stream, v);
+    c->kd.aux = 0; c->kd.skip_prep = keep_skip;
+    return r;
+}
+
+// everything kd_stream was given has to be through before a caller reads the tree, the permutation or the lists, and before a pass that
+// is not an AUTO pass builds in place: the context's stream waits for the last kd query
+static int auto_join(sca_ctx *c) {
+    if (!c->auto_unjoined) return 0;
+    CHK(c, hipStreamWaitEvent(c->stream, c->ev_auto_kd, 0));
+    c->auto_unjoined = false;
+    return 0;
+}
+// will the next pass of an SCA_NBR_AUTO run be an AUTO pass (and not a plain kd pass)?  Decides whether its tree may be built ahead.
+static bool auto_next(const sca_ctx *c) {
+    return c->auto_fits && c->auto_backoff == 0 && !c->part_on && !(c->trk_on && c->trk_in_pass) &&
+           !(c->kdq_last >= 0 && (long long)c->kdq_last * 8 > (long long)c->d.shard_count);
+}
+
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
+    // SCA_NBR_AUTO resolves to a plain kd pass where it cannot help (the cell-owner partition has its own structures; the grid's
+    // candidate lists need the collision reach inside one cell) or where the grid keeps listing a large part of the swarm for the kd
+    // query anyway (a lattice of identical cells: ties everywhere) -- it is tried again every 256 passes
+    bool auto_mode = false;
+    if (mode == SCA_NBR_AUTO) {
+        double ar, orr;
+        collide_reach(c, ar, orr);
+        const bool fits = c->max_radius + ar <= c->P.neighbor_dist && c->max_radius + orr <= c->P.neighbor_dist;
+        if (c->part_on) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
+        if (int r = auto_prepare(c)) return r;
+        if (c->kdq_pending && hipEventQuery(c->ev_auto_cnt) == hipSuccess) { c->kdq_last = c->kdq_host[0]; c->kdq_pending = false; }
+        // (a tree built ahead for this pass -- sca_run_steps, see there -- makes it an AUTO pass whatever the counts say: the build
+        // must not run twice; sca_run_steps only builds ahead when auto_next() holds)
+        if (!c->kd_ahead && c->auto_backoff == 0 && c->kdq_last >= 0 && (long long)c->kdq_last * 8 > (long long)c->d.shard_count) { c->auto_backoff = 256; c->kdq_last = -1; }
+        // (a pass with the tracker inside runs its whole neighbour branch beside the re-plans already: nothing to gain, a grid build to lose)
+        const bool tracked_pass = c->trk_on && c->trk_in_pass;
+        if (!c->kd_ahead && (!fits || tracked_pass || c->auto_backoff > 0)) {
+            if (c->auto_backoff > 0) c->auto_backoff--;
+            mode = SCA_NBR_KDTREE;
+        } else auto_mode = true;
+        c->auto_fits = fits;
+    }
+    const bool kd_prebuilt = auto_mode && c->kd_ahead;
+    c->kd_ahead = false;
+    c->auto_ran = auto_mode;
+    if (!auto_mode) { if (int r = auto_join(c)) return r; }            // (a pass that builds its tree in place: kd_stream must be through)
     int lp_lo = 0, lp_hi = 0;
     choose_lp_form(c, lp_lo, lp_hi);
     const DeviceView &d = c->d;
@@ -1173,7 +1279,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // the tracker's re-plans overlap the device kd build and the neighbour query; the per-agent prologue (which reads
     // v_pref) of the tracker's agents then moves from k_kd_gather to the tracker's kernels (track_store)
     const bool tracked = c->trk_on && c->trk_in_pass;
-    const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID) && !c->trk_serial;
+    const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID || auto_mode) && !c->trk_serial;
     // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
     bool split = choose_solve_split(c, overlap, d.shard_count);
     if (split && !c->d.sw_slot) {
@@ -1212,11 +1318,23 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipEventRecord(c->trk_fork, c->stream));
         CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
     }
+    if (auto_mode && !kd_prebuilt) {
+        // SCA_NBR_AUTO: the kd build (its permutation is history: every step) on a stream of its own, from the pass's start
+        CHK(c, hipEventRecord(c->ev_auto_fork, c->stream));
+        if (int r = auto_enqueue_kd_build(c, c->ev_auto_fork, c->d.rec)) return r;
+    }
     c->trk.prep = overlap ? 1 : 0;
     c->trk.P = c->P;
     if (tracked) { if (int r = launch_tracker(c, true, true)) return r; }
-    c->nbr_mode = mode;
-    if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c)) return r; }
+    c->nbr_mode = auto_mode ? (int)SCA_NBR_GRID : mode;               // (what K4's fallback looks into: the grid in an AUTO pass)
+    if (auto_mode) {
+        c->d.kdq_cap = std::max(1, c->d.shard_count / 8);
+        // the previous AUTO pass's kd query reads the list and its length, which the grid build below resets: it has to be through
+        // (it is, unless the kd build is the longer branch -- then the passes run at its pace)
+        if (c->auto_seq > 0) CHK(c, hipStreamWaitEvent(c->nbr_stream, c->ev_auto_kd, 0));
+        if (int r = build_agent_grid_device(c)) return r;
+    }
+    else if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c, c->nbr_stream, c->d)) return r; }
     else if (mode == SCA_NBR_GRID) { if (int r = build_agent_grid_device(c)) return r; }
     else if (mode == SCA_NBR_KDTREE_HOSTBUILD) {
         if (c->perm_on_device) {
@@ -1238,9 +1356,13 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
     // below that the one-agent-per-wave form with its record stack has the shorter critical path (4096 random: 30 % faster)
     const bool packed = c->k1_force < 0 ? cnt >= per_simd(c, 6144) : c->k1_force != 0;   // four agents per wavefront once that still fills the SIMDs
-    if (mode == SCA_NBR_GRID) {
+    if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_grid, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
+        hipLaunchKernelGGL(k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
+                           c->P, agent_reach, obs_reach, c->max_radius);
+    } else if (mode == SCA_NBR_GRID) {
+        const int per_block = K1P_WAVES * K1P_APW;
+        hipLaunchKernelGGL(k_neighbors_grid<false>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
                            c->P, agent_reach, obs_reach, c->max_radius);
     } else if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
@@ -1251,6 +1373,26 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                            ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
+    if (auto_mode) {
+        // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
+        // build on kd_stream, and nothing reads a list before that query is through
+        const unsigned seq = ++c->auto_seq;
+        if (c->auto_waitvalue) hipLaunchKernelGGL(k_auto_ready, dim3(1), dim3(1), 0, ns, c->kdq_count, c->auto_ready, seq, 1);
+        CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
+        CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));
+        hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius,
+                           c->auto_ready, seq, c->auto_ticket);
+        if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
+            CHK(c, hipMemcpyAsync(c->kdq_host, c->kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
+            CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
+            c->kdq_pending = true;
+        }
+        CHK(c, hipEventRecord(c->ev_auto_kd, c->kd_stream));
+        if (c->auto_waitvalue) {
+            // lists final: at once when the grid query listed nobody, else behind the kd query (see k_auto_ready)
+            CHK(c, hipStreamWaitValue32(ns, c->auto_ready, seq, hipStreamWaitValueGte, 0xffffffffu));
+        } else CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));
+    }
     if (split) {
         hipLaunchKernelGGL(k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, ns, d, c->P);
     }
@@ -1283,6 +1425,12 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (timed || prof) CHK(c, hipEventRecord(e3, c->stream));         // [e2, e3] = k_solve (+ k_lp) (what rocprofv3 reports for them)
     // the agents without any suitable candidate (rare; one wavefront each), then the epilogue (one lane per agent)
     const int ablocks = (cnt + 255) / 256;
+    if (auto_mode && c->auto_waitvalue) {
+        // nothing of this pass waited for the kd build any more.  Two things still must: (i) the integrate stage writes the record
+        // buffer that the build BEFORE this pass's read its positions from (the two buffers alternate): wait for that build's gather;
+        CHK(c, hipStreamWaitEvent(c->stream, c->ev_auto_gather[c->auto_builds & 1u], 0));       // [builds & 1] = the one before the last
+        c->auto_unjoined = true;                                        // (ii) see auto_join
+    }
     if (fuse_integrate) {
         hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
@@ -1347,8 +1495,9 @@ int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (int r = launch_policy(c, neighbor_mode, true, false)) return r;
+    if (int r = auto_join(c)) return r;
     CHK(c, hipStreamSynchronize(c->stream));
-    if (neighbor_mode == SCA_NBR_KDTREE) { if (int r = check_kd_overflow(c)) return r; }
+    if (neighbor_mode == SCA_NBR_KDTREE || neighbor_mode == SCA_NBR_AUTO) { if (int r = check_kd_overflow(c)) return r; }
     CHK(c, hipEventElapsedTime(&c->ms_nbr, c->ev[0], c->ev[1]));
     CHK(c, hipEventElapsedTime(&c->ms_solve, c->ev[2], c->ev[3]));
     return 0;
@@ -1420,9 +1569,18 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
             if (b > 0) CHK(c, hipMemcpyAsync(c->d.rec_new, c->d.rec, sizeof(PubRec) * (size_t)b, hipMemcpyDeviceToDevice, c->stream));
             if (e < c->n) CHK(c, hipMemcpyAsync(c->d.rec_new + e, c->d.rec + e, sizeof(PubRec) * (size_t)(c->n - e), hipMemcpyDeviceToDevice, c->stream));
         }
+        if (neighbor_mode == SCA_NBR_AUTO && c->auto_ran && s + 1 < steps && auto_next(c)) {
+            // SCA_NBR_AUTO: the NEXT pass's kd build needs the moved positions only -- k_collide_finish changes flags, and in an
+            // AUTO pass its fallback looks into the grid, not into the tree -- so it starts here, beside the collision check and the
+            // next pass's grid build and query.  Only inside one call: a caller who reads the permutation between calls sees as many
+            // builds as steps.
+            CHK(c, hipEventRecord(c->ev_auto_moved, c->stream));
+            if (int r = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec_new)) return r;
+            c->kd_ahead = true;
+        }
         if (int r = launch_collide_finish(c, false)) return r;
     }
-    return 0;
+    return auto_join(c);
 }
 int sca_set_shard_emulation(sca_ctx *c, int on) {
     if (!c) return SCA_ERR_ARG;
@@ -1674,7 +1832,8 @@ int sca_step_begin(sca_ctx *c, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
-    return launch_policy(c, neighbor_mode, false, true);
+    if (int r = launch_policy(c, neighbor_mode, false, true)) return r;
+    return auto_join(c);                                                  // (the caller may read anything between the two halves of a step)
 }
 int sca_step_end(sca_ctx *c) {
     if (!c) return SCA_ERR_ARG;

@@ -74,6 +74,8 @@ struct KdScratch {
     int *ticket;              // [KD_MAX_LEVELS + 1] arrival counters of k_kd_lv_rank<true> (chunk index by arrival, see there)
     int skip_prep;            // 1: k_kd_gather leaves the prologue of the tracker's agents to the tracker's kernels (v_pref is still being computed by
                               //    the tracker on another stream)
+    int aux;                  // 1: the build runs BESIDE the pass that owns the step's counters and prologue (SCA_NBR_AUTO: the grid's kernels have them):
+                              //    k_kd_gather touches neither
 };
 
 // order-preserving map double -> u64 so that integer atomics give exact min / max
@@ -110,8 +112,10 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         KdChunkRec r; r.job = 0; r.first = 0; r.nb = 0; r.ne = d.n; r.axis = -1; r.pad = 0; r.split = 0.0;
         s.chunks[0][p] = r;
     }
-    if (p < 256) d.done_count[p * 32] = 0;                                   // start of a step: K4's counters
-    if (p == 0) *d.fb_count = 0;                                             // ... and an empty fallback list
+    if (!s.aux) {
+        if (p < 256) d.done_count[p * 32] = 0;                               // start of a step: K4's counters
+        if (p == 0) *d.fb_count = 0;                                         // ... and an empty fallback list
+    }
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
         const int id = d.aperm[p];
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
         mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
-        if (shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
+        if (!s.aux && shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
     }
     if (d.n > s.wave_max) {
 #pragma unroll

@@ -62,7 +62,7 @@ def test_python_constants_mirror_the_header():
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     hdr = {k: int(v) for k, v in re.findall(r'\b(SCA_[A-Z0-9_]+)\s*=\s*(-?\d+)', txt)}
     hdr.update({k: int(v) for k, v in re.findall(r'#define\s+(SCA_[A-Z0-9_]+)\s+(-?\d+)\b', txt)})
-    pairs = {'SCA_NBR_KDTREE': S.NBR_KDTREE, 'SCA_NBR_GRID': S.NBR_GRID, 'SCA_NBR_KDTREE_HOSTBUILD': S.NBR_KDTREE_HOSTBUILD,
+    pairs = {'SCA_NBR_KDTREE': S.NBR_KDTREE, 'SCA_NBR_GRID': S.NBR_GRID, 'SCA_NBR_KDTREE_HOSTBUILD': S.NBR_KDTREE_HOSTBUILD, 'SCA_NBR_AUTO': S.NBR_AUTO,
              'SCA_POLICY_SCA': S.POL_SCA, 'SCA_POLICY_RVO3D': S.POL_RVO3D, 'SCA_POLICY_SRVO3D': S.POL_SRVO3D,
              'SCA_POLICY_ORCA3D': S.POL_ORCA3D, 'SCA_POLICY_ORCA3D_LP': S.POL_ORCA3D_LP, 'SCA_POLICY_RVO3D_DUBINS': S.POL_RVO3D_DUBINS,
              'SCA_FORM_SOLVE_SPLIT': S.FORM_SOLVE_SPLIT, 'SCA_FORM_TRACK_FUSED': S.FORM_TRACK_FUSED,

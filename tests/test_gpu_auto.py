@@ -1,0 +1,91 @@
+"""SCA_NBR_AUTO (round 4): the grid query for every agent + the kd query for the agents whose list the grid cannot give exactly (more
+than max_neighbors objects in range, or two objects of one kind at the same rounded distance), the kd-tree still built every step --
+beside the grid build and query, and in resident runs already behind the previous step's integrate stage.  Everything must equal
+SCA_NBR_KDTREE: states, action rows, the neighbour lists entry for entry, the carried permutation.  (The recorded reference episodes
+run through it in tests/test_gpu_parity.py::test_policy_pass_vs_golden[auto].)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(kind, n, seed):
+    from sca_amd import scenarios, solver as S
+    rng = np.random.default_rng(seed)
+    if kind == 'circle':
+        sc = scenarios.circle(n)
+        pol = np.zeros(n, np.uint8)
+    elif kind == 'cube':                                         # every policy incl. the Official LP (plane order = list order)
+        sc = scenarios.random_cube(n, seed=seed)
+        pol = (np.arange(n) % 5).astype(np.uint8)
+    elif kind == 'lattice':                                      # integer coordinates: equal distances everywhere -> everybody is handed over
+        sc = scenarios.random_cube(n, seed=seed)
+        side = int(np.ceil(n ** (1 / 3)))
+        idx = np.arange(n)
+        sc['start'][:, 0] = 3.0 * (idx % side); sc['start'][:, 1] = 3.0 * ((idx // side) % side); sc['start'][:, 2] = 40.0 + 3.0 * (idx // (side * side))
+        sc['goal'][:, :3] = sc['start'][rng.permutation(n), :3]
+        pol = np.where(idx % 3 == 0, 4, idx % 4).astype(np.uint8)
+    elif kind == 'dense':                                        # ~40 agents within neighborDist: overflow, collisions, fallback agents
+        sc = scenarios.random_cube(n, seed=seed)
+        sc['start'][:, :3] = rng.uniform(-9, 9, (n, 3)) + np.array([0, 0, 30.0])
+        sc['goal'][:, :3] = rng.uniform(-9, 9, (n, 3)) + np.array([0, 0, 30.0])
+        pol = (np.arange(n) % 5).astype(np.uint8)
+    else:
+        sc = scenarios.takeoff_landing(n)
+        n = len(sc['start'])
+        pol = np.where(np.arange(n) % 2 == 0, 0, 2).astype(np.uint8)
+    return sc, pol, len(sc['start'])
+
+
+def _solver(sc, pol, n, tracked):
+    from sca_amd import scenarios, solver as S
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])))
+    sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
+    sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                   scenarios.max_run_dist(sc['start'], sc['goal']))
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    if tracked:
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+    return sol
+
+
+@pytest.mark.parametrize('kind,n,tracked,steps,burst', [
+    ('cube', 4096, False, 40, 1), ('cube', 4096, False, 40, 8), ('circle', 3000, True, 30, 5), ('circle', 20000, True, 16, 4),
+    ('lattice', 3375, False, 24, 6), ('dense', 600, False, 20, 4), ('takeoff', 1024, True, 30, 6), ('circle', 100000, False, 8, 4),
+    ('circle', 100000, True, 8, 4)])
+def test_auto_mode_equals_kdtree_mode(kind, n, tracked, steps, burst):
+    """side by side from the start state, `burst` steps per library call (burst > 1: the next pass's tree is built ahead, behind the
+    integrate stage; burst = 1: every pass builds its own)"""
+    from sca_amd import solver as S
+    sc, pol, n = _scene(kind, n, seed=7)
+    a, b = _solver(sc, pol, n, tracked), _solver(sc, pol, n, tracked)
+    for t in range(0, steps, burst):
+        a.run_steps(burst, S.NBR_KDTREE); b.run_steps(burst, S.NBR_AUTO)
+        a.synchronize(); b.synchronize()
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (kind, n, t, k, int((sa[k] != sb[k]).sum()))
+        assert np.array_equal(a.actions(), b.actions()), (kind, t)
+        na, nb = a.neighbors(), b.neighbors()
+        for k in ('nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq'):
+            assert np.array_equal(na[k], nb[k]), (kind, n, t, k)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (kind, t)
+        da, db = a.diag(), b.diag()
+        assert np.array_equal(da['diag'], db['diag']) and np.array_equal(da['status'], db['status']), (kind, t)
+    a.close(); b.close()
+
+
+def test_auto_mode_hands_ties_and_overflows_to_the_kd_query():
+    """the lattice scene has equal distances in every list and the dense one more than 16 objects in range: lists in the kd-tree's
+    order all the same (the plain grid mode orders ties by id and flags overflows)"""
+    from sca_amd import solver as S
+    for kind, n in (('lattice', 1000), ('dense', 400)):
+        sc, pol, n = _scene(kind, n, seed=3)
+        a, b, g = _solver(sc, pol, n, False), _solver(sc, pol, n, False), _solver(sc, pol, n, False)
+        for sol, mode in ((a, S.NBR_KDTREE), (b, S.NBR_AUTO), (g, S.NBR_GRID)):
+            sol.run_steps(3, mode); sol.synchronize()
+        na, nb, ng = a.neighbors(), b.neighbors(), g.neighbors()
+        assert np.array_equal(na['nbr_id'], nb['nbr_id']) and np.array_equal(na['nbr_dsq'], nb['nbr_dsq'])
+        assert not np.array_equal(na['nbr_id'], ng['nbr_id']), kind      # (the scene does what it is for: the grid alone differs)
+        for s in (a, b, g):
+            s.close()

@@ -34,18 +34,22 @@ def check_actions(got, ref, ctx):
     assert np.allclose(got[:, 4:], ref[:, 4:], rtol=0, atol=ANG_TOL), ctx + ('angles', np.abs(got[:, 4:] - ref[:, 4:]).max())
 
 
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
 @pytest.mark.parametrize('name', episode_fixtures())
-def test_policy_pass_vs_golden(S, name):
+def test_policy_pass_vs_golden(S, name, mode):
+    """`auto` = SCA_NBR_AUTO (round 4): the grid query for every agent, the kd query for those with more than 16 objects in range or
+    equal rounded distances -- the same assertions as for the kd-tree: lists entry for entry, the permutation, decisions, action rows"""
     fx = load(name)
     st = static_inputs(fx)
     sol = make_solver(S, fx, st)
     T = len(fx['step'])
+    nbr_mode = S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE
     for t in range(T):
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
         sol.set_kd_perm(fx['perm'][t])
         sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
-        sol.policy_pass(S.NBR_KDTREE)
-        ctx = (name, t)
+        sol.policy_pass(nbr_mode)
+        ctx = (name, mode, t)
         assert np.array_equal(sol.get_kd_perm(), fx['perm_after'][t]), ctx
         nb = sol.neighbors()
         valid = fx['nbr_valid'][t].astype(bool)
