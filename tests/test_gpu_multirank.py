@@ -46,13 +46,13 @@ st = ShardedStepper(sol, rank, world, torch_mod=torch, dist_mod=dist, staged=Tru
 st.run(steps); st.sync()
 got = sol.get_state()
 ref_sol = make()
-ref_sol.run_steps(steps, mode); ref_sol.synchronize()
+ref_sol.run_steps(steps, 0 if mode == 3 else mode); ref_sol.synchronize()      # (SCA_NBR_AUTO must equal the kd-tree run)
 ref = ref_sol.get_state()
 lo, hi = st.begin, st.begin + st.count
 ok = np.array_equal(got['pos'], ref['pos']) and np.array_equal(got['vel'], ref['vel'])
 ok = ok and np.array_equal(got['flags'][lo:hi], ref['flags'][lo:hi]) and np.array_equal(got['flags'] & 1, ref['flags'] & 1)
 ok = ok and np.array_equal(got['heading'][lo:hi], ref['heading'][lo:hi]) and np.array_equal(got['total_dist'][lo:hi], ref['total_dist'][lo:hi])
-ok = ok and (mode != 0 or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
+ok = ok and (mode not in (0, 3) or np.array_equal(sol.get_kd_perm(), ref_sol.get_kd_perm()))
 state_ok = ok
 if not ok:                                                    # say what differs (a bug report's worth)
     for k in ('pos', 'vel', 'heading', 'flags', 'total_dist'):
@@ -73,10 +73,11 @@ sys.exit(0 if ok else 1)
 
 
 @pytest.mark.parametrize('track,mode,n', [(False, 0, 3000), (True, 0, 3000), (False, 1, 3000), (True, 1, 3000), (True, 0, 120000),
-                                          (True, 0, -60000)])
+                                          (True, 0, -60000), (False, 3, 3000), (False, 3, -60000), (True, 3, 3000)])
 def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
-    next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  n = 120 000: shards
+    next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  mode 3: SCA_NBR_AUTO on two
+    ranks against the single-rank KD-TREE run.  n = 120 000: shards
     of 60 000 agents, which get k_track_replan and the split solve, the second one with shard_begin != 0 -- the case that found
     the missing fence of the one-launch-per-level kd build (two processes on one GPU is also a scheduling stress).  n < 0: |n|
     agents of all five policies in a random cube."""
