@@ -151,6 +151,8 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
                                                                   double obs_reach, double max_radius) {
     SCA_K1_SETPRIO();
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
+    __shared__ int pfx[K1P_WAVES][K1P_APW][32], fpos[K1P_WAVES][K1P_APW][32];
+    __shared__ unsigned long long pkey[K1P_WAVES][K1P_APW][32];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int grp = lane >> 4, gl = lane & 15, gshift = grp << 4;
@@ -281,7 +283,10 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
         }
     }
 
-    // ---- agents: the 27 cells around the agent's (agent.py:79-99).  Lane gl probes cells gl and gl + 16.
+    // ---- agents: the 27 cells around the agent's (agent.py:79-99).  Lane gl probes cells gl and gl + 16; the members of ALL
+    // non-empty probes are then taken 16 at a time as ONE flat sequence (round 4: probe by probe -- one dependent trip to memory per
+    // non-empty cell, ~14 of them for a sparse 3-D swarm with ~21 members in its 27 cells -- took 27 us at N = 4096; flat: two
+    // rounds).  The flat index -> (probe, member) map is a 32-entry prefix table per group in LDS, searched by bisection.
     {
         const long long cx = grid_cell(pA.x, g.inv_cell), cy = grid_cell(pA.y, g.inv_cell), cz = grid_cell(pA.z, g.inv_cell);
         const unsigned long long key_a = grid_probe_key(cx, cy, cz, gl);
@@ -291,36 +296,50 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
             ra = g.range[grid_bucket(key_a, g.hbits)];
             if (gl + 16 < 27) rb = g.range[grid_bucket(key_b, g.hbits)];
         }
-        unsigned pm = (unsigned)((__ballot(ra.y > 0) >> gshift) & 0xffffull) | ((unsigned)((__ballot(rb.y > 0) >> gshift) & 0xffffull) << 16);
-        while (__any(pm != 0)) {
-            const bool pact = pm != 0;
-            const int q = pact ? __ffs((int)pm) - 1 : 0;
-            pm &= pm - 1;
-            const int src = gshift + (q & 15);
-            const bool second = q >= 16;                             // the same for the whole group
-            const int first_pos = __shfl(second ? rb.x : ra.x, src);
-            const int members = pact ? __shfl(second ? rb.y : ra.y, src) : 0;
-            const unsigned long long key = shfl_u64(second ? key_b : key_a, src);
-            for (int off = 0; __any(off < members); off += 16) {
-                const bool valid = off + gl < members;
-                int o = -1; double dsq = 0.0; bool c = false, r = false, nr = false;
-                if (valid) {
-                    const int at = first_pos + off + gl;
-                    o = g.gid[at];
-                    if (g.gkey[at] == key && o != agent) {           // another cell of the same bucket: not this probe's
-                        dsq = l3normsq(pA, v3(g.gx[at], g.gy[at], g.gz[at]));
-                        r = dsq < rangeSq;
-                        if (r && dsq < rmax2) { const double rs = me.radius + d.rec[o].radius; c = dsq < rs * rs; }
-                        nr = dsq < reach_a * reach_a;
-                    }
+        // exclusive prefix of the member counts in probe order (probes 0..15 on the lanes' first slot, 16..26 on their second)
+        auto row_incl = [](int v) {
+            int t;
+            t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v += t;
+            t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v += t;
+            t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v += t;
+            t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v += t;
+            return v;
+        };
+        const int ia = row_incl(ra.y), ib = row_incl(rb.y);
+        const int tot_a = row_bcast_i<15>(ia), tot_b = row_bcast_i<15>(ib);
+        const int total = tot_a + tot_b;
+        int *pf = pfx[wid][grp];
+        int *fp = fpos[wid][grp];
+        unsigned long long *kq = pkey[wid][grp];
+        pf[gl] = ia - ra.y; fp[gl] = ra.x; kq[gl] = key_a;
+        pf[16 + gl] = gl + 16 < 27 ? tot_a + ib - rb.y : 0x7fffffff;      // (entries 27..31: sentinels above every index)
+        fp[16 + gl] = rb.x; kq[16 + gl] = key_b;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; __any(base < total); base += 16) {
+            const int f = base + gl;
+            const bool valid = f < total;
+            int o = -1; double dsq = 0.0; bool c = false, r = false, nr = false;
+            if (valid) {
+                int q = 0;                                               // the largest q with pf[q] <= f (empty probes have zero width)
+#pragma unroll
+                for (int stp = 16; stp >= 1; stp >>= 1) if (pf[q + stp] <= f) q += stp;
+                const int at = fp[q] + (f - pf[q]);
+                o = g.gid[at];
+                if (g.gkey[at] == kq[q] && o != agent) {                 // another cell of the same bucket: not this probe's
+                    dsq = l3normsq(pA, v3(g.gx[at], g.gy[at], g.gz[at]));
+                    r = dsq < rangeSq;
+                    if (r && dsq < rmax2) { const double rs = me.radius + d.rec[o].radius; c = dsq < rs * rs; }
+                    nr = dsq < reach_a * reach_a;
                 }
-                {
-                    const unsigned nm = (unsigned)((__ballot(nr) >> gshift) & 0xffffull);
-                    if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
-                    near_cnt += __popc(nm);
-                }
-                insert_all((unsigned)((__ballot(r && want_list) >> gshift) & 0xffffull), c, dsq, o);
             }
+            {
+                const unsigned nm = (unsigned)((__ballot(nr) >> gshift) & 0xffffull);
+                if (nr) { const int at = near_cnt + __popc(nm & ((1u << gl) - 1u)); if (at < NEAR_MAX) near_out[at] = o; }
+                near_cnt += __popc(nm);
+            }
+            insert_all((unsigned)((__ballot(r && want_list) >> gshift) & 0xffffull), c, dsq, o);
         }
     }
     if (!exists) return;

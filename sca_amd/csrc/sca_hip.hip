@@ -1574,9 +1574,13 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
             // AUTO pass its fallback looks into the grid, not into the tree -- so it starts here, beside the collision check and the
             // next pass's grid build and query.  Only inside one call: a caller who reads the permutation between calls sees as many
             // builds as steps.
+            // (the collision check goes to its stream FIRST: the host needs ~5 us per launch, and the build's eight or more launches in
+            // front of it left the main stream idle for 50 us at N = 4096)
             CHK(c, hipEventRecord(c->ev_auto_moved, c->stream));
-            if (int r = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec_new)) return r;
+            if (int r = launch_collide_finish(c, false)) return r;                 // (swaps the record buffers: the moved ones are c->d.rec now)
+            if (int r = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec)) return r;
             c->kd_ahead = true;
+            continue;
         }
         if (int r = launch_collide_finish(c, false)) return r;
     }
