@@ -1376,6 +1376,12 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (auto_mode) {
         // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
         // build on kd_stream, and nothing reads a list before that query is through
+        if (c->auto_seq >= 0xfffffff0u) {                              // (the hand-shake word counts passes: start over long before it wraps)
+            CHK(c, hipStreamSynchronize(ns)); CHK(c, hipStreamSynchronize(c->kd_stream)); CHK(c, hipStreamSynchronize(c->stream));
+            CHK(c, hipMemsetAsync(c->auto_ready, 0, sizeof(unsigned), c->stream));
+            CHK(c, hipStreamSynchronize(c->stream));
+            c->auto_seq = 0;
+        }
         const unsigned seq = ++c->auto_seq;
         if (c->auto_waitvalue) hipLaunchKernelGGL(k_auto_ready, dim3(1), dim3(1), 0, ns, c->kdq_count, c->auto_ready, seq, 1);
         CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
