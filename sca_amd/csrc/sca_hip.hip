@@ -1396,7 +1396,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipEventRecord(c->ev_auto_kd, c->kd_stream));
         if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_auto_ready)
-            CHK(c, hipStreamWaitValue32(ns, c->auto_ready, seq, hipStreamWaitValueGte, 0xffffffffu));
+            if (hipStreamWaitValue32(ns, c->auto_ready, seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+                (void)hipGetLastError();                              // a platform without stream memory operations: the event wait from now on
+                c->auto_waitvalue = false;
+                CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));
+            }
         } else CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));
     }
     if (split) {
