@@ -240,6 +240,7 @@ struct sca_ctx {
     unsigned *auto_ready = nullptr;     // device word: the last AUTO pass whose lists are final (k_auto_ready; hipStreamWaitValue32)
     unsigned auto_seq = 0;
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
+    hipEvent_t ev_auto_kdq[2] = {nullptr, nullptr};      // behind the kd query of the last pass of either parity (its list is reused two passes on)
     hipEvent_t ev_auto_gather[2] = {nullptr, nullptr};   // the gather kernel of the last two builds: the integrate stage must not write into
     unsigned auto_builds = 0;                            // the record buffer a build's gather still reads (the two buffers alternate)
     bool auto_unjoined = false;         // kd_stream may still be working on the last AUTO pass's tree / kd query
@@ -729,6 +730,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->auto_ready) (void)hipFree(c->auto_ready);
     if (c->auto_ticket) (void)hipFree(c->auto_ticket);
     for (hipEvent_t e : c->ev_auto_gather) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_auto_kdq) if (e) (void)hipEventDestroy(e);
     if (c->kd_ev) (void)hipEventDestroy(c->kd_ev);
     if (c->kd_host_counts) (void)hipHostFree(c->kd_host_counts);
     if (c->stream_own) (void)hipStreamDestroy(c->stream_own);
@@ -1202,15 +1204,18 @@ static int auto_prepare(sca_ctx *c) {
     CHK(c, hipStreamCreateWithFlags(&c->kd_stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&c->ev_auto_fork, &c->ev_auto_k1g, &c->ev_auto_kd, &c->ev_auto_moved, &c->ev_auto_cnt})
         CHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    CHK(c, hipMalloc((void **)&c->kdq_list, sizeof(int32_t) * (size_t)c->max_n));
-    CHK(c, hipMalloc((void **)&c->kdq_count, sizeof(int32_t)));
-    CHK(c, hipMemsetAsync(c->kdq_count, 0, sizeof(int32_t), c->stream));
+    // two lists, alternating by pass: a pass's kd query may still be reading its list's length (to find it empty) when the next
+    // pass's grid build resets and refills the other one
+    CHK(c, hipMalloc((void **)&c->kdq_list, 2 * sizeof(int32_t) * (size_t)c->max_n));
+    CHK(c, hipMalloc((void **)&c->kdq_count, 2 * sizeof(int32_t)));
+    CHK(c, hipMemsetAsync(c->kdq_count, 0, 2 * sizeof(int32_t), c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ready, sizeof(unsigned)));
     CHK(c, hipMemsetAsync(c->auto_ready, 0, sizeof(unsigned), c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
     CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     for (hipEvent_t &e : c->ev_auto_gather) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : c->ev_auto_kdq) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->auto_seq = 0; c->auto_builds = 0;
     c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
     CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
@@ -1329,9 +1334,13 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     c->nbr_mode = auto_mode ? (int)SCA_NBR_GRID : mode;               // (what K4's fallback looks into: the grid in an AUTO pass)
     if (auto_mode) {
         c->d.kdq_cap = std::max(1, c->d.shard_count / 8);
-        // the previous AUTO pass's kd query reads the list and its length, which the grid build below resets: it has to be through
-        // (it is, unless the kd build is the longer branch -- then the passes run at its pace)
-        if (c->auto_seq > 0) CHK(c, hipStreamWaitEvent(c->nbr_stream, c->ev_auto_kd, 0));
+        {   // this pass's list (the previous pass's kd query may still be looking at the other one's length)
+            const unsigned par = (c->auto_seq + 1) & 1u;
+            c->d.kdq_list = c->kdq_list + (size_t)par * c->max_n;
+            c->d.kdq_count = c->kdq_count + par;
+            // ... which the kd query of two passes ago must be through with (it is, unless the kd stream lags by two whole passes)
+            if (c->auto_seq >= 2) CHK(c, hipStreamWaitEvent(c->nbr_stream, c->ev_auto_kdq[par], 0));
+        }
         if (int r = build_agent_grid_device(c)) return r;
     }
     else if (mode == SCA_NBR_KDTREE) { if (int r = build_agent_tree_device(c, c->nbr_stream, c->d)) return r; }
@@ -1383,17 +1392,18 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->auto_seq = 0;
         }
         const unsigned seq = ++c->auto_seq;
-        if (c->auto_waitvalue) hipLaunchKernelGGL(k_auto_ready, dim3(1), dim3(1), 0, ns, c->kdq_count, c->auto_ready, seq, 1);
+        if (c->auto_waitvalue) hipLaunchKernelGGL(k_auto_ready, dim3(1), dim3(1), 0, ns, d.kdq_count, c->auto_ready, seq, 1);
         CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
         CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));
         hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius,
                            c->auto_ready, seq, c->auto_ticket);
         if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
-            CHK(c, hipMemcpyAsync(c->kdq_host, c->kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
+            CHK(c, hipMemcpyAsync(c->kdq_host, d.kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
             c->kdq_pending = true;
         }
         CHK(c, hipEventRecord(c->ev_auto_kd, c->kd_stream));
+        CHK(c, hipEventRecord(c->ev_auto_kdq[seq & 1u], c->kd_stream));
         if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_auto_ready)
             if (hipStreamWaitValue32(ns, c->auto_ready, seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
