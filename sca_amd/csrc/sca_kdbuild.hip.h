@@ -191,7 +191,7 @@ __device__ __forceinline__ void kd_node_split(const KdScratch &s, int level, int
 // Level pass A: one workgroup per chunk.  The node's box is complete (accumulated by the parent's pass), so the chunk
 // can flag its members against the split plane, scan the flags (chained across the chunks of the node through one
 // 64-bit word per chunk: launch token | count), write the in-node ranks, and accumulate the boxes of the two children.
-struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; double red[KD_LV_T / 64][12]; };
+struct KdRankLds { int wtot[KD_LV_T / 64]; int carry_sh; double red[KD_LV_T / 64][12]; int wt[KD_CHUNK / KD_LV_T][KD_LV_T / 64]; };
 __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsigned token, const KdChunk c, KdRankLds &SH, int blk) {
     constexpr int W = KD_LV_T / 64;
     int (&wtot)[W] = SH.wtot;
@@ -221,6 +221,14 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
     }
     const int wsum = wave_sum_i(mine);
     if (lane == 0) wtot[wid] = wsum;
+    // the ">= split" lanes of every tile, and the wavefront's count per tile for the ranks below (until round 4 the rank loop
+    // exchanged them tile by tile: sixteen workgroup barriers per chunk, ~1.2 us of a ~8-us pass)
+    unsigned long long tm[KD_LV_E];
+#pragma unroll
+    for (int t = 0; t < KD_LV_E; t++) {
+        tm[t] = __ballot((flags >> t) & 1u);
+        if (lane == 0) SH.wt[t][wid] = __popcll(tm[t]);
+    }
     // children boxes: wave reduce, then one set of atomics per workgroup
 #pragma unroll
     for (int sd = 0; sd < 2; sd++)
@@ -271,13 +279,10 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
     for (int t = 0; t < KD_LV_E; t++) {
         const int p = c.begin + t * KD_LV_T + tid;
         const bool ge = (flags >> t) & 1u;
-        const unsigned long long m = __ballot(ge);
-        const int incl_w = __popcll(m & ((2ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) wtot[wid] = __popcll(m);
-        __syncthreads();
+        const int incl_w = __popcll(tm[t] & ((2ull << lane) - 1ull));
         int woff = 0, ttot = 0;
-        for (int w = 0; w < W; w++) { const int v = wtot[w]; if (w < wid) woff += v; ttot += v; }
+#pragma unroll
+        for (int w = 0; w < W; w++) { const int v = SH.wt[t][w]; if (w < wid) woff += v; ttot += v; }
         const int G = carry + woff + incl_w;
         if (p < c.end) {
             s.ps[p] = G;
