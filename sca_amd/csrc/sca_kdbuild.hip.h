@@ -159,7 +159,7 @@ __device__ __forceinline__ void kd_split(const double mn[3], const double mx[3],
 
 // ---- level passes over the large nodes, one workgroup per chunk of KD_CHUNK positions ---------------------------------
 constexpr int KD_LV_T = 512;
-constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 8 strided positions per thread (tile t covers [t*T, (t+1)*T))
+constexpr int KD_LV_E = KD_CHUNK / KD_LV_T;     // 4 strided positions per thread (tile t covers [t*T, (t+1)*T))
 
 
 // workgroup -> (node, chunk, split plane) through the level's chunk table (written by the parent level's swap pass)
@@ -222,7 +222,7 @@ __device__ __forceinline__ void kd_rank_part(const KdScratch s, int level, unsig
     const int wsum = wave_sum_i(mine);
     if (lane == 0) wtot[wid] = wsum;
     // the ">= split" lanes of every tile, and the wavefront's count per tile for the ranks below (until round 4 the rank loop
-    // exchanged them tile by tile: sixteen workgroup barriers per chunk, ~1.2 us of a ~8-us pass)
+    // exchanged them tile by tile: eight workgroup barriers per chunk)
     unsigned long long tm[KD_LV_E];
 #pragma unroll
     for (int t = 0; t < KD_LV_E; t++) {
@@ -327,6 +327,11 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
     const int b = c.node_begin, e = c.node_end;
     const int L = (e - b) - s.nge[(level & 1) * s.job_cap + c.job];
     const int lim = c.end < b + L ? c.end : b + L;
+    // (Taking a thread's positions two or four at a time -- flags, partners, both records, stores: four trips to memory per chunk
+    // instead of four per position -- was measured in round 4: slower.  Two at a time 11.2 us against 10.0 at c5, 7.9 against 6.6
+    // at c4: the bookkeeping wavefront below sets the length, not this loop.  Four at a time needs 121 registers, and then a
+    // workgroup of nine wavefronts no longer finds room on the CUs whose SIMDs hold a 256-register re-plan wavefront each:
+    // 34 us at c5, 45 at c4.  The build's kernels stay under 256 / 3 registers for that reason.)
     for (int p = c.begin + tid; p < lim && tid < KD_LV_T; p += KD_LV_T) {
         if (!(kc[p] < split)) {
             // the k-th ">= split" member of the left part (k = ps - 1) takes the k-th "< split" member from the right,
