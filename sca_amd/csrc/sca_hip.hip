@@ -1928,6 +1928,14 @@ int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds on
 }
 #endif
 
+#ifdef SCA_KT_TIMING
+int sca_debug_read_kdq(sca_ctx *c, int *out, int count) {     // debug builds only: k_track's per-phase ticks
+    CHK(c, hipDeviceSynchronize());
+    CHK(c, hipMemcpy(out, c->d.kdq_list, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, double *fast, double *exact) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, n > 0 && a && b && fast && exact);

@@ -91,17 +91,27 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
     if (K.prep) prep_agent(d, K.P, (Prep *)d.prep, agent);
 }
 
+#ifdef SCA_KT_TIMING    // per-phase wall-clock ticks of workgroup 0's thread 0 into d.kdq_list (debug builds only)
+#define KT_MARK() do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); d.kdq_list[kt_i++] = (int)(t_ - kt_t); kt_t = t_; } } while (0)
+#define KT_MARK_INIT() int kt_i = 0; long long kt_t = wall_clock64()
+#else
+#define KT_MARK() do { } while (0)
+#define KT_MARK_INIT() do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     // the re-plan list: per workgroup the lanes count themselves into their buckets in LDS, ONE vector atomic fetches the
     // workgroup's offsets in all twelve buckets, and the lanes write their slots.  (Until the end of round 3 every wavefront
     // fetched its offsets itself, one bucket after the other: ~5000 dependent same-address atomics per pass, which is what
     // k_track's 52 us at c4 were made of -- it executes 1400 instructions per wavefront.)
     __shared__ int s_cnt[TRK_BUCKETS], s_base[TRK_BUCKETS];
+    KT_MARK_INIT();
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
+    KT_MARK();
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
     if (threadIdx.x < TRK_BUCKETS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    KT_MARK();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_shard = idx < shard_size(d);
     const int agent = in_shard ? shard_agent(d, idx) : 0;
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
             pos[0] = r.px; pos[1] = r.py; pos[2] = r.pz;
             const float vel[3] = {r.vx, r.vy, r.vz};
             sca_dubins::AgentTrack &a = K.st[agent];
+            KT_MARK();
             replan = sca_dubins::track_decide(T, a, agent, pos, vel, nb0, dif);
+            KT_MARK();
             if (replan) {
                 mine = trk_bucket(a.plan.iters);                         // the bucket of the agent's previous search (a.plan still holds it)
                 my_rank = atomicAdd(&s_cnt[mine], 1);
@@ -129,9 +141,11 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
                 sca_dubins::track_finish(T, a, agent, pos, dif, V);
                 track_store(d, K, agent, V);
             }
+            KT_MARK();
         }
     }
     __syncthreads();
+    KT_MARK();
     if (threadIdx.x < TRK_BUCKETS) {
         const int c = s_cnt[threadIdx.x];
         s_base[threadIdx.x] = c > 0 ? atomicAdd(&K.bcount[K.parity * TRK_BUCKETS + threadIdx.x], c) : 0;
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
     }
     __syncthreads();
     if (replan) K.list[(size_t)mine * K.n + s_base[mine] + my_rank] = agent;
+    KT_MARK();
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
