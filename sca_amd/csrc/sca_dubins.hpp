@@ -848,6 +848,15 @@ SCA_DHD static Plan3D plan3d_lean(const double qi[5], const double qf[5], double
 #endif
 
 // ---- the tracker (scaPolicy.py:243-338) ------------------------------------------------------------------------------
+#if defined(SCA_KT_TIMING) && defined(__HIPCC__)   // debug builds: workgroup 0 / thread 0's clock between the pieces of track_decide
+__device__ int g_td_ticks[32];
+__device__ long long g_td_last;
+#endif
+#if defined(SCA_KT_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define SCA_TD_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_td_ticks[k] = (int)(t_ - g_td_last); g_td_last = t_; } } while (0)
+#else
+#define SCA_TD_MARK(k) do { } while (0)
+#endif
 struct AgentTrack {
     bool is_use_dubins = false;
     Plan3D plan;                        // agent.dubins_path == samples [next, plan.count) of this plan, popped in path order
@@ -937,13 +946,16 @@ SCA_DHD static bool is_parallel(const float *vA, const double *vp) {
 SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double *pos, const float *vel, double nbr0_dsq,
                                  double dif[3]) {
     const double *goal = &T.goal[3 * i];
+    SCA_TD_MARK(0);
     const double dis_goal = l3norm(pos, goal);
     const double k = 3.0 * T.turning_radius;
     if (!a.is_use_dubins) {
         a.is_use_dubins = true;
         return true;
     }
+    SCA_TD_MARK(1);
     update_dubins(T, a, i, pos);
+    SCA_TD_MARK(2);
     const double dis = l3norm(pos, a.now_goal);
     const double max_size = round5_py(6 * a.sampling_size);
     const double pApG[3] = {goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]};
@@ -952,12 +964,17 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     double cs = fma3(vA64, pApG) / ((double)nvA * std::sqrt(fma3(pApG, pApG)));
     if (!(cs < 1.0)) cs = 1.0;                                       // min(x, 1.0); nan -> 1.0 as Python's min does here
     if (cs < -1.0) cs = -1.0;                                        // the reference would raise; clamp
+    SCA_TD_MARK(3);
     const double theta = round5_py(m_acos(cs));
+    SCA_TD_MARK(4);
     const double deg100 = round5_np(100.0 * (PI / 180.0));
     const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
     const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
-    if (((is_parallel(vel, a.v_pref) || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
+    const bool par_ = is_parallel(vel, a.v_pref);
+    SCA_TD_MARK(5);
+    if (((par_ || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {
         update_dubins(T, a, i, pos);
+        SCA_TD_MARK(6);
         if (!path_empty(a)) for (int q = 0; q < 3; q++) dif[q] = a.now_goal[q] - pos[q];
         else for (int q = 0; q < 3; q++) dif[q] = goal[q] - pos[q];
         return false;

@@ -1931,7 +1931,8 @@ int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds on
 #ifdef SCA_KT_TIMING
 int sca_debug_read_kdq(sca_ctx *c, int *out, int count) {     // debug builds only: k_track's per-phase ticks
     CHK(c, hipDeviceSynchronize());
-    CHK(c, hipMemcpy(out, c->d.kdq_list, sizeof(int) * count, hipMemcpyDeviceToHost));
+    CHK(c, hipMemcpy(out, c->d.kdq_list, sizeof(int) * (count < 16 ? count : 16), hipMemcpyDeviceToHost));
+    if (count >= 48) CHK(c, hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(sca_dubins::g_td_ticks), sizeof(int) * 32));
     return 0;
 }
 #endif
