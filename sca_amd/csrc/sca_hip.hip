@@ -187,6 +187,7 @@ struct sca_ctx {
     unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
+    int kd_tail_level = -1;             // SCA_KD_TAIL_LEVEL=l: the level at which the tail launch takes over (tuning / tests; -1: from the statistics)
     int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
     int solve_split = -1;               // k_solve in two launches (k_solve_sweep beside the re-plans, k_solve_pick4 behind them): -1 when the
@@ -607,6 +608,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SCA_KD_TAIL_LEVEL")) c->kd_tail_level = std::atoi(e);
     if (const char *e = std::getenv("SCA_KD_TICKET")) c->kd_force_ticket = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_WAVE_CAP")) c->kd_wave_cap = std::min(KD_WAVE_CAP, std::max(2 * KD_WAVE_FLOOR, std::atoi(e)));
     int ndev = 0;
@@ -1005,6 +1007,7 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
             c->kd_ev_pending = false;
         }
         if (c->kd_single_hint > 0 && !c->kd_nohint) first_single = c->kd_single_hint - 1;
+        if (c->kd_tail_level >= 0) first_single = c->kd_tail_level;
         first_single = std::min(first_single, KD_MAX_LEVELS - 2);
         levels = first_single + 1;
         const int grid = std::min(c->kd.chunk_cap, n / KD_CHUNK + n / (wave_max / 2 + 1) + 8);   // >= chunks of any level of n agents (a node of the level passes has > wave_max members... its children > 0)
