@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "sca_dubins.hpp"
 #include "sca_kernels.hip.h"
+#include "sca_spec_trees.h"
 
 namespace sca {
 
@@ -489,21 +490,36 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
 
 // ---- 16 / 32 / 64 lanes per plan: the search several candidates at a time --------------------------------------------------------
 // The local search (dubinsmaneuver3d.py:86-100) is a chain: the next candidate radius is b + 2 step after a success, b - 0.1 step
-// after a failure.  Both are known before the verdict on the current one, and so are their successors: the quads of a 16- or
-// 32- (64-)lane group evaluate the current candidate and the 2 (6, 14) candidates that can follow it within two (three, four) steps, as a binary
-// tree in heap order (node k: success -> 2k, failure -> 2k + 1).  The verdicts are then applied in the sequential loop's order
-// along the path that loop would have taken -- same expressions for the candidates, same comparisons, results off the path are
-// dropped -- so every round advances the chain by D steps.  3/2 (7/3, 15/4) of the four-lane form's work, 1/2 (1/3, 1/4) of its critical
-// path: used while a pass has so few re-plans that most SIMDs would idle anyway.
-constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass: two steps per round, 16 lanes per plan (2048 wavefronts: two per SIMD)
-constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: three steps per round, 32 lanes per plan (2048 wavefronts)
-constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: four steps per round, a whole wavefront per plan -- and a SIMD per wavefront (the kernel sits at the 256-register edge)
+// after a failure.  Both are known before the verdict on the current one, and so are their successors: the quads of a 16- (32-, 64-)
+// lane group evaluate the current candidate and 2 (6, 14) of the candidates that can follow it, a TREE of verdict paths; the verdicts
+// are then applied in the sequential loop's order along the path that loop would have taken -- same expressions for the candidates,
+// same comparisons, results off the path are dropped -- until the path leaves the tree.
+// WHICH tree only sets how far a round gets.  Until round 4 it was the balanced one (2 / 3 / 4 steps per round).  The chain is no coin
+// toss, though: every search runs  F SSSSSS FF SSSSS FF SSSSSS FF ...  (an overshoot, the step back fails too, then five or six
+// doublings to the next overshoot), so the trees of sca_spec_trees.h (generated: tools/gen_spec_trees.py, from the verdicts of the
+// reference's own planner on 256 recorded searches) follow the likely continuations up to ten steps deep, one tree per context =
+// (kind of the current run of verdicts, its length, the previous run's length): 5.8 - 6.8 steps per round with 15 candidates on held-out
+// searches, 4.3 - 5.0 with 7, 2.5 - 2.6 with 3.  A quad finds its candidate by walking its node's path from the round's (b, step).
+constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass: 3 candidates per round, 16 lanes per plan (2048 wavefronts: two per SIMD)
+constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: 7 per round, 32 lanes per plan (2048 wavefronts)
+constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: 15 per round, a whole wavefront per plan -- and a SIMD per wavefront (the kernel sits at the 256-register edge)
+
+template <int D> struct SpecTrees;
+template <> struct SpecTrees<2> { static constexpr int TREES = sca_spec::TREES3, MAXD = sca_spec::MAXD3; static constexpr const uint8_t *of_ctx = sca_spec::TREE3_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE3_NODES; };
+template <> struct SpecTrees<3> { static constexpr int TREES = sca_spec::TREES7, MAXD = sca_spec::MAXD7; static constexpr const uint8_t *of_ctx = sca_spec::TREE7_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE7_NODES; };
+template <> struct SpecTrees<4> { static constexpr int TREES = sca_spec::TREES15, MAXD = sca_spec::MAXD15; static constexpr const uint8_t *of_ctx = sca_spec::TREE15_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE15_NODES; };
+// the trees of a kernel's form in LDS (a round reads its context's tree id and each quad its node; the walk reads through the lanes)
+template <int D> struct SpecLds { uint32_t nodes[SpecTrees<D>::TREES * (1 << D)]; uint8_t of_ctx[sca_spec::CONTEXTS]; };
+template <int D> __device__ __forceinline__ void spec_trees_load(SpecLds<D> &S) {          // all threads, before the workgroup's first barrier
+    for (int i = threadIdx.x; i < SpecTrees<D>::TREES * (1 << D); i += blockDim.x) S.nodes[i] = SpecTrees<D>::nodes[i];
+    for (int i = threadIdx.x; i < sca_spec::CONTEXTS; i += blockDim.x) S.of_ctx[i] = SpecTrees<D>::of_ctx[i];
+}
 
 template <int D>
 __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], const double qf[5], double Rmin, const double pitchlims[2],
-                                                          int sub, int lane) {
+                                                          int sub, int lane, const SpecLds<D> &TR) {
     using namespace sca_dubins;
-    constexpr int NODES = (1 << D) - 1, LANES = 4 << D;
+    constexpr int SLOTS = 1 << D, LANES = 4 << D, MAXD = SpecTrees<D>::MAXD;
     Plan3D P;
     const int quad = (lane & (LANES - 1)) >> 2, base = lane & ~(LANES - 1);
     const double qi2D[3] = {qi[0], qi[1], qi[3]}, qf2D[3] = {qf[0], qf[1], qf[3]};
@@ -527,52 +543,60 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         if (++guard > 200) return P;
     }
     double step = 0.1;
+    int ck = 0, cr = 0, cp = 0;                                          // the context: kind of the current run (1 S, 2 F), its length, the previous run's
     while (::fabs(step) > 1e-10) {
-        // candidates of the tree, heap order; nb / ns = the (b, step) the sequential loop holds when it reaches the node
-        double nb[NODES + 1], ns[NODES + 1], nc[NODES + 1];
-        nb[1] = b; ns[1] = step;
+#if defined(SCA_SPEC_BALANCED)                                          // measurement build: the balanced tree in every round
+        const int tree = 0;
+#else
+        const int tree = TR.of_ctx[(ck * (sca_spec::RUN_CAP + 1) + cr) * (sca_spec::PREV_CAP + 1) + cp];
+#endif
+        const uint32_t me = TR.nodes[tree * SLOTS + quad];               // (the spare quad's word is 0: the root again)
+        // this quad's candidate: the (b, step) the sequential loop holds when it has taken the node's path
+        double nb = b, ns = step;
+        const int plen = (int)((me >> 16) & 15u);
 #pragma unroll
-        for (int k = 1; k <= NODES; k++) {
-            double c = nb[k] + ns[k];
-            if (c < 1.0) c = 1.0;
-            nc[k] = c;
-            if (2 * k + 1 <= NODES) {
-                nb[2 * k] = c; ns[2 * k] = ns[k] * 2.;                     // success: b = c, step *= 2.
-                nb[2 * k + 1] = nb[k]; ns[2 * k + 1] = ns[k] * -0.1;       // failure: step *= -0.1
+        for (int i = 0; i < MAXD; i++) {
+            if (i < plen) {
+                double c = nb + ns;
+                if (c < 1.0) c = 1.0;
+                if ((me >> i) & 1u) { nb = c; ns *= 2.; }                // success: b = c, step *= 2.
+                else ns *= -0.1;                                         // failure: step *= -0.1
             }
         }
-        double myc = nc[1];
-#pragma unroll
-        for (int k = 2; k <= NODES; k++) myc = quad == k - 1 ? nc[k] : myc;
+        double myc = nb + ns;
+        if (myc < 1.0) myc = 1.0;
         double mylen;
         const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
-        // Every node's verdict inputs (feasible?, length) into every lane FIRST -- independent cross-lane reads, and for a whole
-        // wavefront per plan plain v_readlane of a fixed lane -- then the walk along the sequential loop's path is register
-        // arithmetic (the walk only needs lengths; the maneuvers of the radius it ends on are constructed after the search).
-        int nfk[NODES + 1];
-        double lenk[NODES + 1];
-#pragma unroll
-        for (int k = 1; k <= NODES; k++) {
+        const int kids = (int)(me >> 20);                                // (S child + 1) | (F child + 1) << 5
+        // the walk along the sequential loop's path: verdict inputs and children through the lanes that hold the node (a whole
+        // wavefront per plan: v_readlane of a uniform lane)
+        int node = 0;
+#pragma unroll 1
+        for (int depth = 0; depth <= MAXD; depth++) {
+            int nf, kd;
+            double len;
             if constexpr (LANES == 64) {
-                nfk[k] = __builtin_amdgcn_readlane(nfc, 4 * (k - 1));
-                lenk[k] = readlane_f64(mylen, 4 * (k - 1));
+                const int src = __builtin_amdgcn_readfirstlane(4 * node);
+                nf = __builtin_amdgcn_readlane(nfc, src);
+                kd = __builtin_amdgcn_readlane(kids, src);
+                len = readlane_f64(mylen, src);
             } else {
-                nfk[k] = __shfl(nfc, base + 4 * (k - 1));
-                lenk[k] = lane_fetch_d(mylen, base + 4 * (k - 1));
+                nf = __shfl(nfc, base + 4 * node);
+                kd = __shfl(kids, base + 4 * node);
+                len = lane_fetch_d(mylen, base + 4 * node);
             }
-        }
-        int node = 1;
-#pragma unroll
-        for (int depth = 0; depth < D; depth++) {
-            int nf = nfk[1];
-            double len = lenk[1], cn = nc[1];
-#pragma unroll
-            for (int k = 2; k <= NODES; k++) { nf = node == k ? nfk[k] : nf; len = node == k ? lenk[k] : len; cn = node == k ? nc[k] : cn; }
-            const bool acc = nf > 0 && len < best_len;                     // the same in every lane of the group
+            double c = b + step;
+            if (c < 1.0) c = 1.0;
+            const bool acc = nf > 0 && len < best_len;                   // the same in every lane of the group
             P.iters++;
-            if (acc) { b = cn; best_len = len; step *= 2.; node = 2 * node; }
-            else { step *= -0.1; node = 2 * node + 1; }
-            if (!(::fabs(step) > 1e-10)) break;
+            if (acc) { b = c; best_len = len; step *= 2.; }
+            else step *= -0.1;
+            const int kind = acc ? 1 : 2;
+            if (kind == ck) cr = cr < sca_spec::RUN_CAP ? cr + 1 : cr;
+            else { cp = cr < sca_spec::PREV_CAP ? cr : sca_spec::PREV_CAP; cr = 1; ck = kind; }
+            const int next = acc ? (kd & 31) : ((kd >> 5) & 31);
+            if (next == 0 || !(::fabs(step) > 1e-10)) break;
+            node = next - 1;
         }
     }
     Maneuver2D fbh, fbv;
@@ -584,8 +608,8 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
 }
 
 // one group of LANES lanes per plan: 4 = the quad planner, 16 / 32 / 64 = speculative search of depth 2 / 3 / 4
-template <int LANES>
-__device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubins::TrackView T, const TrackDev K, int count) {
+template <int LANES, typename TREES>
+__device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubins::TrackView T, const TrackDev K, int count, const TREES &TR) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid / LANES, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole groups leave together
@@ -598,9 +622,9 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     const double pl[2] = {T.pitch_lo, T.pitch_hi};
     sca_dubins::Plan3D P;
     if constexpr (LANES == 4) P = plan3d_quad(qi, qf, T.turning_radius, pl, sub, lane);
-    else if constexpr (LANES == 16) P = plan3d_spec<2>(qi, qf, T.turning_radius, pl, sub, lane);
-    else if constexpr (LANES == 32) P = plan3d_spec<3>(qi, qf, T.turning_radius, pl, sub, lane);
-    else P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane);
+    else if constexpr (LANES == 16) P = plan3d_spec<2>(qi, qf, T.turning_radius, pl, sub, lane, TR);
+    else if constexpr (LANES == 32) P = plan3d_spec<3>(qi, qf, T.turning_radius, pl, sub, lane, TR);
+    else P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane, TR);
     if ((gid & (LANES - 1)) != 0) return;
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
@@ -616,10 +640,20 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
 constexpr int TRK_GROUP_THREADS = 256;
 template <int LANES>
 __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_replan_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
-    sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
-    const int count = K.count[K.parity];
-    if (count <= K.lo || count > K.hi) return;
-    replan_group<LANES>(d, T, K, count);
+    if constexpr (LANES == 4) {
+        sca_gm::lds_tables_load();                                       // atan2's and sin / cos's tables into LDS (all threads, first)
+        const int count = K.count[K.parity];
+        if (count <= K.lo || count > K.hi) return;
+        replan_group<LANES>(d, T, K, count, 0);
+    } else {
+        constexpr int D = LANES == 16 ? 2 : (LANES == 32 ? 3 : 4);
+        __shared__ SpecLds<D> TR;
+        spec_trees_load<D>(TR);                                          // (the barrier that ends lds_tables_load covers them)
+        sca_gm::lds_tables_load();
+        const int count = K.count[K.parity];
+        if (count <= K.lo || count > K.hi) return;
+        replan_group<LANES>(d, T, K, count, TR);
+    }
 }
 
 // self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them: 0-4 the
