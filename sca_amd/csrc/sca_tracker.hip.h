@@ -497,9 +497,9 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_quad(const double qi[5], co
 // WHICH tree only sets how far a round gets.  Until round 4 it was the balanced one (2 / 3 / 4 steps per round).  The chain is no coin
 // toss, though: every search runs  F SSSSSS FF SSSSS FF SSSSSS FF ...  (an overshoot, the step back fails too, then five or six
 // doublings to the next overshoot), so the trees of sca_spec_trees.h (generated: tools/gen_spec_trees.py, from the verdicts of the
-// reference's own planner on 256 recorded searches) follow the likely continuations up to ten steps deep, one tree per context =
-// (kind of the current run of verdicts, its length, the previous run's length): 5.8 - 6.8 steps per round with 15 candidates on held-out
-// searches, 4.3 - 5.0 with 7, 2.5 - 2.6 with 3.  A quad finds its candidate by walking its node's path from the round's (b, step).
+// reference's own planner on 256 recorded searches) follow the likely continuations up to twelve steps deep, one tree per context =
+// (kind of the current run of verdicts, its length, the lengths of the two runs before it): 6.6 - 7.5 steps per round with 15 candidates
+// on held-out searches, 4.7 - 5.4 with 7, 2.6 - 2.7 with 3.  A quad finds its candidate by walking its node's path from the round's (b, step).
 constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass: 3 candidates per round, 16 lanes per plan (2048 wavefronts: two per SIMD)
 constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: 7 per round, 32 lanes per plan (2048 wavefronts)
 constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: 15 per round, a whole wavefront per plan -- and a SIMD per wavefront (the kernel sits at the 256-register edge)
@@ -543,12 +543,13 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         if (++guard > 200) return P;
     }
     double step = 0.1;
-    int ck = 0, cr = 0, cp = 0;                                          // the context: kind of the current run (1 S, 2 F), its length, the previous run's
+    int ck = 0, cr = 0, cp = 0, cq = 0;                                  // the context: kind of the current run of verdicts (1 S, 2 F), its length, the two runs' before it
     while (::fabs(step) > 1e-10) {
 #if defined(SCA_SPEC_BALANCED)                                          // measurement build: the balanced tree in every round
         const int tree = 0;
 #else
-        const int tree = TR.of_ctx[(ck * (sca_spec::RUN_CAP + 1) + cr) * (sca_spec::PREV_CAP + 1) + cp];
+        const int tree = TR.of_ctx[((ck * (sca_spec::RUN_CAP + 1) + (cr < sca_spec::RUN_CAP ? cr : sca_spec::RUN_CAP)) * (sca_spec::PREV_CAP + 1) +
+                                    (cp < sca_spec::PREV_CAP ? cp : sca_spec::PREV_CAP)) * (sca_spec::PREV2_CAP + 1) + (cq < sca_spec::PREV2_CAP ? cq : sca_spec::PREV2_CAP)];
 #endif
         const uint32_t me = TR.nodes[tree * SLOTS + quad];               // (the spare quad's word is 0: the root again)
         // this quad's candidate: the (b, step) the sequential loop holds when it has taken the node's path
@@ -592,8 +593,8 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             if (acc) { b = c; best_len = len; step *= 2.; }
             else step *= -0.1;
             const int kind = acc ? 1 : 2;
-            if (kind == ck) cr = cr < sca_spec::RUN_CAP ? cr + 1 : cr;
-            else { cp = cr < sca_spec::PREV_CAP ? cr : sca_spec::PREV_CAP; cr = 1; ck = kind; }
+            if (kind == ck) cr++;
+            else { cq = cp; cp = cr; cr = 1; ck = kind; }
             const int next = acc ? (kd & 31) : ((kd >> 5) & 31);
             if (next == 0 || !(::fabs(step) > 1e-10)) break;
             node = next - 1;

@@ -11,7 +11,7 @@ with 15 candidates on held-out searches (4.2-5.0 with 7, 2.5-2.6 with 3).
   python tools/gen_spec_trees.py --record     (build container only: imports /root/reference) runs the reference's own planner on poses of
                                               BASELINE configs 2 / 4 / 5 and of a +-20-m cube and records each search's verdicts as a string
                                               of S / F -> tools/data/radius_search_outcomes.json (data; committed)
-  python tools/gen_spec_trees.py              fits P(S | kind of the current run, its length, the previous run's length) to the first half of
+  python tools/gen_spec_trees.py              fits P(S | kind of the current run, its length, the two previous runs' lengths) to the first half of
                                               every family, builds per context the tree of the 15 / 7 / 3 likeliest continuations, and writes the
                                               header; prints the steps per round on the other half
   python tools/gen_spec_trees.py --check      the same without writing: exit status 1 when the committed header differs (tests/test_spec_trees.py)"""
@@ -25,8 +25,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, 'tools', 'data', 'radius_search_outcomes.json')
 HEADER = os.path.join(ROOT, 'sca_amd', 'csrc', 'sca_spec_trees.h')
-RUN_CAP, PREV_CAP = 8, 4                    # context: run length 0 .. 8, previous run's length 0 .. 4
-MAXD = {15: 10, 7: 6, 3: 3}                 # longest path of a tree (bounds the device's walk and its path loop)
+RUN_CAP, PREV_CAP, PREV2_CAP = 8, 4, 8      # context: run length 0 .. 8, previous run's length 0 .. 4, the run before that 0 .. 8
+MAXD = {15: 12, 7: 6, 3: 3}                 # longest path of a tree (bounds the device's walk and its path loop)
 R, PL = 1.5, [-math.pi / 4, math.pi / 4]
 
 
@@ -105,36 +105,36 @@ def record():
         json.dump(out, f, indent=0)
 
 
-def context(hist):
-    """(kind of the current run: 0 none / 1 S / 2 F, its length capped, the previous run's length capped): what the device tracks"""
-    if not hist:
-        return (0, 0, 0)
-    t = hist[-1]
-    k = 0
-    while k < len(hist) and hist[-1 - k] == t:
-        k += 1
-    j = 0
-    while k + j < len(hist) and hist[-1 - k - j] != t:
-        j += 1
-    return (1 if t == 'S' else 2, min(k, RUN_CAP), min(j, PREV_CAP))
-
-
 def advance(ctx, ch):
-    """the context after one more verdict (the device's update: integers only)"""
+    """the context after one more verdict (the device's update: integers only); ctx = (kind 0 none / 1 S / 2 F, the current run's length,
+    the previous run's, the one before that), lengths uncapped"""
     kind = 1 if ch == 'S' else 2
     if ctx[0] == kind:
-        return (kind, min(ctx[1] + 1, RUN_CAP), ctx[2])
-    return (kind, 1, min(ctx[1], PREV_CAP))
+        return (kind, ctx[1] + 1, ctx[2], ctx[3])
+    return (kind, 1, ctx[1], ctx[2])
+
+
+def capped(ctx):
+    return (ctx[0], min(ctx[1], RUN_CAP), min(ctx[2], PREV_CAP), min(ctx[3], PREV2_CAP))
 
 
 def train(seqs):
-    cnt = collections.defaultdict(lambda: [1.0, 1.0])
+    """P(S | context) and, for contexts the searches never showed, P(S | context without its oldest run)"""
+    cnt, cnt3 = collections.defaultdict(lambda: [0.5, 0.5]), collections.defaultdict(lambda: [1.0, 1.0])
     for s in seqs:
-        ctx = (0, 0, 0)
+        ctx = (0, 0, 0, 0)
         for ch in s:
-            cnt[ctx][0 if ch == 'S' else 1] += 1
+            cnt[capped(ctx)][0 if ch == 'S' else 1] += 1
+            cnt3[capped(ctx)[:3]][0 if ch == 'S' else 1] += 1
             ctx = advance(ctx, ch)
-    return {c: v[0] / (v[0] + v[1]) for c, v in cnt.items()}
+    return ({c: v[0] / (v[0] + v[1]) for c, v in cnt.items()}, {c: v[0] / (v[0] + v[1]) for c, v in cnt3.items()})
+
+
+def p_success(model, ctx):
+    c = capped(ctx)
+    if c in model[0]:
+        return model[0][c]
+    return model[1].get(c[:3], 0.66)
 
 
 def build_tree(model, ctx, nodes):
@@ -147,7 +147,7 @@ def build_tree(model, ctx, nodes):
         chosen.append(path)
         if len(path) >= MAXD[nodes]:
             continue
-        p = model.get(c, 0.66)
+        p = p_success(model, c)
         heapq.heappush(heap, (negp * p, path + 'S', advance(c, 'S')))
         heapq.heappush(heap, (negp * (1 - p), path + 'F', advance(c, 'F')))
     return tuple(chosen)
@@ -174,16 +174,16 @@ def pack(tree):
 
 
 def all_contexts():
-    return [(k, r, p) for k in range(3) for r in range(RUN_CAP + 1) for p in range(PREV_CAP + 1)]
+    return [(k, r, p, q) for k in range(3) for r in range(RUN_CAP + 1) for p in range(PREV_CAP + 1) for q in range(PREV2_CAP + 1)]
 
 
 def simulate(trees, of_ctx, seqs):
     rounds = steps = 0
     for s in seqs:
         i = 0
-        ctx = (0, 0, 0)
+        ctx = (0, 0, 0, 0)
         while i < len(s):
-            tree = set(trees[of_ctx[ctx]])
+            tree = set(trees[of_ctx[capped(ctx)]])
             path = ''
             while i < len(s) and path in tree:
                 path += s[i]
@@ -201,19 +201,19 @@ def generate():
     model = train(fit)
     text = ['// sca_spec_trees.h -- GENERATED by tools/gen_spec_trees.py from tools/data/radius_search_outcomes.json: do not edit.',
             '// Which continuations of the radius search a round of plan3d_spec evaluates, per context (kind of the current run of verdicts,',
-            '// its length, the previous run\'s length).  The trees only set how far a round gets; tree 0 is the balanced one.',
+            '// its length, the lengths of the two runs before it).  The trees only set how far a round gets; tree 0 is the balanced one.',
             '#pragma once', '#include <cstdint>',
             '#if defined(__HIPCC__)', '#define SCA_SPEC_TAB __device__ const', '#else', '#define SCA_SPEC_TAB static const', '#endif',
             'namespace sca_spec {',
-            f'constexpr int RUN_CAP = {RUN_CAP}, PREV_CAP = {PREV_CAP}, CONTEXTS = 3 * (RUN_CAP + 1) * (PREV_CAP + 1);',
-            '// index of a context: (kind * (RUN_CAP + 1) + run) * (PREV_CAP + 1) + prev',
+            f'constexpr int RUN_CAP = {RUN_CAP}, PREV_CAP = {PREV_CAP}, PREV2_CAP = {PREV2_CAP}, CONTEXTS = 3 * (RUN_CAP + 1) * (PREV_CAP + 1) * (PREV2_CAP + 1);',
+            '// index of a context: ((kind * (RUN_CAP + 1) + run) * (PREV_CAP + 1) + prev) * (PREV2_CAP + 1) + prev2   (lengths capped)',
             '// a node: path bits (bit i = 1: the i-th verdict on the way to it is a success) | length << 16 | (S child + 1) << 20 | (F child + 1) << 25']
     report = []
     for nodes in (15, 7, 3):
         trees = [balanced(nodes)]
         of_ctx = {}
         for c in all_contexts():
-            reachable = c == (0, 0, 0) or (c[0] != 0 and c[1] >= 1)
+            reachable = c == (0, 0, 0, 0) or (c[0] != 0 and c[1] >= 1 and (c[2] >= 1 or c[3] == 0))
             t = build_tree(model, c, nodes) if reachable else trees[0]
             if t not in trees:
                 trees.append(t)
