@@ -504,15 +504,47 @@ constexpr int TRK_SPEC2_MAX = 8192;        // <= this many re-plans in the pass:
 constexpr int TRK_SPEC3_MAX = 4096;        // <= this many: 7 per round, 32 lanes per plan (2048 wavefronts)
 constexpr int TRK_SPEC4_MAX = 1024;        // <= this many: 15 per round, a whole wavefront per plan -- and a SIMD per wavefront (the kernel sits at the 256-register edge)
 
+#if defined(SCA_KT_TIMING)   // debug builds: workgroup 0 / thread 0's clock over the pieces of a speculative search, summed over its rounds (tools/phase_clocks.py)
+#define KG_ADD(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); sca_dubins::g_td_ticks[16 + (k)] += (int)(t_ - sca_dubins::g_td_last); sca_dubins::g_td_last = t_; } } while (0)
+#define KG_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k_ = 16; k_ < 32; k_++) sca_dubins::g_td_ticks[k_] = 0; sca_dubins::g_td_last = wall_clock64(); } } while (0)
+#else
+#define KG_ADD(k) do { } while (0)
+#define KG_ZERO() do { } while (0)
+#endif
 template <int D> struct SpecTrees;
 template <> struct SpecTrees<2> { static constexpr int TREES = sca_spec::TREES3, MAXD = sca_spec::MAXD3; static constexpr const uint8_t *of_ctx = sca_spec::TREE3_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE3_NODES; };
 template <> struct SpecTrees<3> { static constexpr int TREES = sca_spec::TREES7, MAXD = sca_spec::MAXD7; static constexpr const uint8_t *of_ctx = sca_spec::TREE7_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE7_NODES; };
 template <> struct SpecTrees<4> { static constexpr int TREES = sca_spec::TREES15, MAXD = sca_spec::MAXD15; static constexpr const uint8_t *of_ctx = sca_spec::TREE15_OF_CONTEXT; static constexpr const uint32_t *nodes = sca_spec::TREE15_NODES; };
 // the trees of a kernel's form in LDS (a round reads its context's tree id and each quad its node; the walk reads through the lanes)
-template <int D> struct SpecLds { uint32_t nodes[SpecTrees<D>::TREES * (1 << D)]; uint8_t of_ctx[sca_spec::CONTEXTS]; };
+template <int D> struct SpecLds { uint2 nodes[SpecTrees<D>::TREES * (1 << D)]; uint8_t of_ctx[sca_spec::CONTEXTS]; };
 template <int D> __device__ __forceinline__ void spec_trees_load(SpecLds<D> &S) {          // all threads, before the workgroup's first barrier
-    for (int i = threadIdx.x; i < SpecTrees<D>::TREES * (1 << D); i += blockDim.x) S.nodes[i] = SpecTrees<D>::nodes[i];
+    for (int i = threadIdx.x; i < SpecTrees<D>::TREES * (1 << D); i += blockDim.x) S.nodes[i] = make_uint2(SpecTrees<D>::nodes[2 * i], SpecTrees<D>::nodes[2 * i + 1]);
     for (int i = threadIdx.x; i < sca_spec::CONTEXTS; i += blockDim.x) S.of_ctx[i] = SpecTrees<D>::of_ctx[i];
+}
+
+// a ballot's bits of the quads' first lanes (lanes 0, 4, 8, ...) as 16 contiguous bits
+__device__ __forceinline__ unsigned quad_bits(unsigned long long m) {
+    m &= 0x1111111111111111ull;
+    m = (m | (m >> 3)) & 0x0303030303030303ull;
+    m = (m | (m >> 6)) & 0x000f000f000f000full;
+    m = (m | (m >> 12)) & 0x000000ff000000ffull;
+    m = (m | (m >> 24)) & 0xffffull;
+    return (unsigned)m;
+}
+// the (b, step) the sequential loop holds after the verdicts `bits` (bit i = 1: success), and the candidate it tries next
+__device__ __forceinline__ void spec_path(unsigned bits, int plen, int maxd, double &nb, double &ns, double &c) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        if (i < maxd) {
+            const bool on = i < plen, succ = on && ((bits >> i) & 1u);
+            double cc = nb + ns;
+            cc = cc < 1.0 ? 1.0 : cc;
+            nb = succ ? cc : nb;                                         // success: b = c, step *= 2.; failure: step *= -0.1
+            ns = ns * (on ? (succ ? 2. : -0.1) : 1.0);
+        }
+    }
+    c = nb + ns;
+    c = c < 1.0 ? 1.0 : c;
 }
 
 template <int D>
@@ -537,27 +569,19 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     // b = 2 goes on as the sequential loop does (all quads the same radius), and the speculated candidates are dropped.
     double b = 1.0, best_len = 0.0, step = 0.1;
     int ck = 0, cr = 0, cp = 0, cq = 0;                                  // the context: kind of the current run of verdicts (1 S, 2 F), its length, the two runs' before it
+    KG_ADD(0);                                                           // frames and constants of the search
     {
         constexpr int DQ = 2, AVAIL = SLOTS - DQ;
         const int tree0 = TR.of_ctx[0];
-        const uint32_t me = quad >= DQ ? TR.nodes[tree0 * SLOTS + (quad - DQ)] : 0u;
-        double nb = 2.0, ns = 0.1;
-        const int plen = (int)((me >> 16) & 15u);
-#pragma unroll
-        for (int i = 0; i < MAXD; i++) {
-            if (i < plen) {
-                double c = nb + ns;
-                if (c < 1.0) c = 1.0;
-                if ((me >> i) & 1u) { nb = c; ns *= 2.; }
-                else ns *= -0.1;
-            }
-        }
-        double myc = nb + ns;
-        if (myc < 1.0) myc = 1.0;
+        const uint32_t me = quad >= DQ ? TR.nodes[tree0 * SLOTS + (quad - DQ)].x : 0u;
+        double nb = 2.0, ns = 0.1, myc;
+        spec_path(me & 0xfffu, (int)((me >> 12) & 15u), MAXD, nb, ns, myc);
         myc = quad == 0 ? 1.0 : (quad == 1 ? 2.0 : myc);
         double mylen;
+        KG_ADD(1);
         const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
-        const int kids = (int)(me >> 20);
+        KG_ADD(2);
+        const int kids = (int)((me >> 16) & 0x3ffu);                     // (S child + 1) | (F child + 1) << 5
         auto fetch = [&](int q, int &nf, int &kd, double &len) {
             if constexpr (LANES == 64) {
                 const int src = __builtin_amdgcn_readfirstlane(4 * q);
@@ -608,67 +632,78 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             }
         }
     }
+    KG_ADD(3);
     while (::fabs(step) > 1e-10) {
+        KG_ADD(7);
 #if defined(SCA_SPEC_BALANCED)                                          // measurement build: the balanced tree in every round
         const int tree = 0;
 #else
         const int tree = TR.of_ctx[((ck * (sca_spec::RUN_CAP + 1) + (cr < sca_spec::RUN_CAP ? cr : sca_spec::RUN_CAP)) * (sca_spec::PREV_CAP + 1) +
                                     (cp < sca_spec::PREV_CAP ? cp : sca_spec::PREV_CAP)) * (sca_spec::PREV2_CAP + 1) + (cq < sca_spec::PREV2_CAP ? cq : sca_spec::PREV2_CAP)];
 #endif
-        const uint32_t me = TR.nodes[tree * SLOTS + quad];               // (the spare quad's word is 0: the root again)
+        const uint2 me = TR.nodes[tree * SLOTS + quad];                  // (the spare quad's words are 0: the root again, counted out below)
         // this quad's candidate: the (b, step) the sequential loop holds when it has taken the node's path
-        double nb = b, ns = step;
-        const int plen = (int)((me >> 16) & 15u);
-#pragma unroll
-        for (int i = 0; i < MAXD; i++) {
-            if (i < plen) {
-                double c = nb + ns;
-                if (c < 1.0) c = 1.0;
-                if ((me >> i) & 1u) { nb = c; ns *= 2.; }                // success: b = c, step *= 2.
-                else ns *= -0.1;                                         // failure: step *= -0.1
-            }
-        }
-        double myc = nb + ns;
-        if (myc < 1.0) myc = 1.0;
+        const unsigned pbits = me.x & 0xfffu;
+        const int plen = (int)((me.x >> 12) & 15u);
+        double nb = b, ns = step, myc;
+        spec_path(pbits, plen, MAXD, nb, ns, myc);
+        const bool valid = ::fabs(ns) > 1e-10;                           // the loop's condition in front of this candidate
         double mylen;
+        KG_ADD(4);
         const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
-        const int kids = (int)(me >> 20);                                // (S child + 1) | (F child + 1) << 5
-        // the walk along the sequential loop's path: verdict inputs and children through the lanes that hold the node (a whole
-        // wavefront per plan: v_readlane of a uniform lane)
-        int node = 0;
+        KG_ADD(5);
+#if defined(SCA_KT_TIMING)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sca_dubins::g_td_ticks[31]++;
+#endif
+        // The walk along the sequential loop's path, all nodes at once.  A node ON that path sees the best length the loop holds
+        // there: the length of the last node whose success its own path assumes (or the round's incoming one) -- so every node can
+        // form the verdict it WOULD get; the path is then the set of nodes whose ancestors' verdicts are the ones their paths assume
+        // (two ballots against the node's ancestor masks), and it ends at the node whose verdict leads out of the tree (or to a
+        // candidate behind the loop's end).  That node's state and verdict are the round's result.  (Until this form the walk went
+        // node by node through v_readlane: 1.6 us of a 7-us round.)
+        const int la = (int)((me.x >> 26) & 31u);
+        // (fetched by every lane: a lane that skipped the fetch would be switched off while others read from it, and read as 0)
+        const double seen_la = lane_fetch_d(mylen, base + 4 * (la > 0 ? la - 1 : 0));
+        const double seen = la > 0 ? seen_la : best_len;
+        const bool acc = nfc > 0 && mylen < seen;
+        const unsigned sh = (unsigned)(base >> 2), gm = (1u << SLOTS) - 1u;
+        const unsigned gA = (quad_bits(__ballot(acc)) >> sh) & gm, gV = (quad_bits(__ballot(valid)) >> sh) & gm;
+        const unsigned am = me.y & 0xffffu, ab = me.y >> 16;
+        const bool on = quad < SLOTS - 1 && valid && (gA & am) == ab && (gV & am) == am;
+        const int child = (int)((me.x >> (acc ? 16 : 21)) & 31u);
+        const bool last = on && !(child > 0 && ((gV >> (child - 1)) & 1u));
+        const unsigned gL = (quad_bits(__ballot(last)) >> sh) & gm;       // exactly one node
+        const int src = base + 4 * (__ffs((int)gL) - 1);
+        double Lb, Ls, Lc, Llen, Lseen;
+        int Lacc, Lplen;
+        unsigned Lbits;
+        if constexpr (LANES == 64) {
+            const int sl = __builtin_amdgcn_readfirstlane(src);
+            Lb = readlane_f64(nb, sl); Ls = readlane_f64(ns, sl); Lc = readlane_f64(myc, sl); Llen = readlane_f64(mylen, sl); Lseen = readlane_f64(seen, sl);
+            Lacc = __builtin_amdgcn_readlane((int)acc, sl); Lplen = __builtin_amdgcn_readlane(plen, sl); Lbits = (unsigned)__builtin_amdgcn_readlane((int)pbits, sl);
+        } else {
+            Lb = lane_fetch_d(nb, src); Ls = lane_fetch_d(ns, src); Lc = lane_fetch_d(myc, src); Llen = lane_fetch_d(mylen, src); Lseen = lane_fetch_d(seen, src);
+            Lacc = __shfl((int)acc, src); Lplen = __shfl(plen, src); Lbits = (unsigned)__shfl((int)pbits, src);
+        }
+        if (Lacc) { b = Lc; best_len = Llen; step = Ls * 2.; }
+        else { b = Lb; best_len = Lseen; step = Ls * -0.1; }
+        P.iters += Lplen + 1;
+        const unsigned verdicts = Lbits | ((unsigned)Lacc << Lplen);       // of the Lplen + 1 candidates the loop has tried in this round
 #pragma unroll 1
-        for (int depth = 0; depth <= MAXD; depth++) {
-            int nf, kd;
-            double len;
-            if constexpr (LANES == 64) {
-                const int src = __builtin_amdgcn_readfirstlane(4 * node);
-                nf = __builtin_amdgcn_readlane(nfc, src);
-                kd = __builtin_amdgcn_readlane(kids, src);
-                len = readlane_f64(mylen, src);
-            } else {
-                nf = __shfl(nfc, base + 4 * node);
-                kd = __shfl(kids, base + 4 * node);
-                len = lane_fetch_d(mylen, base + 4 * node);
-            }
-            double c = b + step;
-            if (c < 1.0) c = 1.0;
-            const bool acc = nf > 0 && len < best_len;                   // the same in every lane of the group
-            P.iters++;
-            if (acc) { b = c; best_len = len; step *= 2.; }
-            else step *= -0.1;
-            const int kind = acc ? 1 : 2;
+        for (int i = 0; i <= Lplen; i++) {
+            const int kind = ((verdicts >> i) & 1u) ? 1 : 2;
             if (kind == ck) cr++;
             else { cq = cp; cp = cr; cr = 1; ck = kind; }
-            const int next = acc ? (kd & 31) : ((kd >> 5) & 31);
-            if (next == 0 || !(::fabs(step) > 1e-10)) break;
-            node = next - 1;
         }
+        KG_ADD(6);
     }
     Maneuver2D fbh, fbv;
     try_to_construct_quad(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
+    KG_ADD(8);
     const int it = P.iters;
     finish_plan(P, fbh, fbv, qi);
     P.iters = it;
+    KG_ADD(9);
     return P;
 }
 
@@ -678,6 +713,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int idx = gid / LANES, sub = gid & 3, lane = threadIdx.x & 63;
     if (idx >= count) return;                                            // whole groups leave together
+    KG_ZERO();
     const int agent = trk_list_agent(K.list, K.bcount + K.parity * TRK_BUCKETS, K.n, idx);
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
@@ -696,6 +732,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);
     track_store(d, K, agent, V);
+    KG_ADD(10);
 }
 
 // The many-lanes-per-plan forms, ONE KERNEL EACH (round 2; they used to share one kernel that picked the form by the count:

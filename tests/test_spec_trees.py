@@ -34,27 +34,31 @@ def test_every_tree_is_consistent():
     contexts = 3 * (consts['RUN_CAP'] + 1) * (consts['PREV_CAP'] + 1) * (consts['PREV2_CAP'] + 1)
     for nodes, t in tabs.items():
         assert len(t['of_ctx']) == contexts and max(t['of_ctx']) < t['trees'] and t['of_ctx'][0] != 0      # the opening context has a tree of its own
-        assert len(t['words']) == t['trees'] * t['slots']
-        assert t['maxd'] <= 15                                       # the path length's field is four bits wide
+        assert len(t['words']) == t['trees'] * t['slots'] * 2
+        assert t['maxd'] <= 12                                       # the path's field is twelve bits wide
         for k in range(t['trees']):
-            w = t['words'][k * t['slots']:(k + 1) * t['slots']]
-            assert w[nodes] == 0                                     # the spare quad: the root again, no children
+            w = t['words'][k * t['slots'] * 2:(k + 1) * t['slots'] * 2]
+            first, second = w[0::2], w[1::2]
+            assert first[nodes] == 0 and second[nodes] == 0          # the spare quad: the root again, counted out by the kernel
             paths = []
-            for x in w[:nodes]:
-                n = (x >> 16) & 15
-                assert n <= t['maxd'] and (x & 0xffff) >> n == 0
+            for x in first[:nodes]:
+                n = (x >> 12) & 15
+                assert n <= t['maxd'] and (x & 0xfff) >> n == 0
                 paths.append(''.join('S' if (x >> i) & 1 else 'F' for i in range(n)))
             assert paths[0] == '' and len(set(paths)) == nodes
             index = {p: i for i, p in enumerate(paths)}
-            for i, (p, x) in enumerate(zip(paths, w)):
+            for i, (p, x, y) in enumerate(zip(paths, first, second)):
                 assert p == '' or p[:-1] in index                    # prefix-closed: the walk reaches every node through its parent
-                for ch, shift in (('S', 20), ('F', 25)):
-                    child = (x >> shift) & 31
-                    assert child == index.get(p + ch, -1) + 1
+                for ch, shift in (('S', 16), ('F', 21)):
+                    assert (x >> shift) & 31 == index.get(p + ch, -1) + 1
+                j = p.rfind('S')                                     # the node whose success the path assumes last: its length is the best one here
+                assert (x >> 26) & 31 == (index[p[:j]] + 1 if j >= 0 else 0)
+                assert y & 0xffff == sum(1 << index[p[:q]] for q in range(len(p)))
+                assert y >> 16 == sum(1 << index[p[:q]] for q in range(len(p)) if p[q] == 'S')
         # tree 0: the balanced one (the fallback of contexts no search showed)
         depth = {15: 4, 7: 3, 3: 2}[nodes]
-        w0 = t['words'][:nodes]
-        assert sorted((x >> 16) & 15 for x in w0) == sorted(d for d in range(depth) for _ in range(2 ** d))
+        w0 = t['words'][:2 * nodes:2]
+        assert sorted((x >> 12) & 15 for x in w0) == sorted(d for d in range(depth) for _ in range(2 ** d))
 
 
 def test_trees_beat_the_balanced_tree_on_the_recorded_searches():

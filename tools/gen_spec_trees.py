@@ -162,14 +162,20 @@ def balanced(nodes):
 
 
 def pack(tree):
-    """per node: path bits (bit i = 1: verdict i on the way is S) | length << 16 | (index of the S child + 1) << 20 | (F child + 1) << 25"""
+    """per node two words.  First: path bits (bit i = 1: verdict i on the way is S; 12 bits) | length << 12 | (index of the S child + 1) << 16
+    | (F child + 1) << 21 | (index of the node whose success the path assumes last, + 1; 0: none) << 26.  Second: the quads of the node's
+    ancestors | the verdicts the path assumes of them << 16."""
     words = []
     index = {p: i for i, p in enumerate(tree)}
     for p in tree:
+        assert len(p) <= 12 and (p == '' or p[:-1] in index), 'a node without its parent'
         bits = sum(1 << i for i, ch in enumerate(p) if ch == 'S')
         cs, cf = index.get(p + 'S', -1) + 1, index.get(p + 'F', -1) + 1
-        assert p == '' or p[:-1] in index, 'a node without its parent'
-        words.append(bits | (len(p) << 16) | (cs << 20) | (cf << 25))
+        last_s = p.rfind('S')
+        la = index[p[:last_s]] + 1 if last_s >= 0 else 0
+        anc_mask = sum(1 << index[p[:j]] for j in range(len(p)))
+        anc_bits = sum(1 << index[p[:j]] for j in range(len(p)) if p[j] == 'S')
+        words.append((bits | (len(p) << 12) | (cs << 16) | (cf << 21) | (la << 26), anc_mask | (anc_bits << 16)))
     return words
 
 
@@ -207,7 +213,8 @@ def generate():
             'namespace sca_spec {',
             f'constexpr int RUN_CAP = {RUN_CAP}, PREV_CAP = {PREV_CAP}, PREV2_CAP = {PREV2_CAP}, CONTEXTS = 3 * (RUN_CAP + 1) * (PREV_CAP + 1) * (PREV2_CAP + 1);',
             '// index of a context: ((kind * (RUN_CAP + 1) + run) * (PREV_CAP + 1) + prev) * (PREV2_CAP + 1) + prev2   (lengths capped)',
-            '// a node: path bits (bit i = 1: the i-th verdict on the way to it is a success) | length << 16 | (S child + 1) << 20 | (F child + 1) << 25']
+            '// a node, two words: path bits (bit i = 1: the i-th verdict on the way to it is a success) | length << 12 | (S child + 1) << 16 | (F child + 1) << 21 |',
+            '// (the node whose success the path assumes last + 1) << 26;   ancestors\' quads | the verdicts the path assumes of them << 16']
     report = []
     for nodes in (15, 7, 3):
         trees = [balanced(nodes)]
@@ -225,11 +232,11 @@ def generate():
         slots = 16 if nodes == 15 else (8 if nodes == 7 else 4)
         text.append(f'constexpr int TREES{nodes} = {len(trees)}, MAXD{nodes} = {max(len(p) for t in trees for p in t)};')
         text.append(f'SCA_SPEC_TAB uint8_t TREE{nodes}_OF_CONTEXT[CONTEXTS] = {{' + ', '.join(str(of_ctx[c]) for c in all_contexts()) + '};')
-        text.append(f'SCA_SPEC_TAB uint32_t TREE{nodes}_NODES[TREES{nodes} * {slots}] = {{')
+        text.append(f'SCA_SPEC_TAB uint32_t TREE{nodes}_NODES[TREES{nodes} * {slots} * 2] = {{')
         for t in trees:
             w = pack(t)
-            w += [0] * (slots - len(w))                   # the spare quad evaluates the root again
-            text.append('    ' + ', '.join(f'0x{x:08x}u' for x in w) + ',    // ' + ' '.join(p or '.' for p in t))
+            w += [(0, 0)] * (slots - len(w))              # the spare quad evaluates the root again
+            text.append('    ' + ', '.join(f'0x{a:08x}u, 0x{b:08x}u' for a, b in w) + ',    // ' + ' '.join(p or '.' for p in t))
         text.append('};')
     text.append('}  // namespace sca_spec')
     return '\n'.join(text) + '\n', report

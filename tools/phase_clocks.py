@@ -68,6 +68,9 @@ def track(kind):
         print(kind, 'k_track, ticks of 10 ns: tables into LDS, barrier, loads, track_decide, finish / bucket, barrier, list:', out[:7].tolist(),
               'sum', int(out[:7].sum()))
         print('    track_decide: norm to the goal, update_dubins, norm + cosine, acos, is_parallel, update_dubins again:', out[17:23].tolist())
+        g = out[32:48].tolist()
+        print(f'    the speculative search of one plan ({g[15]} rounds behind the first): frames {g[0]}, first round: path {g[1]} + candidate {g[2]} + walk {g[3]}; '
+              f'rounds: tree + path {g[7] + g[4]}, candidate {g[5]}, walk {g[6]}; the winner\'s maneuvers {g[8]}, finish_plan {g[9]}, adopt + v_pref + prologue {g[10]}')
 
 
 if __name__ == '__main__':
