@@ -570,110 +570,31 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     double b = 1.0, best_len = 0.0, step = 0.1;
     int ck = 0, cr = 0, cp = 0, cq = 0;                                  // the context: kind of the current run of verdicts (1 S, 2 F), its length, the two runs' before it
     KG_ADD(0);                                                           // frames and constants of the search
-    {
-        constexpr int DQ = 2, AVAIL = SLOTS - DQ;
-        const int tree0 = TR.of_ctx[0];
-        const uint32_t me = quad >= DQ ? TR.nodes[tree0 * SLOTS + (quad - DQ)].x : 0u;
-        double nb = 2.0, ns = 0.1, myc;
-        spec_path(me & 0xfffu, (int)((me >> 12) & 15u), MAXD, nb, ns, myc);
-        myc = quad == 0 ? 1.0 : (quad == 1 ? 2.0 : myc);
-        double mylen;
-        KG_ADD(1);
-        const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
-        KG_ADD(2);
-        const int kids = (int)((me >> 16) & 0x3ffu);                     // (S child + 1) | (F child + 1) << 5
-        auto fetch = [&](int q, int &nf, int &kd, double &len) {
-            if constexpr (LANES == 64) {
-                const int src = __builtin_amdgcn_readfirstlane(4 * q);
-                nf = __builtin_amdgcn_readlane(nfc, src); kd = __builtin_amdgcn_readlane(kids, src); len = readlane_f64(mylen, src);
-            } else {
-                nf = __shfl(nfc, base + 4 * q); kd = __shfl(kids, base + 4 * q); len = lane_fetch_d(mylen, base + 4 * q);
-            }
-        };
-        int nf0, nf1, kd_;
-        double len0, len1;
-        fetch(0, nf0, kd_, len0);
-        fetch(1, nf1, kd_, len1);
-        P.iters = 1;
-        if (nf0 > 0) best_len = len0;                                    // b = 1 is feasible: no doubling; the search starts from there
-        else {
-            b = 2.0;
-            P.iters = 2;
-            if (nf1 > 0) {
-                best_len = len1;
-                int node = 0;
-#pragma unroll 1
-                for (int depth = 0; depth <= MAXD; depth++) {
-                    int nf, kd;
-                    double len;
-                    fetch(DQ + node, nf, kd, len);
-                    double c = b + step;
-                    if (c < 1.0) c = 1.0;
-                    const bool acc = nf > 0 && len < best_len;
-                    P.iters++;
-                    if (acc) { b = c; best_len = len; step *= 2.; }
-                    else step *= -0.1;
-                    const int kind = acc ? 1 : 2;
-                    if (kind == ck) cr++;
-                    else { cq = cp; cp = cr; cr = 1; ck = kind; }
-                    const int next = acc ? (kd & 31) : ((kd >> 5) & 31);
-                    if (next == 0 || next > AVAIL || !(::fabs(step) > 1e-10)) break;
-                    node = next - 1;
-                }
-            } else {
-                bool fb = false;
-                int guard = 1;                                           // (b = 2 was the first doubling)
-                while (!fb) {
-                    b *= 2.0;
-                    fb = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * b, sub, lane, g, best_len);
-                    P.iters++;
-                    if (++guard > 200) return P;
-                }
-            }
-        }
-    }
-    KG_ADD(3);
-    while (::fabs(step) > 1e-10) {
-        KG_ADD(7);
-#if defined(SCA_SPEC_BALANCED)                                          // measurement build: the balanced tree in every round
-        const int tree = 0;
-#else
-        const int tree = TR.of_ctx[((ck * (sca_spec::RUN_CAP + 1) + (cr < sca_spec::RUN_CAP ? cr : sca_spec::RUN_CAP)) * (sca_spec::PREV_CAP + 1) +
-                                    (cp < sca_spec::PREV_CAP ? cp : sca_spec::PREV_CAP)) * (sca_spec::PREV2_CAP + 1) + (cq < sca_spec::PREV2_CAP ? cq : sca_spec::PREV2_CAP)];
-#endif
-        const uint2 me = TR.nodes[tree * SLOTS + quad];                  // (the spare quad's words are 0: the root again, counted out below)
-        // this quad's candidate: the (b, step) the sequential loop holds when it has taken the node's path
+    // The walk along the sequential loop's path, all nodes at once (node k of the round's tree sits on quad QOFF + k).  A node ON
+    // that path sees the best length the loop holds there: the length of the last node whose success its own path assumes (or the
+    // round's incoming one) -- so every node can form the verdict it WOULD get; the path is then the set of nodes whose ancestors'
+    // verdicts are the ones their paths assume (two ballots against the node's ancestor masks), and it ends at the node whose
+    // verdict leads out of the tree (or to a candidate behind the loop's end).  That node's state and verdict are the round's
+    // result: (b, step, best length), the count of candidates tried, the context.  (Until this form the walk went node by node
+    // through v_readlane: 1.6 us of a 7-us round.)
+    auto walk = [&](const int QOFF, const uint2 me, const double nb, const double ns, const double myc, const double mylen, const int nfc) {
+        const int node = quad - QOFF, avail = SLOTS - 1 - (QOFF > 0 ? QOFF - 1 : 0);       // nodes 0 .. avail - 1 are on quads
         const unsigned pbits = me.x & 0xfffu;
         const int plen = (int)((me.x >> 12) & 15u);
-        double nb = b, ns = step, myc;
-        spec_path(pbits, plen, MAXD, nb, ns, myc);
         const bool valid = ::fabs(ns) > 1e-10;                           // the loop's condition in front of this candidate
-        double mylen;
-        KG_ADD(4);
-        const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
-        KG_ADD(5);
-#if defined(SCA_KT_TIMING)
-        if (blockIdx.x == 0 && threadIdx.x == 0) sca_dubins::g_td_ticks[31]++;
-#endif
-        // The walk along the sequential loop's path, all nodes at once.  A node ON that path sees the best length the loop holds
-        // there: the length of the last node whose success its own path assumes (or the round's incoming one) -- so every node can
-        // form the verdict it WOULD get; the path is then the set of nodes whose ancestors' verdicts are the ones their paths assume
-        // (two ballots against the node's ancestor masks), and it ends at the node whose verdict leads out of the tree (or to a
-        // candidate behind the loop's end).  That node's state and verdict are the round's result.  (Until this form the walk went
-        // node by node through v_readlane: 1.6 us of a 7-us round.)
         const int la = (int)((me.x >> 26) & 31u);
         // (fetched by every lane: a lane that skipped the fetch would be switched off while others read from it, and read as 0)
-        const double seen_la = lane_fetch_d(mylen, base + 4 * (la > 0 ? la - 1 : 0));
+        const double seen_la = lane_fetch_d(mylen, base + 4 * (QOFF + (la > 0 ? la - 1 : 0)));
         const double seen = la > 0 ? seen_la : best_len;
         const bool acc = nfc > 0 && mylen < seen;
-        const unsigned sh = (unsigned)(base >> 2), gm = (1u << SLOTS) - 1u;
+        const unsigned sh = (unsigned)(base >> 2) + (unsigned)QOFF, gm = (1u << avail) - 1u;
         const unsigned gA = (quad_bits(__ballot(acc)) >> sh) & gm, gV = (quad_bits(__ballot(valid)) >> sh) & gm;
         const unsigned am = me.y & 0xffffu, ab = me.y >> 16;
-        const bool on = quad < SLOTS - 1 && valid && (gA & am) == ab && (gV & am) == am;
+        const bool on = node >= 0 && node < avail && valid && (gA & am) == ab && (gV & am) == am;
         const int child = (int)((me.x >> (acc ? 16 : 21)) & 31u);
-        const bool last = on && !(child > 0 && ((gV >> (child - 1)) & 1u));
+        const bool last = on && !(child > 0 && child <= avail && ((gV >> (child - 1)) & 1u));
         const unsigned gL = (quad_bits(__ballot(last)) >> sh) & gm;       // exactly one node
-        const int src = base + 4 * (__ffs((int)gL) - 1);
+        const int src = base + 4 * (QOFF + __ffs((int)gL) - 1);
         double Lb, Ls, Lc, Llen, Lseen;
         int Lacc, Lplen;
         unsigned Lbits;
@@ -695,6 +616,65 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
             if (kind == ck) cr++;
             else { cq = cp; cp = cr; cr = 1; ck = kind; }
         }
+    };
+    // The first round: the first try and the first doubling (:74-78) on quads 0 and 1 (b = 1, 2) -- and, since the doubling stage
+    // ends at b = 2 for every pose of the benchmark configurations (33 of 40 in a +-20-m cube), the local search's first candidates
+    // from (b = 2, step = 0.1) on the other quads: the nodes of the opening context's tree that fit.  A stage that does not end at
+    // b = 2 goes on as the sequential loop does (all quads the same radius), and the speculated candidates are dropped.
+    {
+        constexpr int DQ = 2;
+        const int tree0 = TR.of_ctx[0];
+        const uint2 me = quad >= DQ ? TR.nodes[tree0 * SLOTS + (quad - DQ)] : make_uint2(0u, 0u);
+        double nb = 2.0, ns = 0.1, myc;
+        spec_path(me.x & 0xfffu, (int)((me.x >> 12) & 15u), MAXD, nb, ns, myc);
+        myc = quad == 0 ? 1.0 : (quad == 1 ? 2.0 : myc);
+        double mylen;
+        KG_ADD(1);
+        const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
+        KG_ADD(2);
+        const int nf0 = __shfl(nfc, base), nf1 = __shfl(nfc, base + 4);
+        const double len0 = lane_fetch_d(mylen, base), len1 = lane_fetch_d(mylen, base + 4);
+        P.iters = 1;
+        if (nf0 > 0) best_len = len0;                                    // b = 1 is feasible: no doubling; the search starts from there
+        else {
+            b = 2.0;
+            P.iters = 2;
+            if (nf1 > 0) {
+                best_len = len1;
+                walk(DQ, me, nb, ns, myc, mylen, nfc);
+            } else {
+                bool fb = false;
+                int guard = 1;                                           // (b = 2 was the first doubling)
+                while (!fb) {
+                    b *= 2.0;
+                    fb = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * b, sub, lane, g, best_len);
+                    P.iters++;
+                    if (++guard > 200) return P;
+                }
+            }
+        }
+    }
+    KG_ADD(3);
+    while (::fabs(step) > 1e-10) {
+        KG_ADD(7);
+#if defined(SCA_SPEC_BALANCED)                                          // measurement build: the balanced tree in every round
+        const int tree = 0;
+#else
+        const int tree = TR.of_ctx[((ck * (sca_spec::RUN_CAP + 1) + (cr < sca_spec::RUN_CAP ? cr : sca_spec::RUN_CAP)) * (sca_spec::PREV_CAP + 1) +
+                                    (cp < sca_spec::PREV_CAP ? cp : sca_spec::PREV_CAP)) * (sca_spec::PREV2_CAP + 1) + (cq < sca_spec::PREV2_CAP ? cq : sca_spec::PREV2_CAP)];
+#endif
+        const uint2 me = TR.nodes[tree * SLOTS + quad];                  // (the spare quad's words are 0: the root again, counted out by the walk)
+        // this quad's candidate: the (b, step) the sequential loop holds when it has taken the node's path
+        double nb = b, ns = step, myc;
+        spec_path(me.x & 0xfffu, (int)((me.x >> 12) & 15u), MAXD, nb, ns, myc);
+        double mylen;
+        KG_ADD(4);
+        const int nfc = cand_quad(fast_ok, H, K, qi, qf, Rmin, pitchlims, Rmin * myc, sub, lane, g, mylen) ? 2 : 0;
+        KG_ADD(5);
+#if defined(SCA_KT_TIMING)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sca_dubins::g_td_ticks[31]++;
+#endif
+        walk(0, me, nb, ns, myc, mylen, nfc);
         KG_ADD(6);
     }
     Maneuver2D fbh, fbv;
