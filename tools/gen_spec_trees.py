@@ -9,7 +9,8 @@ the next overshoot), so the trees here follow the likely continuations deep and 
 with 15 candidates on held-out searches (4.2-5.0 with 7, 2.5-2.6 with 3).
 
   python tools/gen_spec_trees.py --record     (build container only: imports /root/reference) runs the reference's own planner on poses of
-                                              BASELINE configs 2 / 4 / 5 and of a +-20-m cube and records each search's verdicts as a string
+                                              BASELINE configs 2 / 4 / 5 (perturbed mid-flight poses, and poses out of the episodes themselves:
+                                              tools/dump_episode_poses.py), and of a +-20-m cube and records each search's verdicts as a string
                                               of S / F -> tools/data/radius_search_outcomes.json (data; committed)
   python tools/gen_spec_trees.py              fits P(S | kind of the current run, its length, the two previous runs' lengths) to the first half of
                                               every family, builds per context the tree of the 15 / 7 / 3 likeliest continuations, and writes the
@@ -75,9 +76,12 @@ def record():
     from sca_amd import scenarios
     rng = np.random.default_rng(7)
     out = {}
-    for fam, cnt in (('c2', 80), ('c5', 80), ('c4', 16), ('cube', 80)):
+    episode = json.load(open(os.path.join(ROOT, 'tools', 'data', 'episode_poses.json')))    # tools/dump_episode_poses.py
+    for fam, cnt in (('c2', 80), ('c5', 80), ('c4', 16), ('cube', 80), ('c2ep', 0), ('c5ep', 0)):
         cases = []
-        if fam == 'cube':                                    # the family of tools/gen_dubins_kat.py: poses in a +-20-m cube
+        if fam.endswith('ep'):                               # poses of the benchmark episodes themselves (pos | heading, goal pose)
+            cases = [(np.array(q[:3] + q[3:5] + [0.0]), np.array(g)) for q, g in episode[fam[:2]]]
+        elif fam == 'cube':                                    # the family of tools/gen_dubins_kat.py: poses in a +-20-m cube
             for _ in range(cnt):
                 qi = np.concatenate([rng.uniform(-20, 20, 3), [rng.uniform(0, 2 * math.pi), rng.uniform(-0.6, 0.6), 0.0]])
                 qf = np.concatenate([rng.uniform(-20, 20, 3), [rng.uniform(0, 2 * math.pi), rng.uniform(-0.3, 0.3), 0.0]])
