@@ -209,12 +209,14 @@ int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
  *   SCA_FORM_TRACK_FUSED   k_track_replan instead of k_track + k_replan
  *   SCA_FORM_REPLAN_LANE   the lane-per-plan re-plan kernel was launched (k_replan or k_track_replan)
  *   SCA_FORM_REPLAN_FEW    a k_replan_group kernel (4 .. 64 lanes per plan) was launched
- *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent) */
+ *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent)
+ *   SCA_FORM_SOLVE_FB      k_solve_fb: small shards solve and finish their fallbacks in one launch (no k_fallback launch) */
 #define SCA_FORM_SOLVE_SPLIT 1
 #define SCA_FORM_TRACK_FUSED 2
 #define SCA_FORM_REPLAN_LANE 4
 #define SCA_FORM_REPLAN_FEW 8
 #define SCA_FORM_LP_LANE 16
+#define SCA_FORM_SOLVE_FB 32
 int sca_last_pass_forms(sca_ctx *ctx, int *forms);
 /* Measurement aid for scaling models on one GPU: with a partial shard (sca_set_shard) and no communicator, sca_run_steps
  * runs what ONE rank of a larger job runs per step -- the replicated neighbour structure over all n agents, everything else

@@ -187,6 +187,7 @@ struct sca_ctx {
     unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
+    int solve_fb_max = 0;               // shards up to this many agents solve and fall back in one launch (SCA_SOLVE_FB_MAX; default: two wavefronts per SIMD)
     int kd_tail_level = -1;             // SCA_KD_TAIL_LEVEL=l: the level at which the tail launch takes over (tuning / tests; -1: from the statistics)
     int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
@@ -622,6 +623,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
         CHK(c, hipGetDeviceProperties(&prop, device));
         c->cus = std::max(1, prop.multiProcessorCount);
         c->simds = 4 * c->cus;
+        c->solve_fb_max = std::getenv("SCA_SOLVE_FB_MAX") ? std::atoi(std::getenv("SCA_SOLVE_FB_MAX")) : per_simd(c, 2048);
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_kd_lv_rank<false>, KD_LV_T, 0) == hipSuccess && per_cu > 0)
             c->kd_rank_capacity = per_cu * c->cus;
@@ -1290,6 +1292,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool overlap = tracked && (mode == SCA_NBR_KDTREE || mode == SCA_NBR_GRID || auto_mode) && !c->trk_serial;
     // k_solve's v_pref-independent half right behind the neighbour query, i.e. beside the re-plans when they are overlapped
     bool split = choose_solve_split(c, overlap, d.shard_count);
+    // k_solve that finishes its own fallbacks (k_solve_fb): while all the shard's wavefronts are resident at once even at the fallback
+    // sweep's 252 registers (two per SIMD), and nobody else feeds the fallback list (k_lp does)
+    const bool solve_fb = !split && lp_hi == lp_lo && !c->part_on && d.shard_count <= c->solve_fb_max;
     if (split && !c->d.sw_slot) {
         // scratch of the two-launch solve (cones + survivor lists, ~2 KB per agent): all three buffers or none, and a pass that
         // cannot have them runs the one-launch k_solve instead of failing
@@ -1436,6 +1441,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         const int per_block = SOLVE_WAVES * PICK_APW;
         hipLaunchKernelGGL(k_solve_pick4, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     }
+    else if (solve_fb) {
+        hipLaunchKernelGGL(k_solve_fb, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        c->forms |= SCA_FORM_SOLVE_FB;
+    }
     else {
         hipLaunchKernelGGL(k_solve, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         if (!d.lp_kernel && lp_hi > lp_lo)                            // K3, one wavefront per LP agent (few of them)
@@ -1455,10 +1464,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         c->auto_unjoined = true;                                        // (ii) see auto_join
     }
     if (fuse_integrate) {
-        hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        if (!solve_fb) hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
     } else {
-        hipLaunchKernelGGL(k_fallback<false>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        if (!solve_fb) hipLaunchKernelGGL(k_fallback<false>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         hipLaunchKernelGGL(k_action<false>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
     }
     CHK(c, hipGetLastError());

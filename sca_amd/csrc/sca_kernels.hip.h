@@ -1772,6 +1772,27 @@ __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
 // The list's length is on the device: a fixed grid strides over it (an empty list costs an empty launch).  k_action and
 // k_fallback never touch the same agent, so they need no order between them.
 constexpr int FB_BLOCKS = 256;
+// k_solve + k_fallback in ONE launch, for shards of so few agents that every wavefront is resident at once whatever its registers
+// (round 4): an agent whose sweep leaves no suitable candidate is finished by its own wavefront on the spot instead of going
+// through the list to a launch of its own -- which, list empty or not, sat between the solve and the epilogue on every pass's
+// critical path (5 us + its gap of a 150-us step at N = 1024).  Passes with LP agents keep the list (k_lp's fallbacks need it).
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_fb(DeviceView d, Params P) {
+    __shared__ FastLds S;
+    __shared__ SolveLds S2;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = blockIdx.x * SOLVE_WAVES + wid;
+    if (idx >= shard_size(d)) return;
+    const int agent = shard_agent(d, idx);
+    solve_fast<0, 1>(d, P, S, agent, lane, wid);
+    __builtin_amdgcn_wave_barrier();
+    int fb = 0;
+    if (lane == 0) fb = d.is_fb[agent];                                  // (the lane that wrote it)
+    if (__builtin_amdgcn_readfirstlane(fb) != 1) return;
+    solve_one(d, P, S2, agent, lane, wid);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) d.is_fb[agent] = 0;                                   // the epilogue (k_action) takes it like any other agent
+}
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Params P) {
     __shared__ SolveLds S;
