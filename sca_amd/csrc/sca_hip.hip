@@ -188,6 +188,7 @@ struct sca_ctx {
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
     int solve_fb_max = 0;               // shards up to this many agents solve and fall back in one launch (SCA_SOLVE_FB_MAX; default: two wavefronts per SIMD)
+    bool kd_top = true;                 // SCA_KD_TOP=0: trees of <= KT_M members through the level passes as well (tests, measurements)
     int kd_tail_level = -1;             // SCA_KD_TAIL_LEVEL=l: the level at which the tail launch takes over (tuning / tests; -1: from the statistics)
     int kd_single_hint = 0;             // 1 + first level whose nodes all fit one chunk in an earlier build (0: unknown)
     unsigned kd_token = 0;              // launch token of the chained scan (never reused)
@@ -610,6 +611,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TAIL_LEVEL")) c->kd_tail_level = std::atoi(e);
+    if (const char *e = std::getenv("SCA_KD_TOP")) c->kd_top = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TICKET")) c->kd_force_ticket = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_WAVE_CAP")) c->kd_wave_cap = std::min(KD_WAVE_CAP, std::max(2 * KD_WAVE_FLOOR, std::atoi(e)));
     int ndev = 0;
@@ -975,7 +977,10 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
     // runs beside the tracker's re-plans (a side stream): twice as many, smaller workgroups spread over twice as many CUs, each
     // competing with fewer re-plan wavefronts -- measured at c5 (N = 16 384, 16 subtrees of ~1024 against 32 of ~512): step 0.284
     // -> 0.268 ms; c3 (no tracker, 4 against 8 subtrees) the other way round: 0.127 against 0.129
-    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : ((c->trk_on && c->trk_in_pass && ks != c->stream) ? 1024 : KD_WAVE_CAP);
+    // a tree of up to KT_M members: its top by one workgroup in LDS (k_kd_top), which is cheap enough per level to go one level
+    // further down than the level passes would -- subtrees of ~512 instead of ~1024 members for k_kd_block
+    const bool top = c->kd_top && n <= KT_M && c->kd_tail_level < 0;
+    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : (top ? 768 : ((c->trk_on && c->trk_in_pass && ks != c->stream) ? 1024 : KD_WAVE_CAP));
     int wave_max = (n <= 1024 && cap >= 1024) ? 1024 : cap; // a tree that fits one workgroup: the smaller one if it can
     if (n > cap) {
         double sz = (double)n;
@@ -989,7 +994,10 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
         c->auto_builds++;
     }
     int levels = 0;
-    if (n > wave_max) {
+    if (n > wave_max && top) {
+        hipLaunchKernelGGL(k_kd_top, dim3(1), dim3(KT_T), 0, ks, d, c->kd);
+        levels = 1;
+    } else if (n > wave_max) {
         // Level passes: two launches per level (rank | swap) while the nodes span several chunks, then ONE launch
         // (k_kd_level_tail) in which every remaining node's workgroup finishes its whole subtree down to wave_max.  Where the
         // switch happens only sets the speed -- the tail handles any node size and any depth -- so it is taken from the
@@ -1036,7 +1044,7 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
-    if (n > wave_max && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
+    if (n > wave_max && !top && !c->kd_ev_pending && (c->kd_single_hint == 0 || (c->kd_builds & 7u) == 0)) {
         CHK(c, hipMemcpyAsync(c->kd_host_counts, c->kd.counts, sizeof(int) * (2 * KD_MAX_LEVELS + 3), hipMemcpyDeviceToHost, ks));
         CHK(c, hipEventRecord(c->kd_ev, ks));
         c->kd_ev_pending = true;

@@ -789,4 +789,190 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_kd_top (round 4): the TOP of a tree of up to KT_M members -- every node larger than wave_max -- by ONE workgroup with all
+// coordinates in LDS, level by level, instead of two launches per level plus the tail launch.  At N = 4096 (BASELINE config 3) the
+// level passes were 37 us of a 78-us build: seven dependent launches of 3-8 us whose workgroups mostly wait for global memory and for
+// each other (the chained scan).  Here a level is five LDS phases of one 1024-thread workgroup, four consecutive positions per
+// thread, and because the top is cheap it can go further down: the subtrees handed to k_kd_block are half as large (wave_max 768
+// instead of 1280 at N = 4096), which halves that kernel's instruction stream per level.
+// Same partition as everywhere (see the top of this file), same records; the children's boxes are accumulated while the parent
+// is partitioned (as in the level passes), the subtrees' own boxes are k_kd_block's as before.
+constexpr int KT_M = 4096, KT_T = 1024, KT_E = 4, KT_NODES = 32;
+#define KT_SW(p) ((((p) & 3) << 10) + ((p) >> 2))        // position p of thread p / 4: the k-th positions of all threads side by side
+struct KtLds {
+    double x[KT_M], y[KT_M], z[KT_M];       // swizzled: index KT_SW(position)
+    int id[KT_M];
+    unsigned short ps[KT_M];                // inclusive count of ">= split" members over all positions
+    unsigned short mr[KT_M];                // mr[b + m] = position of the member "< split" that is m-th from the right in its node
+    int nb[2][KT_NODES], ne[2][KT_NODES], nnode[2][KT_NODES], npar[2][KT_NODES], naxis[KT_NODES];
+    double nsplit[KT_NODES];
+    unsigned long long box[2][KT_NODES][6];     // the level's node boxes: keys of the minima, keys of the maxima
+    unsigned long long cbox[KT_NODES][2][6];    // the two children's, accumulated while the node is partitioned
+    int count[2];
+    int wtot[KT_T / 64];
+};
+__global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
+    SCA_KD_SETPRIO();
+    __shared__ KtLds S;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = d.n;
+    for (int i = tid; i < n; i += KT_T) {
+        S.x[KT_SW(i)] = s.kx[i]; S.y[KT_SW(i)] = s.ky[i]; S.z[KT_SW(i)] = s.kz[i]; S.id[i] = d.aperm[i];
+    }
+    if (tid == 0) {
+        S.nb[0][0] = 0; S.ne[0][0] = n; S.nnode[0][0] = 0; S.npar[0][0] = -1; S.count[0] = 1; S.count[1] = 0;
+        for (int k = 0; k < 6; k++) S.box[0][0][k] = s.nbox[k];           // the root's, from k_kd_gather
+    }
+    __syncthreads();
+    int cur = 0;
+    const int p0 = KT_E * tid;
+    for (;;) {
+        const int nc = S.count[cur];
+        if (nc == 0) break;
+        const int nxt = cur ^ 1;
+        // ---- split planes of the level's nodes (kdTree.py:85-96); their children's accumulators
+        if (tid < nc) {
+            double mn[3], mx[3];
+            for (int q = 0; q < 3; q++) { mn[q] = dunkey(S.box[cur][tid][q]); mx[q] = dunkey(S.box[cur][tid][3 + q]); }
+            int axis; double split;
+            kd_split(mn, mx, axis, split);
+            S.naxis[tid] = axis; S.nsplit[tid] = split;
+            for (int sd = 0; sd < 2; sd++)
+                for (int q = 0; q < 3; q++) { S.cbox[tid][sd][q] = dkey(INFINITY); S.cbox[tid][sd][3 + q] = dkey(-INFINITY); }
+        }
+        __syncthreads();
+        // ---- node and flag of this thread's four positions, the children's boxes, block scan of the flags
+        int sl[KT_E], nb_[KT_E], ne_[KT_E];
+        bool ge[KT_E];
+        int cnt = 0;
+        unsigned long long key[2][6];                                    // per side: minima, inverted maxima of this thread's members (all minima)
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) key[sd][q] = ~0ull;
+        int first_sl = -2;                                               // the node all of this thread's members are in; -3: more than one
+#pragma unroll
+        for (int k = 0; k < KT_E; k++) {
+            const int p = p0 + k;
+            sl[k] = -1; nb_[k] = 0; ne_[k] = 0; ge[k] = false;
+            if (p < n)
+                for (int j = 0; j < nc; j++) { const int b = S.nb[cur][j], e = S.ne[cur][j]; if (p >= b && p < e) { sl[k] = j; nb_[k] = b; ne_[k] = e; } }
+            if (sl[k] >= 0) {
+                const double x = S.x[KT_SW(p)], y = S.y[KT_SW(p)], z = S.z[KT_SW(p)];
+                const int axis = S.naxis[sl[k]];
+                const double c = axis == 0 ? x : (axis == 1 ? y : z);
+                ge[k] = !(c < S.nsplit[sl[k]]);
+                cnt += ge[k] ? 1 : 0;
+                const int sd = ge[k] ? 1 : 0;
+                const unsigned long long kx_ = dkey(x), ky_ = dkey(y), kz_ = dkey(z);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    if (t == sd) {
+                        key[t][0] = kx_ < key[t][0] ? kx_ : key[t][0]; key[t][1] = ky_ < key[t][1] ? ky_ : key[t][1]; key[t][2] = kz_ < key[t][2] ? kz_ : key[t][2];
+                        key[t][3] = ~kx_ < key[t][3] ? ~kx_ : key[t][3]; key[t][4] = ~ky_ < key[t][4] ? ~ky_ : key[t][4]; key[t][5] = ~kz_ < key[t][5] ? ~kz_ : key[t][5];
+                    }
+                }
+                first_sl = first_sl == -2 ? sl[k] : (first_sl == sl[k] ? first_sl : -3);
+            }
+        }
+        {
+            // a wavefront's 256 positions sit in one node almost always (nodes here have more than wave_max members): then twelve
+            // wave minima and one lane's atomics; a wavefront across a boundary (or with members and non-members): every lane its own
+            const int ref = __builtin_amdgcn_readfirstlane(first_sl);
+            const bool uni = ref >= 0 && __all(first_sl == ref);
+            if (uni) {
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) key[sd][q] = kb_key_min<true>(key[sd][q]);
+                if (lane == 0)
+                    for (int sd = 0; sd < 2; sd++)
+                        for (int q = 0; q < 3; q++) { atomicMin(&S.cbox[ref][sd][q], key[sd][q]); atomicMax(&S.cbox[ref][sd][3 + q], ~key[sd][3 + q]); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT_E; k++) {
+                    if (sl[k] >= 0) {
+                        const int p = p0 + k, sd = ge[k] ? 1 : 0;
+                        const unsigned long long kx_ = dkey(S.x[KT_SW(p)]), ky_ = dkey(S.y[KT_SW(p)]), kz_ = dkey(S.z[KT_SW(p)]);
+                        atomicMin(&S.cbox[sl[k]][sd][0], kx_); atomicMin(&S.cbox[sl[k]][sd][1], ky_); atomicMin(&S.cbox[sl[k]][sd][2], kz_);
+                        atomicMax(&S.cbox[sl[k]][sd][3], kx_); atomicMax(&S.cbox[sl[k]][sd][4], ky_); atomicMax(&S.cbox[sl[k]][sd][5], kz_);
+                    }
+                }
+            }
+        }
+        const int incl = wave_incl_scan_i32(cnt);
+        if (lane == 63) S.wtot[wid] = incl;
+        __syncthreads();
+        {
+            const int wv = lane < KT_T / 64 ? S.wtot[lane] : 0;
+            const int wscan = wave_incl_scan_i32(wv);
+            const int wbase = wid > 0 ? __builtin_amdgcn_readlane(wscan, wid - 1) : 0;
+            int run = wbase + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < KT_E; k++) { run += ge[k] ? 1 : 0; if (p0 + k < n) S.ps[p0 + k] = (unsigned short)run; }
+        }
+        __syncthreads();
+        // ---- L = #(members < split); the m-th member "< split" of the right part counted from the right
+        int L_[KT_E], G_[KT_E];
+#pragma unroll
+        for (int k = 0; k < KT_E; k++) {
+            L_[k] = 0; G_[k] = 0;
+            if (sl[k] >= 0) {
+                const int p = p0 + k, b = nb_[k], e = ne_[k];
+                const int pb = b > 0 ? (int)S.ps[b - 1] : 0;
+                L_[k] = (e - b) - ((int)S.ps[e - 1] - pb);
+                G_[k] = (int)S.ps[p] - pb;
+                if (!ge[k] && p >= b + L_[k]) S.mr[b + (L_[k] - ((p - b + 1) - G_[k]))] = (unsigned short)p;
+            }
+        }
+        __syncthreads();
+        // ---- the swaps (kdTree.py:108-111) by position; node records and children (kdTree.py:112-122), one lane per node
+#pragma unroll
+        for (int k = 0; k < KT_E; k++) {
+            const int p = p0 + k;
+            if (sl[k] >= 0 && ge[k] && p < nb_[k] + L_[k]) {
+                const int q = S.mr[nb_[k] + G_[k] - 1];
+                const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
+                double t;
+                t = S.x[KT_SW(p)]; S.x[KT_SW(p)] = S.x[KT_SW(q)]; S.x[KT_SW(q)] = t;
+                t = S.y[KT_SW(p)]; S.y[KT_SW(p)] = S.y[KT_SW(q)]; S.y[KT_SW(q)] = t;
+                t = S.z[KT_SW(p)]; S.z[KT_SW(p)] = S.z[KT_SW(q)]; S.z[KT_SW(q)] = t;
+            }
+        }
+        if (tid < nc) {
+            const int b = S.nb[cur][tid], e = S.ne[cur][tid], node = S.nnode[cur][tid], par = S.npar[cur][tid];
+            const int pb = b > 0 ? (int)S.ps[b - 1] : 0;
+            const int L = (e - b) - ((int)S.ps[e - 1] - pb);
+            const int lf = L == 0 ? 1 : L;                               // degenerate: every member on the split plane
+            KdNode nd;
+            nd.begin = b; nd.end = e; nd.left = node + 1; nd.right = node + 2 * lf;
+            for (int q = 0; q < 3; q++) { nd.mn[q] = dunkey(S.box[cur][tid][q]); nd.mx[q] = dunkey(S.box[cur][tid][3 + q]); }
+            if (node == 0) d.atree[0] = nd;                              // the root's box has no parent record to live in
+            kd_publish(d.awide, nd, node, par);
+            const int cbeg[2] = {b, b + lf}, cend[2] = {b + lf, e};
+            for (int k = 0; k < 2; k++) {
+                KdJob j; j.begin = cbeg[k]; j.end = cend[k]; j.node = k == 0 ? nd.left : nd.right; j.pad = 2 * node + k;
+                if (cend[k] - cbeg[k] > s.wave_max) {
+                    const int at = atomicAdd(&S.count[nxt], 1);
+                    if (at < KT_NODES) {
+                        S.nb[nxt][at] = j.begin; S.ne[nxt][at] = j.end; S.nnode[nxt][at] = j.node; S.npar[nxt][at] = j.pad;
+                        // (nobody below the midpoint: the box has no extent, both children have the parent's)
+                        for (int q = 0; q < 6; q++) S.box[nxt][at][q] = L == 0 ? S.box[cur][tid][q] : S.cbox[tid][k][q];
+                    } else atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_JOBS);
+                } else s.small[atomicAdd(&s.counts[KD_MAX_LEVELS], 1)] = j;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { S.count[cur] = 0; if (S.count[nxt] > KT_NODES) S.count[nxt] = KT_NODES; }
+        __syncthreads();
+        cur = nxt;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += KT_T) {
+        d.aperm[i] = S.id[i];
+        s.kx[i] = S.x[KT_SW(i)]; s.ky[i] = S.y[KT_SW(i)]; s.kz[i] = S.z[KT_SW(i)];
+    }
+}
+
 }  // namespace sca

@@ -218,18 +218,23 @@ def test_resident_steps_match_stepwise_oracle(S, oracle):
     sol.close()
 
 
-@pytest.mark.parametrize('cap', ['default', '1024', '768', '512', '256'])
-@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 127, 128, 129, 200, 257, 300, 1000, 1024, 1025, 1500, 1536, 2048, 2049, 3000, 5000, 40000])
+@pytest.mark.parametrize('cap', ['default', '1024', '768', '512', '256', 'levels'])
+@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 127, 128, 129, 200, 257, 300, 1000, 1024, 1025, 1500, 1536, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 40000])
 def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
     """K0: the kd-tree built on the device (nodes, boxes, permutation) against the sequential host replica of
     kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent).  `cap`: the largest subtree one
     workgroup finishes in LDS (SCA_KD_WAVE_CAP; k_kd_block<1536 / 1024 / 768 / 512 / 256>): more, smaller subtrees on more
-    CUs against more level passes above them -- the same tree whatever the cut."""
+    CUs against more passes above them -- the same tree whatever the cut.  Trees of up to 4096 members have their top built by
+    one workgroup in LDS (k_kd_top, round 4); 'levels' sends them through the level passes as larger trees go (SCA_KD_TOP=0)."""
     import ctypes as C
     from sca_amd import _lib
     L = _lib.lib()
-    if cap != 'default':
-        if n in (1, 7, 10, 11, 64, 127, 200, 1024, 2049):
+    if cap == 'levels':
+        if n < 1000 or n > 4097:
+            pytest.skip('the level passes of trees that k_kd_top takes by default')
+        monkeypatch.setenv('SCA_KD_TOP', '0')
+    elif cap != 'default':
+        if n in (1, 7, 10, 11, 64, 127, 200, 1024, 2049, 4095, 4097):
             pytest.skip('the smaller caps are exercised on a subset of the sizes')
         monkeypatch.setenv('SCA_KD_WAVE_CAP', cap)
     rng = np.random.default_rng(n)
@@ -237,7 +242,7 @@ def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
     if n >= 64:
         pos[: n // 4] = np.round(pos[: n // 4], 0)            # duplicates and ties on split planes
         pos[n // 4: n // 3, 2] = 10.0                          # a flat slab (degenerate axis)
-    if n in (300, 1500, 3000):                                 # a geometric progression along x: every split peels one point off
+    if n in (300, 1500, 3000, 4096):                           # a geometric progression along x: every split peels one point off
         k = min(n // 2, 400)                                   # (subtrees hundreds of levels deep, one queued leaf per level)
         pos[-k:, 0] = 100.0 + 2.0 ** (-np.arange(k, dtype=np.float64) / 8.0) * 50.0
         pos[-k:, 1:] = 0.0
