@@ -798,12 +798,17 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
 // instead of 1280 at N = 4096), which halves that kernel's instruction stream per level.
 // Same partition as everywhere (see the top of this file), same records; the children's boxes are accumulated while the parent
 // is partitioned (as in the level passes), the subtrees' own boxes are k_kd_block's as before.
-constexpr int KT_M = 4096, KT_T = 1024, KT_E = 4, KT_NODES = 32;
-#define KT_SW(p) ((((p) & 3) << 10) + ((p) >> 2))        // position p of thread p / 4: the k-th positions of all threads side by side
+#ifndef SCA_KT_THREADS
+#define SCA_KT_THREADS 1024
+#endif
+constexpr int KT_M = 4096, KT_T = SCA_KT_THREADS, KT_E = KT_M / KT_T, KT_NODES = 32;
+// Sixteen wavefronts, four consecutive positions per thread.  (Measured with 256 / 512 / 1024 threads, i.e. 16 / 8 / 4 positions each:
+// k_kd_top 42 / 30 / 26 us at N = 4096 -- a level is a chain of LDS round trips, and the wavefronts hide each other's.)
+#define KT_SW(p) ((((p) & (KT_E - 1)) * KT_T) + ((p) / KT_E))   // position p of thread p / KT_E: the k-th positions of all threads side by side
 struct KtLds {
     double x[KT_M], y[KT_M], z[KT_M];       // swizzled: index KT_SW(position)
-    int id[KT_M];
-    unsigned short ps[KT_M];                // inclusive count of ">= split" members over all positions
+    int id[KT_M];                           // swizzled
+    unsigned short ps[KT_M];                // swizzled: inclusive count of ">= split" members over all positions
     unsigned short mr[KT_M];                // mr[b + m] = position of the member "< split" that is m-th from the right in its node
     int nb[2][KT_NODES], ne[2][KT_NODES], nnode[2][KT_NODES], npar[2][KT_NODES], naxis[KT_NODES];
     double nsplit[KT_NODES];
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = d.n;
     for (int i = tid; i < n; i += KT_T) {
-        S.x[KT_SW(i)] = s.kx[i]; S.y[KT_SW(i)] = s.ky[i]; S.z[KT_SW(i)] = s.kz[i]; S.id[i] = d.aperm[i];
+        S.x[KT_SW(i)] = s.kx[i]; S.y[KT_SW(i)] = s.ky[i]; S.z[KT_SW(i)] = s.kz[i]; S.id[KT_SW(i)] = d.aperm[i];
     }
     if (tid == 0) {
         S.nb[0][0] = 0; S.ne[0][0] = n; S.nnode[0][0] = 0; S.npar[0][0] = -1; S.count[0] = 1; S.count[1] = 0;
@@ -828,10 +833,11 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
     int cur = 0;
     const int p0 = KT_E * tid;
     for (;;) {
-        const int nc = S.count[cur];
+        const int nc = S.count[cur] < KT_NODES ? S.count[cur] : KT_NODES;
         if (nc == 0) break;
         const int nxt = cur ^ 1;
-        // ---- split planes of the level's nodes (kdTree.py:85-96); their children's accumulators
+        // ---- split planes of the level's nodes (kdTree.py:85-96); their children's accumulators; the next level's counter
+        if (tid == KT_T - 1) S.count[nxt] = 0;                           // (read last at the previous level's top, written next by this level's records)
         if (tid < nc) {
             double mn[3], mx[3];
             for (int q = 0; q < 3; q++) { mn[q] = dunkey(S.box[cur][tid][q]); mx[q] = dunkey(S.box[cur][tid][3 + q]); }
@@ -842,108 +848,130 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
                 for (int q = 0; q < 3; q++) { S.cbox[tid][sd][q] = dkey(INFINITY); S.cbox[tid][sd][3 + q] = dkey(-INFINITY); }
         }
         __syncthreads();
-        // ---- node and flag of this thread's four positions, the children's boxes, block scan of the flags
-        int sl[KT_E], nb_[KT_E], ne_[KT_E];
-        bool ge[KT_E];
-        int cnt = 0;
-        unsigned long long key[2][6];                                    // per side: minima, inverted maxima of this thread's members (all minima)
-#pragma unroll
-        for (int sd = 0; sd < 2; sd++)
-#pragma unroll
-            for (int q = 0; q < 6; q++) key[sd][q] = ~0ull;
-        int first_sl = -2;                                               // the node all of this thread's members are in; -3: more than one
+        // ---- the (at most two: a node here has more than wave_max >= 256 members) nodes this thread's sixteen positions are in
+        int sA = -1, bA = 0, eA = 0, sB = -1, bB = 0, eB = 0;
+        for (int j = 0; j < nc; j++) {
+            const int b = S.nb[cur][j], e = S.ne[cur][j];
+            if (b < p0 + KT_E && e > p0) {
+                if (sA < 0) { sA = j; bA = b; eA = e; }
+                else { sB = j; bB = b; eB = e; }
+            }
+        }
+        const int axA = sA >= 0 ? S.naxis[sA] : 0, axB = sB >= 0 ? S.naxis[sB] : 0;
+        const double spA = sA >= 0 ? S.nsplit[sA] : 0.0, spB = sB >= 0 ? S.nsplit[sB] : 0.0;
+        const bool full = sA >= 0 && sB < 0 && p0 >= bA && p0 + KT_E <= eA;      // all sixteen in one node: the usual thread
+        // ---- flags; the children's boxes
+        unsigned gebits = 0, inbits = 0;
+        double acc[2][6] = {{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}};
 #pragma unroll
         for (int k = 0; k < KT_E; k++) {
             const int p = p0 + k;
-            sl[k] = -1; nb_[k] = 0; ne_[k] = 0; ge[k] = false;
-            if (p < n)
-                for (int j = 0; j < nc; j++) { const int b = S.nb[cur][j], e = S.ne[cur][j]; if (p >= b && p < e) { sl[k] = j; nb_[k] = b; ne_[k] = e; } }
-            if (sl[k] >= 0) {
+            const bool inA = p >= bA && p < eA, inB = sB >= 0 && p >= bB && p < eB;
+            if (inA || inB) {
                 const double x = S.x[KT_SW(p)], y = S.y[KT_SW(p)], z = S.z[KT_SW(p)];
-                const int axis = S.naxis[sl[k]];
+                const int axis = inA ? axA : axB;
                 const double c = axis == 0 ? x : (axis == 1 ? y : z);
-                ge[k] = !(c < S.nsplit[sl[k]]);
-                cnt += ge[k] ? 1 : 0;
-                const int sd = ge[k] ? 1 : 0;
-                const unsigned long long kx_ = dkey(x), ky_ = dkey(y), kz_ = dkey(z);
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    if (t == sd) {
-                        key[t][0] = kx_ < key[t][0] ? kx_ : key[t][0]; key[t][1] = ky_ < key[t][1] ? ky_ : key[t][1]; key[t][2] = kz_ < key[t][2] ? kz_ : key[t][2];
-                        key[t][3] = ~kx_ < key[t][3] ? ~kx_ : key[t][3]; key[t][4] = ~ky_ < key[t][4] ? ~ky_ : key[t][4]; key[t][5] = ~kz_ < key[t][5] ? ~kz_ : key[t][5];
-                    }
+                const bool g = !(c < (inA ? spA : spB));
+                inbits |= 1u << k;
+                gebits |= g ? (1u << k) : 0u;
+                if (full) {
+                    // (v_min_f64 / v_max_f64 order -0 below +0 as the keys do)
+                    acc[0][0] = __builtin_fmin(acc[0][0], g ? INFINITY : x); acc[0][3] = __builtin_fmax(acc[0][3], g ? -INFINITY : x);
+                    acc[0][1] = __builtin_fmin(acc[0][1], g ? INFINITY : y); acc[0][4] = __builtin_fmax(acc[0][4], g ? -INFINITY : y);
+                    acc[0][2] = __builtin_fmin(acc[0][2], g ? INFINITY : z); acc[0][5] = __builtin_fmax(acc[0][5], g ? -INFINITY : z);
+                    acc[1][0] = __builtin_fmin(acc[1][0], g ? x : INFINITY); acc[1][3] = __builtin_fmax(acc[1][3], g ? x : -INFINITY);
+                    acc[1][1] = __builtin_fmin(acc[1][1], g ? y : INFINITY); acc[1][4] = __builtin_fmax(acc[1][4], g ? y : -INFINITY);
+                    acc[1][2] = __builtin_fmin(acc[1][2], g ? z : INFINITY); acc[1][5] = __builtin_fmax(acc[1][5], g ? z : -INFINITY);
+                } else {
+                    const int sl = inA ? sA : sB, sd = g ? 1 : 0;
+                    atomicMin(&S.cbox[sl][sd][0], dkey(x)); atomicMin(&S.cbox[sl][sd][1], dkey(y)); atomicMin(&S.cbox[sl][sd][2], dkey(z));
+                    atomicMax(&S.cbox[sl][sd][3], dkey(x)); atomicMax(&S.cbox[sl][sd][4], dkey(y)); atomicMax(&S.cbox[sl][sd][5], dkey(z));
                 }
-                first_sl = first_sl == -2 ? sl[k] : (first_sl == sl[k] ? first_sl : -3);
             }
         }
         {
-            // a wavefront's 256 positions sit in one node almost always (nodes here have more than wave_max members): then twelve
-            // wave minima and one lane's atomics; a wavefront across a boundary (or with members and non-members): every lane its own
-            const int ref = __builtin_amdgcn_readfirstlane(first_sl);
-            const bool uni = ref >= 0 && __all(first_sl == ref);
-            if (uni) {
+            // a 16-lane row's 256 positions sit in one node almost always: twelve row minima of keys, one lane's atomics; else each
+            // full lane its own.  All keys as minima (maxima inverted), as in k_kd_block.
+            unsigned long long key[2][6];
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) { key[sd][q] = full ? dkey(acc[sd][q]) : ~0ull; key[sd][3 + q] = full ? ~dkey(acc[sd][3 + q]) : ~0ull; }
+            const int rs = row_bcast_i<0>(full ? sA : -1);
+            const unsigned long long um = __ballot(full && sA == rs);
+            const bool row_uni = ((um >> (lane & 48)) & 0xffffull) == 0xffffull;
+            if (row_uni) {
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++)
 #pragma unroll
-                    for (int q = 0; q < 6; q++) key[sd][q] = kb_key_min<true>(key[sd][q]);
-                if (lane == 0)
-                    for (int sd = 0; sd < 2; sd++)
-                        for (int q = 0; q < 3; q++) { atomicMin(&S.cbox[ref][sd][q], key[sd][q]); atomicMax(&S.cbox[ref][sd][3 + q], ~key[sd][3 + q]); }
-            } else {
-#pragma unroll
-                for (int k = 0; k < KT_E; k++) {
-                    if (sl[k] >= 0) {
-                        const int p = p0 + k, sd = ge[k] ? 1 : 0;
-                        const unsigned long long kx_ = dkey(S.x[KT_SW(p)]), ky_ = dkey(S.y[KT_SW(p)]), kz_ = dkey(S.z[KT_SW(p)]);
-                        atomicMin(&S.cbox[sl[k]][sd][0], kx_); atomicMin(&S.cbox[sl[k]][sd][1], ky_); atomicMin(&S.cbox[sl[k]][sd][2], kz_);
-                        atomicMax(&S.cbox[sl[k]][sd][3], kx_); atomicMax(&S.cbox[sl[k]][sd][4], ky_); atomicMax(&S.cbox[sl[k]][sd][5], kz_);
-                    }
-                }
+                    for (int q = 0; q < 6; q++) key[sd][q] = kb_key_min<false>(key[sd][q]);
+            }
+            if (full && (!row_uni || (lane & 15) == 0)) {
+                for (int sd = 0; sd < 2; sd++)
+                    for (int q = 0; q < 3; q++) { atomicMin(&S.cbox[sA][sd][q], key[sd][q]); atomicMax(&S.cbox[sA][sd][3 + q], ~key[sd][3 + q]); }
             }
         }
+        // ---- block scan of the flags
+        const int cnt = __popc(gebits);
         const int incl = wave_incl_scan_i32(cnt);
         if (lane == 63) S.wtot[wid] = incl;
         __syncthreads();
+        int excl;
         {
             const int wv = lane < KT_T / 64 ? S.wtot[lane] : 0;
             const int wscan = wave_incl_scan_i32(wv);
             const int wbase = wid > 0 ? __builtin_amdgcn_readlane(wscan, wid - 1) : 0;
-            int run = wbase + incl - cnt;
+            excl = wbase + incl - cnt;
+            int run = excl;
 #pragma unroll
-            for (int k = 0; k < KT_E; k++) { run += ge[k] ? 1 : 0; if (p0 + k < n) S.ps[p0 + k] = (unsigned short)run; }
+            for (int k = 0; k < KT_E; k++) { run += (gebits >> k) & 1u; if (p0 + k < n) S.ps[KT_SW(p0 + k)] = (unsigned short)run; }
         }
         __syncthreads();
         // ---- L = #(members < split); the m-th member "< split" of the right part counted from the right
-        int L_[KT_E], G_[KT_E];
+        int pbA = 0, LA = 0, pbB = 0, LB = 0;
+        if (sA >= 0) { pbA = bA > 0 ? (int)S.ps[KT_SW(bA - 1)] : 0; LA = (eA - bA) - ((int)S.ps[KT_SW(eA - 1)] - pbA); }
+        if (sB >= 0) { pbB = bB > 0 ? (int)S.ps[KT_SW(bB - 1)] : 0; LB = (eB - bB) - ((int)S.ps[KT_SW(eB - 1)] - pbB); }
+        {
+            int run = excl;
 #pragma unroll
-        for (int k = 0; k < KT_E; k++) {
-            L_[k] = 0; G_[k] = 0;
-            if (sl[k] >= 0) {
-                const int p = p0 + k, b = nb_[k], e = ne_[k];
-                const int pb = b > 0 ? (int)S.ps[b - 1] : 0;
-                L_[k] = (e - b) - ((int)S.ps[e - 1] - pb);
-                G_[k] = (int)S.ps[p] - pb;
-                if (!ge[k] && p >= b + L_[k]) S.mr[b + (L_[k] - ((p - b + 1) - G_[k]))] = (unsigned short)p;
+            for (int k = 0; k < KT_E; k++) {
+                const int p = p0 + k;
+                const bool g = (gebits >> k) & 1u;
+                run += g ? 1 : 0;
+                if ((inbits >> k) & 1u) {
+                    const bool inA = p >= bA && p < eA;
+                    const int b = inA ? bA : bB, L = inA ? LA : LB, G = run - (inA ? pbA : pbB);
+                    if (!g && p >= b + L) S.mr[b + (L - ((p - b + 1) - G))] = (unsigned short)p;
+                }
             }
         }
         __syncthreads();
         // ---- the swaps (kdTree.py:108-111) by position; node records and children (kdTree.py:112-122), one lane per node
+        {
+            int run = excl;
 #pragma unroll
-        for (int k = 0; k < KT_E; k++) {
-            const int p = p0 + k;
-            if (sl[k] >= 0 && ge[k] && p < nb_[k] + L_[k]) {
-                const int q = S.mr[nb_[k] + G_[k] - 1];
-                const int ip = S.id[p]; S.id[p] = S.id[q]; S.id[q] = ip;
-                double t;
-                t = S.x[KT_SW(p)]; S.x[KT_SW(p)] = S.x[KT_SW(q)]; S.x[KT_SW(q)] = t;
-                t = S.y[KT_SW(p)]; S.y[KT_SW(p)] = S.y[KT_SW(q)]; S.y[KT_SW(q)] = t;
-                t = S.z[KT_SW(p)]; S.z[KT_SW(p)] = S.z[KT_SW(q)]; S.z[KT_SW(q)] = t;
+            for (int k = 0; k < KT_E; k++) {
+                const int p = p0 + k;
+                const bool g = (gebits >> k) & 1u;
+                run += g ? 1 : 0;
+                if (g && ((inbits >> k) & 1u)) {
+                    const bool inA = p >= bA && p < eA;
+                    const int b = inA ? bA : bB, L = inA ? LA : LB, G = run - (inA ? pbA : pbB);
+                    if (p < b + L) {
+                        const int q = S.mr[b + G - 1];
+                        const int ip = S.id[KT_SW(p)]; S.id[KT_SW(p)] = S.id[KT_SW(q)]; S.id[KT_SW(q)] = ip;
+                        double t;
+                        t = S.x[KT_SW(p)]; S.x[KT_SW(p)] = S.x[KT_SW(q)]; S.x[KT_SW(q)] = t;
+                        t = S.y[KT_SW(p)]; S.y[KT_SW(p)] = S.y[KT_SW(q)]; S.y[KT_SW(q)] = t;
+                        t = S.z[KT_SW(p)]; S.z[KT_SW(p)] = S.z[KT_SW(q)]; S.z[KT_SW(q)] = t;
+                    }
+                }
             }
         }
         if (tid < nc) {
             const int b = S.nb[cur][tid], e = S.ne[cur][tid], node = S.nnode[cur][tid], par = S.npar[cur][tid];
-            const int pb = b > 0 ? (int)S.ps[b - 1] : 0;
-            const int L = (e - b) - ((int)S.ps[e - 1] - pb);
+            const int pb = b > 0 ? (int)S.ps[KT_SW(b - 1)] : 0;
+            const int L = (e - b) - ((int)S.ps[KT_SW(e - 1)] - pb);
             const int lf = L == 0 ? 1 : L;                               // degenerate: every member on the split plane
             KdNode nd;
             nd.begin = b; nd.end = e; nd.left = node + 1; nd.right = node + 2 * lf;
@@ -964,13 +992,11 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
             }
         }
         __syncthreads();
-        if (tid == 0) { S.count[cur] = 0; if (S.count[nxt] > KT_NODES) S.count[nxt] = KT_NODES; }
-        __syncthreads();
         cur = nxt;
     }
     __syncthreads();
     for (int i = tid; i < n; i += KT_T) {
-        d.aperm[i] = S.id[i];
+        d.aperm[i] = S.id[KT_SW(i)];
         s.kx[i] = S.x[KT_SW(i)]; s.ky[i] = S.y[KT_SW(i)]; s.kz[i] = S.z[KT_SW(i)];
     }
 }
