@@ -16,6 +16,8 @@
 //   k_kd_lv_*   : two launches per tree level for the nodes with more than wave_max members; a node is cut into
 //                 chunks of KD_CHUNK positions, one workgroup per chunk: (flags + chained scan + ranks + children's
 //                 boxes) -> (swaps + query record + children and their chunk records)
+//   k_kd_top    : (trees of <= 4096 members, round 4) the nodes with more than wave_max members by ONE workgroup in LDS instead of
+//                 the level passes
 //   k_kd_block  : every subtree of <= wave_max members is finished by ONE WORKGROUP entirely in LDS, level by level,
 //                 all nodes of a level at once (element-parallel; boxes as DPP minima of order-preserving keys, LDS
 //                 atomics for what is left, one lane per node for the records)
