@@ -979,8 +979,11 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
     // -> 0.268 ms; c3 (no tracker, 4 against 8 subtrees) the other way round: 0.127 against 0.129
     // a tree of up to KT_M members: its top by one workgroup in LDS (k_kd_top), which is cheap enough per level to go one level
     // further down than the level passes would -- subtrees of ~512 instead of ~1024 members for k_kd_block
-    const bool top = c->kd_top && n <= KT_M && c->kd_tail_level < 0;
-    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : (top ? 768 : ((c->trk_on && c->trk_in_pass && ks != c->stream) ? 1024 : KD_WAVE_CAP));
+    // (not beside the tracker's re-plans, whose ~250-register wavefronts sit on every SIMD: a workgroup of sixteen wavefronts and 139 KB
+    // of LDS then waits for room and for issue slots -- measured as a middle tier under the level passes: 60 us instead of 30 at c5)
+    const bool beside = c->trk_on && c->trk_in_pass && ks != c->stream;
+    const bool top = c->kd_top && n <= KT_M && c->kd_tail_level < 0 && !beside;
+    const int cap = c->kd_wave_cap > 0 ? c->kd_wave_cap : (top ? 768 : (beside ? 1024 : KD_WAVE_CAP));
     int wave_max = (n <= 1024 && cap >= 1024) ? 1024 : cap; // a tree that fits one workgroup: the smaller one if it can
     if (n > cap) {
         double sz = (double)n;

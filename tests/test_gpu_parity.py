@@ -219,7 +219,7 @@ def test_resident_steps_match_stepwise_oracle(S, oracle):
 
 
 @pytest.mark.parametrize('cap', ['default', '1024', '768', '512', '256', 'levels'])
-@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 127, 128, 129, 200, 257, 300, 1000, 1024, 1025, 1500, 1536, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 40000])
+@pytest.mark.parametrize('n', [1, 7, 10, 11, 64, 127, 128, 129, 200, 257, 300, 1000, 1024, 1025, 1500, 1536, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 9000, 16384, 40000])
 def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
     """K0: the kd-tree built on the device (nodes, boxes, permutation) against the sequential host replica of
     kdTree.py:60-122, over several consecutive rebuilds (the permutation is history dependent).  `cap`: the largest subtree one
@@ -234,7 +234,7 @@ def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
             pytest.skip('the level passes of trees that k_kd_top takes by default')
         monkeypatch.setenv('SCA_KD_TOP', '0')
     elif cap != 'default':
-        if n in (1, 7, 10, 11, 64, 127, 200, 1024, 2049, 4095, 4097):
+        if n in (1, 7, 10, 11, 64, 127, 200, 1024, 2049, 4095, 4097, 9000):
             pytest.skip('the smaller caps are exercised on a subset of the sizes')
         monkeypatch.setenv('SCA_KD_WAVE_CAP', cap)
     rng = np.random.default_rng(n)
