@@ -593,8 +593,8 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         const bool on = node >= 0 && node < avail && valid && (gA & am) == ab && (gV & am) == am;
         const int child = (int)((me.x >> (acc ? 16 : 21)) & 31u);
         const bool last = on && !(child > 0 && child <= avail && ((gV >> (child - 1)) & 1u));
-        const unsigned gL = (quad_bits(__ballot(last)) >> sh) & gm;       // exactly one node
-        const int src = base + 4 * (QOFF + __ffs((int)gL) - 1);
+        const unsigned gL = (quad_bits(__ballot(last)) >> sh) & gm;       // exactly one node (were it none, the root alone: its verdict always holds)
+        const int src = base + 4 * (QOFF + (gL ? __ffs((int)gL) - 1 : 0));
         double Lb, Ls, Lc, Llen, Lseen;
         int Lacc, Lplen;
         unsigned Lbits;
