@@ -69,3 +69,60 @@ def test_trees_beat_the_balanced_tree_on_the_recorded_searches():
         m = re.search(r'(\d+) candidates per round: ([\d.]+) steps .*balanced tree: ([\d.]+)', line)
         nodes, got, bal = int(m.group(1)), float(m.group(2)), float(m.group(3))
         assert got > bal * {15: 1.5, 7: 1.4, 3: 1.2}[nodes], line
+
+
+def test_all_nodes_walk_on_the_recorded_searches():
+    """The device's walk (sca_tracker.hip.h, plan3d_spec) restated on the tables: every node forms the verdict it would get on the
+    path, the path is the set of nodes whose ancestors' verdicts are the ones their paths assume, it ends at the one node whose
+    verdict leads out of the tree -- and that must advance every recorded search exactly as the sequential loop does.  Nodes off
+    the path get random verdicts and random validity (they hold candidates the loop never tries)."""
+    import json
+    import random
+    consts, tabs = _tables()
+    run, prev, prev2 = consts['RUN_CAP'], consts['PREV_CAP'], consts['PREV2_CAP']
+    data = json.load(open(os.path.join(ROOT, 'tools', 'data', 'radius_search_outcomes.json')))
+    rnd = random.Random(5)
+    for nodes, t in tabs.items():
+        slots = t['slots']
+        rounds = 0
+        for fam in sorted(data):
+            for s in data[fam][::3]:
+                i = 0
+                ck = cr = cp = cq = 0
+                while i < len(s):
+                    tree = t['of_ctx'][((ck * (run + 1) + min(cr, run)) * (prev + 1) + min(cp, prev)) * (prev2 + 1) + min(cq, prev2)]
+                    w = t['words'][tree * slots * 2:(tree + 1) * slots * 2]
+                    first, second = w[0::2], w[1::2]
+                    acc, valid = [], []
+                    for q in range(slots):
+                        n = (first[q] >> 12) & 15
+                        path = ''.join('S' if (first[q] >> k) & 1 else 'F' for k in range(n))
+                        on_path = s[i:i + n] == path
+                        if on_path and i + n < len(s):
+                            acc.append(s[i + n] == 'S'); valid.append(True)
+                        elif on_path:
+                            acc.append(rnd.random() < 0.5); valid.append(False)          # behind the loop's end
+                        else:
+                            acc.append(rnd.random() < 0.5); valid.append(rnd.random() < 0.9)
+                    ga = sum(1 << q for q in range(slots) if acc[q])
+                    gv = sum(1 << q for q in range(slots) if valid[q])
+                    last = []
+                    for q in range(slots - 1):
+                        am, ab = second[q] & 0xffff, second[q] >> 16
+                        on = valid[q] and (ga & am) == ab and (gv & am) == am
+                        child = (first[q] >> (16 if acc[q] else 21)) & 31
+                        if on and not (child > 0 and (gv >> (child - 1)) & 1):
+                            last.append(q)
+                    assert len(last) == 1, (nodes, fam, i, last)
+                    n = (first[last[0]] >> 12) & 15
+                    got = ''.join('S' if (first[last[0]] >> k) & 1 else 'F' for k in range(n)) + ('S' if acc[last[0]] else 'F')
+                    assert got == s[i:i + n + 1], (nodes, fam, i, got)
+                    for ch in got:
+                        kind = 1 if ch == 'S' else 2
+                        if kind == ck:
+                            cr += 1
+                        else:
+                            cq, cp, cr, ck = cp, cr, 1, kind
+                    i += n + 1
+                    rounds += 1
+        assert rounds > 500
