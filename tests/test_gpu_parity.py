@@ -272,6 +272,50 @@ def test_device_kd_build_matches_host_replica(S, n, cap, monkeypatch):
     sol.close()
 
 
+@pytest.mark.parametrize('top', ['top', 'levels'])
+@pytest.mark.parametrize('n', [1500, 3000, 4096, 9000])
+def test_device_kd_build_of_coincident_points(S, n, top, monkeypatch):
+    """Every member on the split plane (kdTree.py:113-116 then puts one member left, the rest right, and both children keep the
+    parent's box): a swarm that is ONE point, and one made of a few points with hundreds of members each -- through k_kd_top, the
+    level passes and k_kd_block alike."""
+    import ctypes as C
+    from sca_amd import _lib
+    L = _lib.lib()
+    if top == 'levels':
+        monkeypatch.setenv('SCA_KD_TOP', '0')
+    rng = np.random.default_rng(n)
+    for kind in ('one', 'few'):
+        pos = np.tile(np.array([[3.0, -2.0, 7.0]]), (n, 1)) if kind == 'one' else rng.integers(-2, 3, (7, 3)).astype(np.float64)[rng.integers(0, 7, n)]
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), np.zeros((n, 3)), np.full(n, 1, np.uint8))
+        href = rng.permutation(n).astype(np.int32)
+        sol.set_kd_perm(href.copy())
+        # thousands of members on ONE point are a chain as deep as the swarm is large: the level passes give up after 40 levels and say so
+        # (the reference's recursion would have hit Python's limit at 1000); k_kd_top and k_kd_block walk any depth
+        hopeless = kind == 'one' and n > 1536 and (top == 'levels' or n > 4096)
+        for it in range(2):
+            sol.set_state(pos, np.full((n, 3), 0.3, np.float32), np.zeros((n, 3)), np.zeros(n, np.uint8))
+            if hopeless:
+                with pytest.raises(S.ScaError, match='code 16'):
+                    sol.policy_pass(S.NBR_KDTREE)
+                break
+            sol.policy_pass(S.NBR_KDTREE)
+            t_dev = sol.get_kd_tree()
+            t_ref = np.zeros((2 * n - 1, 10))
+            assert L.sca_kd_build_host(n, _lib.ptr(pos, C.c_double), _lib.ptr(href, C.c_int32), _lib.ptr(t_ref, C.c_double)) == 0
+            assert np.array_equal(sol.get_kd_perm(), href), (n, kind, it)
+            used = np.zeros(2 * n - 1, bool)
+            stack = [0]
+            while stack:
+                i = stack.pop()
+                used[i] = True
+                if t_ref[i, 1] - t_ref[i, 0] > 10:
+                    stack += [int(t_ref[i, 2]), int(t_ref[i, 3])]
+            assert np.array_equal(t_dev[used], t_ref[used]), (n, kind, it)
+        sol.close()
+
+
 @pytest.mark.parametrize('n,force', [(300000, True), (2300000, False)])
 def test_kd_level_chunks_taken_by_arrival(S, n, force, monkeypatch):
     """k_kd_lv_rank<true>: a level pass whose workgroups take their chunk by arrival instead of by block index (ADVICE r1 #5 /
