@@ -367,6 +367,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
             if ((int)(threadIdx.x & 63) == leader) {
                 const int seen = __atomic_load_n(d.kdq_count, __ATOMIC_RELAXED);        // (a stale value only costs an atomic)
                 base = seen > d.kdq_cap ? -1 : atomicAdd(d.kdq_count, __popcll(am));
+                if ((__atomic_load_n(d.kdq_busy, __ATOMIC_RELAXED) & 1u) == 0) atomicOr(d.kdq_busy, 1u);   // somebody is listed: the pass waits for the kd query
             }
             base = __shfl(base, leader);
             if (again && gl == 0 && base >= 0) {

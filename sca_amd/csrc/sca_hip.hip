@@ -240,7 +240,7 @@ struct sca_ctx {
     hipEvent_t ev_auto_fork = nullptr, ev_auto_k1g = nullptr, ev_auto_kd = nullptr, ev_auto_moved = nullptr, ev_auto_cnt = nullptr;
     int32_t *kdq_list = nullptr, *kdq_count = nullptr;
     int *auto_ticket = nullptr;         // k_neighbors_kd_auto's last-workgroup ticket
-    unsigned *auto_ready = nullptr;     // device word: the last AUTO pass whose lists are final (k_auto_ready; hipStreamWaitValue32)
+    unsigned *auto_busy = nullptr;      // device word, bit 0: somebody is listed for the kd query and it has not answered yet (hipStreamWaitValue32)
     unsigned auto_seq = 0;
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
     hipEvent_t ev_auto_kdq[2] = {nullptr, nullptr};      // behind the kd query of the last pass of either parity (its list is reused two passes on)
@@ -733,7 +733,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->kdq_list) (void)hipFree(c->kdq_list);
     if (c->kdq_count) (void)hipFree(c->kdq_count);
     if (c->kdq_host) (void)hipHostFree(c->kdq_host);
-    if (c->auto_ready) (void)hipFree(c->auto_ready);
+    if (c->auto_busy) (void)hipFree(c->auto_busy);
     if (c->auto_ticket) (void)hipFree(c->auto_ticket);
     for (hipEvent_t e : c->ev_auto_gather) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_auto_kdq) if (e) (void)hipEventDestroy(e);
@@ -1225,8 +1225,8 @@ static int auto_prepare(sca_ctx *c) {
     CHK(c, hipMalloc((void **)&c->kdq_list, 2 * sizeof(int32_t) * (size_t)c->max_n));
     CHK(c, hipMalloc((void **)&c->kdq_count, 2 * sizeof(int32_t)));
     CHK(c, hipMemsetAsync(c->kdq_count, 0, 2 * sizeof(int32_t), c->stream));
-    CHK(c, hipMalloc((void **)&c->auto_ready, sizeof(unsigned)));
-    CHK(c, hipMemsetAsync(c->auto_ready, 0, sizeof(unsigned), c->stream));
+    CHK(c, hipMalloc((void **)&c->auto_busy, sizeof(unsigned)));
+    CHK(c, hipMemsetAsync(c->auto_busy, 0, sizeof(unsigned), c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
     CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
@@ -1235,7 +1235,7 @@ static int auto_prepare(sca_ctx *c) {
     c->auto_seq = 0; c->auto_builds = 0;
     c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
     CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
-    c->d.kdq_list = c->kdq_list; c->d.kdq_count = c->kdq_count;
+    c->d.kdq_list = c->kdq_list; c->d.kdq_count = c->kdq_count; c->d.kdq_busy = c->auto_busy;
     c->kdq_pending = false; c->kdq_last = -1; c->auto_backoff = 0; c->kd_ahead = false;
     return 0;
 }
@@ -1404,18 +1404,11 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (auto_mode) {
         // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
         // build on kd_stream, and nothing reads a list before that query is through
-        if (c->auto_seq >= 0xfffffff0u) {                              // (the hand-shake word counts passes: start over long before it wraps)
-            CHK(c, hipStreamSynchronize(ns)); CHK(c, hipStreamSynchronize(c->kd_stream)); CHK(c, hipStreamSynchronize(c->stream));
-            CHK(c, hipMemsetAsync(c->auto_ready, 0, sizeof(unsigned), c->stream));
-            CHK(c, hipStreamSynchronize(c->stream));
-            c->auto_seq = 0;
-        }
-        const unsigned seq = ++c->auto_seq;
-        if (c->auto_waitvalue) hipLaunchKernelGGL(k_auto_ready, dim3(1), dim3(1), 0, ns, d.kdq_count, c->auto_ready, seq, 1);
+        const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
         CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
         CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));
         hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius,
-                           c->auto_ready, seq, c->auto_ticket);
+                           c->auto_ticket);
         if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
             CHK(c, hipMemcpyAsync(c->kdq_host, d.kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
@@ -1424,8 +1417,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipEventRecord(c->ev_auto_kd, c->kd_stream));
         CHK(c, hipEventRecord(c->ev_auto_kdq[seq & 1u], c->kd_stream));
         if (c->auto_waitvalue) {
-            // lists final: at once when the grid query listed nobody, else behind the kd query (see k_auto_ready)
-            if (hipStreamWaitValue32(ns, c->auto_ready, seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+            // lists final: at once when the grid query listed nobody, else behind the kd query (see k_neighbors_kd_auto)
+            if (hipStreamWaitValue32(ns, c->auto_busy, 0u, hipStreamWaitValueEq, 1u) != hipSuccess) {
                 (void)hipGetLastError();                              // a platform without stream memory operations: the event wait from now on
                 c->auto_waitvalue = false;
                 CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));

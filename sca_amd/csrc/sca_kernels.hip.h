@@ -119,6 +119,7 @@ struct DeviceView {
     int32_t *kdq_list;       // [n]
     int32_t *kdq_count;      // [1] how many the grid query listed; more than kdq_cap: "too many for a list" -- the list is then incomplete and
     int kdq_cap;             //     the kd query of EVERY agent of the shard runs instead (k_neighbors_kd_auto)
+    unsigned *kdq_busy;      // [1] bit 0: the grid query of this pass listed somebody and the kd query has not answered yet (the pass's stream waits for 0)
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
                              // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
 };
@@ -504,21 +505,22 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
 }
 
 // SCA_NBR_AUTO: the kd query behind the build, ONE launch on the build's stream: nobody listed by the grid query (the usual case) --
-// the word the pass may be waiting for is set and that is all; a list of up to kdq_cap agents -- one wavefront each, a fixed grid
-// striding over the list; more ("too many for a list": the list is incomplete) -- every agent of the shard the same way, i.e. a whole
-// kd pass's query.  The last workgroup to finish sets the word (see k_auto_ready).  Overwrites everything the grid query left for
-// the agents it queries.
+// nothing to do; a list of up to kdq_cap agents -- one wavefront each, a fixed grid striding over the list; more ("too many for a list":
+// the list is incomplete) -- every agent of the shard the same way, i.e. a whole kd pass's query.  Overwrites everything the grid query
+// left for the agents it queries.
+// The hand-shake: one word in device memory, bit 0 = "the grid query of this pass listed somebody and the kd query has not answered
+// yet" -- set by the grid query's listing wavefronts, cleared by the last workgroup here.  The stream that goes on to the solve waits
+// for the bit to be clear with hipStreamWaitValue32: a wait that costs nothing when nobody was listed, which is what keeps the kd
+// build (beside, on its own stream) off the pass's critical path in the common case.  (Until late in round 4 a word counting passes,
+// and a one-lane launch behind the grid query to advance it when nobody was listed: 4 us + its gap on every pass's path.)
 constexpr int KDQ_BLOCKS = 1024;
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView d, Params P, double agent_reach, double obs_reach,
-                                                                     double max_radius, unsigned *ready, unsigned seq, int *ticket) {
+                                                                     double max_radius, int *ticket) {
     __shared__ double rstacks[K1_WAVES][KD_RSTACK][16];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = *d.kdq_count;
-    if (n == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(ready, seq);
-        return;
-    }
+    if (n == 0) return;
     if (n <= d.kdq_cap) {
         for (int i = (int)blockIdx.x * K1_WAVES + wid; i < n; i += KDQ_BLOCKS * K1_WAVES)
             neighbors_one(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], d.kdq_list[i], lane);
@@ -529,16 +531,8 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView 
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) { *ticket = 0; __threadfence(); atomicMax(ready, seq); }
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) { *ticket = 0; __threadfence(); atomicAnd(d.kdq_busy, ~1u); }
     }
-}
-
-// SCA_NBR_AUTO's hand-shake: `ready` (one word in device memory) holds the number of the last pass whose lists are final.  Behind
-// the grid query: final already when nobody was listed for the kd query; behind the kd query: final in any case.  The stream that
-// goes on to the solve waits for the word with hipStreamWaitValue32 -- a wait that costs nothing when the word is already there,
-// which is what keeps the kd build (beside, on its own stream) off the pass's critical path in the common case.
-__global__ void k_auto_ready(const int32_t *kdq_count, unsigned *ready, unsigned seq, int only_if_empty) {
-    if (!only_if_empty || *kdq_count == 0) atomicMax(ready, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
