@@ -1407,8 +1407,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
         CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
         CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));
-        hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius,
-                           c->auto_ticket);
+        hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P,
+                           agent_reach, obs_reach, c->max_radius, c->auto_ticket);
         if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
             CHK(c, hipMemcpyAsync(c->kdq_host, d.kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));

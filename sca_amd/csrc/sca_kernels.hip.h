@@ -513,7 +513,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
 // for the bit to be clear with hipStreamWaitValue32: a wait that costs nothing when nobody was listed, which is what keeps the kd
 // build (beside, on its own stream) off the pass's critical path in the common case.  (Until late in round 4 a word counting passes,
 // and a one-lane launch behind the grid query to advance it when nobody was listed: 4 us + its gap on every pass's path.)
-constexpr int KDQ_BLOCKS = 1024;
+constexpr int KDQ_BLOCKS = 1024, KDQ_BLOCKS_FEW = 64;   // (the few: while the counts that came back say a wavefront each is enough -- an empty launch of 64 workgroups is half as long)
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                      double max_radius, int *ticket) {
     __shared__ double rstacks[K1_WAVES][KD_RSTACK][16];
@@ -522,10 +522,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView 
     const int n = *d.kdq_count;
     if (n == 0) return;
     if (n <= d.kdq_cap) {
-        for (int i = (int)blockIdx.x * K1_WAVES + wid; i < n; i += KDQ_BLOCKS * K1_WAVES)
+        for (int i = (int)blockIdx.x * K1_WAVES + wid; i < n; i += (int)gridDim.x * K1_WAVES)
             neighbors_one(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], d.kdq_list[i], lane);
     } else {
-        for (int i = (int)blockIdx.x * K1_WAVES + wid; i < d.shard_count; i += KDQ_BLOCKS * K1_WAVES)
+        for (int i = (int)blockIdx.x * K1_WAVES + wid; i < d.shard_count; i += (int)gridDim.x * K1_WAVES)
             neighbors_one(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], d.shard_begin + i, lane);
     }
     __syncthreads();
