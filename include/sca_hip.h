@@ -206,7 +206,7 @@ int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
 /* Which kernel forms the last policy pass was launched with (the library picks them per pass from the shard size and the
  * re-plan count of a recent pass; none of them changes a result bit -- tests/test_gpu_solve_split.py, test_gpu_tracker.py):
  *   SCA_FORM_SOLVE_SPLIT   k_solve as k_solve_sweep (beside the tracker's re-plans) + k_solve_pick4 (behind them)
- *   SCA_FORM_TRACK_FUSED   k_track_replan instead of k_track + k_replan
+ *   SCA_FORM_TRACK_FUSED   k_track_replan instead of k_track + k_replan (with SCA_FORM_REPLAN_FEW: k_track_group, decision + 64-lane search per agent)
  *   SCA_FORM_REPLAN_LANE   the lane-per-plan re-plan kernel was launched (k_replan or k_track_replan)
  *   SCA_FORM_REPLAN_FEW    a k_replan_group kernel (4 .. 64 lanes per plan) was launched
  *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent)

@@ -255,6 +255,7 @@ struct sca_ctx {
     bool kd_ahead = false;              // the kd build of the NEXT pass is already enqueued on kd_stream (sca_run_steps, behind the integrate stage)
     unsigned auto_passes = 0;
     int kd_wave_cap = 0;                // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536); 0: chosen per pass
+    bool trk_group_fuse = true;         // k_track_group (decision + 64-lane search in one launch) for shards of <= TRK_SPEC4_MAX agents; SCA_TRACKER_NOGROUPFUSE=1: never
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
     unsigned prof_tick = 0;             // with profiling on, every 16th pass carries the event pairs (six records, ~35 us on that pass)
     bool trk_serial = false;            // SCA_TRACKER_SERIAL=1: everything on one stream (diagnostics)
@@ -554,6 +555,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_passes = 0;
     c->trk_serial = getenv("SCA_TRACKER_SERIAL") != nullptr;
     c->trk_quad = getenv("SCA_TRACKER_NOQUAD") == nullptr;
+    c->trk_group_fuse = getenv("SCA_TRACKER_NOGROUPFUSE") == nullptr;   // k_track_group for shards of <= TRK_SPEC4_MAX agents
     c->trk_fuse = getenv("SCA_TRACKER_FUSE") != nullptr;          // k_track_replan (no list, hence no ordering by expected length): opt-in since round 3
     c->trk.mid_max = getenv("SCA_TRK_MID_MAX") ? atoi(getenv("SCA_TRK_MID_MAX")) : per_simd(c, TRK_MID_MAX);
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : per_simd(c, TRK_SPEC2_MAX);
@@ -1133,8 +1135,11 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     if (nwant == 0) { want[4] = true; nwant = 1; }
     const bool lane = want[4];
     const bool fused = in_pass && lane && nwant == 1 && c->trk_fuse && !c->part_on && (long long)lc * 4 >= (long long)cnt * 3;
-    c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (nwant > (lane ? 1 : 0) ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
-    if (!fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
+    // a shard of so few agents that each can have a wavefront (and a SIMD): decision and search in one launch (k_track_group)
+    const bool group_fused = in_pass && c->trk_quad && c->trk_group_fuse && !c->part_on && cnt <= K.spec4_max;
+    if (group_fused) c->forms |= SCA_FORM_TRACK_FUSED | SCA_FORM_REPLAN_FEW;
+    else c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (nwant > (lane ? 1 : 0) ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
+    if (!fused && !group_fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
     hipStream_t rs = c->stream;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->profiling && (c->prof_tick & 15u) == 0 && c->pool_trk_used + 2 <= 2 * 4096) {
@@ -1144,7 +1149,11 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
         }
         CHK(c, hipEventRecord(t0, rs));
     }
-    if (fused) {
+    if (group_fused) {
+        K.lo = -1; K.hi = INT_MAX;
+        hipLaunchKernelGGL(k_track_group, dim3((unsigned)(((long long)cnt * 64 + TRK_GROUP_THREADS - 1) / TRK_GROUP_THREADS)), dim3(TRK_GROUP_THREADS), 0,
+                           rs, c->d, c->trk_view, K);
+    } else if (fused) {
         K.lo = -1; K.hi = INT_MAX;
         hipLaunchKernelGGL(k_track_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
                            c->trk_view, K);

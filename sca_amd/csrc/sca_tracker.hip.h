@@ -738,6 +738,46 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_repla
     }
 }
 
+// k_track + k_replan_group<64> in ONE launch for shards of so few agents that every AGENT can have a wavefront (round 4): the
+// wavefront's first lane takes the follow-or-re-plan decision (k_track's chain of restated-libm calls, ~10 us, which a launch of its own
+// only pads with its tables and its gap), then the whole wavefront searches if the agent re-plans -- no list, no order by expected length
+// (every plan has a SIMD of its own anyway).  Counts the re-plans for the host's choice of forms as k_track does.
+__global__ __launch_bounds__(TRK_GROUP_THREADS, 1) void k_track_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    __shared__ SpecLds<4> TR;
+    spec_trees_load<4>(TR);                                              // (the barrier that ends lds_tables_load covers them)
+    sca_gm::lds_tables_load();
+    if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < TRK_BUCKETS) K.bcount[((K.parity + 1) & 3) * TRK_BUCKETS + threadIdx.x] = 0;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gid >> 6, sub = gid & 3, lane = threadIdx.x & 63;
+    if (idx >= shard_size(d)) return;                                    // whole wavefronts leave together
+    const int agent = shard_agent(d, idx);
+    if (!track_active(d, agent)) return;
+    const PubRec r = d.rec[agent];
+    const double pos[3] = {r.px, r.py, r.pz};
+    sca_dubins::AgentTrack &a = K.st[agent];
+    double dif[3] = {0, 0, 0}, V[3];
+    int replan = 0;
+    if (lane == 0) {
+        const float vel[3] = {r.vx, r.vy, r.vz};
+        replan = sca_dubins::track_decide(T, a, agent, pos, vel, K.nbr0[agent], dif) ? 1 : 0;
+        if (!replan) {
+            sca_dubins::track_finish(T, a, agent, pos, dif, V);
+            track_store(d, K, agent, V);
+        } else atomicAdd(&K.count[K.parity], 1);
+    }
+    if (__builtin_amdgcn_readfirstlane(replan) == 0) return;
+    const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
+    double qi[5], qf[5];
+    sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    const sca_dubins::Plan3D P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane, TR);
+    if (lane != 0) return;
+    sca_dubins::track_adopt(a, P, pos, dif);
+    sca_dubins::track_finish(T, a, agent, pos, dif, V);
+    track_store(d, K, agent, V);
+}
+
 // self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them: 0-4 the
 // branch-free forms the kernels use, 5-8 the literal restatements, 9 / 10 the two results of the fused sincos)
 __global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, const double *b, int n, double *out) {

@@ -391,3 +391,38 @@ def test_device_planner_long_range_kats(family, form, monkeypatch):
         assert o[1] == k['tpq'][i, 0] and o[2] == k['tpq'][i, 1] and o[5] == k['tpq'][i, 3] and o[6] == k['tpq'][i, 4], (family, form, i)
         assert o[9] == k['sampling'][i] and int(o[13]) == k['n'][i], (family, form, i)
     sol.close()
+
+
+def test_group_fused_form_gives_the_same_episode(monkeypatch):
+    """k_track_group (round 4: shards of <= 1024 agents take the follow-or-re-plan decision and the 64-lane search in ONE launch, a
+    wavefront per agent) against k_track + k_replan_group<64> (SCA_TRACKER_NOGROUPFUSE=1): state, v_pref, re-plan counters equal after
+    every step of a crossing with followers, re-planners, arrivals and agents of an untracked policy."""
+    from sca_amd import scenarios, solver as S
+    n = 700
+    sc = scenarios.circle(n)
+    pol = np.where(np.arange(n) % 7 == 3, 2, 0).astype(np.uint8)          # SCA, every seventh agent S-RVO3D (not tracked)
+    sols = []
+    for nofuse in ('1', None):
+        if nofuse:
+            monkeypatch.setenv('SCA_TRACKER_NOGROUPFUSE', nofuse)
+        else:
+            monkeypatch.delenv('SCA_TRACKER_NOGROUPFUSE', raising=False)
+        sol = S.BatchedSolver(max_agents=n)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
+                       scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])                     # reads the switch
+        sols.append(sol)
+    plain, fused = sols
+    for t in range(60):
+        plain.run_steps(1); fused.run_steps(1)
+        plain.synchronize(); fused.synchronize()
+        assert not (plain.pass_forms() & S.FORM_TRACK_FUSED) and (fused.pass_forms() & S.FORM_TRACK_FUSED)
+        a, b = plain.get_state(), fused.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(a[k], b[k]), (t, k)
+        assert np.array_equal(plain.diag()['vpref'], fused.diag()['vpref'], equal_nan=True), t
+    assert np.array_equal(plain.device_tracker_replans(), fused.device_tracker_replans())
+    assert plain.device_tracker_replans().sum() > 10 * n
+    plain.close(); fused.close()
