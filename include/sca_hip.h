@@ -34,7 +34,10 @@ extern "C" {
 
 typedef struct sca_ctx sca_ctx;
 
-/* agent.py:27-36 + config.py; sca_default_params() fills the reference's values */
+/* agent.py:27-41 + config.py; sca_default_params() fills the reference's values.  The reference keeps these per Agent object; a context holds
+ * ONE value of each for all its agents (sca_amd.env.MACAEnv reads them off the agents and refuses a swarm whose agents disagree).
+ * sca_create refuses values the kernels were not built for: non-finite or non-positive distances / steps / speeds, max_neighbors outside
+ * 1 .. 16, max_heading_change outside [0, pi].  Parity at non-default values: tests/golden/F16_params_*. */
 typedef struct sca_params {
     double neighbor_dist;        /* agent.py:33  10.0 */
     double time_step;            /* agent.py:34  DT = 0.1 */
@@ -42,8 +45,10 @@ typedef struct sca_params {
     double max_speed;            /* agent.py:36  1.0 */
     double max_heading_change;   /* agent.py:29  pi/4 */
     double near_goal_threshold;  /* config.py:3  0.5 */
-    int32_t max_neighbors;       /* agent.py:32  16 (<= SCA_MAX_NEIGHBORS) */
+    int32_t max_neighbors;       /* agent.py:32  16 (1 .. SCA_MAX_NEIGHBORS) */
     int32_t reserved;
+    double dt_nominal;           /* agent.py:41  DT = 0.1: the integrator's step (mampenv.py:90-92); time_step is the one the constraints
+                                    read (util.py:8, orca3dPolicyOfficial.py:98).  Version 101 on. */
 } sca_params;
 
 enum sca_policy {                 /* which find_next_action the agent runs */

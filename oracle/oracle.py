@@ -4,6 +4,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 The product path (sca_amd) never does.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -66,6 +67,8 @@ def lib():
         L.orc_straight_v_pref.argtypes = [dp, dp, C.c_double, C.c_int, dp]
         L.orc_set_params.restype = None
         L.orc_set_params.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_set_dt_nominal.restype = None
+        L.orc_set_dt_nominal.argtypes = [C.c_double]
         L.orc_policy_step.restype = C.c_int
         L.orc_policy_step.argtypes = [C.c_int, C.c_int, dp, fp, dp, dp, dp, bp, dp, bp, bp, dp, bp, ip, dp, dp, dp, fp,
                                       ip, ip, bp, dp, bp, dp, ip, ip, C.c_int]
@@ -74,6 +77,24 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+DEFAULT_PARAMS = dict(neighbor_dist=10.0, max_neighbors=16, time_step=0.1, time_horizon=10.0, max_speed=1.0,
+                      max_heading_change=math.pi / 4, near_goal_threshold=0.5, dt_nominal=0.1)
+
+
+def set_params(**kw):
+    """The solver attributes of agent.py:27-41 / config.py:3 for every following call (process-wide); set_params() restores the
+    reference's defaults."""
+    p = dict(DEFAULT_PARAMS)
+    unknown = set(kw) - set(p)
+    if unknown:
+        raise TypeError(f'unknown oracle parameter(s): {sorted(unknown)}')
+    p.update(kw)
+    L = lib()
+    L.orc_set_params(p['neighbor_dist'], int(p['max_neighbors']), p['time_step'], p['time_horizon'], p['max_speed'],
+                     p['max_heading_change'], p['near_goal_threshold'])
+    L.orc_set_dt_nominal(p['dt_nominal'])
 
 
 def _p(a, t):

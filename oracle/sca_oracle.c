@@ -48,9 +48,10 @@ typedef struct {
     double max_speed;           /* agent.py:36  1.0 */
     double max_heading_change;  /* agent.py:29  pi/4 */
     double near_goal_threshold; /* config.py:3  0.5 */
+    double dt_nominal;          /* agent.py:41  DT = 0.1: the integrator's step (mampenv.py:90-92), not timeStep */
 } OrcParams;
 
-static OrcParams g_par = {10.0, 16, 0.1, 10.0, 1.0, 0.78539816339744830962, 0.5};
+static OrcParams g_par = {10.0, 16, 0.1, 10.0, 1.0, 0.78539816339744830962, 0.5, 0.1};
 
 void orc_set_params(double neighbor_dist, int max_neighbors, double time_step, double time_horizon,
                     double max_speed, double max_heading_change, double near_goal_threshold) {
@@ -58,6 +59,7 @@ void orc_set_params(double neighbor_dist, int max_neighbors, double time_step, d
     g_par.time_horizon = time_horizon; g_par.max_speed = max_speed; g_par.max_heading_change = max_heading_change;
     g_par.near_goal_threshold = near_goal_threshold;
 }
+void orc_set_dt_nominal(double dt_nominal) { g_par.dt_nominal = dt_nominal; }
 
 /* ------------------------------------------------------------------ numpy / Python arithmetic idioms */
 
@@ -835,7 +837,7 @@ int orc_policy_step(int n, int m, const double *pos, const float *vel, const dou
 int orc_env_update(int n, int m, double *pos, float *vel, double *heading, const double *radius, uint8_t *flags,
                    const double *goal, const float *action32, double *total_dist, const double *max_run_dist,
                    int32_t *step_num, const double *obs_pos, const double *obs_radius) {
-    double dt = g_par.time_step;                                          /* agent.dt_nominal = DT */
+    double dt = g_par.dt_nominal;                                         /* agent.dt_nominal (agent.py:41) */
     for (int i = 0; i < n; i++) {
         const float *act = &action32[7 * i];
         double speed = (double)act[3];

@@ -20,7 +20,7 @@ bp = C.POINTER(C.c_uint8)
 class Params(C.Structure):
     _fields_ = [('neighbor_dist', C.c_double), ('time_step', C.c_double), ('time_horizon', C.c_double),
                 ('max_speed', C.c_double), ('max_heading_change', C.c_double), ('near_goal_threshold', C.c_double),
-                ('max_neighbors', C.c_int32), ('reserved', C.c_int32)]
+                ('max_neighbors', C.c_int32), ('reserved', C.c_int32), ('dt_nominal', C.c_double)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/sca_hip.h

@@ -49,6 +49,7 @@ struct Params {                 // agent.py:27-36, config.py
     double cos_heading_thr;     // smallest c with acos(c) <= max_heading_change (host libm bisection)
     int max_neighbors;          // 16
     int pad;
+    double dt_nominal;          // 0.1: the integrator's step (agent.py:41, mampenv.py:90-92)
 };
 
 // 48-byte public record: everything another agent (or another GPU) needs to know about an agent.

@@ -289,9 +289,9 @@ extern "C" {
 
 void sca_default_params(sca_params *p) {
     p->neighbor_dist = 10.0; p->time_step = 0.1; p->time_horizon = 10.0; p->max_speed = 1.0;
-    p->max_heading_change = M_PI / 4; p->near_goal_threshold = 0.5; p->max_neighbors = 16; p->reserved = 0;
+    p->max_heading_change = M_PI / 4; p->near_goal_threshold = 0.5; p->max_neighbors = 16; p->reserved = 0; p->dt_nominal = 0.1;
 }
-int sca_version(void) { return 100; }
+int sca_version(void) { return 101; }
 
 const char *sca_last_error(const sca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -603,11 +603,19 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     sca_params def;
     sca_default_params(&def);
     if (!p) p = &def;
-    if (p->max_neighbors < 1 || p->max_neighbors > SCA_MAX_NEIGHBORS) { c->err = "max_neighbors out of range"; return SCA_ERR_ARG; }
+    if (p->max_neighbors < 1 || p->max_neighbors > SCA_MAX_NEIGHBORS) { c->err = "max_neighbors out of range (1 .. 16)"; return SCA_ERR_ARG; }
+    {   // the kernels divide by these, size grid cells with them and bisect acos on max_heading_change: refuse what they were not built for
+        auto pos = [](double x) { return std::isfinite(x) && x > 0.0; };
+        const char *bad = !pos(p->neighbor_dist) ? "neighbor_dist" : !pos(p->time_step) ? "time_step" : !pos(p->time_horizon) ? "time_horizon"
+                        : !pos(p->max_speed) ? "max_speed" : !pos(p->dt_nominal) ? "dt_nominal"
+                        : !(std::isfinite(p->near_goal_threshold) && p->near_goal_threshold >= 0.0) ? "near_goal_threshold"
+                        : !(p->max_heading_change >= 0.0 && p->max_heading_change <= M_PI) ? "max_heading_change" : nullptr;
+        if (bad) { c->err = std::string("sca_params.") + bad + " out of range"; return SCA_ERR_ARG; }
+    }
     c->device = device; c->max_n = max_agents; c->max_m = max_obstacles;
     c->P.neighbor_dist = p->neighbor_dist; c->P.time_step = p->time_step; c->P.time_horizon = p->time_horizon;
     c->P.max_speed = p->max_speed; c->P.max_heading_change = p->max_heading_change;
-    c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0;
+    c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0; c->P.dt_nominal = p->dt_nominal;
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
@@ -1084,7 +1092,7 @@ static int check_kd_overflow(sca_ctx *c) {
 // A pair that touches after the move was within r_a + r_b + 2 * max_step of each other before it (an obstacle:
 // r_a + r_o + max_step); l3norm rounds to 5 dp, hence the 1e-4.  The kernels add the agent's own radius.
 static void collide_reach(const sca_ctx *c, double &agent_reach, double &obs_reach) {
-    const double max_step = 1.01 * std::max(c->max_pref_speed, c->P.max_speed) * c->P.time_step;
+    const double max_step = 1.01 * std::max(c->max_pref_speed, c->P.max_speed) * c->P.dt_nominal;
     agent_reach = c->max_radius + 2.0 * max_step + 1e-4;
     obs_reach = c->max_obs_radius + max_step + 1e-4;
 }

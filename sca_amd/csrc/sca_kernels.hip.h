@@ -797,9 +797,9 @@ __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Param
     const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
     const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
     const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
-    const double dx = speed * cos(b) * cos(a) * P.time_step;
-    const double dy = speed * cos(b) * sin(a) * P.time_step;
-    const double dz = speed * sin(b) * P.time_step;
+    const double dx = speed * cos(b) * cos(a) * P.dt_nominal;
+    const double dy = speed * cos(b) * sin(a) * P.dt_nominal;
+    const double dz = speed * sin(b) * P.dt_nominal;
     const double len = sqrt(dx * dx + dy * dy + dz * dz);
     d.total_dist[agent] += len;
     r.px += dx; r.py += dy; r.pz += dz;

@@ -255,14 +255,22 @@ class MACAEnv:
         self._ext = np.array([a.policy.needs_external_vpref for a in agents], bool)
         start = np.array([a.initial_pos for a in agents], dtype=np.float64)
         goal6 = np.array([a.goal_pos for a in agents], dtype=np.float64)
-        self.solver = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), device=self.device)
+        # the solver attributes the reference keeps per Agent (agent.py:24-41) and its policies read per call (scaPolicy.py:95,112,272,302,
+        # util.py:8,17, orca3dPolicyOfficial.py:44,98,108, agent.py:87-99, mampenv.py:90-92): a context holds one value of each
+        params = dict(neighbor_dist=self._uniform('neighborDist', float), max_neighbors=self._uniform('maxNeighbors', int),
+                      time_step=self._uniform('timeStep', float), time_horizon=self._uniform('timeHorizon', float),
+                      max_speed=self._uniform('maxSpeed', float), max_heading_change=self._uniform('max_heading_change', float),
+                      dt_nominal=self._uniform('dt_nominal', float))
+        self.solver = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), device=self.device, params=params)
         self.solver.set_obstacles(np.array([o.pos_global_frame for o in obstacles], dtype=np.float64).reshape(m, 3),
                                   np.array([o.radius for o in obstacles], dtype=np.float64))
         self.solver.set_agents([a.radius for a in agents], [a.pref_speed for a in agents], self.goal, self.policy_ids,
                                S.zaxis_flags(start, goal6), [a.max_run_dist for a in agents])
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
         if self.device_tracker and self._ext.any():
-            self.solver.device_tracker_enable(goal6[:, 3:6])
+            self.solver.device_tracker_enable(goal6[:, 3:6], turning_radius=self._uniform('turning_radius', float),
+                                              pitchlims=(self._uniform('pitchlims', lambda p: float(p[0])),
+                                                         self._uniform('pitchlims', lambda p: float(p[1]))))
         for a in agents:
             a._env = self
             a.policy._env = self
@@ -281,6 +289,15 @@ class MACAEnv:
             self.history_capacity = capped
         if self.history_capacity:
             self.solver.history_enable(self.history_capacity)
+
+    def _uniform(self, attr, conv):
+        """The one value of a solver attribute all agents carry.  The reference reads these per agent; libsca_hip keeps one per context
+        (sca_params, include/sca_hip.h) and this env refuses a swarm whose agents disagree rather than pick one."""
+        vals = {conv(getattr(a, attr)) for a in self.agents}
+        if len(vals) != 1:
+            raise ValueError(f'agents carry {len(vals)} different values of Agent.{attr} ({sorted(vals)[:4]} ...): one libsca_hip context '
+                             f'solves with one value per swarm -- not supported (SCA_ERR_UNSUPPORTED)')
+        return vals.pop()
 
     # ---- host mirrors of the device state, refreshed on first use after a step (the reference's per-agent attributes) -------
     def _state(self, name):

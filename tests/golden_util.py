@@ -27,3 +27,36 @@ def static_inputs(fx):
     vpref_mode = np.isin(policy, (POL_SCA, POL_RVO_DUBINS)).astype(np.uint8)
     return dict(zaxis=zaxis, policy=policy, vpref_mode=vpref_mode, radius=fx['radius'], pref_speed=fx['pref_speed'],
                 obs_pos=fx['obs_pos'], obs_radius=fx['obs_radius'], max_run_dist=fx['max_run_dist'])
+
+
+_ATTR_TO_PARAM = dict(neighborDist='neighbor_dist', maxNeighbors='max_neighbors', timeStep='time_step', timeHorizon='time_horizon',
+                      maxSpeed='max_speed', max_heading_change='max_heading_change', dt_nominal='dt_nominal')
+
+
+def fixture_params(fx):
+    """The solver parameters a fixture was recorded under (F16: `attr_*` arrays, the reference's Agent attributes read back after the
+    generator changed them, tools/gen_golden.py::_apply_attrs).  Returns (params, tracker): `params` in sca_params / oracle.set_params
+    names, `tracker` = dict(turning_radius, pitchlims) for sca_device_tracker_enable / DubinsTracker.  Both empty for fixtures recorded at
+    the reference's defaults (agent.py:24-41).  One value per scene: sca_params is per context."""
+    params, tracker = {}, {}
+    for attr, name in _ATTR_TO_PARAM.items():
+        if 'attr_' + attr in fx:
+            v = fx['attr_' + attr]
+            assert (v == v[0]).all(), attr
+            params[name] = int(v[0]) if name == 'max_neighbors' else float(v[0])
+    if 'attr_turning_radius' in fx:
+        for k in ('turning_radius', 'pitch_lo', 'pitch_hi'):
+            assert (fx['attr_' + k] == fx['attr_' + k][0]).all(), k
+        tracker = dict(turning_radius=float(fx['attr_turning_radius'][0]),
+                       pitchlims=(float(fx['attr_pitch_lo'][0]), float(fx['attr_pitch_hi'][0])))
+    return params, tracker
+
+
+def param_fixtures():
+    return [n for n in episode_fixtures() if n.startswith('F16_params')]
+
+
+def tracked_param_fixtures():
+    """F16 scenes with SCA / RVO3D+Dubins agents: their recorded v_pref is the reference's Dubins tracker at the scene's
+    turning_radius / pitchlims / neighborDist."""
+    return [n for n in param_fixtures() if np.isin(load(n)['policy'], (POL_SCA, POL_RVO_DUBINS)).any()]

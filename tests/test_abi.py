@@ -1,6 +1,8 @@
 """The C-ABI library loads without a GPU and exports every symbol include/sca_hip.h declares; the ctypes table in
 sca_amd/_lib.py covers exactly that set.  No compute calls here."""
 import os
+
+import pytest
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +34,25 @@ def test_default_params_are_the_reference_constants():
     # agent.py:27-36, config.py:2-3
     assert (p.neighbor_dist, p.max_neighbors, p.time_step, p.time_horizon, p.max_speed) == (10.0, 16, 0.1, 10.0, 1.0)
     assert p.max_heading_change == math.pi / 4 and p.near_goal_threshold == 0.5
+    assert p.dt_nominal == 0.1                                    # agent.py:41
+    assert C.sizeof(_lib.Params) == 64 and _lib.lib().sca_version() >= 101
+
+
+@pytest.mark.parametrize('field,value', [('neighbor_dist', 0.0), ('neighbor_dist', float('nan')), ('time_step', -0.1), ('time_horizon', 0.0),
+                                         ('max_speed', float('inf')), ('dt_nominal', 0.0), ('max_neighbors', 0), ('max_neighbors', 17),
+                                         ('max_heading_change', -0.1), ('max_heading_change', 3.2), ('near_goal_threshold', -1.0)])
+def test_create_refuses_parameters_the_kernels_were_not_built_for(field, value):
+    """sca_create checks sca_params before it touches the device: SCA_ERR_ARG and a message that names the field."""
+    import ctypes as C
+    from sca_amd import _lib
+    L = _lib.lib()
+    p = _lib.Params()
+    L.sca_default_params(C.byref(p))
+    setattr(p, field, value)
+    ctx = C.c_void_p()
+    assert L.sca_create(C.byref(p), 0, 8, 1, C.byref(ctx)) == -1          # SCA_ERR_ARG
+    assert field in L.sca_last_error(ctx).decode()
+    L.sca_destroy(ctx)
 
 
 def test_no_cpu_path_without_gpu():

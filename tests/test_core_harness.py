@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, load, static_inputs
+from golden_util import episode_fixtures, fixture_params, load, static_inputs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -158,7 +158,10 @@ def test_host_kd_build_matches_oracle(oracle):
 def test_core_solve_matches_reference(harness, tables, name):
     fx = load(name)
     st = static_inputs(fx)
-    par = np.array([10.0, 0.1, 10.0, 1.0, math.pi / 4, 0.5, cos_threshold(math.pi / 4)])
+    fp = dict(neighbor_dist=10.0, time_step=0.1, time_horizon=10.0, max_speed=1.0, max_heading_change=math.pi / 4)
+    fp.update({k: v for k, v in fixture_params(fx)[0].items() if k in fp})          # F16: the parameters the scene was recorded under
+    par = np.array([fp['neighbor_dist'], fp['time_step'], fp['time_horizon'], fp['max_speed'], fp['max_heading_change'], 0.5,
+                    cos_threshold(fp['max_heading_change'])])
     T = len(fx['step'])
     n = len(st['radius'])
     u256, p256 = tables[256]

@@ -9,7 +9,7 @@ bit.  The LP of orca3dPolicyOfficial.py walks the planes in list order: checked 
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, load, static_inputs
+from golden_util import episode_fixtures, fixture_params, load, static_inputs
 from test_gpu_parity import ANG_TOL, _scenario_state, make_solver
 
 pytestmark = pytest.mark.gpu
@@ -67,12 +67,21 @@ def test_grid_pass_vs_golden(S, name):
     fx = load(name)
     st = static_inputs(fx)
     sol = make_solver(S, fx, st)
+    maxn = fixture_params(fx)[0].get('max_neighbors', 16)
     T = len(fx['step'])
     n_over = n_checked = 0
     for t in range(0, T, max(1, T // 25)):
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
         sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
-        sol.policy_pass(S.NBR_GRID)
+        try:
+            sol.policy_pass(S.NBR_GRID)
+        except S.ScaError as e:
+            # F16 scenes with a neighborDist below radius + collision reach: a cell of neighborDist cannot hold the collision test's
+            # partners, and the library says so instead of answering (SCA_ERR_UNSUPPORTED); SCA_NBR_AUTO runs such scenes on the kd-tree
+            assert 'SCA_NBR_GRID needs' in str(e) and name.startswith('F16_params'), (name, str(e))
+            assert fixture_params(fx)[0]['neighbor_dist'] < 4.0
+            sol.close()
+            return
         ctx = (name, t)
         nb = sol.neighbors()
         dg = sol.diag()
@@ -83,7 +92,7 @@ def test_grid_pass_vs_golden(S, name):
         # a list of fewer than 16 entries never overflowed (a collision cleared list may have: then the bit is spurious but allowed)
         rows = valid & ~over
         compare_lists(nb, fx['nbr_n'][t], fx['nbr_id'][t], fx['nbr_kind'][t], fx['nbr_dsq'][t], rows, ctx)
-        assert not (over & valid & (fx['nbr_n'][t] < 16) & (fx['coll_after_policy'][t] == 0)).any(), ctx + ('spurious overflow',)
+        assert not (over & valid & (fx['nbr_n'][t] < maxn) & (fx['coll_after_policy'][t] == 0)).any(), ctx + ('spurious overflow',)
         # velocities: the sampled policies do not see the order of equal distances; the LP does
         called = fx['called'][t].astype(bool)
         lp = st['policy'] == 4

@@ -1,0 +1,125 @@
+"""Parity away from the reference's default parameters (-m gpu).  The reference keeps its solver parameters on every Agent
+(mamp/agents/agent.py:24-41) and reads them per call (scaPolicy.py:95,112,272,299-302, util.py:8,17, orca3dPolicyOfficial.py:44,98,108,
+agent.py:87-99, mampenv.py:90-92); the boundary exports them as sca_params + sca_device_tracker_enable's turning radius / pitch limits.
+The F16 fixtures are the reference stepped with those attributes changed after Agent.__init__ (tools/gen_golden.py::_apply_attrs); they
+ride in every episode-parametrised test (tests/golden_util.py::episode_fixtures) -- here: the drop-in MACAEnv built from Agent objects
+that carry the changed attributes, closed loop, nothing from the fixture but the start state."""
+import numpy as np
+import pytest
+
+from golden_util import fixture_params, load, param_fixtures, static_inputs
+
+pytestmark = pytest.mark.gpu
+
+VEL_TOL = 1e-5
+EPISODES = [n for n in param_fixtures() if len(load(n)['step']) > 1]
+
+
+def _agents_from_fixture(E, fx, with_attrs=True):
+    pol_cls = {0: E.SCAPolicy, 1: E.RVO3DPolicy, 2: E.SRVO3DPolicy, 3: E.ORCA3DPolicy, 4: E.ORCA3DPolicyOfficial, 5: E.RVO3dDubinsPolicy}
+    n = len(fx['radius'])
+    agents = [E.Agent(start_pos=list(fx['start'][i]), goal_pos=list(fx['goal6'][i]), vel=[0.0, 0.0, 0.0], radius=float(fx['radius'][i]),
+                      pref_speed=float(fx['pref_speed'][i]), policy=pol_cls[int(fx['policy'][i])], id=i) for i in range(n)]
+    if with_attrs:
+        for i, a in enumerate(agents):                 # what a user of the reference writes: attributes set after the constructor
+            for k in ('maxNeighbors', 'neighborDist', 'timeStep', 'timeHorizon', 'maxSpeed', 'min_heading_change', 'max_heading_change',
+                      'turning_radius', 'dt_nominal'):
+                v = fx['attr_' + k][i]
+                setattr(a, k, int(v) if k == 'maxNeighbors' else float(v))
+            a.pitchlims = [float(fx['attr_pitch_lo'][i]), float(fx['attr_pitch_hi'][i])]
+    obstacles = [E.Obstacle(pos=list(fx['obs_pos'][j]), shape_dict={'shape': 'sphere', 'feature': float(fx['obs_radius'][j])}, id=j)
+                 for j in range(len(fx['obs_radius']))]
+    return agents, obstacles
+
+
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
+@pytest.mark.parametrize('name', EPISODES)
+def test_env_closed_loop_with_agent_attributes(name, mode):
+    """`while not env.step()` on Agent objects with non-default attributes, the Dubins tracker on the device with the agents' turning
+    radius and pitch limits: every step's velocities within 1e-5 of the reference's (they are discrete picks: equal or a candidate apart),
+    the same agents arrive / collide / time out at the same steps, positions to 1e-6."""
+    from sca_amd import env as E, solver as S
+    fx = load(name)
+    agents, obstacles = _agents_from_fixture(E, fx)
+    env = E.MACAEnv(device_tracker=True, neighbor_mode=S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE)
+    env.set_agents(agents, obstacles=obstacles)
+    params, trk = fixture_params(fx)
+    for k, v in params.items():
+        assert getattr(env.solver.params, k) == v, k
+    T = len(fx['step'])
+    assert np.array_equal(fx['step'], np.arange(T))
+    worst = 0.0
+    for t in range(T):
+        env.step({})
+        worst = max(worst, float(np.abs(env.vel - fx['vel_after'][t]).max()))
+        assert worst <= VEL_TOL, (name, mode, t, worst)
+        assert np.array_equal(env.flags, fx['flags_after'][t]), (name, mode, t)
+        assert np.allclose(env.pos, fx['pos_after'][t], rtol=0, atol=1e-6), (name, mode, t)
+    assert np.array_equal(np.array(env.kdTree.agentIDs), fx['perm_after'][-1])
+
+
+def test_defaults_would_not_reproduce_these_scenes():
+    """The fixtures bite: the same scenes under the reference's DEFAULT attributes leave the recorded trajectories (otherwise the tests
+    above would pass with the parameters ignored)."""
+    from sca_amd import env as E
+    differ = 0
+    for name in EPISODES:
+        fx = load(name)
+        agents, obstacles = _agents_from_fixture(E, fx, with_attrs=False)
+        env = E.MACAEnv(device_tracker=True)
+        env.set_agents(agents, obstacles=obstacles)
+        for t in range(len(fx['step'])):
+            env.step({})
+            if np.abs(env.vel - fx['vel_after'][t]).max() > VEL_TOL or not np.array_equal(env.flags, fx['flags_after'][t]):
+                differ += 1
+                break
+    assert differ == len(EPISODES), (differ, len(EPISODES))
+
+
+def test_heterogeneous_attributes_are_refused():
+    """The reference reads the attributes per agent; a context holds one value per swarm, and the env says so instead of picking one."""
+    from sca_amd import env as E
+    agents = E.build_circle_agents(8, policy=E.RVO3DPolicy, rad=10.0)
+    agents[3].neighborDist = 5.0
+    with pytest.raises(ValueError, match='neighborDist'):
+        E.MACAEnv().set_agents(agents, obstacles=[])
+    agents[3].neighborDist = 10.0
+    agents[5].pitchlims = [-0.3, 0.3]
+    sca = E.build_circle_agents(8, policy=E.SCAPolicy, rad=10.0)
+    sca[5].pitchlims = [-0.3, 0.3]
+    with pytest.raises(ValueError, match='pitchlims'):
+        E.MACAEnv(device_tracker=True).set_agents(sca, obstacles=[])
+
+
+@pytest.mark.parametrize('name', EPISODES)
+def test_policy_pass_grid_mode_with_parameters(name):
+    """SCA_NBR_GRID sizes its cells with neighbor_dist and keeps max_neighbors entries: whenever nobody overflows (the status bit says so)
+    the lists are the reference's as sets with the same distances, and the sampled policies' velocities are the reference's."""
+    from sca_amd import solver as S
+    from test_gpu_parity import make_solver
+    fx = load(name)
+    st = static_inputs(fx)
+    params, _ = fixture_params(fx)
+    sol = make_solver(S, fx, st)
+    checked = 0
+    for t in range(len(fx['step'])):
+        sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
+        sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
+        try:
+            sol.policy_pass(S.NBR_GRID)
+        except S.ScaError as e:
+            assert 'SCA_NBR_GRID needs' in str(e) and params['neighbor_dist'] < 4.0, str(e)
+            sol.close()
+            return
+        nb, dg = sol.neighbors(), sol.diag()
+        valid = fx['nbr_valid'][t].astype(bool)
+        rows = np.nonzero(valid & ((dg['status'] & 32) == 0))[0]
+        for i in rows:
+            k = int(fx['nbr_n'][t][i])
+            assert nb['nbr_n'][i] == k, (name, t, i)
+            got = sorted(zip(nb['nbr_dsq'][i][:k].round(9), nb['nbr_kind'][i][:k], nb['nbr_id'][i][:k]))
+            ref = sorted(zip(fx['nbr_dsq'][t][i][:k].round(9), fx['nbr_kind'][t][i][:k], fx['nbr_id'][t][i][:k]))
+            assert got == ref, (name, t, i)
+            checked += 1
+    assert checked > 0
+    sol.close()

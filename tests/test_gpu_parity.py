@@ -6,7 +6,7 @@ heading deltas within one float32 ulp (they pass through atan2); tolerance of th
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, load, static_inputs
+from golden_util import episode_fixtures, fixture_params, load, static_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,7 @@ def S():
 def make_solver(S, fx, st):
     n = len(st['radius'])
     m = len(st['obs_radius'])
-    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1))
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), params=fixture_params(fx)[0])     # F16: recorded off the defaults
     sol.set_obstacles(st['obs_pos'], st['obs_radius'])
     sol.set_agents(st['radius'], st['pref_speed'], fx['goal'][0], st['policy'], st['zaxis'], st['max_run_dist'])
     return sol
@@ -155,8 +155,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
 @pytest.mark.parametrize('label,kind,n,pol', CASES)
-def test_policy_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
+def test_policy_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol, mode):
+    """`auto` = SCA_NBR_AUTO, the mode bench.py's c3 leg runs: the same oracle, the same assertions (lists entry for entry)"""
     from sca_amd import scenarios
     sc = {'circle': lambda: scenarios.circle(n), 'random': lambda: scenarios.random_cube(n, seed=0),
           'random_low': lambda: scenarios.random_cube(n, seed=0, z_offset=30.0),
@@ -173,7 +175,7 @@ def test_policy_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
     sol.set_obstacles(s['obs_pos'], s['obs_radius'])
     sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], s['zaxis'], s['max_run_dist'])
     sol.set_state(s['pos'], s['vel'], s['heading'], s['flags'])
-    sol.policy_pass(S.NBR_KDTREE)
+    sol.policy_pass(S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE)
     nb = sol.neighbors()
     assert np.array_equal(sol.get_kd_perm(), ref['perm'])
     assert np.array_equal(nb['nbr_n'], ref['nbr_n'])

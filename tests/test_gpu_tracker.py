@@ -11,22 +11,24 @@ away, because the planner's radius search ends on comparisons of nearly equal pa
 import numpy as np
 import pytest
 
-from golden_util import load, static_inputs
+from golden_util import fixture_params, load, static_inputs, tracked_param_fixtures
 
 pytestmark = pytest.mark.gpu
 
 EPISODES = ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16', 'F4_mixed_takeoff16', 'F10_sca_exp3_map',
             'F13_fuzz_track_00', 'F13_fuzz_track_01', 'F13_fuzz_track_02', 'F13_fuzz_track_03',
             'F15_sca_circle1024']             # BASELINE config 2 itself, steps 0-3 stepped by the reference (2038 plans of 412 m)
+EPISODES += tracked_param_fixtures()  # F16: turning_radius 0.8 / 2 / 3 / 10, pitchlims +-pi/6, (-0.5, 0.9), ..., neighborDist 1.5 ... 30
 
 
 def _solver_for(fx, st, in_pass):
     from sca_amd import solver as S
     n = len(st['radius'])
-    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(st['obs_radius'])))
+    params, trk = fixture_params(fx)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(st['obs_radius'])), params=params)
     sol.set_obstacles(st['obs_pos'], st['obs_radius'])
     sol.set_agents(st['radius'], st['pref_speed'], fx['goal'][0], st['policy'], st['zaxis'], st['max_run_dist'])
-    sol.device_tracker_enable(fx['goal6'][:, 3:6], in_pass=in_pass)
+    sol.device_tracker_enable(fx['goal6'][:, 3:6], in_pass=in_pass, **trk)
     return sol
 
 
@@ -390,6 +392,47 @@ def test_device_planner_long_range_kats(family, form, monkeypatch):
         assert o[0] == k['radii'][i, 0] and o[4] == k['radii'][i, 1], (family, form, i)
         assert o[1] == k['tpq'][i, 0] and o[2] == k['tpq'][i, 1] and o[5] == k['tpq'][i, 3] and o[6] == k['tpq'][i, 4], (family, form, i)
         assert o[9] == k['sampling'][i] and int(o[13]) == k['n'][i], (family, form, i)
+    sol.close()
+
+
+@pytest.mark.parametrize('form', ['spec4', 'spec3', 'spec2', 'quad', 'lane'])
+@pytest.mark.parametrize('pset', range(6))
+def test_device_planner_param_kats(pset, form, monkeypatch):
+    """F7c (tests/test_dubins_kat_params.py): the reference's planner at Rmin 0.8 / 3 / 10 and pitch limits -+pi/4, -+pi/6, (-0.5, 0.9),
+    (-0.2, 0.2) -- every re-plan kernel with sca_device_tracker_enable(..., turning_radius, pitch_lo, pitch_hi): length, word, radii,
+    t / p, sampling size and sample count of the record each kernel leaves are the reference's bits (the speculation trees were fitted at
+    Rmin = 1.5: a walk that leaves them must still end where the search ends)."""
+    import ctypes as C
+    from sca_amd import _lib, solver as S
+    from test_dubins_kat_long import words_of
+    from test_dubins_kat_params import load_kats
+    k = load_kats()
+    sel = np.flatnonzero(k['set'] == pset)
+    n = len(sel)
+    env = {'spec4': None, 'spec3': ('0', None, None, None), 'spec2': ('0', '0', None, None), 'quad': ('0', '0', '0', None),
+           'lane': ('0', '0', '0', '1')}[form]
+    for key, v in zip(('SCA_TRK_SPEC4_MAX', 'SCA_TRK_SPEC3_MAX', 'SCA_TRK_SPEC2_MAX', 'SCA_TRK_MID_MAX'), env or (None,) * 4):
+        if v is None:
+            monkeypatch.delenv(key, raising=False)
+        else:
+            monkeypatch.setenv(key, v)
+    qi, qf = k['qi'][sel], k['qf'][sel]
+    sol = S.BatchedSolver(max_agents=n)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    start6 = np.concatenate([qi, np.zeros((n, 1))], 1)
+    goal6 = np.concatenate([qf, np.zeros((n, 1))], 1)
+    sol.set_agents(np.full(n, 0.5), np.ones(n), qf[:, :3], np.zeros(n, np.uint8), S.zaxis_flags(start6, goal6), np.full(n, 1e9))
+    sol.set_state(qi[:, :3], np.zeros((n, 3), np.float32), start6[:, 3:6], np.zeros(n, np.uint8))
+    sol.device_tracker_enable(goal6[:, 3:6], turning_radius=float(k['set_rmin'][pset]), pitchlims=tuple(k['set_pitchlims'][pset]), in_pass=False)
+    sol.device_tracker_vpref(np.full(n, -1.0))
+    assert np.array_equal(sol.device_tracker_replans(), np.ones(n, np.int32))
+    o = np.zeros(24)
+    for j, i in enumerate(sel):
+        assert sol.L.sca_device_tracker_debug(sol.ctx, j, _lib.ptr(o, C.c_double)) == 0
+        assert o[8] == k['length'][i] and words_of(o) == k['mode'][i], (pset, form, i, o[8], k['length'][i], words_of(o), k['mode'][i])
+        assert o[0] == k['radii'][i, 0] and o[4] == k['radii'][i, 1], (pset, form, i)
+        assert o[1] == k['tpq'][i, 0] and o[2] == k['tpq'][i, 1] and o[5] == k['tpq'][i, 3] and o[6] == k['tpq'][i, 4], (pset, form, i)
+        assert o[9] == k['sampling'][i] and int(o[13]) == k['n'][i], (pset, form, i)
     sol.close()
 
 

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, load, static_inputs
+from golden_util import episode_fixtures, fixture_params, load, static_inputs
 
 
 def test_candidate_table(oracle):
@@ -57,9 +57,17 @@ def test_round5_python_semantics(oracle):
         assert L.orc_round5_py(float(x)) == round(float(x), 5)
 
 
+@pytest.fixture
+def oracle_params(oracle):
+    """oracle.set_params is process-wide: every test that sets the recorded parameters of an F16 fixture restores the defaults."""
+    yield lambda fx: oracle.set_params(**fixture_params(fx)[0])
+    oracle.set_params()
+
+
 @pytest.mark.parametrize('name', episode_fixtures())
-def test_policy_step_matches_reference(oracle, name):
+def test_policy_step_matches_reference(oracle, oracle_params, name):
     fx = load(name)
+    oracle_params(fx)
     st = static_inputs(fx)
     T = len(fx['step'])
     for t in range(T):
@@ -94,8 +102,9 @@ def test_policy_step_matches_reference(oracle, name):
 
 
 @pytest.mark.parametrize('name', episode_fixtures())
-def test_env_update_matches_reference(oracle, name):
+def test_env_update_matches_reference(oracle, oracle_params, name):
     fx = load(name)
+    oracle_params(fx)
     st = static_inputs(fx)
     T = len(fx['step'])
     n = len(st['radius'])

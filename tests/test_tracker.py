@@ -7,7 +7,9 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN, load, static_inputs
+from golden_util import GOLDEN, fixture_params, load, static_inputs, tracked_param_fixtures
+
+TRACKED_PARAM_EPISODES = tracked_param_fixtures()
 
 
 def test_dubins_planner_kats():
@@ -26,7 +28,7 @@ def test_dubins_planner_kats():
 
 @pytest.mark.parametrize('name', ['F1_sca_circle8', 'F2_sca_circle100', 'F2_rvodubins_circle100', 'F4_sca_takeoff16',
                                   'F4_mixed_takeoff16', 'F10_sca_exp3_map', 'F13_fuzz_track_00', 'F13_fuzz_track_01',
-                                  'F13_fuzz_track_02', 'F13_fuzz_track_03', 'F15_sca_circle1024'])
+                                  'F13_fuzz_track_02', 'F13_fuzz_track_03', 'F15_sca_circle1024'] + TRACKED_PARAM_EPISODES)
 def test_tracker_reproduces_reference_v_pref(name):
     """Open loop on the solver (states come from the fixture), closed loop on the tracker's own state: every
     compute_v_pref of the episode, including all re-plans, must return the reference's V_des bit for bit."""
@@ -35,15 +37,19 @@ def test_tracker_reproduces_reference_v_pref(name):
     st = static_inputs(fx)
     n = len(st['radius'])
     ext = st['vpref_mode'].astype(bool)
-    tr = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=4)
+    params, trk = fixture_params(fx)                           # F16: turning_radius / pitchlims / neighborDist off their defaults
+    tr = tracker.DubinsTracker(fx['goal'][0], fx['goal6'][:, 3:6], st['pref_speed'], st['zaxis'], nthreads=4,
+                               neighbor_dist=params.get('neighbor_dist', 10.0), **trk)
     T = len(fx['step'])
     assert np.array_equal(fx['step'], np.arange(T))           # every step recorded: the tracker state can be replayed
+    ever = np.zeros(n, bool)
     for t in range(T):
         active = fx['called'][t].astype(bool) & ext
+        ever |= active
         got = tr.vpref(fx['pos'][t], fx['vel'][t], fx['heading'][t], active.astype(np.uint8))
         assert np.array_equal(got[active], fx['vpref'][t][active]), (name, t, np.abs(got[active] - fx['vpref'][t][active]).max())
         tr.note_neighbors(fx['nbr_valid'][t], fx['nbr_n'][t], fx['nbr_dsq'][t])
-    assert tr.replans()[ext].min() >= 1
+    assert tr.replans()[ever].min() >= 1                          # (the F16 fuzz scenes hold agents that are done from the start)
     tr.close()
 
 

@@ -173,9 +173,35 @@ def _snapshot(agents):
     return pos, vel, head, fl, td, goal
 
 
+ATTR_KEYS = ('maxNeighbors', 'neighborDist', 'timeStep', 'timeHorizon', 'maxSpeed', 'min_heading_change', 'max_heading_change',
+             'turning_radius', 'dt_nominal')
+
+
+def _apply_attrs(agents, attrs):
+    """F16: solver attributes changed after Agent.__init__ (agent.py:24-41), the way a user of the reference does it.
+    Values are scalars or per-agent sequences; 'pitchlims' is a (lo, hi) pair and changes ONLY agent.pitchlims (what the Dubins planner
+    reads, scaPolicy.py:95) -- agent.max_heading_change (util.py:17) was derived from it inside __init__ and is its own key here."""
+    n = len(agents)
+    for name, val in (attrs or {}).items():
+        if name == 'pitchlims':
+            for a in agents:
+                a.pitchlims = [float(val[0]), float(val[1])]
+            continue
+        vals = np.broadcast_to(np.asarray(val), (n,))
+        for a, v in zip(agents, vals):
+            setattr(a, name, int(v) if name == 'maxNeighbors' else float(v))
+
+
+def _attr_arrays(agents):
+    out = {f'attr_{k}': np.array([getattr(a, k) for a in agents], np.int32 if k == 'maxNeighbors' else np.float64) for k in ATTR_KEYS}
+    out['attr_pitch_lo'] = np.array([a.pitchlims[0] for a in agents], np.float64)
+    out['attr_pitch_hi'] = np.array([a.pitchlims[1] for a in agents], np.float64)
+    return out
+
+
 def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, obstacles_spec, max_steps,
-                    record_every=1, record_first=0, radius=0.5, pref_speed=1.0, outdir='tests/golden'):
-    """radius / pref_speed may be scalars or per-agent sequences."""
+                    record_every=1, record_first=0, radius=0.5, pref_speed=1.0, outdir='tests/golden', attrs=None):
+    """radius / pref_speed may be scalars or per-agent sequences; attrs: see _apply_attrs (recorded as attr_* arrays)."""
     """Runs MACAEnv.step (mampenv.py:22) and records every `record_every`-th step (and the first
     `record_first` steps) completely."""
     global REC
@@ -186,6 +212,7 @@ def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, ob
     agents = [agent_mod.Agent(start_pos=list(pos[i]), goal_pos=list(goal[i]), vel=[0.0, 0.0, 0.0], radius=radius_l[i],
                               pref_speed=ps_l[i], policy=classes[int(policy_ids[i])], id=i, dt=0.1)
               for i in range(n)]
+    _apply_attrs(agents, attrs)
     obstacles = [Obstacle(pos=list(p), shape_dict={'shape': 'sphere', 'feature': r}, id=i)
                  for i, (p, r) in enumerate(obstacles_spec)]
     env = env_mod.MACAEnv()
@@ -251,6 +278,8 @@ def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, ob
         obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
         obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64),
         numpy_version=np.__version__, ))
+    if attrs:
+        out.update(_attr_arrays(agents))
     path = os.path.join(outdir, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: {step + 1} steps ({len(rec["step"])} recorded), done_step={done_step}, '
@@ -259,7 +288,7 @@ def run_env_episode(agent_mod, env_mod, classes, name, pos, goal, policy_ids, ob
 
 
 def single_step_cluster(agent_mod, env_mod, classes, name, n, box, policy_id, seed, n_obs=0, min_sep=0.0,
-                        outdir='tests/golden'):
+                        outdir='tests/golden', attrs=None):
     """Hand-built dense state (F5): random positions in a cube, random float32 velocities (so the
     'first step' branch is not taken), one env.step.  Exercises >16 in range (agent.py:87-99 quirk),
     collisions (agent.py:82-85) and the no-suitable-candidate fallback (scaPolicy.py:224-238)."""
@@ -276,6 +305,7 @@ def single_step_cluster(agent_mod, env_mod, classes, name, n, box, policy_id, se
     goal = [list(-np.array(p[:3]) + np.array([0, 0, 40.0])) + [0.0, 0.0, 0.0] for p in pos]
     agents = [agent_mod.Agent(start_pos=pos[i], goal_pos=goal[i], vel=[0.0, 0.0, 0.0], radius=0.5, pref_speed=1.0,
                               policy=classes[policy_id], id=i, dt=0.1) for i in range(n)]
+    _apply_attrs(agents, attrs)
     for a in agents:
         v = rng.normal(size=3)
         v = v / np.linalg.norm(v) * rng.uniform(0.4, 1.0)
@@ -328,13 +358,15 @@ def single_step_cluster(agent_mod, env_mod, classes, name, n, box, policy_id, se
                     max_run_dist=np.array([a.max_run_dist for a in agents]),
                     obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
                     obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64), numpy_version=np.__version__))
+    if attrs:
+        out.update(_attr_arrays(agents))
     path = os.path.join(outdir, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: n={n} nbr_n max={REC.nbr_n.max()} fallback={int(REC.fallback.sum())} '
           f'collisions={int(coll_after.sum())} lp4={int(REC.lp4.sum())} {time.time() - t0:.1f} s', flush=True)
 
 
-def single_step_random(agent_mod, env_mod, classes, name, seed, outdir='tests/golden'):
+def single_step_random(agent_mod, env_mod, classes, name, seed, outdir='tests/golden', attrs=None):
     """Fuzz fixtures (F12): a random small scene -- all six policies mixed, radii and preferred speeds of several sizes,
     obstacles that may overlap agents, agents done from the start (at goal / collided / timed out), agents at rest
     (bootstrap branch), goals straight above the start (is_zAxis), dense or sparse -- and one env.step of the reference."""
@@ -357,6 +389,7 @@ def single_step_random(agent_mod, env_mod, classes, name, seed, outdir='tests/go
     ps_l = [float(x) for x in rng.choice([1.0, 1.0, 0.8, 1.5], n)]
     agents = [agent_mod.Agent(start_pos=pos[i], goal_pos=goal[i], vel=[0.0, 0.0, 0.0], radius=radius_l[i], pref_speed=ps_l[i],
                               policy=classes[policy_ids[i]], id=i, dt=0.1) for i in range(n)]
+    _apply_attrs(agents, attrs)
     rest = rng.random(n) < 0.2
     for a in agents:
         v = rng.normal(size=3)
@@ -414,6 +447,8 @@ def single_step_random(agent_mod, env_mod, classes, name, seed, outdir='tests/go
                     max_run_dist=np.array([a.max_run_dist for a in agents]),
                     obs_pos=np.array([p for p, _ in obstacles_spec], dtype=np.float64).reshape(-1, 3),
                     obs_radius=np.array([r for _, r in obstacles_spec], dtype=np.float64), numpy_version=np.__version__))
+    if attrs:
+        out.update(_attr_arrays(agents))
     path = os.path.join(outdir, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: n={n} m={m} side={side} called={int(REC.called.sum())} nbr_n max={REC.nbr_n.max()} '
@@ -656,6 +691,126 @@ def main():
         pos = [[float(v) for v in p_] for p_ in pos]
         goal = [[float(v) for v in g_] for g_ in goal]
         run_env_episode(agent_mod, env_mod, classes, 'F15_sca_circle1024', pos, goal, [POL_SCA] * 1024, [], 4, outdir=od)
+    # F16: the parameter space the C-ABI exports (sca_params, sca_device_tracker_enable) -- the reference stepped with the solver attributes
+    # changed after Agent.__init__ (agent.py:24-41), one value per scene for all agents.  Readers: scaPolicy.py:95,112,272,299-302,
+    # util.py:8,17, orca3dPolicyOfficial.py:44,98,108, agent.py:87-99, mampenv.py:90-92 (dt_nominal).
+    def _cube(rng, n, side, z0, min_sep):
+        pts = []
+        while len(pts) < n:
+            q = rng.uniform(-side, side, 3) + np.array([0.0, 0.0, z0])
+            if all(np.linalg.norm(q - r_) >= min_sep for r_ in pts):
+                pts.append(q)
+        return np.array(pts)
+
+    if want('F16_params_nbr4_dense40'):
+        # more than maxNeighbors = 4 objects inside neighborDist = 4.0 for most agents; all six policies; radii 0.3 / 0.8
+        rng = np.random.default_rng(1601)
+        n = 40
+        xyz = _cube(rng, n, 4.0, 20.0, 1.9)
+        g = -xyz + np.array([0.0, 0.0, 40.0])
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        pol = [i % 6 for i in range(n)]
+        rad = rng.choice([0.3, 0.8], n)
+        obs = [([0.5, -0.5, 20.0], 0.7), ([3.0, 3.0, 22.0], 0.4)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_nbr4_dense40', pos, goal, pol, obs, 16, radius=rad, outdir=od,
+                        attrs=dict(maxNeighbors=4, neighborDist=4.0))
+    if want('F16_params_nbr8_far60'):
+        # neighborDist = 15 (a wider search than the default's 10) with maxNeighbors = 8: circle of 60, every policy
+        pos, goal = rs.set_circle_pos((0, 0), 12.0, 60)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        pol = [i % 6 for i in range(60)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_nbr8_far60', pos, goal, pol, [], 14, outdir=od,
+                        attrs=dict(maxNeighbors=8, neighborDist=15.0))
+    if want('F16_params_orca_h3_v15'):
+        # timeHorizon = 3, maxSpeed = 1.5, pref_speed = 1.2: both ORCA policies (planes, LP3 / LP4 with the larger speed ball) beside RVO / S-RVO
+        rng = np.random.default_rng(1603)
+        n = 60
+        xyz = _cube(rng, n, 6.0, 25.0, 1.3)
+        g = -xyz + np.array([0.0, 0.0, 50.0])
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [0.0, 0.0, 0.0] for i in range(n)]
+        pol = [[POL_ORCA_LP, POL_ORCA, POL_ORCA_LP, POL_RVO, POL_ORCA_LP, POL_SRVO][i % 6] for i in range(n)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_orca_h3_v15', pos, goal, pol, [([0.0, 0.0, 25.0], 1.0)], 30,
+                        pref_speed=1.2, outdir=od, attrs=dict(timeHorizon=3.0, maxSpeed=1.5))
+    if want('F16_params_pitch30'):
+        # pitchlims = +-pi/6 for the planner AND max_heading_change = pi/6 for the posture filter: take-off / landing scene with
+        # obstacles, SCA / RVO3D+Dubins (tracked) beside RVO / S-RVO
+        obs = [([round(4.0 * np.cos(2 * j * np.pi / 8), 2), round(4.0 * np.sin(2 * j * np.pi / 8), 2), 5.0], 1.0) for j in range(8)]
+        pos, goal = rs.set_takeoff_landing_pos(16)
+        pol = [[POL_SCA, POL_RVO_DUBINS, POL_SCA, POL_SRVO, POL_SCA, POL_RVO][i % 6] for i in range(16)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_pitch30', pos, goal, pol, obs, 60, outdir=od,
+                        attrs=dict(pitchlims=(-math.pi / 6, math.pi / 6), min_heading_change=-math.pi / 6, max_heading_change=math.pi / 6))
+    if want('F16_params_turn3_sca16'):
+        # turning_radius = 3.0 (k = 9, condition_dist at 6, scaPolicy.py:272,302): SCA circle of 16 with its tracker, radii 0.3 / 0.8, 40 steps
+        rng = np.random.default_rng(1605)
+        pos, goal = rs.set_circle_pos((0, 0), 10.0, 16)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_turn3_sca16', pos, goal, [POL_SCA] * 16, [], 40,
+                        radius=rng.choice([0.3, 0.8], 16), outdir=od, attrs=dict(turning_radius=3.0))
+    if want('F16_params_turn08_takeoff12'):
+        # turning_radius = 0.8 with take-off agents (is_zAxis: condition_dist compares the nearest neighbour with 1.6) and pitchlims (-0.5, 0.9)
+        pos, goal = rs.set_takeoff_landing_pos(12)
+        pol = [POL_SCA if i % 3 else POL_RVO_DUBINS for i in range(12)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_turn08_takeoff12', pos, goal, pol, [([0.0, 0.0, 6.0], 1.2)], 50, outdir=od,
+                        attrs=dict(turning_radius=0.8, pitchlims=(-0.5, 0.9), neighborDist=2.5))
+    if want('F16_params_timestep02'):
+        # timeStep = 0.2 while the integrator keeps dt_nominal = 0.1 (util.py:8, orca3dPolicyOfficial.py:98 against mampenv.py:90-92)
+        rng = np.random.default_rng(1607)
+        n = 36
+        xyz = _cube(rng, n, 4.0, 3.0, 1.2)
+        xyz[:, 2] = np.abs(xyz[:, 2] - 3.0) * 0.3                                  # near the ground: the next_pA[2] >= 0 test bites
+        g = -xyz + np.array([0.0, 0.0, 6.0])
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [0.0, 0.0, 0.0] for i in range(n)]
+        pol = [[POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP][i % 4] for i in range(n)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_timestep02', pos, goal, pol, [], 20, outdir=od, attrs=dict(timeStep=0.2))
+    if want('F16_params_dt005'):
+        # dt_nominal = 0.05 and timeStep = 0.05: half-length steps in the integrator and in the constraints
+        rng = np.random.default_rng(1608)
+        n = 24
+        xyz = _cube(rng, n, 3.0, 10.0, 1.2)
+        g = -xyz + np.array([0.0, 0.0, 20.0])
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [0.0, 0.0, 0.0] for i in range(n)]
+        pol = [[POL_SCA, POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP, POL_RVO_DUBINS][i % 6] for i in range(n)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_dt005', pos, goal, pol, [], 24, outdir=od,
+                        attrs=dict(timeStep=0.05, dt_nominal=0.05))
+    if want('F16_params_all_mixed48'):
+        # everything off its default at once, obstacles among the agents, three preferred speeds
+        rng = np.random.default_rng(1609)
+        n = 48
+        xyz = _cube(rng, n, 5.0, 12.0, 1.7)
+        g = -xyz + np.array([0.0, 0.0, 24.0])
+        g[: n // 6, :2] = xyz[: n // 6, :2]                                         # a few take-off agents
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.3, 0.3)), 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        pol = [int(x) for x in rng.integers(0, 6, n)]
+        obs = [(list(map(float, rng.uniform(-5, 5, 3) + np.array([0, 0, 12.0]))), float(rng.choice([0.4, 1.0]))) for _ in range(5)]
+        run_env_episode(agent_mod, env_mod, classes, 'F16_params_all_mixed48', pos, goal, pol, obs, 30, radius=rng.choice([0.3, 0.5, 0.8], n),
+                        pref_speed=rng.choice([0.8, 1.0, 1.5], n), outdir=od,
+                        attrs=dict(maxNeighbors=6, neighborDist=7.5, timeHorizon=5.0, maxSpeed=2.0, min_heading_change=-0.6, max_heading_change=0.6,
+                                   pitchlims=(-0.5, 0.7), turning_radius=2.0, timeStep=0.1))
+    # F16 fuzz: the F12 scenes (one step, everything mixed, agents done from the start, obstacles overlapping agents) under random parameter sets
+    for k in range(8):
+        nm = f'F16_params_fuzz_{k:02d}'
+        if want(nm):
+            rng = np.random.default_rng(1650 + k)
+            mhc = float(rng.choice([math.pi / 4, math.pi / 6, 0.3, 1.2, math.pi / 2]))
+            at = dict(maxNeighbors=int(rng.choice([1, 2, 4, 8, 12, 16])), neighborDist=float(rng.choice([1.5, 2.5, 4.0, 10.0, 15.0, 30.0])),
+                      timeHorizon=float(rng.choice([1.0, 3.0, 10.0, 20.0])), maxSpeed=float(rng.choice([0.7, 1.0, 1.5, 3.0])),
+                      min_heading_change=-mhc, max_heading_change=mhc, turning_radius=float(rng.choice([0.8, 1.5, 3.0, 10.0])),
+                      pitchlims=(-float(rng.choice([0.3, math.pi / 6, math.pi / 4, 1.0])), float(rng.choice([0.3, math.pi / 6, math.pi / 4, 1.0]))),
+                      timeStep=float(rng.choice([0.05, 0.1, 0.2])))
+            single_step_random(agent_mod, env_mod, classes, nm, seed=1660 + k, outdir=od, attrs=at)
+    # F16 dense one-step clusters (the F5 scenes) with a short list and a short range: > maxNeighbors in range, collisions, fallbacks
+    for pid in (POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP):
+        nm = f'F16_params_{names[pid]}_packed60'
+        if want(nm):
+            single_step_cluster(agent_mod, env_mod, classes, nm, 60, 9.0, pid, seed=31 + pid, n_obs=14, min_sep=1.05, outdir=od,
+                                attrs=dict(maxNeighbors=5, neighborDist=3.0, timeHorizon=2.0, maxSpeed=1.3, max_heading_change=1.0))
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
