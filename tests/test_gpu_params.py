@@ -101,7 +101,8 @@ def test_policy_pass_grid_mode_with_parameters(name):
     st = static_inputs(fx)
     params, _ = fixture_params(fx)
     sol = make_solver(S, fx, st)
-    checked = 0
+    checked = overflowed = 0
+    maxn = params.get('max_neighbors', 16)
     for t in range(len(fx['step'])):
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
         sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
@@ -121,5 +122,11 @@ def test_policy_pass_grid_mode_with_parameters(name):
             ref = sorted(zip(fx['nbr_dsq'][t][i][:k].round(9), fx['nbr_kind'][t][i][:k], fx['nbr_id'][t][i][:k]))
             assert got == ref, (name, t, i)
             checked += 1
-    assert checked > 0
+        # overflowing lists: the max_neighbors nearest, ascending, all inside neighbor_dist (the reference's own list is visit-order dependent)
+        for i in np.nonzero(valid & ((dg['status'] & 32) != 0) & (fx['coll_after_policy'][t] == 0))[0]:
+            d = nb['nbr_dsq'][i][:maxn]
+            assert nb['nbr_n'][i] == maxn and (np.diff(d) >= 0).all() and d[-1] < params.get('neighbor_dist', 10.0) ** 2, (name, t, i)
+            assert d[0] <= fx['nbr_dsq'][t][i][0] * (1 + 4e-16), (name, t, i)   # nothing nearer was missed (obstacles: x * x against pow(x, 2), 1 ulp)
+            overflowed += 1
+    assert checked + overflowed > 0
     sol.close()
