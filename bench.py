@@ -152,6 +152,28 @@ def timed_leg(sol, scene, stepper, timer, steps, warmup, tracked):
                 my_plans=plans, k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=rp, forms=sol.pass_forms())
 
 
+def kernel_forms(forms):
+    """sca_last_pass_forms (SCA_FORM_*) as kernel names.  TRACK_FUSED | REPLAN_FEW together = k_track_group (shards of <= 1024 agents: the
+    follow-or-re-plan decision and the 64-lane search in one launch); TRACK_FUSED alone = k_track_replan."""
+    out = []
+    if forms & 1:
+        out.append('k_solve_sweep + k_solve_pick4')
+    if (forms & 2) and (forms & 8):
+        out.append('k_track_group')
+    else:
+        if forms & 2:
+            out.append('k_track_replan')
+        if forms & 8:
+            out.append('k_replan_group (4 .. 64 lanes per plan)')
+    if forms & 4:
+        out.append('lane-per-plan re-plan kernel (k_replan)')
+    if forms & 16:
+        out.append('k_lp')
+    if forms & 32:
+        out.append('k_solve_fb')
+    return out or ['k_solve']
+
+
 def roofline_of(leg, steps, tracked, wname):
     """the dominant kernel of the leg: k_replan when the tracker runs inside the step (73 % of the c4 step), else k_solve"""
     solve_s = leg['k_solve_ms'] * 1e-3
@@ -165,14 +187,17 @@ def roofline_of(leg, steps, tracked, wname):
     if not tracked or leg['replan_ms'] <= max(leg['k_solve_ms'], 1e-9):
         return k_solve, None
     plans_per_launch = leg['my_plans'] / max(steps, 1)
+    group = bool(leg['forms'] & 2) and bool(leg['forms'] & 8)          # SCA_FORM_TRACK_FUSED | SCA_FORM_REPLAN_FEW: k_track_group
+    fused = bool(leg['forms'] & 2) and not group
     gbs = BYTES_PER_REPLAN * plans_per_launch / (leg['replan_ms'] * 1e-3) / 1e9
     k_replan = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                'traffic': measured_traffic(wname, 'k_track_replan' if leg['forms'] & 2 else 'k_replan'),
-                'kernel': ('k_track_replan (follow-or-re-plan decision + the re-plan, one lane per agent)' if leg['forms'] & 2 else
+                'traffic': measured_traffic(wname, 'k_track_group' if group else 'k_track_replan' if fused else 'k_replan'),
+                'kernel': ('k_track_group (follow-or-re-plan decision + the 64-lane speculative search, a wavefront per agent)' if group else
+                           'k_track_replan (follow-or-re-plan decision + the re-plan, one lane per agent)' if fused else
                            'k_replan (or k_replan_group<lanes per plan>)') + ', beside the kd build, the neighbour query'
                           + (' and k_solve_sweep' if leg['forms'] & 1 else '') + ' of the same pass',
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
-                'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if leg['forms'] & 2 else
+                'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if fused else
                                                     'k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
                                     / VALU_PEAK_WAVE_INSTS) or None,
                 'note': 'a sequential fp64 search per plan (~69 candidate radii, each two 2-D Dubins problems on the restated glibc libm, lean form): '
@@ -246,6 +271,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='value leg only: no solver_only / grid_mode / scale_model / extra_legs')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the c2 / c3 / c3lp / c5 legs')
+    ap.add_argument('--no-env-api', action='store_true', help='skip env_api (the drop-in MACAEnv.step loop at c2 / c3 / c4)')
+    ap.add_argument('--env-api-only', default=None, metavar='LIST', help='measurement: print only the env_api legs of these workloads (c2,c3,c4)')
     ap.add_argument('--no-weak-model', action='store_true', help='skip scale_model.weak (one rank of 2 / 8 at N = G x 100000, timed on this GPU)')
     args = ap.parse_args()
 
@@ -277,6 +304,9 @@ def main():
     from sca_amd import solver as S
     from sca_amd.distributed import ShardedStepper
 
+    if args.env_api_only:
+        print(json.dumps({'env_api': env_api_legs(S, local_rank, args.steps, args.warmup, tuple(args.env_api_only.split(',')))}), flush=True)
+        return
     wname = args.workload or 'c4'
     w = dict(WORKLOADS[wname])
     if args.policy:
@@ -412,6 +442,8 @@ def main():
             extras['value_parity'] = value_parity(S, scene, local_rank, steps=12, mode=mode)
         if not args.no_extra_legs and wname == 'c4' and not args.agents:
             extras['extra_legs'] = extra_legs(S, timer, local_rank, args.steps, args.warmup)
+        if not args.no_env_api and wname == 'c4' and not args.agents:
+            extras['env_api'] = env_api_legs(S, local_rank, args.steps, args.warmup)
 
     if rank == 0:
         roof, roof2 = roofline_of(main_leg, args.steps, tracked, wname)
@@ -439,8 +471,7 @@ def main():
         out['rccl_ranks_seen'] = dist.get_world_size() if dist is not None else 1
         out['process_group'] = {'backend': dist.get_backend() if dist is not None else None, 'exchange': exchange,
                                 'ranks_sharing_gpu0_test_hook': share_gpu}
-        FORMS = {1: 'k_solve_sweep + k_solve_pick4', 2: 'k_track_replan', 4: 'lane-per-plan re-plan kernel', 8: 'k_replan_group (4 .. 64 lanes per plan)', 16: 'k_lp'}
-        out['config']['kernel_forms'] = [v for k, v in FORMS.items() if main_leg['forms'] & k] or ['k_solve']
+        out['config']['kernel_forms'] = kernel_forms(main_leg['forms'])
         if roof2 is None and tracked and 'solver_only' in extras:
             roof2 = dict(extras['solver_only']['roofline'], source='the solver_only leg (in the tracked step k_solve runs as k_solve_sweep '
                          'beside the re-plans + k_solve_pick4 behind them: pick alone %.4f ms)' % main_leg['k_solve_ms'])
@@ -673,6 +704,67 @@ def extra_legs(S, timer, device, steps, warmup):
                 row['neighbor_search'] = 'kd (see kd_mode; auto_mode beside it)'
         out[name] = row
         sol.close()
+    return out
+
+
+def env_api_legs(S, device, steps, warmup, names=('c2', 'c3', 'c4')):
+    """The drop-in API itself (SURVEY.md 8(d) "end-to-end"): sca_amd.env.MACAEnv built from Agent objects and driven by the loop a user
+    of the reference writes -- `while not env.step(): ...` (run_example/run_sca.py:174-178) -- with the Dubins tracker on the device
+    for SCA.  Three variants per config, ms per step and agent-steps/s:
+      step            env.step() alone (one resident library call + the done count)
+      step_actions    + the float32 action rows of every agent read back every step (the reference's all_actions, mampenv.py:31,40)
+      step_agent_pos  + agent.pos_global_frame of EVERY Agent object read every step (the per-agent attribute the reference exposes)
+    `resident_ms_per_step` beside them is the same scene through sca_run_steps bursts (what `value` / extra_legs time)."""
+    from sca_amd import env as E
+    from sca_amd.distributed import ShardedStepper
+    pol_cls = {0: E.SCAPolicy, 1: E.RVO3DPolicy, 2: E.SRVO3DPolicy, 3: E.ORCA3DPolicy, 4: E.ORCA3DPolicyOfficial, 5: E.RVO3dDubinsPolicy}
+    out = {}
+    for name in names:
+        w = WORKLOADS[name]
+        scene = build_scene(w, w['n'])
+        sc, n = scene['sc'], scene['n']
+        tracked = w['policy'] in ('sca', 'mixed')
+        mode = NBR['kd'] if tracked else NBR['auto']
+        t0 = time.perf_counter()
+        agents = [E.Agent(start_pos=list(sc['start'][i]), goal_pos=list(sc['goal'][i]), vel=[0.0, 0.0, 0.0], radius=0.5, pref_speed=1.0,
+                          policy=pol_cls[int(scene['policy'][i])], id=i) for i in range(n)]
+        obstacles = [E.Obstacle(pos=list(sc['obs_pos'][j]), shape_dict={'shape': 'sphere', 'feature': float(sc['obs_radius'][j])}, id=j)
+                     for j in range(len(sc['obs_radius']))]
+        build_s = time.perf_counter() - t0
+        row = {'workload': w['desc'], 'agents': n, 'device_tracker': tracked, 'neighbor_search': 'kd' if tracked else 'auto',
+               'agent_objects_build_s': round(build_s, 3)}
+        for variant in ('step', 'step_actions', 'step_agent_pos'):
+            env = E.MACAEnv(device_tracker=tracked, neighbor_mode=mode, device=device)
+            t0 = time.perf_counter()
+            env.set_agents(agents, obstacles=obstacles)
+            set_s = time.perf_counter() - t0
+            k_steps = steps if variant != 'step_agent_pos' else max(3, min(steps, 2_000_000 // n))
+            for _ in range(warmup):
+                env.step({})
+            env.solver.synchronize()
+            served = 0
+            t0 = time.perf_counter()
+            for _ in range(k_steps):
+                served += env._active
+                done = env.step({})
+                if variant == 'step_actions':
+                    a = env.all_actions
+                elif variant == 'step_agent_pos':
+                    p = [ag.pos_global_frame for ag in agents]
+                if done:
+                    break
+            env.solver.synchronize()
+            dt = time.perf_counter() - t0
+            row[variant] = {'ms_per_step': dt / k_steps * 1e3, 'value': served / dt, 'unit': 'agent-steps/s', 'steps': k_steps}
+            if variant == 'step':
+                row['set_agents_s'] = round(set_s, 3)
+            env.solver.close()
+        sol = make_solver(S, scene, device)
+        leg = timed_leg(sol, scene, ShardedStepper(sol, 0, 1, mode=mode), Timer(__import__('torch'), None, 'cuda'), steps, warmup, tracked)
+        row['resident_ms_per_step'] = leg['ms_per_step']
+        row['step_over_resident'] = row['step']['ms_per_step'] / leg['ms_per_step']
+        sol.close()
+        out[name] = row
     return out
 
 

@@ -280,7 +280,9 @@ int sca_dubins_plan(const double *qi5, const double *qf5, double rmin, double pi
  * build the reference itself prints other last bits there, and this library keeps printing 2.35's.  sca_libm_check compares the
  * restatement with the running libm on a fixed set of 5 x 4096 arguments: returns 0 when they agree, 1 when they do not
  * (mismatches[5], nullable: sin, cos, atan2, acos, pow(x, 2)).  sca_tracker_create prints one note on stderr in the second case
- * (SCA_QUIET silences it) and sca_device_tracker_enable leaves the condition in sca_last_error; behaviour never changes. */
+ * (SCA_QUIET silences it), and so does the first sca_device_tracker_enable; sca_last_error stays reserved for failures (round 4 put the
+ * note there after a SUCCESSFUL enable; callers that test it for emptiness saw a failure).  Thread-safe (one check per process).
+ * Behaviour never changes. */
 int sca_libm_check(int64_t *mismatches);
 
 /* The same tracker on the device: one lane per agent for the tracking, tracker records resident in HBM, the re-planning

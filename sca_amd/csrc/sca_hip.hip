@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -327,8 +328,13 @@ static double (*volatile p_cos)(double) = std::cos;
 static double (*volatile p_atan2)(double, double) = std::atan2;
 static int g_libm_state = -1;                   // -1 unknown, 0 equal, 1 different
 static int64_t g_libm_bad[5] = {0, 0, 0, 0, 0};
+static std::once_flag g_libm_once;              // trackers may be created from several threads: one check, no race on the statics
+static void libm_check_once();
 static int libm_check_run() {
-    if (g_libm_state >= 0) return g_libm_state;
+    std::call_once(g_libm_once, libm_check_once);
+    return g_libm_state;
+}
+static void libm_check_once() {
     unsigned long long st = 0x9E3779B97F4A7C15ull;
     auto u01 = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
     auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0 || (a != a && b != b); };
@@ -357,7 +363,6 @@ static int libm_check_run() {
                         "libm (the one the golden vectors were recorded with); a Python reference run on this host would differ from both "
                         "in the last bit of some path lengths.\n",
                 (long long)total, (long long)bad[0], (long long)bad[1], (long long)bad[2], (long long)bad[3], (long long)bad[4]);
-    return g_libm_state;
 }
 int sca_libm_check(int64_t *mismatches /*5, nullable*/) {
     const int r = libm_check_run();
@@ -547,9 +552,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
                               (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4})
             (void)hipFuncGetAttributes(&fa, f);
     }
-    if (libm_check_run())                                                // informational (the call succeeds): sca_last_error carries the condition
-        c->err = "note: this host's libm is not the restated glibc 2.35 x86-64 FMA build (sca_libm_check): the tracker reproduces that "
-                 "build's bits, a Python reference run on this host would not";
+    (void)libm_check_run();              // informational: one note on stderr, the verdict through sca_libm_check(); sca_last_error stays for failures
     c->trk_on = true; c->trk_in_pass = in_pass != 0;
     c->d.trk_nbr0 = c->trk_in_pass ? c->trk.nbr0 : nullptr;
     c->trk_passes = 0;
@@ -841,6 +844,8 @@ int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double 
     }
     c->h_pos.assign(pos, pos + 3 * (size_t)n);
     c->kd_single_hint = 0; c->kd_gen++;   // a new state: the previous trees' depth profile says nothing
+    c->kd_ahead = false; c->kdq_last = -1; c->auto_backoff = 0;           // ... and neither do the AUTO passes' counts (no tree is built ahead
+                                                                          // across calls: sca_run_steps consumes its own or abandons it)
     c->h_pos_valid = true;
     c->near_valid = false;
     CHK(c, hipMemcpyAsync(c->d.rec, c->h_rec.data(), sizeof(PubRec) * n, hipMemcpyHostToDevice, c->stream));
@@ -1001,6 +1006,7 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
         wave_max = std::min(cap, std::max(cap / 2 + 1, (int)std::ceil(1.25 * sz)));
     }
     c->kd.wave_max = wave_max;
+    if (top && KT_M / (wave_max + 1) >= KT_NODES) { c->err = "k_kd_top: wave_max below its table bound"; return SCA_ERR_STATE; }   // (static_assert'ed unreachable)
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, ks, d, c->kd, c->P);
     if (c->kd.aux) {                                                    // SCA_NBR_AUTO: the last kernel of the build that reads the record buffer
         CHK(c, hipEventRecord(c->ev_auto_gather[c->auto_builds & 1u], ks));
@@ -1417,7 +1423,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
                            ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
-    if (timed || prof) CHK(c, hipEventRecord(e1, ns));                // [e0, e1] = K1
+    if ((timed || prof) && !auto_mode) CHK(c, hipEventRecord(e1, ns));    // [e0, e1] = K1
     if (auto_mode) {
         // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
         // build on kd_stream, and nothing reads a list before that query is through
@@ -1441,6 +1447,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                 CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));
             }
         } else CHK(c, hipStreamWaitEvent(ns, c->ev_auto_kd, 0));
+        if (timed || prof) CHK(c, hipEventRecord(e1, ns));               // [e0, e1] of an AUTO pass: the grid query AND the wait for the kd query
+                                                                        // of the listed agents behind it (the lists are final here)
     }
     if (split) {
         hipLaunchKernelGGL(k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, ns, d, c->P);
@@ -1596,8 +1604,22 @@ static int exchange_moved_records(sca_ctx *c) {
     return 0;
 }
 
+static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode);
+// A failure in the middle of the loop (an exchange, a launch, a partition commit) must not leave the AUTO bookkeeping pointing at a tree
+// built ahead from positions the caller is about to replace: forget the build-ahead, let the context's stream wait for whatever
+// kd_stream still holds, and have the next AUTO pass decide afresh.
+static void auto_abandon(sca_ctx *c) {
+    c->kd_ahead = false; c->kdq_last = -1; c->kdq_pending = false; c->auto_backoff = 0;
+    if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipGetLastError(); }
+    c->auto_unjoined = false;
+}
 int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c) return SCA_ERR_ARG;
+    const int r = run_steps_loop(c, steps, neighbor_mode);
+    if (r != 0) { const std::string keep = c->err; auto_abandon(c); c->err = keep; }
+    return r;
+}
+static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (c->part_on && c->part_nranks > 1 && !c->shard_emulation) {
         c->err = "cell-owner partition over several ranks: drive the step with sca_step_begin / sca_partition_pack / [exchange] / "
@@ -2123,6 +2145,7 @@ int sca_set_shard(sca_ctx *c, int begin, int count) {
     if (c->part_on) { c->err = "sca_set_shard with the cell-owner partition active (sca_partition_disable first)"; return SCA_ERR_STATE; }
     if (c->comm) { c->err = "sca_set_shard with an active communicator (the shard follows from rank / nranks; sca_comm_destroy first)"; return SCA_ERR_STATE; }
     c->d.shard_begin = begin; c->d.shard_count = count;
+    c->kd_ahead = false; c->kdq_last = -1; c->auto_backoff = 0;           // another shard: the AUTO passes' counts described the old one
     return 0;
 }
 int sca_public_records(sca_ctx *c, int which, void **device_ptr, int64_t *bytes_per_agent) {

@@ -121,9 +121,14 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (p < d.n) {
         const int id = d.aperm[p];
-        const PubRec r = d.rec[id];
-        s.kx[p] = r.px; s.ky[p] = r.py; s.kz[p] = r.pz;
-        mn[0] = mx[0] = r.px; mn[1] = mx[1] = r.py; mn[2] = mx[2] = r.pz;
+        // the three position fields and nothing else of the record: a build beside a pass (aux, SCA_NBR_AUTO's build-ahead in
+        // sca_run_steps) runs while k_collide_finish / k_goal_flags_others / the next k_action write `.flags` (and the velocity) of the same
+        // records on the main stream -- the positions are final by then (ev_auto_moved), the rest is not this kernel's to look at
+        static_assert(offsetof(PubRec, px) == 0 && offsetof(PubRec, py) == 8 && offsetof(PubRec, pz) == 16, "PubRec starts with the position");
+        const double *rp = &d.rec[id].px;
+        const double rx = rp[0], ry = rp[1], rz = rp[2];
+        s.kx[p] = rx; s.ky[p] = ry; s.kz[p] = rz;
+        mn[0] = mx[0] = rx; mn[1] = mx[1] = ry; mn[2] = mx[2] = rz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
         if (!s.aux && shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
     }
@@ -804,6 +809,11 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
 #define SCA_KT_THREADS 1024
 #endif
 constexpr int KT_M = 4096, KT_T = SCA_KT_THREADS, KT_E = KT_M / KT_T, KT_NODES = 32;
+// A node of the top has more than wave_max members, and wave_max >= cap / 2 + 1 >= KD_WAVE_FLOOR + 1 (build_agent_tree_device; SCA_KD_WAVE_CAP
+// is clamped to 2 * KD_WAVE_FLOOR): a level of the top therefore holds at most KT_M / (KD_WAVE_FLOOR + 2) nodes, and a thread's KT_E consecutive
+// positions lie in at most two of them.  The host checks the same bound with the pass's actual wave_max before it takes this path.
+static_assert(KT_M / (KD_WAVE_FLOOR + 2) < KT_NODES, "k_kd_top: a level's nodes must fit KtLds' per-level tables at the smallest wave_max");
+static_assert(KT_E <= KD_WAVE_FLOOR + 1, "k_kd_top: a thread's positions must not span more than two nodes");
 // Sixteen wavefronts, four consecutive positions per thread.  (Measured with 256 / 512 / 1024 threads, i.e. 16 / 8 / 4 positions each:
 // k_kd_top 42 / 30 / 26 us at N = 4096 -- a level is a chain of LDS round trips, and the wavefronts hide each other's.)
 #define KT_SW(p) ((((p) & (KT_E - 1)) * KT_T) + ((p) / KT_E))   // position p of thread p / KT_E: the k-th positions of all threads side by side
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
                 for (int q = 0; q < 3; q++) { S.cbox[tid][sd][q] = dkey(INFINITY); S.cbox[tid][sd][3 + q] = dkey(-INFINITY); }
         }
         __syncthreads();
-        // ---- the (at most two: a node here has more than wave_max >= 256 members) nodes this thread's sixteen positions are in
+        // ---- the (at most two: a node here has more than wave_max >= 129 members) nodes this thread's KT_E consecutive positions are in
         int sA = -1, bA = 0, eA = 0, sB = -1, bB = 0, eB = 0;
         for (int j = 0; j < nc; j++) {
             const int b = S.nb[cur][j], e = S.ne[cur][j];
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
         }
         const int axA = sA >= 0 ? S.naxis[sA] : 0, axB = sB >= 0 ? S.naxis[sB] : 0;
         const double spA = sA >= 0 ? S.nsplit[sA] : 0.0, spB = sB >= 0 ? S.nsplit[sB] : 0.0;
-        const bool full = sA >= 0 && sB < 0 && p0 >= bA && p0 + KT_E <= eA;      // all sixteen in one node: the usual thread
+        const bool full = sA >= 0 && sB < 0 && p0 >= bA && p0 + KT_E <= eA;      // all KT_E in one node: the usual thread
         // ---- flags; the children's boxes
         unsigned gebits = 0, inbits = 0;
         double acc[2][6] = {{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}};

@@ -329,6 +329,14 @@ class MACAEnv:
             self._stale = True                                    # is_collision set inside insert*Neighbor (agent.py:84)
         return self._row_cache
 
+    @property
+    def all_actions(self):
+        """The [N, 7] float32 action rows of the last step (the reference's `all_actions` inside _take_action, mampenv.py:31,40): read back
+        from the device when asked for."""
+        if self._row_cache is not None:
+            return self._row_cache
+        return self.solver.actions()
+
     def _policy_row(self, i):
         return list(self._policy_pass()[i])
 
