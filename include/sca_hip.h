@@ -138,6 +138,10 @@ int sca_get_diag(sca_ctx *ctx, int32_t *diag /*n*5*/, int32_t *status /*n*/, dou
 int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/);
 /* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising */
 int sca_run_steps(sca_ctx *ctx, int steps, int neighbor_mode);
+/* MACAEnv.step (mampenv.py:22-25) in one call: one resident step (both loops of _take_action + is_done), then the number of agents of
+ * this rank still running after it (0 == is_done) -- sca_run_steps(ctx, 1, mode) + sca_active_count with one stream synchronisation and
+ * one pinned 32-KB read-back.  What `while not env.step()` of the drop-in env costs per step beyond the kernels (bench.py `env_api`). */
+int sca_env_step(sca_ctx *ctx, int neighbor_mode, int *active);
 int sca_synchronize(sca_ctx *ctx);
 /* number of this rank's agents that are not done (at goal, collided or timed out) after the last env update; 0 == the
  * `all(agent.is_run_done)` of MACAEnv.is_done (mampenv.py:51-59).  Synchronises; reports a failed device kd build. */

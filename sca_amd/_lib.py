@@ -45,6 +45,7 @@ SIGNATURES = {
     'sca_get_diag': (C.c_int, [C.c_void_p, ip, ip, dp]),
     'sca_env_update': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_run_steps': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    'sca_env_step': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     'sca_synchronize': (C.c_int, [C.c_void_p]),
     'sca_active_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_set_shard': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

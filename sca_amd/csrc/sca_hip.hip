@@ -213,6 +213,7 @@ struct sca_ctx {
                                         // structure (K0) and the neighbour query (K1) of the pass run on this one beside them
     hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     hipStream_t nbr_stream = nullptr;   // where K0 / K1 of the current pass go: trk_stream when overlapped, else the main stream
+    int32_t *h_done = nullptr;          // pinned: K4's 256 counters (stride 32) + the kd build's error word (read_active)
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
     bool trk_count_pending = false;
@@ -730,6 +731,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->comm) { (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     (void)tracker_free(c);
     (void)part_free(c);
+    if (c->h_done) { (void)hipHostFree(c->h_done); c->h_done = nullptr; }
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
@@ -1564,35 +1566,41 @@ int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
     return 0;
 }
 
+static int read_active(sca_ctx *c, int *active, bool kd_word);
 int sca_env_update(sca_ctx *c, int *all_done) {
     if (!c) return SCA_ERR_ARG;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     CHK(c, hipEventRecord(c->ev[4], c->stream));
     if (int r = launch_update(c, true)) return r;
     if (all_done) {
-        std::vector<int32_t> parts(256 * 32);
-        CHK(c, hipMemcpyAsync(parts.data(), c->d.done_count, sizeof(int32_t) * parts.size(), hipMemcpyDeviceToHost, c->stream));
-        CHK(c, hipStreamSynchronize(c->stream));
-        CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[4], c->ev[5]));
         int active = 0;
-        for (int v : parts) active += v;
+        if (int r = read_active(c, &active, false)) return r;
+        CHK(c, hipEventElapsedTime(&c->ms_update, c->ev[4], c->ev[5]));
         *all_done = (active == 0);
     }
     return 0;
 }
 
+// K4's counters (and the kd build's error word) in ONE round trip through a pinned buffer: this is the per-step synchronisation of the
+// drop-in loop `while not env.step()` (round 4: two pageable copies with a stream synchronisation each)
+static int read_active(sca_ctx *c, int *active, bool kd_word) {
+    constexpr int PARTS = 256 * 32;
+    if (!c->h_done) CHK(c, hipHostMalloc((void **)&c->h_done, sizeof(int32_t) * (PARTS + 1)));
+    c->h_done[PARTS] = 0;
+    CHK(c, hipMemcpyAsync(c->h_done, c->d.done_count, sizeof(int32_t) * PARTS, hipMemcpyDeviceToHost, c->stream));
+    if (kd_word) CHK(c, hipMemcpyAsync(c->h_done + PARTS, c->kd.counts + KD_MAX_LEVELS + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_done[PARTS]) return check_kd_overflow(c);                      // (reports, resets the word)
+    int n = 0;
+    for (int i = 0; i < PARTS; i += 32) n += c->h_done[i];
+    *active = n;
+    return 0;
+}
 int sca_active_count(sca_ctx *c, int *active) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, active);
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
-    std::vector<int32_t> parts(256 * 32);
-    CHK(c, hipMemcpyAsync(parts.data(), c->d.done_count, sizeof(int32_t) * parts.size(), hipMemcpyDeviceToHost, c->stream));
-    CHK(c, hipStreamSynchronize(c->stream));
-    if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
-    int n = 0;
-    for (int v : parts) n += v;
-    *active = n;
-    return 0;
+    return read_active(c, active, c->perm_on_device);
 }
 
 // the step's exchange: every rank contributes its shard's moved records, in place
@@ -1660,6 +1668,12 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
         if (int r = launch_collide_finish(c, false)) return r;
     }
     return auto_join(c);
+}
+int sca_env_step(sca_ctx *c, int neighbor_mode, int *active) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, active);
+    if (int r = sca_run_steps(c, 1, neighbor_mode)) return r;
+    return read_active(c, active, c->perm_on_device);
 }
 int sca_set_shard_emulation(sca_ctx *c, int on) {
     if (!c) return SCA_ERR_ARG;

@@ -364,8 +364,7 @@ class MACAEnv:
         t0 = time.perf_counter()
         served = max(1, self._active)
         if self._row_cache is None and self.v_pref_fn is None:
-            self.solver.run_steps(1, self.neighbor_mode)
-            self._active = self.solver.active_count()           # synchronises: the step is over when this returns
+            self._active = self.solver.env_step(self.neighbor_mode)   # one call; synchronises: the step is over when this returns
             t_policy = time.perf_counter() - t0
             done = self._active == 0
             self._nbr_cache = None

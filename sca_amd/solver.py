@@ -156,6 +156,12 @@ class BatchedSolver:
     def run_steps(self, steps, mode=NBR_KDTREE):
         self._chk(self.L.sca_run_steps(self.ctx, int(steps), int(mode)), 'sca_run_steps')
 
+    def env_step(self, mode=NBR_KDTREE):
+        """One resident step + the agents still running after it (MACAEnv.step in one library call; synchronises)."""
+        v = C.c_int(0)
+        self._chk(self.L.sca_env_step(self.ctx, int(mode), C.byref(v)), 'sca_env_step')
+        return int(v.value)
+
     def synchronize(self):
         self._chk(self.L.sca_synchronize(self.ctx), 'sca_synchronize')
 

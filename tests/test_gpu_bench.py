@@ -82,3 +82,19 @@ def test_bench_self_launch_partition_variant():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert out['rccl_ranks_seen'] == 2 and out['process_group']['exchange'] == 'partition'
+
+
+def test_env_api_key_times_the_drop_in_loop():
+    """`env_api` (round 5): the drop-in MACAEnv built from Agent objects, `while not env.step()` -- three variants per config (step alone,
+    + the action rows read back, + every Agent's pos_global_frame read), the resident burst of the same scene beside them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--env-api-only', 'c2,c3', '--steps', '20', '--warmup', '5'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])['env_api']
+    for name, n in (('c2', 1024), ('c3', 4096)):
+        row = out[name]
+        assert row['agents'] == n and row['device_tracker'] == (name == 'c2')
+        for v in ('step', 'step_actions', 'step_agent_pos'):
+            assert row[v]['ms_per_step'] > 0 and row[v]['value'] > 0 and row[v]['steps'] > 0
+        assert row['step']['ms_per_step'] <= row['step_agent_pos']['ms_per_step']
+        assert 0.8 < row['step_over_resident'] < 4.0, row           # the loop costs the kernels + one synchronising read-back per step
