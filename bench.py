@@ -61,6 +61,9 @@ WORKLOADS = {
     'c3lp': dict(kind='random', n=4096, policy='orcalp', desc='c3: random N=4096, ORCA3D Official (LP1-4)'),
     'c4': dict(kind='circle', n=100000, policy='sca', desc='c4: circle N=100000, SCA policy'),
     'c5': dict(kind='takeoff', n=16384, policy='mixed', desc='c5: take-off/landing N=16384, SCA even ids / S-RVO3D odd ids'),
+    # not a BASELINE config: a scene the speculation trees of sca_spec_trees.h never saw (they were fitted on searches recorded in the c2 /
+    # c5 episodes, tools/gen_spec_trees.py) -- random starts, random goals, random yaw / pitch at both ends, SCA with its tracker
+    'heldout': dict(kind='random_posed', n=1024, policy='sca', desc='held-out: random cube N=1024, goals and poses at random, SCA policy'),
 }
 POL = {'sca': 0, 'rvo': 1, 'srvo': 2, 'orca': 3, 'orcalp': 4}
 NBR = {'kd': 0, 'grid': 1, 'auto': 3}
@@ -77,6 +80,14 @@ def build_scene(w, n):
         sc = scenarios.circle(n)
     elif w['kind'] == 'random':
         sc = scenarios.random_cube(n, seed=0)
+    elif w['kind'] == 'random_posed':
+        sc = scenarios.random_cube(n, seed=11)
+        rng = np.random.default_rng(12)
+        sc['goal'] = sc['goal'].copy(); sc['start'] = sc['start'].copy()
+        sc['goal'][:, :3] = sc['start'][rng.permutation(n), :3] + rng.normal(0, 2.0, (n, 3))          # somebody else's corner of the cube
+        for arr in (sc['start'], sc['goal']):
+            arr[:, 3] = rng.uniform(0, 2 * np.pi, n)
+            arr[:, 4] = rng.uniform(-0.5, 0.5, n)
     else:
         sc = scenarios.takeoff_landing(n)
     n = len(sc['start'])
@@ -136,12 +147,18 @@ def timed_leg(sol, scene, stepper, timer, steps, warmup, tracked):
     sol.agent_steps(reset=True)
     plans0 = int(sol.device_tracker_replans()[stepper.begin:stepper.begin + stepper.count].sum()) if tracked else 0
     sol.set_profiling(True)
+    if hasattr(stepper, 'measure_exchange'):
+        stepper.measure_exchange = True                     # an event pair around every collective of the timed steps
+        stepper._xch_events = []
     timer.barrier()
     t0 = time.perf_counter()
     stepper.run(steps)
     stepper.sync()
     timer.barrier()
     dt = time.perf_counter() - t0
+    xch = stepper.exchange_ms() if hasattr(stepper, 'exchange_ms') else None
+    if hasattr(stepper, 'measure_exchange'):
+        stepper.measure_exchange = False
     sol.set_profiling(False)
     my_steps = sol.agent_steps(reset=True)
     plans = (int(sol.device_tracker_replans()[stepper.begin:stepper.begin + stepper.count].sum()) - plans0) if tracked else 0
@@ -244,6 +261,43 @@ def self_launch(n):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+def inlib_stepper(sol, torch, dist, rank, world, local_rank, mode):
+    """A ShardedStepper on the library's own RCCL communicator, or None (on EVERY rank) when some rank cannot have one.
+    sca_comm_init is a collective (ncclCommInitRank): a rank that cannot load RCCL must say so BEFORE any rank enters it, or the
+    others would wait inside it forever.  So: every rank probes (dlopen + symbols, no collective), the ranks agree (MIN), and only
+    then the id travels and the communicators are made; a failure after that point (init error on some rank) is agreed on the same
+    way and every rank falls back to torch.distributed."""
+    from sca_amd.distributed import ShardedStepper
+    dev = torch.device('cuda', local_rank)
+    flag = torch.tensor([1 if sol.comm_probe() else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item())
+    if not ok and rank == 0:
+        print('[bench] librccl not loadable on some rank: exchange through torch.distributed', file=sys.stderr)
+    stepper = None
+    box = [None]
+    if ok:
+        if rank == 0:
+            try:
+                box = [sol.comm_unique_id()]
+            except Exception as e:                          # noqa: BLE001 -- reported, every rank then falls back
+                print(f'[bench rank 0] sca_comm_unique_id failed: {e}', file=sys.stderr)
+        dist.broadcast_object_list(box, src=0, device=dev)
+        ok = 0 if box[0] is None else 1                     # the same on every rank: they all hold rank 0's answer
+    if ok:
+        try:
+            stepper = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0])
+        except Exception as e:                              # noqa: BLE001
+            ok = 0
+            print(f'[bench rank {rank}] sca_comm_init failed: {e}', file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and stepper is not None:
+            sol.comm_destroy()
+            stepper = None
+    return stepper
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -332,36 +386,7 @@ def main():
     exchange = args.exchange if world > 1 and not share_gpu else ('torch' if world > 1 else 'none')
     stepper = None
     if exchange == 'inlib':
-        # The library's own RCCL communicator.  sca_comm_init is a collective (ncclCommInitRank): a rank that cannot load RCCL
-        # must say so BEFORE any rank enters it, or the others would wait inside it forever.  So: every rank probes (dlopen +
-        # symbols, no collective), the ranks agree (MIN), and only then the id travels and the communicators are made; a failure
-        # after that point (init error on some rank) is agreed on the same way and every rank falls back to torch.distributed.
-        dev = torch.device('cuda', local_rank)
-        flag = torch.tensor([1 if sol.comm_probe() else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
-        if not ok and rank == 0:
-            print('[bench] librccl not loadable on some rank: exchange through torch.distributed', file=sys.stderr)
-        if ok:
-            box = [None]
-            if rank == 0:
-                try:
-                    box = [sol.comm_unique_id()]
-                except Exception as e:                          # noqa: BLE001 -- reported, every rank then falls back
-                    print(f'[bench rank 0] sca_comm_unique_id failed: {e}', file=sys.stderr)
-            dist.broadcast_object_list(box, src=0, device=dev)
-            ok = 0 if box[0] is None else 1                     # the same on every rank: they all hold rank 0's answer
-        if ok:
-            try:
-                stepper = ShardedStepper(sol, rank, world, mode=mode, inlib=True, unique_id=box[0])
-            except Exception as e:                              # noqa: BLE001
-                ok = 0
-                print(f'[bench rank {rank}] sca_comm_init failed: {e}', file=sys.stderr)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and stepper is not None:
-                sol.comm_destroy()
-                stepper = None
+        stepper = inlib_stepper(sol, torch, dist, rank, world, local_rank, mode)
         if stepper is None:
             exchange = 'torch'
     if args.partition and args.emulate_rank_of > 1:
@@ -404,6 +429,22 @@ def main():
         tracked = vpref == 'dubins-device'
         main_leg = timed_leg(sol, scene, stepper, timer, args.steps, args.warmup, tracked)
 
+    other_exchange = None
+    if world > 1 and not share_gpu and exchange in ('torch', 'inlib') and os.environ.get('SCA_BENCH_BOTH_EXCHANGES') and vpref != 'dubins':
+        # the other way to run the step's all-gather, on a solver of its own, same leg: both lines on the first real lease
+        other = 'inlib' if exchange == 'torch' else 'torch'
+        sol2 = make_solver(S, scene, local_rank)
+        reset_state(sol2, scene)
+        st2 = inlib_stepper(sol2, torch, dist, rank, world, local_rank, mode) if other == 'inlib' else \
+            ShardedStepper(sol2, rank, world, torch_mod=torch, dist_mod=dist, mode=mode)
+        if st2 is not None:
+            leg2 = timed_leg(sol2, scene, st2, timer, args.steps, args.warmup, tracked)
+            other_exchange = {'exchange': other, 'value': leg2['value'], 'ms_per_step': leg2['ms_per_step'], 'exchange_ms_measured': leg2.get('exchange_ms')}
+            if other == 'inlib':
+                sol2.comm_destroy()
+        else:
+            other_exchange = {'exchange': other, 'error': 'the library could not create its RCCL communicator on every rank'}
+        sol2.close()
     extras = {}
     single = world == 1 and not args.no_extra and vpref != 'dubins'
     cpu = None
@@ -470,7 +511,12 @@ def main():
         # how many ranks the process group itself reported (not what --gpus asked for), and what carried the exchange
         out['rccl_ranks_seen'] = dist.get_world_size() if dist is not None else 1
         out['process_group'] = {'backend': dist.get_backend() if dist is not None else None, 'exchange': exchange,
-                                'ranks_sharing_gpu0_test_hook': share_gpu}
+                                'ranks_sharing_gpu0_test_hook': share_gpu,
+                                # device time of the step's collective on rank 0 (event pair on the stream it is issued on); None with one rank
+                                # and in the host-staged test hook.  Replaces scale_model's allgather_ms_assumed on the first real lease.
+                                'exchange_ms_measured': main_leg.get('exchange_ms')}
+        if other_exchange is not None:
+            out['other_exchange'] = other_exchange
         out['config']['kernel_forms'] = kernel_forms(main_leg['forms'])
         if roof2 is None and tracked and 'solver_only' in extras:
             roof2 = dict(extras['solver_only']['roofline'], source='the solver_only leg (in the tracked step k_solve runs as k_solve_sweep '
@@ -665,13 +711,28 @@ def value_parity(S, scene, device, steps=6, mode=0):
     return out
 
 
+def spec_stats(sol, n, max_agents=2048):
+    """search steps per round of the speculative re-plan kernels, from the tracker records the last plans left (candidate radii tried /
+    rounds; sca_device_tracker_debug slots 22 and 10) -- over the agents whose last plan came from a many-steps-per-round form"""
+    import ctypes as C
+    from sca_amd import _lib
+    o = np.zeros(24)
+    iters = rounds = plans = 0
+    for i in range(0, n, max(1, n // max_agents)):
+        sol.L.sca_device_tracker_debug(sol.ctx, int(i), _lib.ptr(o, C.c_double))
+        if o[10] > 0:
+            iters += o[22] / 64; rounds += o[10]; plans += 1
+    return {'plans_sampled': plans, 'candidates_per_plan': iters / max(plans, 1), 'rounds_per_plan': rounds / max(plans, 1),
+            'steps_per_round': iters / max(rounds, 1)}
+
+
 def extra_legs(S, timer, device, steps, warmup):
     """the other BASELINE configs as short driver-timed legs: value (SCA workloads: as shipped, tracker on the device),
     ms_per_step, the dominant kernel's roofline entry, max |v_hip - v_oracle| of one policy pass given the v_pref it used (kd mode:
     must be 0.0) and, for SCA workloads, value_parity against the host-tracker run"""
     from sca_amd.distributed import ShardedStepper
     out = {}
-    for name in ('c2', 'c3', 'c3lp', 'c5'):
+    for name in ('c2', 'c3', 'c3lp', 'c5', 'heldout'):
         w = WORKLOADS[name]
         scene = build_scene(w, w['n'])
         sol = make_solver(S, scene, device)
@@ -681,6 +742,11 @@ def extra_legs(S, timer, device, steps, warmup):
         row = {'workload': w['desc'], 'value': leg['value'], 'unit': 'agent-steps/s', 'ms_per_step': leg['ms_per_step'],
                'v_pref': 'Dubins tracker on the device' if tracked else 'straight-line rule (the policy\'s own)',
                'k_solve_ms': leg['k_solve_ms'], 'neighbors_kernel_ms': leg['k1_ms']}
+        if tracked:
+            row['re_plans_per_step'] = leg['plans'] / max(steps, 1)
+            row['replan_kernel_ms'] = leg['replan_ms']
+            row['kernel_forms'] = kernel_forms(leg['forms'])
+            row['speculative_search'] = spec_stats(sol, scene['n'])
         if tracked:
             leg2 = timed_leg(sol, scene, st, timer, steps, warmup, False)
             row['solver_only'] = {'value': leg2['value'], 'ms_per_step': leg2['ms_per_step']}

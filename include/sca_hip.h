@@ -212,6 +212,8 @@ int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float
 
 /* the same for the tracker's re-plan kernels (k_replan_group<4 .. 64 lanes per plan>, k_replan, k_track_replan), events on the stream they run on */
 int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
+/* the same for the step's exchange when the library issues it (sca_comm_init: ncclAllGather inside sca_run_steps); 0 without a communicator */
+int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
 /* Which kernel forms the last policy pass was launched with (the library picks them per pass from the shard size and the
  * re-plan count of a recent pass; none of them changes a result bit -- tests/test_gpu_solve_split.py, test_gpu_tracker.py):
  *   SCA_FORM_SOLVE_SPLIT   k_solve as k_solve_sweep (beside the tracker's re-plans) + k_solve_pick4 (behind them)
@@ -300,6 +302,7 @@ int sca_libm_check(int64_t *mismatches);
  * the neighbour lists on the device), otherwise only through sca_device_tracker_vpref.  sca_set_agents disables it. */
 int sca_device_tracker_enable(sca_ctx *ctx, const double *goal_heading /*n*3, agent.py:19*/, double turning_radius,
                               double pitch_min, double pitch_max, int in_pass);
+/* the tracked agents take v_pref from their policy's own straight-line rule again (sca_set_vpref afterwards to feed it from the host) */
 int sca_device_tracker_disable(sca_ctx *ctx);
 /* one compute_v_pref per active tracked agent on the current state; nbr0_dsq as in sca_tracker_vpref, NULL = from the
  * device's neighbour lists; vpref_out nullable */
@@ -307,7 +310,8 @@ int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*
 int sca_device_tracker_replans(sca_ctx *ctx, int32_t *replans /*n*/);
 
 /* diagnostics: the tracker record of one agent as 24 doubles -- horizontal maneuver (r_min, t, p, length), vertical maneuver
- * (the same four), plan length, sampling size, two unused slots, cursor, sample count, tracked node[3], untruncated v_pref[3],
+ * (the same four), plan length, sampling size, rounds of the speculative search that produced the plan (0: a one-step-at-a-time form), one
+ * unused slot, cursor, sample count, tracked node[3], untruncated v_pref[3],
  * the two words, 64 x candidate radii tried, re-plan count -- of the host tracker / the device tracker */
 int sca_tracker_debug(void *tracker, int agent, double *out24);
 int sca_device_tracker_debug(sca_ctx *ctx, int agent, double *out24);

@@ -322,6 +322,8 @@ struct Plan3D {
     char mode[7] = {0};
     bool ok = false;
     int iters = 0;                       // candidate radii the search tried (statistics; sca_*_tracker_debug)
+    int rounds = 0;                      // rounds of the speculative search that tried them (k_replan_group<16 / 32 / 64>: several steps per round;
+                                         // 0: a form that takes one step at a time).  Statistics only (sits in the record's padding).
     long count = 0;                      // number of samples compute_sampling (dubinsmaneuver3d.py:116-132) would produce
     // sample i of the path: a pure function of i, so the tracker evaluates samples on demand
     // (the reference materialises all ~1000 of them at every re-plan and then discards most)

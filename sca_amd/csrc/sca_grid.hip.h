@@ -57,6 +57,7 @@ __device__ __forceinline__ int grid_bucket(unsigned long long key, int hbits) {
 }
 
 __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Params P) {
+    SCA_TL(d, TL_GRID_COUNT);
     SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 256) d.done_count[i * 32] = 0;                                   // start of a step: K4's counters
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void k_grid_alloc(GridDev g) {
 }
 
 __global__ __launch_bounds__(256) void k_grid_fill(DeviceView d, GridDev g) {
+    SCA_TL(d, TL_GRID_FILL);
     SCA_KD_SETPRIO();                                                    // (see sca_kdbuild.hip.h: short launches beside the re-plan kernel)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= present_count(d)) return;
@@ -149,6 +151,7 @@ __device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long 
 template <bool AUTO>
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
                                                                   double obs_reach, double max_radius) {
+    SCA_TL(d, TL_NBR_GRID);
     SCA_K1_SETPRIO();
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     __shared__ int pfx[K1P_WAVES][K1P_APW][32], fpos[K1P_WAVES][K1P_APW][32];
@@ -413,6 +416,7 @@ __device__ __forceinline__ bool collide_scan_grid(const DeviceView &d, const Gri
 
 __global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish_grid(DeviceView d, GridDev g, Params P, double agent_reach,
                                                                      double obs_reach, int check_arrived) {
+    SCA_TL(d, TL_COLLIDE);
     __shared__ int stacks[K4_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

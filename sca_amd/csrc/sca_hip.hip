@@ -166,6 +166,9 @@ struct sca_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> pool;       // 4 events per profiled pass: around K1 (on its stream), around k_solve
     int pool_used = 0;
+    std::vector<hipEvent_t> pool_xch;   // 2 events per profiled step around the in-library ncclAllGather (sca_last_exchange_ms)
+    int pool_xch_used = 0;
+    float ms_exchange = 0.0f;
     std::vector<hipEvent_t> pool_trk;   // 2 events per step on the stream the re-plan kernels run on: before / after them
     int pool_trk_used = 0;
     float ms_replan = 0;
@@ -213,6 +216,7 @@ struct sca_ctx {
                                         // structure (K0) and the neighbour query (K1) of the pass run on this one beside them
     hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     hipStream_t nbr_stream = nullptr;   // where K0 / K1 of the current pass go: trk_stream when overlapped, else the main stream
+    bool kd_ahead_enqueue = false;      // (timeline builds: the build being enqueued belongs to the next pass)
     int32_t *h_done = nullptr;          // pinned: K4's 256 counters (stride 32) + the kd build's error word (read_active)
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
@@ -404,7 +408,7 @@ int sca_tracker_vpref(void *tr, const double *pos, const float *vel, const doubl
 static void track_dump(const sca_dubins::AgentTrack &a, double *o) {
     const sca_dubins::Plan3D &P = a.plan;
     o[0] = P.h.r_min; o[1] = P.h.t; o[2] = P.h.p; o[3] = P.h.length; o[4] = P.v.r_min; o[5] = P.v.t; o[6] = P.v.p; o[7] = P.v.length;
-    o[8] = P.length; o[9] = P.sampling_size; o[10] = 0.0; o[11] = 0.0; o[12] = (double)a.next; o[13] = (double)P.count;
+    o[8] = P.length; o[9] = P.sampling_size; o[10] = (double)P.rounds; o[11] = 0.0; o[12] = (double)a.next; o[13] = (double)P.count;
     for (int q = 0; q < 3; q++) { o[14 + q] = a.now_goal[q]; o[17 + q] = a.v_pref[q]; }
     o[20] = P.mode[0] * 65536.0 + P.mode[1] * 256.0 + P.mode[2]; o[21] = P.mode[3] * 65536.0 + P.mode[4] * 256.0 + P.mode[5];
     o[22] = 64.0 * P.iters; o[23] = (double)a.replans;
@@ -505,6 +509,9 @@ static int tracker_free(sca_ctx *c) {
     c->kd.skip_prep = 0;
     c->trk = TrackDev{}; c->trk_goal_heading = nullptr; c->trk_on = false; c->trk_in_pass = false;
     c->d.trk_nbr0 = nullptr;
+    // the tracked agents go back to their policy's own v_pref rule (rvo3dPolicy.py:182-196): until round 5 they kept vpref_mode = 1 and the
+    // tracker's LAST output, frozen -- bench.py's `solver_only` legs ran on that instead of the straight-line rule they are labelled with
+    if (c->d.vpref_mode && c->n > 0) { CHK(c, hipMemsetAsync(c->d.vpref_mode, 0, c->n, c->stream)); CHK(c, hipStreamSynchronize(c->stream)); }
     return 0;
 }
 int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double turning_radius, double pitch_min, double pitch_max,
@@ -743,8 +750,9 @@ void sca_destroy(sca_ctx *c) {
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->pool) (void)hipEventDestroy(e);
     for (auto &e : c->pool_trk) (void)hipEventDestroy(e);
+    for (auto &e : c->pool_xch) (void)hipEventDestroy(e);
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipStreamDestroy(c->kd_stream); }
-    for (hipEvent_t e : {c->ev_auto_fork, c->ev_auto_k1g, c->ev_auto_kd, c->ev_auto_moved, c->ev_auto_cnt}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_auto_fork, c->ev_auto_k1g, c->ev_auto_moved, c->ev_auto_cnt}) if (e) (void)hipEventDestroy(e);   // (ev_auto_kd aliases ev_auto_kdq[])
     if (c->kdq_list) (void)hipFree(c->kdq_list);
     if (c->kdq_count) (void)hipFree(c->kdq_count);
     if (c->kdq_host) (void)hipHostFree(c->kdq_host);
@@ -1240,10 +1248,20 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
 }
 
 // SCA_NBR_AUTO's resources, on first use
+// An SCA_NBR_AUTO step is bound by what the HOST needs to enqueue it (tools/gpu/exp_host.py: 79 us per step of 91 at N = 4096 -- twelve
+// launches at ~2.3 us and ten event operations at ~5 us), so a cross-stream wait is only enqueued when the event it would wait for has
+// not fired yet (in the steady state the kd stream is a whole pass ahead of what these guards protect; the query costs < 1 us).
+static int wait_if_pending(sca_ctx *c, hipStream_t s, hipEvent_t e) {
+    const hipError_t q = hipEventQuery(e);
+    if (q == hipSuccess) return 0;
+    (void)hipGetLastError();                                             // (hipErrorNotReady is an answer, not a failure)
+    CHK(c, hipStreamWaitEvent(s, e, 0));
+    return 0;
+}
 static int auto_prepare(sca_ctx *c) {
     if (c->kd_stream) return 0;
     CHK(c, hipStreamCreateWithFlags(&c->kd_stream, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&c->ev_auto_fork, &c->ev_auto_k1g, &c->ev_auto_kd, &c->ev_auto_moved, &c->ev_auto_cnt})
+    for (hipEvent_t *e : {&c->ev_auto_fork, &c->ev_auto_k1g, &c->ev_auto_moved, &c->ev_auto_cnt})
         CHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     // two lists, alternating by pass: a pass's kd query may still be reading its list's length (to find it empty) when the next
     // pass's grid build resets and refills the other one
@@ -1270,6 +1288,9 @@ static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *pos
     CHK(c, hipStreamWaitEvent(c->kd_stream, after, 0));
     DeviceView v = c->d;
     v.rec = const_cast<PubRec *>(positions);
+#ifdef SCA_TIMELINE
+    if (c->kd_ahead_enqueue) v.tl_step = c->d.tl_step + 1;              // a build enqueued ahead belongs to the NEXT pass
+#endif
     const int keep_skip = c->kd.skip_prep;
     c->kd.aux = 1;
     const int r = build_agent_tree_device(c, c->kd_stream, v);
@@ -1292,6 +1313,9 @@ static bool auto_next(const sca_ctx *c) {
 }
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
+#ifdef SCA_TIMELINE
+    c->d.tl_step++;
+#endif
     // SCA_NBR_AUTO resolves to a plain kd pass where it cannot help (the cell-owner partition has its own structures; the grid's
     // candidate lists need the collision reach inside one cell) or where the grid keeps listing a large part of the swarm for the kd
     // query anyway (a lattice of identical cells: ties everywhere) -- it is tried again every 256 passes
@@ -1383,7 +1407,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->d.kdq_list = c->kdq_list + (size_t)par * c->max_n;
             c->d.kdq_count = c->kdq_count + par;
             // ... which the kd query of two passes ago must be through with (it is, unless the kd stream lags by two whole passes)
-            if (c->auto_seq >= 2) CHK(c, hipStreamWaitEvent(c->nbr_stream, c->ev_auto_kdq[par], 0));
+            if (c->auto_seq >= 2) { if (int r = wait_if_pending(c, c->nbr_stream, c->ev_auto_kdq[par])) return r; }
         }
         if (int r = build_agent_grid_device(c)) return r;
     }
@@ -1439,8 +1463,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
             c->kdq_pending = true;
         }
-        CHK(c, hipEventRecord(c->ev_auto_kd, c->kd_stream));
-        CHK(c, hipEventRecord(c->ev_auto_kdq[seq & 1u], c->kd_stream));
+        CHK(c, hipEventRecord(c->ev_auto_kdq[seq & 1u], c->kd_stream));   // (also "the last kd query": auto_join and the event form of the wait)
+        c->ev_auto_kd = c->ev_auto_kdq[seq & 1u];
         if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_neighbors_kd_auto)
             if (hipStreamWaitValue32(ns, c->auto_busy, 0u, hipStreamWaitValueEq, 1u) != hipSuccess) {
@@ -1491,7 +1515,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (auto_mode && c->auto_waitvalue) {
         // nothing of this pass waited for the kd build any more.  Two things still must: (i) the integrate stage writes the record
         // buffer that the build BEFORE this pass's read its positions from (the two buffers alternate): wait for that build's gather;
-        CHK(c, hipStreamWaitEvent(c->stream, c->ev_auto_gather[c->auto_builds & 1u], 0));       // [builds & 1] = the one before the last
+        if (int r = wait_if_pending(c, c->stream, c->ev_auto_gather[c->auto_builds & 1u])) return r;       // [builds & 1] = the one before the last
         c->auto_unjoined = true;                                        // (ii) see auto_join
     }
     if (fuse_integrate) {
@@ -1606,9 +1630,18 @@ int sca_active_count(sca_ctx *c, int *active) {
 // the step's exchange: every rank contributes its shard's moved records, in place
 static int exchange_moved_records(sca_ctx *c) {
     const size_t bytes = sizeof(PubRec) * (size_t)c->d.shard_count;
+    hipEvent_t x0 = nullptr, x1 = nullptr;
+    if (c->profiling && c->pool_xch_used + 2 <= 2 * 4096) {              // the collective's device time, on the stream it is enqueued on
+        for (hipEvent_t *ev : {&x0, &x1}) {
+            if (c->pool_xch_used == (int)c->pool_xch.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_xch.push_back(n_); }
+            *ev = c->pool_xch[c->pool_xch_used++];
+        }
+        CHK(c, hipEventRecord(x0, c->stream));
+    }
     const ncclResult_t e = g_rccl.AllGather((const char *)c->d.rec_new + sizeof(PubRec) * (size_t)c->d.shard_begin, c->d.rec_new, bytes,
                                             ncclChar, c->comm, c->stream);
     if (e != ncclSuccess) { c->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(e); return SCA_ERR_HIP; }
+    if (x1) CHK(c, hipEventRecord(x1, c->stream));
     return 0;
 }
 
@@ -1661,7 +1694,10 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
             // front of it left the main stream idle for 50 us at N = 4096)
             CHK(c, hipEventRecord(c->ev_auto_moved, c->stream));
             if (int r = launch_collide_finish(c, false)) return r;                 // (swaps the record buffers: the moved ones are c->d.rec now)
-            if (int r = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec)) return r;
+            c->kd_ahead_enqueue = true;
+            const int rb = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec);
+            c->kd_ahead_enqueue = false;
+            if (rb) return rb;
             c->kd_ahead = true;
             continue;
         }
@@ -1685,6 +1721,12 @@ int sca_last_pass_forms(sca_ctx *c, int *forms) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, forms);
     *forms = c->forms;
+    return 0;
+}
+int sca_last_exchange_ms(sca_ctx *c, float *exchange_ms) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, exchange_ms);
+    *exchange_ms = c->ms_exchange;
     return 0;
 }
 int sca_last_replan_ms(sca_ctx *c, float *replan_ms) {
@@ -1950,6 +1992,17 @@ int sca_synchronize(sca_ctx *c) {
         c->ms_nbr = (float)(a / steps); c->ms_solve = (float)(b / steps);
         c->pool_used = 0;
     }
+    if (c->profiling && c->pool_xch_used >= 2) {
+        double a = 0;
+        const int steps = c->pool_xch_used / 2;
+        for (int s = 0; s < steps; s++) {
+            float t = 0;
+            CHK(c, hipEventElapsedTime(&t, c->pool_xch[2 * s], c->pool_xch[2 * s + 1]));
+            a += t;
+        }
+        c->ms_exchange = (float)(a / steps);
+        c->pool_xch_used = 0;
+    }
     if (c->profiling && c->pool_trk_used >= 2) {
         if (c->trk_stream) CHK(c, hipStreamSynchronize(c->trk_stream));
         double a = 0;
@@ -1970,6 +2023,7 @@ int sca_set_profiling(sca_ctx *c, int on) {
     c->profiling = on != 0;
     c->pool_used = 0;
     c->pool_trk_used = 0;
+    c->pool_xch_used = 0;
     c->prof_tick = 0;
     return 0;
 }
@@ -1993,6 +2047,28 @@ int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
 int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds only: k_kd_block's per-phase ticks
     CHK(c, hipStreamSynchronize(c->stream));
     CHK(c, hipMemcpy(out, c->kd.ps, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
+#ifdef SCA_TIMELINE
+// debug builds only (SCA_BUILD_DEFS=-DSCA_TIMELINE): the device-side timeline of the next TL_RING steps (tools/device_timeline.py)
+int sca_debug_timeline_enable(sca_ctx *c) {
+    if (!c) return SCA_ERR_ARG;
+    const size_t cells = (size_t)TL_KERNELS * TL_RING;
+    if (!c->d.tl) CHK(c, hipMalloc((void **)&c->d.tl, sizeof(unsigned long long) * 2 * cells));
+    std::vector<unsigned long long> init(2 * cells);
+    for (size_t i = 0; i < cells; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    CHK(c, hipDeviceSynchronize());
+    CHK(c, hipMemcpy(c->d.tl, init.data(), sizeof(unsigned long long) * 2 * cells, hipMemcpyHostToDevice));
+    c->d.tl_step = -1;                                                  // the next pass is ring entry 0
+    return 0;
+}
+int sca_debug_timeline_read(sca_ctx *c, unsigned long long *out /*[TL_KERNELS][TL_RING][2]*/, int *kernels, int *ring) {
+    if (!c || !c->d.tl) return SCA_ERR_ARG;
+    CHK(c, hipDeviceSynchronize());
+    CHK(c, hipMemcpy(out, c->d.tl, sizeof(unsigned long long) * 2 * TL_KERNELS * TL_RING, hipMemcpyDeviceToHost));
+    *kernels = TL_KERNELS; *ring = TL_RING;
     return 0;
 }
 #endif

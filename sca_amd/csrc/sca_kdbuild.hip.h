@@ -96,6 +96,7 @@ __device__ __forceinline__ int wave_sum_i(int v) { return wave_sum_i32(v); }
 
 // Coordinates into position order, and the root's box (its accumulator was reset by the previous build's last kernel).
 __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Params P) {
+    SCA_TL(d, TL_KD_GATHER);
     SCA_KD_SETPRIO();
     __shared__ double red[4][6];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,6 +433,7 @@ __device__ __forceinline__ void kd_swap_part(const DeviceView d, const KdScratch
 }
 
 __global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScratch s, int level) {
+    SCA_TL(d, TL_KD_LEVELS);
     SCA_KD_SETPRIO();
     const KdChunk c = kd_find_chunk(s, level, blockIdx.x);
     if (!c.valid) return;
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(KD_LV_T + 64) void k_kd_lv_swap(DeviceView d, KdScr
 // changed since -- a node with many chunks, more levels -- it is slower, never wrong: the statistics only set the speed.
 constexpr int KD_TAIL_STACK = 2 * KD_MAX_LEVELS;
 __global__ __launch_bounds__(KD_LV_T) void k_kd_level_tail(DeviceView d, KdScratch s, int level, unsigned token) {
+    SCA_TL(d, TL_KD_LEVELS);
     SCA_KD_SETPRIO();
     __shared__ KdRankLds SH;
     __shared__ KdTailOut out;
@@ -568,6 +571,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 
 template <int KBM, int KBT>
 __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+    SCA_TL(d, TL_KD_BLOCK);
     SCA_KD_SETPRIO();
     static_assert(KBM == 2 * KBT, "k_kd_block is written for two consecutive positions per thread");
     constexpr int KB_SWROW = KbLds<KBM, KBT>::SWROW, KB_MAX = KBM, KB_T = KBT, KB_E = 2;
@@ -830,6 +834,7 @@ struct KtLds {
     int wtot[KT_T / 64];
 };
 __global__ __launch_bounds__(KT_T) void k_kd_top(DeviceView d, KdScratch s) {
+    SCA_TL(d, TL_KD_TOP);
     SCA_KD_SETPRIO();
     __shared__ KtLds S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

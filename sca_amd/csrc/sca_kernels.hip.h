@@ -122,7 +122,39 @@ struct DeviceView {
     unsigned *kdq_busy;      // [1] bit 0: the grid query of this pass listed somebody and the kd query has not answered yet (the pass's stream waits for 0)
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
                              // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
+#ifdef SCA_TIMELINE
+    unsigned long long *tl;  // [TL_KERNELS][TL_RING][2] first start / last end of a kernel's wavefronts, 100-MHz wall clock (sca_debug_timeline)
+    int tl_step;             // the step the launch belongs to (ring index)
+#endif
 };
+// ---- device-side timeline (DEBUG builds: SCA_BUILD_DEFS=-DSCA_TIMELINE, tools/device_timeline.py) -----------------------------------
+// rocprofv3's kernel trace serialises dispatches: a chain of 5-us kernels runs ~2x slower traced than untraced (c3: 161 against 92 us per
+// step, tools/timeline.py), so the un-perturbed timeline of the short steps is taken on the device instead: lane 0 of every wavefront of
+// every pass kernel's first workgroup stamps the wall clock when it starts, a sample of its workgroups when they end (atomicMin / atomicMax
+// into the kernel's slot of the step's ring entry).  The product build contains none of this.
+enum TlKernel { TL_KD_GATHER, TL_KD_TOP, TL_KD_LEVELS, TL_KD_BLOCK, TL_GRID_COUNT, TL_GRID_FILL, TL_NBR_GRID, TL_NBR_KD, TL_NBR_KD_AUTO, TL_SOLVE, TL_SOLVE_SWEEP,
+                TL_SOLVE_PICK, TL_LP, TL_FALLBACK, TL_ACTION, TL_COLLIDE, TL_GOAL_FLAGS, TL_TRACK, TL_REPLAN, TL_KERNELS };
+constexpr int TL_RING = 64;
+#ifdef SCA_TIMELINE
+// (first form: every wavefront stamped both ends and the slot pointer lived in two VGPRs across the kernel -- 8192 same-address atomics and
+// two spilled registers made k_solve 94 us instead of 12.  Now: the START is workgroup 0's first wavefront (dispatch is in order: it is the
+// first to run), the END the maximum over a SAMPLE of workgroups -- all of a launch of up to 64, else every sixteenth, the first and the last eight -- and
+// the slot is recomputed from the kernel arguments, which live in SGPRs.)
+struct TlScope {
+    const DeviceView &d;
+    const int kid;
+    __device__ __forceinline__ unsigned long long *slot() const { return d.tl + 2 * ((size_t)kid * TL_RING + (size_t)(d.tl_step & (TL_RING - 1))); }
+    __device__ __forceinline__ TlScope(const DeviceView &d_, int kid_) : d(d_), kid(kid_) {
+        if (d.tl && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(slot(), (unsigned long long)wall_clock64());
+    }
+    __device__ __forceinline__ ~TlScope() {
+        if (d.tl && threadIdx.x == 0 && (gridDim.x <= 64u || (blockIdx.x & 15u) == 15u || blockIdx.x + 8u >= gridDim.x || blockIdx.x < 8u)) atomicMax(slot() + 1, (unsigned long long)wall_clock64());
+    }
+};
+#define SCA_TL(d, kid) TlScope tl_scope_((d), (kid))
+#else
+#define SCA_TL(d, kid) do { } while (0)
+#endif
 
 // the i-th agent of this rank (i < shard_count) / the i-th agent whose record this rank holds (i < present_count(d))
 __device__ __forceinline__ int shard_agent(const DeviceView &d, int i) { return d.own ? d.own[i] : d.shard_begin + i; }
@@ -497,6 +529,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
 
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                 double max_radius) {
+    SCA_TL(d, TL_NBR_KD);
     __shared__ double rstacks[K1_WAVES][KD_RSTACK][16];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -516,6 +549,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
 constexpr int KDQ_BLOCKS = 1024, KDQ_BLOCKS_FEW = 64;   // (the few: while the counts that came back say a wavefront each is enough -- an empty launch of 64 workgroups is half as long)
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                      double max_radius, int *ticket) {
+    SCA_TL(d, TL_NBR_KD_AUTO);
     __shared__ double rstacks[K1_WAVES][KD_RSTACK][16];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -560,6 +594,7 @@ constexpr int K1P_APW = 4;
 #endif
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                  double max_radius) {
+    SCA_TL(d, TL_NBR_KD);
     SCA_K1_SETPRIO();
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     const int lane = threadIdx.x & 63;
@@ -1453,6 +1488,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P,
 }
 
 __global__ __launch_bounds__(SOLVE_WAVES * 64, 8) void k_solve(DeviceView d, Params P) {
+    SCA_TL(d, TL_SOLVE);
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1463,6 +1499,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64, 8) void k_solve(DeviceView d, Par
 // K3, wave-per-agent form: the ORCA3D-Official agents of the shard (positions [lo, hi) of the sorted list of their ids) when
 // they are too few for k_lp to fill the chip
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_lpw(DeviceView d, Params P, const int32_t *list, int lo, int hi) {
+    SCA_TL(d, TL_LP);
     __shared__ FastLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1472,6 +1509,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_lpw(DeviceView d, Pa
 }
 // the first half of k_solve for passes whose v_pref arrives late (solve_fast); the second is k_solve_pick4
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_sweep(DeviceView d, Params P) {
+    SCA_TL(d, TL_SOLVE_SWEEP);
 #if defined(SCA_SWEEP_PRIO) && SCA_SWEEP_PRIO > 0
     __builtin_amdgcn_s_setprio(SCA_SWEEP_PRIO);
 #endif
@@ -1635,6 +1673,7 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
 }
 
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, Params P) {
+    SCA_TL(d, TL_SOLVE_PICK);
     __shared__ PickLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1663,6 +1702,7 @@ struct LpAccess {
     }
 };
 __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t *list, int lo, int hi) {
+    SCA_TL(d, TL_LP);
     __shared__ LpPlanes S;
     const int lane = threadIdx.x;
     const int at = lo + blockIdx.x * 64 + lane;
@@ -1754,6 +1794,7 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
 // VGPRs and the one-lane-per-agent epilogue ran at one wavefront per SIMD; alone it takes a quarter of that.)
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
+    SCA_TL(d, TL_ACTION);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
@@ -1771,6 +1812,7 @@ constexpr int FB_BLOCKS = 256;
 // through the list to a launch of its own -- which, list empty or not, sat between the solve and the epilogue on every pass's
 // critical path (5 us + its gap of a 150-us step at N = 1024).  Passes with LP agents keep the list (k_lp's fallbacks need it).
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_fb(DeviceView d, Params P) {
+    SCA_TL(d, TL_SOLVE);
     __shared__ FastLds S;
     __shared__ SolveLds S2;
     const int lane = threadIdx.x & 63;
@@ -1789,6 +1831,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_fb(DeviceView d, Par
 }
 template <bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Params P) {
+    SCA_TL(d, TL_FALLBACK);
     __shared__ SolveLds S;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1803,6 +1846,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Par
 }
 
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
+    SCA_TL(d, TL_ACTION);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= shard_size(d)) return;
     const int agent = shard_agent(d, idx);
@@ -1918,6 +1962,7 @@ __device__ __forceinline__ void collide_finish_body(const DeviceView &d, const P
 
 __global__ __launch_bounds__(K4_WAVES * 64) void k_collide_finish(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                 int check_arrived) {
+    SCA_TL(d, TL_COLLIDE);
     __shared__ int stacks[K4_WAVES][KD_STACK];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1943,6 +1988,7 @@ __global__ __launch_bounds__(256) void k_nbr0(DeviceView d, double *out) {
 // multi-GPU only: agents of other shards arrived by all-gather with the flags their owner published one step ago;
 // replicate the at-goal test for them -- the only flag of another agent the policy reads (scaPolicy.py:53).
 __global__ __launch_bounds__(256) void k_goal_flags_others(DeviceView d, Params P) {
+    SCA_TL(d, TL_GOAL_FLAGS);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int agent;
     if (d.present) {                                                     // partition mode: the halo copies, behind the owned agents

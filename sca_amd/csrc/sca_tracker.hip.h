@@ -100,6 +100,7 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
 #define KT_MARK_INIT() do { } while (0)
 #endif
 __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    SCA_TL(d, TL_TRACK);
     // the re-plan list: per workgroup the lanes count themselves into their buckets in LDS, ONE vector atomic fetches the
     // workgroup's offsets in all twelve buckets, and the lanes write their slots.  (Until the end of round 3 every wavefront
     // fetched its offsets itself, one bucket after the other: ~5000 dependent same-address atomics per pass, which is what
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
 }
 
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    SCA_TL(d, TL_REPLAN);
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = K.count[K.parity];
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
 // (the circle: 96 %), where compacting the re-planners into a list buys nothing and costs a launch on the pass's critical
 // path.  Lanes that follow their path finish early inside their wavefront.  Only counts the re-plans (no list).
 __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    SCA_TL(d, TL_REPLAN);
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     if (blockIdx.x == 0 && threadIdx.x == 0) K.count[(K.parity + 1) & 3] = 0;
     // (the next pass may be k_track's again: it appends to the bucket counts of that parity)
@@ -675,14 +678,15 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
         if (blockIdx.x == 0 && threadIdx.x == 0) sca_dubins::g_td_ticks[31]++;
 #endif
         walk(0, me, nb, ns, myc, mylen, nfc);
+        P.rounds++;
         KG_ADD(6);
     }
     Maneuver2D fbh, fbv;
     try_to_construct_quad(H, K, qi, qf, Rmin, pitchlims, Rmin * b, fbh, fbv, sub, lane);      // the winner's maneuvers
     KG_ADD(8);
-    const int it = P.iters;
+    const int it = P.iters, rd = P.rounds + 1;                           // (+ the opening round)
     finish_plan(P, fbh, fbv, qi);
-    P.iters = it;
+    P.iters = it; P.rounds = rd;
     KG_ADD(9);
     return P;
 }
@@ -722,6 +726,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
 constexpr int TRK_GROUP_THREADS = 256;
 template <int LANES>
 __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_replan_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    SCA_TL(d, TL_REPLAN);
     if constexpr (LANES == 4) {
         sca_gm::lds_tables_load();                                       // atan2's and sin / cos's tables into LDS (all threads, first)
         const int count = K.count[K.parity];
@@ -743,6 +748,7 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, LANES == 4 ? 2 : 1) void k_repla
 // only pads with its tables and its gap), then the whole wavefront searches if the agent re-plans -- no list, no order by expected length
 // (every plan has a SIMD of its own anyway).  Counts the re-plans for the host's choice of forms as k_track does.
 __global__ __launch_bounds__(TRK_GROUP_THREADS, 1) void k_track_group(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+    SCA_TL(d, TL_REPLAN);
     __shared__ SpecLds<4> TR;
     spec_trees_load<4>(TR);                                              // (the barrier that ends lds_tables_load covers them)
     sca_gm::lds_tables_load();

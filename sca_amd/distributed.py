@@ -31,6 +31,8 @@ class ShardedStepper:
         self.dist = dist_mod
         self.mode = mode
         self._stream = None
+        self.measure_exchange = False           # True: an event pair around every collective issued from here (exchange_ms())
+        self._xch_events = []
         n = solver.n
         if self.exchange:
             if n % self.world:
@@ -89,13 +91,35 @@ class ShardedStepper:
                 self.torch.cuda.synchronize()
             elif getattr(self, '_stream', None) is not None:
                 with self.torch.cuda.stream(self._stream):           # ordered with the library's kernels (see _setup_exchange)
-                    self.dist.all_gather_into_tensor(full, mine)
+                    if self.measure_exchange:
+                        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                        e0.record(self._stream)
+                        self.dist.all_gather_into_tensor(full, mine)
+                        e1.record(self._stream)
+                        self._xch_events.append((e0, e1))
+                    else:
+                        self.dist.all_gather_into_tensor(full, mine)
             else:                                                    # a backend with its own buffers (the CPU checker of the tests)
                 self.dist.all_gather_into_tensor(full, mine)
             self.sol.step_end()
 
     def sync(self):
         self.sol.synchronize()
+
+    def exchange_ms(self, reset=True):
+        """Mean device time of the step's collective over the steps run with measure_exchange (torch path: events on the stepper's
+        stream around all_gather_into_tensor; inlib: the library's own event pair around ncclAllGather, needs set_profiling).  None
+        when nothing was measured (one rank, staged test exchange)."""
+        if self.inlib:
+            v = self.sol.exchange_ms()
+            return v if v > 0 else None
+        if not self._xch_events:
+            return None
+        self.sol.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._xch_events]
+        if reset:
+            self._xch_events = []
+        return sum(ms) / len(ms)
 
 
 class PartitionedStepper:

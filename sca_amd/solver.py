@@ -207,6 +207,12 @@ class BatchedSolver:
         self._chk(self.L.sca_last_replan_ms(self.ctx, C.byref(a)), 'sca_last_replan_ms')
         return a.value
 
+    def exchange_ms(self):
+        """mean device time of the in-library all-gather over the profiled steps (0.0 without a communicator)"""
+        a = C.c_float(0)
+        self._chk(self.L.sca_last_exchange_ms(self.ctx, C.byref(a)), 'sca_last_exchange_ms')
+        return a.value
+
     def pass_forms(self):
         """SCA_FORM_* bits of the last policy pass (which kernel forms the library picked)"""
         a = C.c_int(0)

@@ -72,15 +72,18 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('track,mode,n', [(False, 0, 3000), (True, 0, 3000), (False, 1, 3000), (True, 1, 3000), (True, 0, 120000),
-                                          (True, 0, -60000), (False, 3, 3000), (False, 3, -60000), (True, 3, 3000)])
-def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n):
+@pytest.mark.parametrize('track,mode,n,world', [(False, 0, 3000, 2), (True, 0, 3000, 2), (False, 1, 3000, 2), (True, 1, 3000, 2), (True, 0, 120000, 2),
+                                                (True, 0, -60000, 2), (False, 3, 3000, 2), (False, 3, -60000, 2), (True, 3, 3000, 2),
+                                                # 1 / 2 / 4 / 8 shards bit-identical to one -- kd-tree, grid, with and without the tracker
+                                                (True, 0, 4096, 4), (True, 1, 4096, 4), (False, 3, 4096, 4),
+                                                (True, 0, 4096, 8), (True, 1, 4096, 8), (False, 0, 4096, 8), (False, 3, 4096, 8)])
+def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n, world):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
     next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  mode 3: SCA_NBR_AUTO on two
     ranks against the single-rank KD-TREE run.  n = 120 000: shards
     of 60 000 agents, which get k_track_replan and the split solve, the second one with shard_begin != 0 -- the case that found
     the missing fence of the one-launch-per-level kd build (two processes on one GPU is also a scheduling stress).  n < 0: |n|
-    agents of all five policies in a random cube."""
+    agents of all five policies in a random cube.  world = 4 / 8: as many processes sharing GPU 0, shards of 1024 / 512 agents."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode), SCA_TEST_N=str(abs(n)))
@@ -88,11 +91,11 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n):
         env['SCA_TEST_SCENE'] = 'mixed'                         # every policy in every shard, random cube
     if track:
         env['SCA_TEST_TRACK'] = '1'
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
                         '--master-addr', '127.0.0.1', '--master-port', '29541', str(script), ROOT],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count('OK') == 2, r.stdout[-3000:]
+    assert r.stdout.count('OK') == world, r.stdout[-3000:]
 
 
 RCCL_WORKER = r'''
