@@ -145,6 +145,8 @@ def timed_leg(sol, scene, stepper, timer, steps, warmup, tracked):
     stepper.run(warmup)
     stepper.sync()
     sol.agent_steps(reset=True)
+    if getattr(stepper, 'mode', None) == NBR['auto']:
+        sol.auto_stats(reset=True)
     plans0 = int(sol.device_tracker_replans()[stepper.begin:stepper.begin + stepper.count].sum()) if tracked else 0
     sol.set_profiling(True)
     if hasattr(stepper, 'measure_exchange'):
@@ -164,9 +166,12 @@ def timed_leg(sol, scene, stepper, timer, steps, warmup, tracked):
     plans = (int(sol.device_tracker_replans()[stepper.begin:stepper.begin + stepper.count].sum()) - plans0) if tracked else 0
     kms = sol.kernel_ms()
     rp = sol.replan_ms() if tracked else 0.0
+    kd_ms = sol.kd_build_ms()
+    auto = sol.auto_stats(reset=True) if getattr(stepper, 'mode', None) == NBR['auto'] else None
     dt, (total, plans_all) = timer.reduce(dt, (my_steps, plans))
     return dict(value=total / dt, ms_per_step=dt / steps * 1e3, agent_steps=total, my_agent_steps=my_steps, plans=plans_all,
-                my_plans=plans, k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=rp, forms=sol.pass_forms())
+                my_plans=plans, k_solve_ms=kms['solve'], k1_ms=kms['neighbors'], replan_ms=rp, forms=sol.pass_forms(), exchange_ms=xch,
+                kd_build_ms=kd_ms, auto=auto, n_all=scene['n'])
 
 
 def kernel_forms(forms):
@@ -216,7 +221,9 @@ def roofline_of(leg, steps, tracked, wname):
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
                 'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if fused else
                                                     'k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
-                                    / VALU_PEAK_WAVE_INSTS) or None,
+                                    / valu_peak('k_replan')[0]) or None,
+                'valu_price': valu_peak('k_replan')[1],
+                'valu_busy_step': step_valu_busy(wname, leg['ms_per_step']),
                 'note': 'a sequential fp64 search per plan (~69 candidate radii, each two 2-D Dubins problems on the restated glibc libm, lean form): '
                         'pure compute -- the kernel lasts as long as its longest search (~119 candidates x 4.5 us per wavefront) and the pass as a '
                         'whole issues VALU work without a gap between k_track and the join (DESIGN.md section 5); the HBM fraction is reported as required'}
@@ -225,20 +232,31 @@ def roofline_of(leg, steps, tracked, wname):
     return k_replan, (None if leg['forms'] & 1 else k_solve)
 
 
-def leg_roofline(leg, steps, tracked, wname):
+def leg_roofline(leg, steps, tracked, wname, mode_name='kd'):
     """the dominant kernel of a leg among the ones the library times with events (re-plan kernel, k_solve, neighbour query): its
     algorithmic HBM rate against the 8 TB/s peak, and -- where a PMC capture of this workload exists -- its share of the chip's
     VALU issue rate (all three are compute / latency kernels; the HBM fraction is reported as the task requires)"""
     per_launch = leg['my_agent_steps'] / max(steps, 1)
-    cands = [('k_solve', leg['k_solve_ms'], BYTES_PER_AGENT_STEP, per_launch, 'agent-step'),
-             ('k_neighbors_kd / k_neighbors_kd4', leg['k1_ms'], 48 + 16 * 48, per_launch, 'agent-step (own record + 16 neighbour records)')]
+    auto = leg.get('auto') is not None and leg['auto']['auto_passes'] > 0
+    nbr_name = ('k_neighbors_grid<true> (+ the wait for k_neighbors_kd_auto when somebody was listed)' if auto else
+                'k_neighbors_kd / k_neighbors_kd4' if mode_name != 'grid' else 'k_neighbors_grid<false>')
+    cands = [('k_solve' + (' / k_solve_fb' if leg['forms'] & 32 else ''), leg['k_solve_ms'], BYTES_PER_AGENT_STEP, per_launch, 'agent-step'),
+             (nbr_name, leg['k1_ms'], 48 + 16 * 48, per_launch, 'agent-step (own record + 16 neighbour records)')]
+    if leg.get('kd_build_ms', 0) > 0 and mode_name != 'grid':
+        # the kd build of kdTree.py:56-122: reads every agent's 24-B position and its 4-B permutation entry, writes both back in tree order and
+        # one 80-B node per agent (2N - 1 nodes of 80 B, half of them leaves): ~ 24 + 4 + 24 + 4 + 160 = 216 B per agent.  In an AUTO pass it
+        # runs on a stream of its own beside the pass (the step's pace when it is the longest chain)
+        cands.append(('kd build: k_kd_gather + ' + ('k_kd_top + k_kd_block' if leg.get('n_all', 0) <= 4096 else 'k_kd_lv_rank / k_kd_lv_swap per level + k_kd_level_tail + k_kd_block')
+                      + (' (on its own stream beside the pass)' if auto else ''), leg['kd_build_ms'], 216, leg.get('n_all', per_launch), 'agent in the tree'))
     if tracked and leg['replan_ms'] > 0:
         cands.append(('re-plan kernel (k_replan / k_replan_group)', leg['replan_ms'], BYTES_PER_REPLAN, leg['my_plans'] / max(steps, 1), 're-plan'))
     name, ms, bpu, units, uname = max(cands, key=lambda t: t[1])
     gbs = bpu * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {'bound': 'hbm', 'kernel': name, 'kernel_ms': ms, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
             'bytes_per_unit': bpu, 'unit_name': uname, 'units_per_launch': units,
-            'traffic': measured_traffic(wname, name.split(' ')[0]), 'valu_issue_frac': valu_issue_frac(wname, per_launch, ms * 1e-3) if name == 'k_solve' else None}
+            'traffic': kd_build_traffic(wname) if name.startswith('kd build') else measured_traffic(wname, name.split(' ')[0]),
+            'valu_issue_frac': valu_issue_frac(wname, per_launch, ms * 1e-3) if name.startswith('k_solve') else None,
+            'candidates_ms': {c[0].split(' ')[0] if not c[0].startswith('kd build') else 'kd_build': round(c[1], 5) for c in cands}}
 
 
 def self_launch(n):
@@ -763,9 +781,14 @@ def extra_legs(S, timer, device, steps, warmup):
             leg4 = timed_leg(sol, scene, ShardedStepper(sol, 0, 1, mode=NBR['auto']), timer, steps, warmup, False)
             row['kd_mode'] = {'value': row['value'], 'ms_per_step': row['ms_per_step'], 'neighbor_search': NBR_DESC['kd']}
             row['auto_mode'] = {'value': leg4['value'], 'ms_per_step': leg4['ms_per_step'], 'neighbor_search': NBR_DESC['auto'],
-                                'max_abs_dv_solver_given_vpref': parity_sample(scene, sol, S, False, warmup, mode=NBR['auto'])}
+                                'max_abs_dv_solver_given_vpref': parity_sample(scene, sol, S, False, warmup, mode=NBR['auto']),
+                                # how many agents per pass the grid query hands to the kd query (lists it cannot give exactly); a pass with
+                                # nobody listed never waits for the kd stream
+                                'auto_listed_per_step': leg4['auto'], 'kd_build_ms': leg4['kd_build_ms'],
+                                'roofline': leg_roofline(leg4, steps, False, name, 'auto')}
             if leg4['value'] > row['value']:
-                row.update({'value': leg4['value'], 'ms_per_step': leg4['ms_per_step'], 'neighbor_search': 'auto (see auto_mode; kd_mode beside it)'})
+                row.update({'value': leg4['value'], 'ms_per_step': leg4['ms_per_step'], 'neighbor_search': 'auto (see auto_mode; kd_mode beside it)',
+                            'roofline': row['auto_mode']['roofline'], 'k_solve_ms': leg4['k_solve_ms'], 'neighbors_kernel_ms': leg4['k1_ms']})
             else:
                 row['neighbor_search'] = 'kd (see kd_mode; auto_mode beside it)'
         out[name] = row
@@ -856,11 +879,53 @@ def parity_sample(scene, sol, S, tracked, warmup, mode=0):
     return float(np.abs(a[:, :3] - ref['action'][:, :3]).max())
 
 
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4      # SIMDs x clock / cycles per wave64 fp64 VALU instruction
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4      # the flat price of rounds 1-4: SIMDs x clock / 4 cycles per wave64 VALU instruction (fallback)
+
+
+def _calib():
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')) as f:
+            return json.load(f).get('valu_calibration', {})
+    except (OSError, ValueError):
+        return {}
+
+
+def valu_peak(kernel):
+    """(wave-instructions per second the chip can issue of THIS kernel's VALU mix, which price that is): the measured per-class issue rates
+    of tools/valu_calib.hip at two wavefronts per SIMD x the kernel's static instruction mix (tools/valu_price.py), else the flat 4 cycles"""
+    k = _calib().get('kernels', {}).get(kernel)
+    if k:
+        return 1024 * k['mix_wave_insts_per_us_per_simd_w2'] * 1e6, ('calibrated: %.0f wave-instructions per us per SIMD for this kernel\'s mix at two '
+                                                                      'wavefronts per SIMD (profiles/r05_pmc_traffic.json valu_calibration)' % k['mix_wave_insts_per_us_per_simd_w2'])
+    return VALU_PEAK_WAVE_INSTS, 'flat: 4 cycles of 2.4 GHz per wave-instruction (no calibration entry for this kernel)'
+
+
+def step_valu_busy(wname, ms_per_step):
+    """Share of the chip's VALU issue capacity the WHOLE step uses: every kernel's VALU wave-instructions per step (PMC capture) priced with its
+    own calibrated mix rate, summed, over 1024 SIMDs x the step's wall time.  The step -- not one kernel -- is what is VALU-issue bound here:
+    the re-plans, the kd build, the neighbour query and the sweep share the SIMDs for 85 % of it."""
+    p, cal = _pmc(wname), _calib().get('kernels', {})
+    if not p or not cal or ms_per_step <= 0:
+        return None
+    launches = {'k_kd_lv_rank': 7, 'k_kd_lv_swap': 7}
+    busy_us = 0.0
+    parts = {}
+    for key, v in p.items():
+        if not key.endswith('_valu_wave_insts_per_launch'):
+            continue
+        k = key[:-len('_valu_wave_insts_per_launch')]
+        if k.startswith('k_replan_group') or k in ('k_track_replans', 'k_track_replan'):
+            continue                                             # (launched and empty in a lane-per-plan pass)
+        rate = cal.get(k, {}).get('mix_wave_insts_per_us_per_simd_w2', 556.0)
+        us = v * launches.get(k, 1) / rate / 1024.0
+        parts[k] = round(us, 1)
+        busy_us += us
+    return {'frac': busy_us / (ms_per_step * 1e3), 'valu_busy_us_per_simd_per_step': round(busy_us, 1), 'by_kernel_us': parts,
+            'source': 'VALU wave-instructions per launch from the PMC capture of this workload (profiles/r0x_pmc_traffic.json) / calibrated mix rates'}
 
 
 def _pmc(wname):
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f).get(wname)
@@ -877,7 +942,14 @@ def valu_issue_frac(wname, agents_per_launch, kernel_s):
     per_agent = _pmc(wname).get('k_solve_valu_wave_insts_per_agent')
     if not per_agent or kernel_s <= 0:
         return None
-    return per_agent * agents_per_launch / kernel_s / VALU_PEAK_WAVE_INSTS
+    return per_agent * agents_per_launch / kernel_s / valu_peak('k_solve')[0]
+
+
+def kd_build_traffic(wname):
+    """HBM bytes of one kd build at N <= 4096 (k_kd_gather + k_kd_top + k_kd_block, one launch each) from the PMC capture, or None"""
+    p = _pmc(wname)
+    parts = [p.get(k + '_hbm_bytes_per_launch') for k in ('k_kd_gather', 'k_kd_top', 'k_kd_block')]
+    return sum(parts) if all(x is not None for x in parts) else None
 
 
 def measured_traffic(wname, kernel):

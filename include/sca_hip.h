@@ -212,6 +212,8 @@ int sca_last_kernel_ms(sca_ctx *ctx, float *neighbors_ms, float *solve_ms, float
 
 /* the same for the tracker's re-plan kernels (k_replan_group<4 .. 64 lanes per plan>, k_replan, k_track_replan), events on the stream they run on */
 int sca_last_replan_ms(sca_ctx *ctx, float *replan_ms);
+/* the kd build of kdTree.py:56-122 (k_kd_gather .. k_kd_block), events on the stream it ran on, every 16th build while profiling */
+int sca_last_kd_build_ms(sca_ctx *ctx, float *kd_build_ms);
 /* the same for the step's exchange when the library issues it (sca_comm_init: ncclAllGather inside sca_run_steps); 0 without a communicator */
 int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
 /* Which kernel forms the last policy pass was launched with (the library picks them per pass from the shard size and the
@@ -229,6 +231,9 @@ int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
 #define SCA_FORM_LP_LANE 16
 #define SCA_FORM_SOLVE_FB 32
 int sca_last_pass_forms(sca_ctx *ctx, int *forms);
+/* SCA_NBR_AUTO statistics since the last reset: out4 = {AUTO passes, agents the grid query listed for the kd query (sum over the passes), the
+ * largest list, passes in which somebody was listed}.  A pass with nobody listed never waits for the kd stream. */
+int sca_auto_stats(sca_ctx *ctx, int64_t *out4, int reset);
 /* Measurement aid for scaling models on one GPU: with a partial shard (sca_set_shard) and no communicator, sca_run_steps
  * runs what ONE rank of a larger job runs per step -- the replicated neighbour structure over all n agents, everything else
  * for the shard -- and copies the other agents' records over unchanged where the all-gather would deliver them. */

@@ -69,6 +69,8 @@ SIGNATURES = {
     'sca_partition_owned': (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_int)]),
     'sca_last_kernel_ms': (C.c_int, [C.c_void_p, fp, fp, fp]),
     'sca_last_exchange_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'sca_last_kd_build_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'sca_auto_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     'sca_last_replan_ms': (C.c_int, [C.c_void_p, fp]),
     'sca_last_pass_forms': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     'sca_set_shard_emulation': (C.c_int, [C.c_void_p, C.c_int]),

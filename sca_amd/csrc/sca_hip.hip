@@ -166,6 +166,9 @@ struct sca_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> pool;       // 4 events per profiled pass: around K1 (on its stream), around k_solve
     int pool_used = 0;
+    std::vector<hipEvent_t> pool_kd;    // 2 events around every 16th kd build while profiling (sca_last_kd_build_ms)
+    int pool_kd_used = 0;
+    float ms_kd_build = 0.0f;
     std::vector<hipEvent_t> pool_xch;   // 2 events per profiled step around the in-library ncclAllGather (sca_last_exchange_ms)
     int pool_xch_used = 0;
     float ms_exchange = 0.0f;
@@ -751,6 +754,7 @@ void sca_destroy(sca_ctx *c) {
     for (auto &e : c->pool) (void)hipEventDestroy(e);
     for (auto &e : c->pool_trk) (void)hipEventDestroy(e);
     for (auto &e : c->pool_xch) (void)hipEventDestroy(e);
+    for (auto &e : c->pool_kd) (void)hipEventDestroy(e);
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipStreamDestroy(c->kd_stream); }
     for (hipEvent_t e : {c->ev_auto_fork, c->ev_auto_k1g, c->ev_auto_moved, c->ev_auto_cnt}) if (e) (void)hipEventDestroy(e);   // (ev_auto_kd aliases ev_auto_kdq[])
     if (c->kdq_list) (void)hipFree(c->kdq_list);
@@ -758,6 +762,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->kdq_host) (void)hipHostFree(c->kdq_host);
     if (c->auto_busy) (void)hipFree(c->auto_busy);
     if (c->auto_ticket) (void)hipFree(c->auto_ticket);
+    if (c->d.kdq_stats) (void)hipFree(c->d.kdq_stats);
     for (hipEvent_t e : c->ev_auto_gather) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_auto_kdq) if (e) (void)hipEventDestroy(e);
     if (c->kd_ev) (void)hipEventDestroy(c->kd_ev);
@@ -1016,6 +1021,14 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
         wave_max = std::min(cap, std::max(cap / 2 + 1, (int)std::ceil(1.25 * sz)));
     }
     c->kd.wave_max = wave_max;
+    hipEvent_t kb0 = nullptr, kb1 = nullptr;                            // profiling: the build's device time on the stream it runs on, every 16th build
+    if (c->profiling && (c->kd_builds & 15u) == 0 && c->pool_kd_used + 2 <= 2 * 1024) {
+        for (hipEvent_t *ev : {&kb0, &kb1}) {
+            if (c->pool_kd_used == (int)c->pool_kd.size()) { hipEvent_t n_; CHK(c, hipEventCreate(&n_)); c->pool_kd.push_back(n_); }
+            *ev = c->pool_kd[c->pool_kd_used++];
+        }
+        CHK(c, hipEventRecord(kb0, ks));
+    }
     if (top && KT_M / (wave_max + 1) >= KT_NODES) { c->err = "k_kd_top: wave_max below its table bound"; return SCA_ERR_STATE; }   // (static_assert'ed unreachable)
     hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, ks, d, c->kd, c->P);
     if (c->kd.aux) {                                                    // SCA_NBR_AUTO: the last kernel of the build that reads the record buffer
@@ -1070,6 +1083,7 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
     else if (wave_max <= 1280) hipLaunchKernelGGL((k_kd_block<1280, 640>), dim3(sgrid), dim3(640), 0, ks, d, c->kd, levels);
     else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, ks, d, c->kd, levels);
     CHK(c, hipGetLastError());
+    if (kb1) CHK(c, hipEventRecord(kb1, ks));
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
     // 8th build, every build while no hint exists yet
     c->kd_builds++;
@@ -1270,6 +1284,8 @@ static int auto_prepare(sca_ctx *c) {
     CHK(c, hipMemsetAsync(c->kdq_count, 0, 2 * sizeof(int32_t), c->stream));
     CHK(c, hipMalloc((void **)&c->auto_busy, sizeof(unsigned)));
     CHK(c, hipMemsetAsync(c->auto_busy, 0, sizeof(unsigned), c->stream));
+    CHK(c, hipMalloc((void **)&c->d.kdq_stats, sizeof(unsigned long long) * 4));
+    CHK(c, hipMemsetAsync(c->d.kdq_stats, 0, sizeof(unsigned long long) * 4, c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
     CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
@@ -1723,6 +1739,24 @@ int sca_last_pass_forms(sca_ctx *c, int *forms) {
     *forms = c->forms;
     return 0;
 }
+int sca_last_kd_build_ms(sca_ctx *c, float *kd_build_ms) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, kd_build_ms);
+    *kd_build_ms = c->ms_kd_build;
+    return 0;
+}
+int sca_auto_stats(sca_ctx *c, int64_t *out4, int reset) {
+    if (!c) return SCA_ERR_ARG;
+    ARG(c, out4);
+    for (int k = 0; k < 4; k++) out4[k] = 0;
+    if (!c->d.kdq_stats) return 0;                                       // no SCA_NBR_AUTO pass has run
+    if (c->kd_stream) CHK(c, hipStreamSynchronize(c->kd_stream));
+    unsigned long long h[4];
+    CHK(c, hipMemcpy(h, c->d.kdq_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) out4[k] = (int64_t)h[k];
+    if (reset) CHK(c, hipMemset(c->d.kdq_stats, 0, sizeof(h)));
+    return 0;
+}
 int sca_last_exchange_ms(sca_ctx *c, float *exchange_ms) {
     if (!c) return SCA_ERR_ARG;
     ARG(c, exchange_ms);
@@ -1992,6 +2026,19 @@ int sca_synchronize(sca_ctx *c) {
         c->ms_nbr = (float)(a / steps); c->ms_solve = (float)(b / steps);
         c->pool_used = 0;
     }
+    if (c->profiling && c->pool_kd_used >= 2) {
+        if (c->kd_stream) CHK(c, hipStreamSynchronize(c->kd_stream));
+        if (c->trk_stream) CHK(c, hipStreamSynchronize(c->trk_stream));
+        double a = 0;
+        const int builds = c->pool_kd_used / 2;
+        for (int s = 0; s < builds; s++) {
+            float t = 0;
+            CHK(c, hipEventElapsedTime(&t, c->pool_kd[2 * s], c->pool_kd[2 * s + 1]));
+            a += t;
+        }
+        c->ms_kd_build = (float)(a / builds);
+        c->pool_kd_used = 0;
+    }
     if (c->profiling && c->pool_xch_used >= 2) {
         double a = 0;
         const int steps = c->pool_xch_used / 2;
@@ -2024,6 +2071,7 @@ int sca_set_profiling(sca_ctx *c, int on) {
     c->pool_used = 0;
     c->pool_trk_used = 0;
     c->pool_xch_used = 0;
+    c->pool_kd_used = 0;
     c->prof_tick = 0;
     return 0;
 }

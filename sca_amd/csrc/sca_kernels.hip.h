@@ -119,6 +119,7 @@ struct DeviceView {
     int32_t *kdq_list;       // [n]
     int32_t *kdq_count;      // [1] how many the grid query listed; more than kdq_cap: "too many for a list" -- the list is then incomplete and
     int kdq_cap;             //     the kd query of EVERY agent of the shard runs instead (k_neighbors_kd_auto)
+    unsigned long long *kdq_stats;   // [4] AUTO passes, agents listed over them (sum, max), passes in which somebody was listed (sca_auto_stats)
     unsigned *kdq_busy;      // [1] bit 0: the grid query of this pass listed somebody and the kd query has not answered yet (the pass's stream waits for 0)
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
                              // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
@@ -138,7 +139,7 @@ constexpr int TL_RING = 64;
 #ifdef SCA_TIMELINE
 // (first form: every wavefront stamped both ends and the slot pointer lived in two VGPRs across the kernel -- 8192 same-address atomics and
 // two spilled registers made k_solve 94 us instead of 12.  Now: the START is workgroup 0's first wavefront (dispatch is in order: it is the
-// first to run), the END the maximum over a SAMPLE of workgroups -- all of a launch of up to 64, else every sixteenth, the first and the last eight -- and
+// first to run), the END the maximum over the workgroups' first threads -- all of a launch of up to 2048 workgroups, else every eighth, the first and the last eight -- and
 // the slot is recomputed from the kernel arguments, which live in SGPRs.)
 struct TlScope {
     const DeviceView &d;
@@ -148,7 +149,10 @@ struct TlScope {
         if (d.tl && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(slot(), (unsigned long long)wall_clock64());
     }
     __device__ __forceinline__ ~TlScope() {
-        if (d.tl && threadIdx.x == 0 && (gridDim.x <= 64u || (blockIdx.x & 15u) == 15u || blockIdx.x + 8u >= gridDim.x || blockIdx.x < 8u)) atomicMax(slot() + 1, (unsigned long long)wall_clock64());
+        if (!d.tl) return;
+        const bool every_wave = gridDim.x <= 512u && (threadIdx.x & 63u) == 0u;                  // small launches: every wavefront (a wavefront per agent / plan ends when ITS search does)
+        const bool sampled = threadIdx.x == 0 && (gridDim.x <= 2048u || (blockIdx.x & 7u) == 7u || blockIdx.x + 8u >= gridDim.x || blockIdx.x < 8u);
+        if (every_wave || sampled) atomicMax(slot() + 1, (unsigned long long)wall_clock64());
     }
 };
 #define SCA_TL(d, kid) TlScope tl_scope_((d), (kid))
@@ -554,6 +558,11 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd_auto(DeviceView 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = *d.kdq_count;
+    if (d.kdq_stats && blockIdx.x == 0 && threadIdx.x == 0) {           // statistics: passes, listed agents (sum, max), passes with somebody listed
+        d.kdq_stats[0] += 1; d.kdq_stats[1] += (unsigned long long)n;
+        if ((unsigned long long)n > d.kdq_stats[2]) d.kdq_stats[2] = (unsigned long long)n;
+        if (n > 0) d.kdq_stats[3] += 1;
+    }
     if (n == 0) return;
     if (n <= d.kdq_cap) {
         for (int i = (int)blockIdx.x * K1_WAVES + wid; i < n; i += (int)gridDim.x * K1_WAVES)

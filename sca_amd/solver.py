@@ -207,6 +207,18 @@ class BatchedSolver:
         self._chk(self.L.sca_last_replan_ms(self.ctx, C.byref(a)), 'sca_last_replan_ms')
         return a.value
 
+    def auto_stats(self, reset=False):
+        """SCA_NBR_AUTO since the last reset: passes, agents listed for the kd query per pass (mean, max), share of passes with a list"""
+        a = (C.c_int64 * 4)()
+        self._chk(self.L.sca_auto_stats(self.ctx, a, 1 if reset else 0), 'sca_auto_stats')
+        p = max(int(a[0]), 1)
+        return {'auto_passes': int(a[0]), 'listed_per_pass_mean': a[1] / p, 'listed_per_pass_max': int(a[2]), 'passes_with_a_list_frac': a[3] / p}
+
+    def kd_build_ms(self):
+        a = C.c_float(0)
+        self._chk(self.L.sca_last_kd_build_ms(self.ctx, C.byref(a)), 'sca_last_kd_build_ms')
+        return a.value
+
     def exchange_ms(self):
         """mean device time of the in-library all-gather over the profiled steps (0.0 without a communicator)"""
         a = C.c_float(0)

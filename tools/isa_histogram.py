@@ -15,18 +15,22 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from kernel_regs import LLVM, code_object  # noqa: E402
 
 CLASSES = [
-    ('valu_f64_fma', r'^v_(fma|fmac)_f64'),
-    ('valu_f64_mul_add', r'^v_(mul|add|sub|min|max|ldexp|fract|trunc|floor|ceil|rndne|frexp_mant)_f64|^v_(min|max)(imum|imum3|3)?_f64|^v_pk_(add|mul|fma)_f64'),
-    ('valu_f64_trans', r'^v_(rcp|rsq|sqrt|div_fmas|div_fixup|div_scale|trig_preop)_f64'),
-    ('valu_f64_cmp', r'^v_cmpx?_\w+_f64|^v_cmp_class_f64'),
-    ('valu_cvt', r'^v_cvt_'),
-    ('valu_cndmask_mov', r'^v_(cndmask_b32|mov_b32|mov_b64|readfirstlane_b32|readlane_b32|writelane_b32|accvgpr|swap|permlane|dpp|bfrev)'),
-    ('valu_int32', r'^v_(add|sub|subrev|addc|subb|and|or|xor|not|lshl|lshr|ashr|bfe|bfi|bfm|min|max|med3|mad|mul|alignbit|alignbyte|perm|lshlrev|lshrrev|ashrrev|add3|lshl_add|add_lshl|and_or|or3|xad|sad|mbcnt|ffb|cmp|cmpx|mul_lo|mul_hi|mad_u64|mad_i64|frexp_exp)\w*'),
-    ('lds', r'^ds_'),
-    ('vmem', r'^(global|flat|buffer|scratch)_'),
-    ('salu', r'^s_(?!waitcnt|nop|endpgm|barrier|setprio|sleep|sethalt|branch|cbranch|code_end)'),
-    ('branch', r'^s_(branch|cbranch)'),
-    ('wait_misc', r'^s_(waitcnt|nop|barrier|setprio|sleep|endpgm)'),
+    # (class, regex, the calibration row of tools/valu_calib.hip that prices it)
+    ('valu_f64_fma', r'^v_(fma|fmac)_f64', 'v_fma_f64'),
+    ('valu_f64_mul', r'^v_(mul|ldexp)_f64|^v_pk_(mul|fma)_f64', 'v_mul_f64'),
+    ('valu_f64_add', r'^v_(add|sub|min|max|fract|trunc|floor|ceil|rndne|frexp_mant)_f64|^v_(min|max)(imum|imum3|3)?_f64|^v_pk_add_f64', 'v_add_f64'),
+    ('valu_f64_trans', r'^v_(rcp|rsq|sqrt|div_fmas|div_fixup|div_scale|trig_preop)_f64', 'v_rcp_f64'),
+    ('valu_f64_cmp', r'^v_cmpx?_\w+_f64|^v_cmp_class_f64', 'v_cmp_lt_f64'),
+    ('valu_cvt', r'^v_cvt_', 'v_cmp_lt_f64'),
+    ('valu_select', r'^v_cndmask_b32', 'v_cndmask_b32(sgpr mask)'),
+    ('valu_mov', r'^v_(mov_b32|mov_b64|readfirstlane_b32|readlane_b32|writelane_b32|accvgpr|swap|permlane|bfrev|pk_mov)', 'v_mov_b32'),
+    ('valu_int_half_rate', r'^v_(lshl|lshr|ashr|lshlrev|lshrrev|ashrrev|mul_lo|mul_hi|mad_u64|mad_i64|mad_u32|mad_i32|bfe|bfi|bfm|alignbit|alignbyte|perm|cmp|cmpx|mbcnt|ffb|lshl_add|add_lshl|lshl_or|frexp_exp|sad|bitop3)\w*', 'v_lshlrev_b32'),
+    ('valu_int_full_rate', r'^v_(add|sub|subrev|addc|subb|subbrev|and|or|xor|not|min|max|med3|add3|and_or|or3|xad|xor3)\w*', 'v_add_u32'),
+    ('lds', r'^ds_', None),
+    ('vmem', r'^(global|flat|buffer|scratch)_', None),
+    ('salu', r'^s_(?!waitcnt|nop|endpgm|barrier|setprio|sleep|sethalt|branch|cbranch|code_end)', None),
+    ('branch', r'^s_(branch|cbranch)', None),
+    ('wait_misc', r'^s_(waitcnt|nop|barrier|setprio|sleep|endpgm)', None),
 ]
 
 
@@ -55,7 +59,7 @@ def histogram(text, kernel):
             continue
         op = ins.split()[0]
         total += 1
-        for cls, pat in CLASSES:
+        for cls, pat, _ in CLASSES:
             if re.match(pat, op):
                 out[cls] = out.get(cls, 0) + 1
                 break
@@ -70,6 +74,7 @@ if __name__ == '__main__':
     lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'sca_amd', 'lib', 'libsca_hip.so')
     total, hist, other = histogram(disassemble(lib), kernel)
     valu = sum(v for k, v in hist.items() if k.startswith('valu'))
-    print(json.dumps({'kernel': kernel, 'static_instructions': total, 'by_class': hist, 'valu_static': valu,
-                      'valu_mix': {k: round(v / max(valu, 1), 4) for k, v in hist.items() if k.startswith('valu')},
-                      'unclassified_top': dict(sorted(other.items(), key=lambda kv: -kv[1])[:12])}, indent=1))
+    out = {'kernel': kernel, 'static_instructions': total, 'by_class': hist, 'valu_static': valu,
+           'valu_mix': {k: round(v / max(valu, 1), 4) for k, v in hist.items() if k.startswith('valu')},
+           'priced_by': {c: row for c, _, row in CLASSES if row}, 'unclassified_top': dict(sorted(other.items(), key=lambda kv: -kv[1])[:12])}
+    print(json.dumps(out, indent=1))
