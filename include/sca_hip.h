@@ -35,7 +35,8 @@ extern "C" {
 typedef struct sca_ctx sca_ctx;
 
 /* agent.py:27-41 + config.py; sca_default_params() fills the reference's values.  The reference keeps these per Agent object; a context holds
- * ONE value of each for all its agents (sca_amd.env.MACAEnv reads them off the agents and refuses a swarm whose agents disagree).
+ * ONE value of each as the default for all its agents; sca_set_agent_params hands over the agents' own where they differ
+ * (sca_amd.env.MACAEnv reads them off the agents and does both).
  * sca_create refuses values the kernels were not built for: non-finite or non-positive distances / steps / speeds, max_neighbors outside
  * 1 .. 16, max_heading_change outside [0, pi].  Parity at non-default values: tests/golden/F16_params_*. */
 typedef struct sca_params {
@@ -112,6 +113,14 @@ int sca_set_obstacles(sca_ctx *ctx, int m, const double *pos /*m*3*/, const doub
 int sca_set_agents(sca_ctx *ctx, int n, const double *radius /*n*/, const double *pref_speed /*n*/,
                    const double *goal /*n*3*/, const uint8_t *policy /*n*/, const uint8_t *zaxis /*n*/,
                    const double *max_run_dist /*n*/);
+
+/* The solver attributes PER AGENT, as the reference keeps them (agent.py:24-41: maxNeighbors, neighborDist, timeStep, timeHorizon, maxSpeed,
+ * max_heading_change, dt_nominal are attributes of every Agent object, read by its own policy calls).  Arrays of n (= sca_set_agents' n); a NULL
+ * array keeps the context's sca_params value for every agent; n = 0 or all NULL: back to one value per context.  Call after sca_set_agents
+ * (which clears them) and before sca_device_tracker_enable.  turning_radius and the pitch limits stay one value per context
+ * (sca_device_tracker_enable).  Not with the cell-owner partition.  Parity: tests/golden/F17_hetero_*. */
+int sca_set_agent_params(sca_ctx *ctx, int n, const double *neighbor_dist, const int32_t *max_neighbors, const double *time_step,
+                         const double *time_horizon, const double *max_speed, const double *max_heading_change, const double *dt_nominal);
 
 /* dynamic state (host <-> device) ---------------------------------------------------------------- */
 int sca_set_state(sca_ctx *ctx, const double *pos /*n*3*/, const float *vel /*n*3*/, const double *heading /*n*3*/,
@@ -275,6 +284,8 @@ int sca_get_history(sca_ctx *ctx, int first_row, int nrows, int agent_begin, int
 void *sca_tracker_create(int n, const double *goal /*n*3*/, const double *goal_heading /*n*3*/, const double *pref_speed /*n*/,
                          const uint8_t *zaxis /*n, nullable*/, double turning_radius /*agent.py:24 1.5*/,
                          double pitch_min, double pitch_max /*agent.py:27*/, double neighbor_dist /*agent.py:33*/);
+/* agent.neighborDist per agent (scaPolicy.py:299 reads the agent's own when its list is empty); NULL: the one value of sca_tracker_create */
+int sca_tracker_set_neighbor_dist(void *tracker, const double *neighbor_dist /*n, nullable*/);
 void sca_tracker_destroy(void *tracker);
 /* one compute_v_pref per agent with active[i] != 0; nbr0_dsq[i] = distSq of agent.neighbors[0] as left by the previous
  * policy pass, negative when the list is empty (scaPolicy.py:299) */

@@ -69,6 +69,8 @@ def lib():
         L.orc_set_params.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_set_dt_nominal.restype = None
         L.orc_set_dt_nominal.argtypes = [C.c_double]
+        L.orc_set_agent_params.restype = None
+        L.orc_set_agent_params.argtypes = [C.c_int, dp, ip, dp, dp, dp, dp, dp]
         L.orc_policy_step.restype = C.c_int
         L.orc_policy_step.argtypes = [C.c_int, C.c_int, dp, fp, dp, dp, dp, bp, dp, bp, bp, dp, bp, ip, dp, dp, dp, fp,
                                       ip, ip, bp, dp, bp, dp, ip, ip, C.c_int]
@@ -95,6 +97,24 @@ def set_params(**kw):
     L.orc_set_params(p['neighbor_dist'], int(p['max_neighbors']), p['time_step'], p['time_horizon'], p['max_speed'],
                      p['max_heading_change'], p['near_goal_threshold'])
     L.orc_set_dt_nominal(p['dt_nominal'])
+
+
+def set_agent_params(n=0, neighbor_dist=None, max_neighbors=None, time_step=None, time_horizon=None, max_speed=None, max_heading_change=None,
+                     dt_nominal=None):
+    """Per-agent solver attributes (the reference keeps them on every Agent object): arrays of n, None = the scene's value (set_params).
+    set_agent_params() switches them off again."""
+    L = lib()
+    keep = []
+
+    def arr(a, dt, ct):
+        if a is None or n == 0:
+            return None
+        b = np.ascontiguousarray(a, dt).reshape(n)
+        keep.append(b)
+        return _p(b, ct)
+    L.orc_set_agent_params(int(n), arr(neighbor_dist, np.float64, C.c_double), arr(max_neighbors, np.int32, C.c_int32), arr(time_step, np.float64, C.c_double),
+                           arr(time_horizon, np.float64, C.c_double), arr(max_speed, np.float64, C.c_double), arr(max_heading_change, np.float64, C.c_double),
+                           arr(dt_nominal, np.float64, C.c_double))
 
 
 def _p(a, t):

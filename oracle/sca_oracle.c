@@ -51,15 +51,47 @@ typedef struct {
     double dt_nominal;          /* agent.py:41  DT = 0.1: the integrator's step (mampenv.py:90-92), not timeStep */
 } OrcParams;
 
-static OrcParams g_par = {10.0, 16, 0.1, 10.0, 1.0, 0.78539816339744830962, 0.5, 0.1};
+/* g_ctx: what orc_set_params set (one value per scene).  g_par: what the functions below read -- the agent's own attributes while
+ * orc_policy_step / orc_env_update work on that agent (the reference reads them off the Agent object per call), thread-local because
+ * orc_policy_step runs agents in parallel. */
+static OrcParams g_ctx = {10.0, 16, 0.1, 10.0, 1.0, 0.78539816339744830962, 0.5, 0.1};
+static _Thread_local OrcParams g_par = {10.0, 16, 0.1, 10.0, 1.0, 0.78539816339744830962, 0.5, 0.1};
+/* per-agent attributes (agent.py:24-41 are per-object): NULL = the scene's value.  Set by orc_set_agent_params, n entries each. */
+static int g_pa_n = 0;
+static double *g_pa_neighbor_dist, *g_pa_time_step, *g_pa_time_horizon, *g_pa_max_speed, *g_pa_max_heading_change, *g_pa_dt_nominal;
+static int32_t *g_pa_max_neighbors;
+static void par_for_agent(int i) {
+    g_par = g_ctx;
+    if (i < 0 || i >= g_pa_n) return;
+    if (g_pa_neighbor_dist) g_par.neighbor_dist = g_pa_neighbor_dist[i];
+    if (g_pa_max_neighbors) g_par.max_neighbors = g_pa_max_neighbors[i];
+    if (g_pa_time_step) g_par.time_step = g_pa_time_step[i];
+    if (g_pa_time_horizon) g_par.time_horizon = g_pa_time_horizon[i];
+    if (g_pa_max_speed) g_par.max_speed = g_pa_max_speed[i];
+    if (g_pa_max_heading_change) g_par.max_heading_change = g_pa_max_heading_change[i];
+    if (g_pa_dt_nominal) g_par.dt_nominal = g_pa_dt_nominal[i];
+}
+static double *dup_d(const double *a, int n) { if (!a) return NULL; double *r = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); memcpy(r, a, sizeof(double) * (size_t)n); return r; }
+/* n = 0 (or all arrays NULL): back to one value per scene */
+void orc_set_agent_params(int n, const double *neighbor_dist, const int32_t *max_neighbors, const double *time_step, const double *time_horizon,
+                          const double *max_speed, const double *max_heading_change, const double *dt_nominal) {
+    free(g_pa_neighbor_dist); free(g_pa_time_step); free(g_pa_time_horizon); free(g_pa_max_speed); free(g_pa_max_heading_change); free(g_pa_dt_nominal);
+    free(g_pa_max_neighbors);
+    g_pa_n = n;
+    g_pa_neighbor_dist = dup_d(neighbor_dist, n); g_pa_time_step = dup_d(time_step, n); g_pa_time_horizon = dup_d(time_horizon, n);
+    g_pa_max_speed = dup_d(max_speed, n); g_pa_max_heading_change = dup_d(max_heading_change, n); g_pa_dt_nominal = dup_d(dt_nominal, n);
+    g_pa_max_neighbors = NULL;
+    if (max_neighbors && n > 0) { g_pa_max_neighbors = (int32_t *)malloc(sizeof(int32_t) * (size_t)n); memcpy(g_pa_max_neighbors, max_neighbors, sizeof(int32_t) * (size_t)n); }
+}
 
 void orc_set_params(double neighbor_dist, int max_neighbors, double time_step, double time_horizon,
                     double max_speed, double max_heading_change, double near_goal_threshold) {
-    g_par.neighbor_dist = neighbor_dist; g_par.max_neighbors = max_neighbors; g_par.time_step = time_step;
-    g_par.time_horizon = time_horizon; g_par.max_speed = max_speed; g_par.max_heading_change = max_heading_change;
-    g_par.near_goal_threshold = near_goal_threshold;
+    g_ctx.neighbor_dist = neighbor_dist; g_ctx.max_neighbors = max_neighbors; g_ctx.time_step = time_step;
+    g_ctx.time_horizon = time_horizon; g_ctx.max_speed = max_speed; g_ctx.max_heading_change = max_heading_change;
+    g_ctx.near_goal_threshold = near_goal_threshold;
+    g_par = g_ctx;                                            /* (the scalar helpers called directly by the KAT tests read g_par on this thread) */
 }
-void orc_set_dt_nominal(double dt_nominal) { g_par.dt_nominal = dt_nominal; }
+void orc_set_dt_nominal(double dt_nominal) { g_ctx.dt_nominal = dt_nominal; g_par = g_ctx; }
 
 /* ------------------------------------------------------------------ numpy / Python arithmetic idioms */
 
@@ -733,12 +765,13 @@ int orc_policy_step(int n, int m, const double *pos, const float *vel, const dou
     }
     uint8_t *flags_in = (uint8_t *)malloc((size_t)n + 1);
     memcpy(flags_in, flags, (size_t)n);
-    double rangeSq = pow(g_par.neighbor_dist, 2.0);                      /* scaPolicy.py:112 */
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 8)
 #endif
     for (int i = 0; i < n; i++) {
+        par_for_agent(i);                                                /* the attributes find_next_action reads off THIS agent */
+        double rangeSq = pow(g_par.neighbor_dist, 2.0);                  /* scaPolicy.py:112 */
         int st = 0;
         for (int k = 0; k < 7; k++) { action64[7 * i + k] = 0.0; action32[7 * i + k] = 0.0f; }
         nbr_valid[i] = 0; nbr_n[i] = 0;
@@ -837,8 +870,9 @@ int orc_policy_step(int n, int m, const double *pos, const float *vel, const dou
 int orc_env_update(int n, int m, double *pos, float *vel, double *heading, const double *radius, uint8_t *flags,
                    const double *goal, const float *action32, double *total_dist, const double *max_run_dist,
                    int32_t *step_num, const double *obs_pos, const double *obs_radius) {
-    double dt = g_par.dt_nominal;                                         /* agent.dt_nominal (agent.py:41) */
     for (int i = 0; i < n; i++) {
+        par_for_agent(i);
+        const double dt = g_par.dt_nominal;                              /* agent.dt_nominal (agent.py:41) */
         const float *act = &action32[7 * i];
         double speed = (double)act[3];
         double a = orc_pi_2_pi(heading[3 * i + 0] + (double)act[4]);
@@ -866,7 +900,7 @@ int orc_env_update(int n, int m, double *pos, float *vel, double *heading, const
     }
     int all_done = 1;
     for (int i = 0; i < n; i++) {
-        if (orc_l3norm(&pos[3 * i], &goal[3 * i]) <= g_par.near_goal_threshold) flags[i] |= FLAG_AT_GOAL;
+        if (orc_l3norm(&pos[3 * i], &goal[3 * i]) <= g_ctx.near_goal_threshold) flags[i] |= FLAG_AT_GOAL;
         if (!(flags[i] & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) all_done = 0;
     }
     return all_done;

@@ -32,6 +32,7 @@ SIGNATURES = {
     'sca_last_error': (C.c_char_p, [C.c_void_p]),
     'sca_set_obstacles': (C.c_int, [C.c_void_p, C.c_int, dp, dp]),
     'sca_set_agents': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp, bp, bp, dp]),
+    'sca_set_agent_params': (C.c_int, [C.c_void_p, C.c_int, dp, ip, dp, dp, dp, dp, dp]),
     'sca_set_state': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, ip]),
     'sca_get_state': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, ip]),
     'sca_set_kd_perm': (C.c_int, [C.c_void_p, ip]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     'sca_history_rows': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sca_get_history': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, fp]),
     'sca_tracker_create': (C.c_void_p, [C.c_int, dp, dp, dp, bp, C.c_double, C.c_double, C.c_double, C.c_double]),
+    'sca_tracker_set_neighbor_dist': (C.c_int, [C.c_void_p, dp]),
     'sca_tracker_destroy': (None, [C.c_void_p]),
     'sca_tracker_vpref': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, dp, C.c_int]),
     'sca_tracker_replans': (C.c_int, [C.c_void_p, ip]),

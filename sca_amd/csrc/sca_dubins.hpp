@@ -876,6 +876,7 @@ struct TrackView {
     const double *pref_speed;     // [n]
     const uint8_t *zaxis;         // [n] is_zAxis of scaPolicy.py:188-190 (condition_dist :300)
     double turning_radius, pitch_lo, pitch_hi, neighbor_dist;
+    const double *nd_per_agent;   // [n] agent.neighborDist where the agents differ (scaPolicy.py:299 reads the agent's own), else null
 };
 
 struct Pool;
@@ -885,10 +886,11 @@ struct Tracker {
     std::vector<double> goal, goal_heading, pref_speed;
     std::vector<uint8_t> zaxis;
     double turning_radius = 1.5, pitchlims[2] = {-PI / 4, PI / 4}, neighbor_dist = 10.0;
+    std::vector<double> nd_per_agent;                              // empty: neighbor_dist for everybody (sca_tracker_set_neighbor_dist)
     std::vector<AgentTrack> st;
     TrackView view() const {
         return TrackView{goal.data(), goal_heading.data(), pref_speed.data(), zaxis.data(), turning_radius, pitchlims[0], pitchlims[1],
-                         neighbor_dist};
+                         neighbor_dist, nd_per_agent.empty() ? nullptr : nd_per_agent.data()};
     }
 };
 
@@ -970,7 +972,7 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double theta = round5_py(m_acos(cs));
     SCA_TD_MARK(4);
     const double deg100 = round5_np(100.0 * (PI / 180.0));
-    const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.neighbor_dist);
+    const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.nd_per_agent ? T.nd_per_agent[i] : T.neighbor_dist);
     const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
     const bool par_ = is_parallel(vel, a.v_pref);
     SCA_TD_MARK(5);

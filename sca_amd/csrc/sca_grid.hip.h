@@ -174,8 +174,9 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
     const bool scan = exists && !done;
     const bool want_list = scan && !bootstrap;
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double rangeSq = P.neighbor_dist * P.neighbor_dist;       // scaPolicy.py:112
-    const int maxn = P.max_neighbors;
+    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;   // (the agent's own where the swarm is heterogeneous; a cell is the LARGEST)
+    const double rangeSq = nd_ * nd_;                               // scaPolicy.py:112
+    const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
     const int tk = gl >= 2 ? (gl - 2) >> 2 : 0;                     // box term of this lane (see k_neighbors_kd4)

@@ -220,6 +220,9 @@ struct sca_ctx {
     hipEvent_t trk_fork = nullptr, trk_join = nullptr;
     hipStream_t nbr_stream = nullptr;   // where K0 / K1 of the current pass go: trk_stream when overlapped, else the main stream
     bool kd_ahead_enqueue = false;      // (timeline builds: the build being enqueued belongs to the next pass)
+    Params P_ctx{};                     // sca_create's parameters; P holds the ENVELOPE of the agents' own while sca_set_agent_params is in force
+    AgentPar *ap_dev = nullptr;         // [n] per-agent solver attributes on the device (DeviceView::ap), null: one value per context
+    double *ap_nd = nullptr;            // [n] the agents' neighborDist alone, for the tracker (TrackView::nd_per_agent)
     int32_t *h_done = nullptr;          // pinned: K4's 256 counters (stride 32) + the kd build's error word (read_active)
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
@@ -396,6 +399,12 @@ void *sca_tracker_create(int n, const double *goal, const double *goal_heading, 
     T->st.assign((size_t)n, sca_dubins::AgentTrack());
     return T;
 }
+int sca_tracker_set_neighbor_dist(void *tr, const double *neighbor_dist /*n, nullable: back to the one value*/) {
+    if (!tr) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    if (neighbor_dist) T->nd_per_agent.assign(neighbor_dist, neighbor_dist + T->n); else T->nd_per_agent.clear();
+    return 0;
+}
 void sca_tracker_destroy(void *tr) {
     auto *T = (sca_dubins::Tracker *)tr;
     if (T) { delete T->pool; delete T; }
@@ -498,6 +507,7 @@ static inline int per_simd(const sca_ctx *c, long long at_1024_simds) { return (
 static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass);
 static int part_free(sca_ctx *c);
 static int part_classify(sca_ctx *c);
+static int agent_params_clear(sca_ctx *c);
 static int tracker_free(sca_ctx *c) {
     if (!c->trk.st) { c->trk_on = false; return 0; }
     CHK(c, hipStreamSynchronize(c->stream));
@@ -554,7 +564,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipStreamSynchronize(c->stream));
     c->trk.parity = 0;
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
-                                        pitch_max, c->P.neighbor_dist};
+                                        pitch_max, c->P.neighbor_dist, c->ap_nd};
     {   // resolve the tracker's kernels now: the first launch of a kernel pays for looking it up in the code object, and the
         // forms are picked while the episode runs (k_track_replan's first launch used to fall into a timed step)
         hipFuncAttributes fa;
@@ -631,6 +641,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P.max_speed = p->max_speed; c->P.max_heading_change = p->max_heading_change;
     c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0; c->P.dt_nominal = p->dt_nominal;
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
+    c->P_ctx = c->P;
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
@@ -742,6 +753,7 @@ void sca_destroy(sca_ctx *c) {
     (void)tracker_free(c);
     (void)part_free(c);
     if (c->h_done) { (void)hipHostFree(c->h_done); c->h_done = nullptr; }
+    if (c->ap_dev) { (void)hipFree(c->ap_dev); (void)hipFree(c->ap_nd); c->ap_dev = nullptr; c->ap_nd = nullptr; }
     void *ptrs[] = {c->rec_own, c->rec_new_own, d.heading, d.goal, d.pref_speed, d.vpref_ext, d.total_dist, d.max_run_dist,
                     d.step_num, d.vpref_mode, d.policy, d.zaxis, d.obs, d.obs_sorted, d.awide, d.owide, d.atree, d.aperm, d.otree, d.operm, d.nbr_n,
                     d.nbr_id, d.nbr_dsq, d.coll_new, d.nbr_valid, d.near_n, d.near_id, d.action, d.vpref_used, d.vpost, d.fb_list, d.fb_count, d.is_fb, d.prep, d.diag, d.status,
@@ -798,6 +810,72 @@ int sca_set_obstacles(sca_ctx *c, int m, const double *pos, const double *radius
     return 0;
 }
 
+static int agent_params_clear(sca_ctx *c) {
+    if (!c->ap_dev) return 0;
+    CHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->ap_dev); (void)hipFree(c->ap_nd);
+    c->ap_dev = nullptr; c->ap_nd = nullptr; c->d.ap = nullptr;
+    c->P = c->P_ctx;
+    c->grid.inv_cell = grid_inv_cell(c->P.neighbor_dist);
+    if (c->trk_on) c->trk_view.nd_per_agent = nullptr;
+    return 0;
+}
+// The reference keeps maxNeighbors / neighborDist / timeStep / timeHorizon / maxSpeed / max_heading_change / dt_nominal on every Agent object
+// (agent.py:24-41) and every policy reads its own agent's (scaPolicy.py:112, util.py:8,17, orca3dPolicyOfficial.py:44,98,108, agent.py:87-99,
+// mampenv.py:90-92).  Arrays of n = the agents of sca_set_agents; a NULL array keeps the context's value for everybody; n = 0 (or all NULL)
+// returns to one value per context.  The grid's cells are sized for the largest neighborDist, the collision reach for the largest step.
+int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const int32_t *max_neighbors, const double *time_step,
+                         const double *time_horizon, const double *max_speed, const double *max_heading_change, const double *dt_nominal) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
+    if (c->part_on) { c->err = "per-agent solver attributes with the cell-owner partition: not supported"; return SCA_ERR_UNSUPPORTED; }
+    const bool any = neighbor_dist || max_neighbors || time_step || time_horizon || max_speed || max_heading_change || dt_nominal;
+    if (n == 0 || !any) return agent_params_clear(c);
+    ARG(c, n == c->n);
+    std::vector<AgentPar> h((size_t)n);
+    std::vector<double> nd((size_t)n);
+    auto pos = [](double x) { return std::isfinite(x) && x > 0.0; };
+    std::vector<std::pair<double, double>> thr_cache;               // (max_heading_change, its cosine threshold): few distinct values
+    Params env = c->P_ctx;
+    double nd_max = 0, ms_max = 0, dt_max = 0;
+    for (int i = 0; i < n; i++) {
+        AgentPar a;
+        a.neighbor_dist = neighbor_dist ? neighbor_dist[i] : c->P_ctx.neighbor_dist;
+        a.time_step = time_step ? time_step[i] : c->P_ctx.time_step;
+        a.time_horizon = time_horizon ? time_horizon[i] : c->P_ctx.time_horizon;
+        a.max_speed = max_speed ? max_speed[i] : c->P_ctx.max_speed;
+        a.dt_nominal = dt_nominal ? dt_nominal[i] : c->P_ctx.dt_nominal;
+        a.max_neighbors = max_neighbors ? max_neighbors[i] : c->P_ctx.max_neighbors;
+        a.pad = 0;
+        const double mhc = max_heading_change ? max_heading_change[i] : c->P_ctx.max_heading_change;
+        if (!pos(a.neighbor_dist) || !pos(a.time_step) || !pos(a.time_horizon) || !pos(a.max_speed) || !pos(a.dt_nominal) ||
+            a.max_neighbors < 1 || a.max_neighbors > SCA_MAX_NEIGHBORS || !(mhc >= 0.0 && mhc <= M_PI)) {
+            c->err = "sca_set_agent_params: agent " + std::to_string(i) + " has an attribute out of range (see sca_params)";
+            return SCA_ERR_ARG;
+        }
+        a.cos_heading_thr = c->P_ctx.cos_heading_thr;
+        if (max_heading_change) {
+            bool hit = false;
+            for (auto &e : thr_cache) if (e.first == mhc) { a.cos_heading_thr = e.second; hit = true; break; }
+            if (!hit) { a.cos_heading_thr = cos_threshold(mhc); thr_cache.push_back({mhc, a.cos_heading_thr}); }
+        }
+        h[i] = a; nd[i] = a.neighbor_dist;
+        nd_max = std::max(nd_max, a.neighbor_dist); ms_max = std::max(ms_max, a.max_speed); dt_max = std::max(dt_max, a.dt_nominal);
+    }
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (!c->ap_dev) { CHK(c, hipMalloc((void **)&c->ap_dev, sizeof(AgentPar) * (size_t)c->max_n)); CHK(c, hipMalloc((void **)&c->ap_nd, sizeof(double) * (size_t)c->max_n)); }
+    CHK(c, hipMemcpy(c->ap_dev, h.data(), sizeof(AgentPar) * (size_t)n, hipMemcpyHostToDevice));
+    CHK(c, hipMemcpy(c->ap_nd, nd.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    c->d.ap = c->ap_dev;
+    // the context's own Params become the envelope: what sizes the grid's cells (largest range) and the collision reach (largest step)
+    env.neighbor_dist = nd_max; env.max_speed = ms_max; env.dt_nominal = dt_max;
+    c->P = env;
+    c->grid.inv_cell = grid_inv_cell(c->P.neighbor_dist);
+    if (c->trk_on) c->trk_view.nd_per_agent = c->ap_nd;
+    c->near_valid = false;
+    return 0;
+}
+
 int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_speed, const double *goal,
                    const uint8_t *policy, const uint8_t *zaxis, const double *max_run_dist) {
     if (!c) return SCA_ERR_ARG;
@@ -809,6 +887,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
         c->d.hist = nullptr; c->d.hist_cap = 0; c->d.hist_row = 0;
     }
     if (int r = tracker_free(c)) return r;                            // the tracker records belong to the old agent set
+    if (int r = agent_params_clear(c)) return r;                      // ... and so do the agents' own solver attributes
     if (int r = part_free(c)) return r;                               // ... and so do the partition's lists
     if (c->comm && n % c->comm_nranks) { c->err = "agent count must be a multiple of the communicator's rank count"; return SCA_ERR_ARG; }
     c->n = n; c->d.n = n; c->d.shard_begin = 0; c->d.shard_count = n;
@@ -1887,6 +1966,7 @@ static int part_classify(sca_ctx *c) {                                      // f
     return part_adopt(c, true);
 }
 int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double *cuts, int cap_halo, int cap_mig) {
+    if (c && c->ap_dev) { c->err = "the cell-owner partition with per-agent solver attributes: not supported"; return SCA_ERR_UNSUPPORTED; }
     if (!c) return SCA_ERR_ARG;
     ARG(c, nranks >= 1 && rank >= 0 && rank < nranks && axis >= 0 && axis <= 2 && cap_halo >= 0 && cap_mig >= 0);
     if (!c->agents_set || !c->state_set) { c->err = "sca_set_agents and sca_set_state (the complete state, on every rank) first"; return SCA_ERR_STATE; }

@@ -119,6 +119,7 @@ struct DeviceView {
     int32_t *kdq_list;       // [n]
     int32_t *kdq_count;      // [1] how many the grid query listed; more than kdq_cap: "too many for a list" -- the list is then incomplete and
     int kdq_cap;             //     the kd query of EVERY agent of the shard runs instead (k_neighbors_kd_auto)
+    const AgentPar *ap;      // [n] per-agent solver attributes (null: the context's Params for everybody) -- agent_params()
     unsigned long long *kdq_stats;   // [4] AUTO passes, agents listed over them (sum, max), passes in which somebody was listed (sca_auto_stats)
     unsigned *kdq_busy;      // [1] bit 0: the grid query of this pass listed somebody and the kd query has not answered yet (the pass's stream waits for 0)
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
@@ -159,6 +160,17 @@ struct TlScope {
 #else
 #define SCA_TL(d, kid) do { } while (0)
 #endif
+
+// the solver attributes of one agent: the context's, or the agent's own where the swarm is heterogeneous (sca_set_agent_params)
+__device__ __forceinline__ Params agent_params(const DeviceView &d, const Params &P, int agent) {
+    Params Q = P;
+    if (d.ap) {
+        const AgentPar a = d.ap[agent];
+        Q.neighbor_dist = a.neighbor_dist; Q.time_step = a.time_step; Q.time_horizon = a.time_horizon; Q.max_speed = a.max_speed;
+        Q.cos_heading_thr = a.cos_heading_thr; Q.dt_nominal = a.dt_nominal; Q.max_neighbors = a.max_neighbors;
+    }
+    return Q;
+}
 
 // the i-th agent of this rank (i < shard_count) / the i-th agent whose record this rank holds (i < present_count(d))
 __device__ __forceinline__ int shard_agent(const DeviceView &d, int i) { return d.own ? d.own[i] : d.shard_begin + i; }
@@ -445,8 +457,9 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double rangeSq = P.neighbor_dist * P.neighbor_dist;                      // scaPolicy.py:112
-    const int maxn = P.max_neighbors;
+    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;         // (the agent's own where the swarm is heterogeneous)
+    const double rangeSq = nd_ * nd_;                                              // scaPolicy.py:112
+    const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     WaveList L; L.dsq = 0.0; L.id = -1; L.cnt = 0;
     bool coll = false;
     // obstacles first (scaPolicy.py:114-116), agent.py:101-124
@@ -621,8 +634,9 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;    // scaPolicy.py:34: no computeNeighbors on the bootstrap step
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double rangeSq = P.neighbor_dist * P.neighbor_dist;       // scaPolicy.py:112
-    const int maxn = P.max_neighbors;
+    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;   // (the agent's own where the swarm is heterogeneous)
+    const double rangeSq = nd_ * nd_;                               // scaPolicy.py:112
+    const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
     // which box term this lane squares: lanes 2..13 hold bx[0..11] of the node record (axis, min/max, side interleaved)
@@ -780,7 +794,8 @@ __device__ __forceinline__ bool tracker_owns(const DeviceView &d, int agent) {
     const int pol = d.policy[agent];
     return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;
 }
-__device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &P, Prep *out, int agent) {
+__device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pctx, Prep *out, int agent) {
+    const Params P = agent_params(d, Pctx, agent);
     const PubRec me = d.rec[agent];
     const int pol = d.policy[agent];
     const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
@@ -841,9 +856,10 @@ __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Param
     const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
     const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
     const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
-    const double dx = speed * cos(b) * cos(a) * P.dt_nominal;
-    const double dy = speed * cos(b) * sin(a) * P.dt_nominal;
-    const double dz = speed * sin(b) * P.dt_nominal;
+    const double dt = d.ap ? d.ap[agent].dt_nominal : P.dt_nominal;               // agent.dt_nominal (mampenv.py:90-92)
+    const double dx = speed * cos(b) * cos(a) * dt;
+    const double dy = speed * cos(b) * sin(a) * dt;
+    const double dz = speed * sin(b) * dt;
     const double len = sqrt(dx * dx + dy * dy + dz * dz);
     d.total_dist[agent] += len;
     r.px += dx; r.py += dy; r.pz += dz;
@@ -963,7 +979,8 @@ __device__ __forceinline__ bool sweep_split(const double (*slot)[SL], int K, int
     return hit;
 }
 
-__device__ __forceinline__ void solve_one(const DeviceView &d, const Params &P, SolveLds &S, int agent, int lane, int wid) {
+__device__ __forceinline__ void solve_one(const DeviceView &d, const Params &Pctx, SolveLds &S, int agent, int lane, int wid) {
+    const Params P = agent_params(d, Pctx, agent);        // (agent is wavefront-uniform: scalar loads)
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35: row stays zero
@@ -1215,7 +1232,8 @@ struct FastLds {
 // a 7-waves-per-SIMD build): an ORCA3D-Official agent past its bootstrap step is left to k_solve_lpw / k_lp, everything else
 // about it (done flags, bootstrap velocity) is still handled here.  LPMODE 2 (k_solve_lpw): those agents only, after k_solve.
 template <int PHASE, int LPMODE>
-__device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &P, FastLds &S, int agent, int lane, int wid) {
+__device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &Pctx, FastLds &S, int agent, int lane, int wid) {
+    const Params P = agent_params(d, Pctx, agent);        // (agent is wavefront-uniform: scalar loads)
     const PubRec me = d.rec[agent];
     int32_t *diag = d.diag + (size_t)agent * 8;
     if (PHASE != 1 && LPMODE != 2 && lane == 0) d.is_fb[agent] = 0;
@@ -1710,7 +1728,7 @@ struct LpAccess {
         return q;
     }
 };
-__global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t *list, int lo, int hi) {
+__global__ __launch_bounds__(64) void k_lp(DeviceView d, Params Pctx, const int32_t *list, int lo, int hi) {
     SCA_TL(d, TL_LP);
     __shared__ LpPlanes S;
     const int lane = threadIdx.x;
@@ -1718,6 +1736,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params P, const int32_t
     if (at >= hi) return;
     if (d.count_dev && at >= shard_size(d)) return;                                 // partition mode: `hi` is the host's bound, the list the owned agents
     const int agent = list[at];
+    const Params P = agent_params(d, Pctx, agent);                                  // (a lane per agent: the agent's own time horizon / step / max speed)
     if (d.policy[agent] != POL_ORCA_LP) return;                                     // (partition mode hands over all owned agents)
     const PubRec me = d.rec[agent];
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) return;          // mampenv.py:35 (k_solve wrote the bookkeeping)

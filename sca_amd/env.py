@@ -19,6 +19,8 @@ Differences that matter:
     MACAEnv(device_tracker=True): the same tracker as kernels inside every pass (state stays in HBM; equal to the host
     tracker bit for bit -- same statements, same restated glibc libm); without either the straight-line rule of rvo3dPolicy.py:182-196
     is used and `env.dubins_tracker` is False;
+  * the solver attributes of agent.py:24-41 are read off the agents in set_agents (per agent where they differ); turning_radius and pitchlims
+    must be the same for all tracked agents;
   * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
 There is no CPU path: constructing the env without a GPU raises.
 """
@@ -257,20 +259,31 @@ class MACAEnv:
         goal6 = np.array([a.goal_pos for a in agents], dtype=np.float64)
         # the solver attributes the reference keeps per Agent (agent.py:24-41) and its policies read per call (scaPolicy.py:95,112,272,302,
         # util.py:8,17, orca3dPolicyOfficial.py:44,98,108, agent.py:87-99, mampenv.py:90-92): a context holds one value of each
-        params = dict(neighbor_dist=self._uniform('neighborDist', float), max_neighbors=self._uniform('maxNeighbors', int),
-                      time_step=self._uniform('timeStep', float), time_horizon=self._uniform('timeHorizon', float),
-                      max_speed=self._uniform('maxSpeed', float), max_heading_change=self._uniform('max_heading_change', float),
-                      dt_nominal=self._uniform('dt_nominal', float))
+        # Attributes all agents agree on become the context's sca_params; the ones that differ from agent to agent go to the device as
+        # per-agent arrays (sca_set_agent_params), the context keeping the first agent's value as its default.
+        attr_of = dict(neighbor_dist=('neighborDist', float), max_neighbors=('maxNeighbors', int), time_step=('timeStep', float),
+                       time_horizon=('timeHorizon', float), max_speed=('maxSpeed', float), max_heading_change=('max_heading_change', float),
+                       dt_nominal=('dt_nominal', float))
+        params, per_agent = {}, {}
+        for name, (attr, conv) in attr_of.items():
+            vals = [conv(getattr(a, attr)) for a in agents]
+            params[name] = vals[0]
+            if any(v != vals[0] for v in vals):
+                per_agent[name] = vals
         self.solver = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), device=self.device, params=params)
         self.solver.set_obstacles(np.array([o.pos_global_frame for o in obstacles], dtype=np.float64).reshape(m, 3),
                                   np.array([o.radius for o in obstacles], dtype=np.float64))
         self.solver.set_agents([a.radius for a in agents], [a.pref_speed for a in agents], self.goal, self.policy_ids,
                                S.zaxis_flags(start, goal6), [a.max_run_dist for a in agents])
+        if per_agent:
+            self.solver.set_agent_params(**per_agent)
+        self.per_agent_attributes = sorted(per_agent)             # which attributes the agents disagree on (empty: one value per context)
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
         if self.device_tracker and self._ext.any():
-            self.solver.device_tracker_enable(goal6[:, 3:6], turning_radius=self._uniform('turning_radius', float),
-                                              pitchlims=(self._uniform('pitchlims', lambda p: float(p[0])),
-                                                         self._uniform('pitchlims', lambda p: float(p[1]))))
+            tracked = [a for a in agents if a.policy.needs_external_vpref]
+            self.solver.device_tracker_enable(goal6[:, 3:6], turning_radius=self._uniform('turning_radius', float, tracked),
+                                              pitchlims=(self._uniform('pitchlims', lambda p: float(p[0]), tracked),
+                                                         self._uniform('pitchlims', lambda p: float(p[1]), tracked)))
         for a in agents:
             a._env = self
             a.policy._env = self
@@ -290,13 +303,15 @@ class MACAEnv:
         if self.history_capacity:
             self.solver.history_enable(self.history_capacity)
 
-    def _uniform(self, attr, conv):
-        """The one value of a solver attribute all agents carry.  The reference reads these per agent; libsca_hip keeps one per context
-        (sca_params, include/sca_hip.h) and this env refuses a swarm whose agents disagree rather than pick one."""
-        vals = {conv(getattr(a, attr)) for a in self.agents}
+    def _uniform(self, attr, conv, agents=None):
+        """The one value of a TRACKER attribute (turning_radius, pitchlims) all tracked agents carry: the device tracker takes one value of
+        each per context (sca_device_tracker_enable) and this env refuses a swarm whose tracked agents disagree rather than pick one.  (The
+        solver attributes -- maxNeighbors, neighborDist, timeStep, timeHorizon, maxSpeed, max_heading_change, dt_nominal -- may differ
+        from agent to agent: sca_set_agent_params.)"""
+        vals = {conv(getattr(a, attr)) for a in (self.agents if agents is None else agents)}
         if len(vals) != 1:
-            raise ValueError(f'agents carry {len(vals)} different values of Agent.{attr} ({sorted(vals)[:4]} ...): one libsca_hip context '
-                             f'solves with one value per swarm -- not supported (SCA_ERR_UNSUPPORTED)')
+            raise ValueError(f'tracked agents carry {len(vals)} different values of Agent.{attr} ({sorted(vals)[:4]} ...): the device tracker '
+                             f'plans with one value per context -- not supported (SCA_ERR_UNSUPPORTED)')
         return vals.pop()
 
     # ---- host mirrors of the device state, refreshed on first use after a step (the reference's per-agent attributes) -------

@@ -76,6 +76,24 @@ class BatchedSolver:
                                         _lib.ptr(goal, C.c_double), _lib.ptr(policy, C.c_uint8),
                                         _lib.ptr(zaxis, C.c_uint8), _lib.ptr(mrd, C.c_double)), 'sca_set_agents')
 
+    def set_agent_params(self, neighbor_dist=None, max_neighbors=None, time_step=None, time_horizon=None, max_speed=None,
+                         max_heading_change=None, dt_nominal=None):
+        """The solver attributes per agent (the reference keeps them on every Agent object, agent.py:24-41): arrays of n, None = the context's
+        value for everybody; with no argument: back to one value per context.  After set_agents, before device_tracker_enable."""
+        n = self.n
+        keep = []
+
+        def arr(a, dt, ct):
+            if a is None:
+                return None
+            b = np.ascontiguousarray(np.broadcast_to(a, (n,)), dt)
+            keep.append(b)
+            return _lib.ptr(b, ct)
+        args = [arr(neighbor_dist, np.float64, C.c_double), arr(max_neighbors, np.int32, C.c_int32), arr(time_step, np.float64, C.c_double),
+                arr(time_horizon, np.float64, C.c_double), arr(max_speed, np.float64, C.c_double), arr(max_heading_change, np.float64, C.c_double),
+                arr(dt_nominal, np.float64, C.c_double)]
+        self._chk(self.L.sca_set_agent_params(self.ctx, n if keep else 0, *args), 'sca_set_agent_params')
+
     # ---- dynamic state -------------------------------------------------------------------------------
     def set_state(self, pos, vel, heading, flags, total_dist=None, step_num=None):
         n = self.n

@@ -40,6 +40,16 @@ class DubinsTracker:
         except Exception:
             pass
 
+    def set_neighbor_dist(self, neighbor_dist=None):
+        """agent.neighborDist per agent (None: the one value given to the constructor)"""
+        if neighbor_dist is None:
+            rc = self.L.sca_tracker_set_neighbor_dist(self.h, None)
+        else:
+            nd = _lib.as_d(np.broadcast_to(neighbor_dist, (self.n,)))
+            rc = self.L.sca_tracker_set_neighbor_dist(self.h, _lib.ptr(nd, C.c_double))
+        if rc != 0:
+            raise RuntimeError(f'sca_tracker_set_neighbor_dist rc={rc}')
+
     def note_neighbors(self, nbr_valid, nbr_n, nbr_dsq):
         """Remember agent.neighbors[0] of the policy pass that just ran (read by the next compute_v_pref, scaPolicy.py:299)."""
         v = np.asarray(nbr_valid).astype(bool)

@@ -42,7 +42,8 @@ def fixture_params(fx):
     for attr, name in _ATTR_TO_PARAM.items():
         if 'attr_' + attr in fx:
             v = fx['attr_' + attr]
-            assert (v == v[0]).all(), attr
+            if not (v == v[0]).all():
+                continue                                   # F17: this attribute differs from agent to agent -- fixture_agent_params
             params[name] = int(v[0]) if name == 'max_neighbors' else float(v[0])
     if 'attr_turning_radius' in fx:
         for k in ('turning_radius', 'pitch_lo', 'pitch_hi'):
@@ -52,6 +53,22 @@ def fixture_params(fx):
     return params, tracker
 
 
+def fixture_agent_params(fx):
+    """F17: the attributes that differ from agent to agent, as arrays in sca_set_agent_params / oracle.set_agent_params names ({} for
+    every other fixture).  The reference keeps all of them per Agent object (agent.py:24-41)."""
+    out = {}
+    for attr, name in _ATTR_TO_PARAM.items():
+        if 'attr_' + attr in fx:
+            v = fx['attr_' + attr]
+            if not (v == v[0]).all():
+                out[name] = v.astype(np.int32) if name == 'max_neighbors' else v.astype(np.float64)
+    return out
+
+
+def hetero_fixtures():
+    return [n for n in episode_fixtures() if n.startswith('F17_hetero')]
+
+
 def param_fixtures():
     return [n for n in episode_fixtures() if n.startswith('F16_params')]
 
@@ -59,4 +76,4 @@ def param_fixtures():
 def tracked_param_fixtures():
     """F16 scenes with SCA / RVO3D+Dubins agents: their recorded v_pref is the reference's Dubins tracker at the scene's
     turning_radius / pitchlims / neighborDist."""
-    return [n for n in param_fixtures() if np.isin(load(n)['policy'], (POL_SCA, POL_RVO_DUBINS)).any()]
+    return [n for n in param_fixtures() + hetero_fixtures() if np.isin(load(n)['policy'], (POL_SCA, POL_RVO_DUBINS)).any()]

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, fixture_params, load, static_inputs
+from golden_util import episode_fixtures, fixture_agent_params, fixture_params, load, static_inputs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -160,8 +160,13 @@ def test_core_solve_matches_reference(harness, tables, name):
     st = static_inputs(fx)
     fp = dict(neighbor_dist=10.0, time_step=0.1, time_horizon=10.0, max_speed=1.0, max_heading_change=math.pi / 4)
     fp.update({k: v for k, v in fixture_params(fx)[0].items() if k in fp})          # F16: the parameters the scene was recorded under
-    par = np.array([fp['neighbor_dist'], fp['time_step'], fp['time_horizon'], fp['max_speed'], fp['max_heading_change'], 0.5,
-                    cos_threshold(fp['max_heading_change'])])
+    per_agent = fixture_agent_params(fx)                                             # F17: attributes that differ from agent to agent
+
+    def par_of(i):
+        q = dict(fp)
+        q.update({k: float(v[i]) for k, v in per_agent.items() if k in q})
+        return np.array([q['neighbor_dist'], q['time_step'], q['time_horizon'], q['max_speed'], q['max_heading_change'], 0.5,
+                         cos_threshold(q['max_heading_change'])])
     T = len(fx['step'])
     n = len(st['radius'])
     u256, p256 = tables[256]
@@ -189,6 +194,7 @@ def test_core_solve_matches_reference(harness, tables, name):
             vin = np.ascontiguousarray(np.nan_to_num(fx['vpref'][t][i]))
             p_i = np.ascontiguousarray(pos[i]); v_i = np.ascontiguousarray(vel[i], np.float32)
             h_i = np.ascontiguousarray(head[i]); g_i = np.ascontiguousarray(fx['goal'][t][i])
+            par = par_of(i)
             stt = harness.core_solve_agent(_d(par), int(st['policy'][i]), int(st['zaxis'][i]), float(st['pref_speed'][i]),
                                            _d(p_i), v_i.ctypes.data_as(fpt), float(st['radius'][i]), _d(h_i), _d(g_i),
                                            given, _d(vin), K, _d(nb_pos), nb_vel.ctypes.data_as(fpt), _d(nb_rad),

@@ -7,12 +7,12 @@ that carry the changed attributes, closed loop, nothing from the fixture but the
 import numpy as np
 import pytest
 
-from golden_util import fixture_params, load, param_fixtures, static_inputs
+from golden_util import fixture_agent_params, fixture_params, hetero_fixtures, load, param_fixtures, static_inputs
 
 pytestmark = pytest.mark.gpu
 
 VEL_TOL = 1e-5
-EPISODES = [n for n in param_fixtures() if len(load(n)['step']) > 1]
+EPISODES = [n for n in param_fixtures() + hetero_fixtures() if len(load(n)['step']) > 1]
 
 
 def _agents_from_fixture(E, fx, with_attrs=True):
@@ -46,6 +46,7 @@ def test_env_closed_loop_with_agent_attributes(name, mode):
     params, trk = fixture_params(fx)
     for k, v in params.items():
         assert getattr(env.solver.params, k) == v, k
+    assert env.per_agent_attributes == sorted(fixture_agent_params(fx))       # F17: what the agents disagree on went over as arrays
     T = len(fx['step'])
     assert np.array_equal(fx['step'], np.arange(T))
     worst = 0.0
@@ -76,15 +77,17 @@ def test_defaults_would_not_reproduce_these_scenes():
     assert differ == len(EPISODES), (differ, len(EPISODES))
 
 
-def test_heterogeneous_attributes_are_refused():
-    """The reference reads the attributes per agent; a context holds one value per swarm, and the env says so instead of picking one."""
+def test_heterogeneous_tracker_attributes_are_refused_solver_attributes_are_not():
+    """The reference reads every attribute per agent.  The solver attributes travel per agent (sca_set_agent_params, F17 fixtures); the device
+    tracker takes ONE turning radius and ONE pair of pitch limits per context, and the env says so instead of picking one."""
     from sca_amd import env as E
     agents = E.build_circle_agents(8, policy=E.RVO3DPolicy, rad=10.0)
     agents[3].neighborDist = 5.0
-    with pytest.raises(ValueError, match='neighborDist'):
-        E.MACAEnv().set_agents(agents, obstacles=[])
-    agents[3].neighborDist = 10.0
-    agents[5].pitchlims = [-0.3, 0.3]
+    agents[5].pitchlims = [-0.3, 0.3]                              # nobody is tracked: the planner's limits are never read
+    env = E.MACAEnv()
+    env.set_agents(agents, obstacles=[])
+    assert env.per_agent_attributes == ['neighbor_dist']
+    env.step({})
     sca = E.build_circle_agents(8, policy=E.SCAPolicy, rad=10.0)
     sca[5].pitchlims = [-0.3, 0.3]
     with pytest.raises(ValueError, match='pitchlims'):
@@ -102,14 +105,17 @@ def test_policy_pass_grid_mode_with_parameters(name):
     params, _ = fixture_params(fx)
     sol = make_solver(S, fx, st)
     checked = overflowed = 0
-    maxn = params.get('max_neighbors', 16)
+    per_agent = fixture_agent_params(fx)
+    n_agents = len(st['radius'])
+    maxn_of = per_agent.get('max_neighbors', np.full(n_agents, params.get('max_neighbors', 16)))
+    nd_of = per_agent.get('neighbor_dist', np.full(n_agents, params.get('neighbor_dist', 10.0)))
     for t in range(len(fx['step'])):
         sol.set_state(fx['pos'][t], fx['vel'][t], fx['heading'][t], fx['flags'][t], fx['total_dist'][t])
         sol.set_vpref(fx['vpref'][t], st['vpref_mode'])
         try:
             sol.policy_pass(S.NBR_GRID)
         except S.ScaError as e:
-            assert 'SCA_NBR_GRID needs' in str(e) and params['neighbor_dist'] < 4.0, str(e)
+            assert 'SCA_NBR_GRID needs' in str(e) and nd_of.max() < 4.0, str(e)
             sol.close()
             return
         nb, dg = sol.neighbors(), sol.diag()
@@ -124,8 +130,9 @@ def test_policy_pass_grid_mode_with_parameters(name):
             checked += 1
         # overflowing lists: the max_neighbors nearest, ascending, all inside neighbor_dist (the reference's own list is visit-order dependent)
         for i in np.nonzero(valid & ((dg['status'] & 32) != 0) & (fx['coll_after_policy'][t] == 0))[0]:
+            maxn = int(maxn_of[i])
             d = nb['nbr_dsq'][i][:maxn]
-            assert nb['nbr_n'][i] == maxn and (np.diff(d) >= 0).all() and d[-1] < params.get('neighbor_dist', 10.0) ** 2, (name, t, i)
+            assert nb['nbr_n'][i] == maxn and (np.diff(d) >= 0).all() and d[-1] < nd_of[i] ** 2, (name, t, i)
             assert d[0] <= fx['nbr_dsq'][t][i][0] * (1 + 4e-16), (name, t, i)   # nothing nearer was missed (obstacles: x * x against pow(x, 2), 1 ulp)
             overflowed += 1
     assert checked + overflowed > 0

@@ -6,7 +6,7 @@ heading deltas within one float32 ulp (they pass through atan2); tolerance of th
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, fixture_params, load, static_inputs
+from golden_util import episode_fixtures, fixture_agent_params, fixture_params, load, static_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -26,6 +26,9 @@ def make_solver(S, fx, st):
     sol = S.BatchedSolver(max_agents=n, max_obstacles=max(m, 1), params=fixture_params(fx)[0])     # F16: recorded off the defaults
     sol.set_obstacles(st['obs_pos'], st['obs_radius'])
     sol.set_agents(st['radius'], st['pref_speed'], fx['goal'][0], st['policy'], st['zaxis'], st['max_run_dist'])
+    per_agent = fixture_agent_params(fx)                          # F17: attributes that differ from agent to agent (sca_set_agent_params)
+    if per_agent:
+        sol.set_agent_params(**per_agent)
     return sol
 
 

@@ -11,7 +11,7 @@ away, because the planner's radius search ends on comparisons of nearly equal pa
 import numpy as np
 import pytest
 
-from golden_util import fixture_params, load, static_inputs, tracked_param_fixtures
+from golden_util import fixture_agent_params, fixture_params, load, static_inputs, tracked_param_fixtures
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,8 @@ def _solver_for(fx, st, in_pass):
     sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(st['obs_radius'])), params=params)
     sol.set_obstacles(st['obs_pos'], st['obs_radius'])
     sol.set_agents(st['radius'], st['pref_speed'], fx['goal'][0], st['policy'], st['zaxis'], st['max_run_dist'])
+    if fixture_agent_params(fx):                                   # F17: attributes that differ from agent to agent
+        sol.set_agent_params(**fixture_agent_params(fx))
     sol.device_tracker_enable(fx['goal6'][:, 3:6], in_pass=in_pass, **trk)
     return sol
 

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from golden_util import episode_fixtures, fixture_params, load, static_inputs
+from golden_util import episode_fixtures, fixture_agent_params, fixture_params, load, static_inputs
 
 
 def test_candidate_table(oracle):
@@ -60,8 +60,13 @@ def test_round5_python_semantics(oracle):
 @pytest.fixture
 def oracle_params(oracle):
     """oracle.set_params is process-wide: every test that sets the recorded parameters of an F16 fixture restores the defaults."""
-    yield lambda fx: oracle.set_params(**fixture_params(fx)[0])
+    def apply(fx):
+        oracle.set_params(**fixture_params(fx)[0])
+        per_agent = fixture_agent_params(fx)                  # F17: attributes that differ from agent to agent
+        oracle.set_agent_params(len(fx['radius']) if per_agent else 0, **per_agent)
+    yield apply
     oracle.set_params()
+    oracle.set_agent_params()
 
 
 @pytest.mark.parametrize('name', episode_fixtures())

@@ -182,6 +182,8 @@ def _apply_attrs(agents, attrs):
     Values are scalars or per-agent sequences; 'pitchlims' is a (lo, hi) pair and changes ONLY agent.pitchlims (what the Dubins planner
     reads, scaPolicy.py:95) -- agent.max_heading_change (util.py:17) was derived from it inside __init__ and is its own key here."""
     n = len(agents)
+    if callable(attrs):                                  # F17: per-agent values drawn once the scene knows its agent count
+        attrs = attrs(n)
     for name, val in (attrs or {}).items():
         if name == 'pitchlims':
             for a in agents:
@@ -811,6 +813,47 @@ def main():
         if want(nm):
             single_step_cluster(agent_mod, env_mod, classes, nm, 60, 9.0, pid, seed=31 + pid, n_obs=14, min_sep=1.05, outdir=od,
                                 attrs=dict(maxNeighbors=5, neighborDist=3.0, timeHorizon=2.0, maxSpeed=1.3, max_heading_change=1.0))
+    # F17: the attributes PER AGENT, as the reference keeps them (agent.py:24-41 are per-object; every policy reads its own agent's) -- each agent
+    # draws its own maxNeighbors / neighborDist / timeStep / timeHorizon / maxSpeed / max_heading_change / dt_nominal (turning_radius and pitchlims
+    # stay uniform: the tracker's context takes one value of each)
+    def _hetero(seed):
+        def draw(n):
+            rng = np.random.default_rng(seed)
+            mhc = rng.choice([0.5, math.pi / 4, 1.0, math.pi / 2], n)
+            return dict(maxNeighbors=rng.choice([2, 5, 9, 16], n), neighborDist=rng.choice([3.0, 6.5, 10.0, 15.0], n), timeStep=rng.choice([0.05, 0.1, 0.2], n),
+                        timeHorizon=rng.choice([2.0, 5.0, 10.0], n), maxSpeed=rng.choice([0.8, 1.0, 1.5, 2.5], n), min_heading_change=-mhc, max_heading_change=mhc,
+                        dt_nominal=rng.choice([0.05, 0.1], n))
+        return draw
+    if want('F17_hetero_mixed48'):
+        rng = np.random.default_rng(1701)
+        n = 48
+        xyz = _cube(rng, n, 5.0, 12.0, 1.7)
+        g = -xyz + np.array([0.0, 0.0, 24.0])
+        g[: n // 6, :2] = xyz[: n // 6, :2]
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.3, 0.3)), 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        pol = [int(x) for x in rng.integers(0, 6, n)]
+        obs = [(list(map(float, rng.uniform(-5, 5, 3) + np.array([0, 0, 12.0]))), float(rng.choice([0.4, 1.0]))) for _ in range(5)]
+        run_env_episode(agent_mod, env_mod, classes, 'F17_hetero_mixed48', pos, goal, pol, obs, 30, radius=rng.choice([0.3, 0.5, 0.8], n),
+                        pref_speed=rng.choice([0.8, 1.0, 1.5], n), outdir=od, attrs=_hetero(1711))
+    if want('F17_hetero_circle60'):
+        pos, goal = rs.set_circle_pos((0, 0), 12.0, 60)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        run_env_episode(agent_mod, env_mod, classes, 'F17_hetero_circle60', pos, goal, [i % 6 for i in range(60)], [], 18, outdir=od, attrs=_hetero(1712))
+    if want('F17_hetero_dense40'):
+        rng = np.random.default_rng(1703)
+        n = 40
+        xyz = _cube(rng, n, 4.0, 20.0, 1.9)
+        g = -xyz + np.array([0.0, 0.0, 40.0])
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [0.0, 0.0, 0.0] for i in range(n)]
+        run_env_episode(agent_mod, env_mod, classes, 'F17_hetero_dense40', pos, goal, [[POL_RVO, POL_SRVO, POL_ORCA, POL_ORCA_LP][i % 4] for i in range(n)],
+                        [([0.5, -0.5, 20.0], 0.7)], 16, radius=rng.choice([0.3, 0.8], n), outdir=od, attrs=_hetero(1713))
+    for k in range(6):
+        nm = f'F17_hetero_fuzz_{k:02d}'
+        if want(nm):
+            single_step_random(agent_mod, env_mod, classes, nm, seed=1760 + k, outdir=od, attrs=_hetero(1770 + k))
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
