@@ -286,6 +286,8 @@ void *sca_tracker_create(int n, const double *goal /*n*3*/, const double *goal_h
                          double pitch_min, double pitch_max /*agent.py:27*/, double neighbor_dist /*agent.py:33*/);
 /* agent.neighborDist per agent (scaPolicy.py:299 reads the agent's own when its list is empty); NULL: the one value of sca_tracker_create */
 int sca_tracker_set_neighbor_dist(void *tracker, const double *neighbor_dist /*n, nullable*/);
+/* agent.turning_radius / agent.pitchlims per agent for the host tracker (arrays of n, NULL = the constructor's value) */
+int sca_tracker_set_agent_params(void *tracker, const double *turning_radius, const double *pitch_lo, const double *pitch_hi);
 void sca_tracker_destroy(void *tracker);
 /* one compute_v_pref per agent with active[i] != 0; nbr0_dsq[i] = distSq of agent.neighbors[0] as left by the previous
  * policy pass, negative when the list is empty (scaPolicy.py:299) */
@@ -320,6 +322,11 @@ int sca_device_tracker_enable(sca_ctx *ctx, const double *goal_heading /*n*3, ag
                               double pitch_min, double pitch_max, int in_pass);
 /* the tracked agents take v_pref from their policy's own straight-line rule again (sca_set_vpref afterwards to feed it from the host) */
 int sca_device_tracker_disable(sca_ctx *ctx);
+/* agent.turning_radius / agent.pitchlims PER AGENT (the reference keeps them on every Agent object; scaPolicy.py:95,272,302 read the agent's own).
+ * Arrays of n, a NULL array = sca_device_tracker_enable's value for everybody, all NULL = back to one value.  The tracked agents are grouped
+ * into classes of equal (turning_radius, pitch_lo, pitch_hi), at most 16, and the re-plan kernels run once per class (the search keeps these
+ * three in scalar registers).  After sca_device_tracker_enable.  Parity: tests/golden/F18_hetero_track_*. */
+int sca_device_tracker_set_agent_params(sca_ctx *ctx, int n, const double *turning_radius, const double *pitch_lo, const double *pitch_hi);
 /* one compute_v_pref per active tracked agent on the current state; nbr0_dsq as in sca_tracker_vpref, NULL = from the
  * device's neighbour lists; vpref_out nullable */
 int sca_device_tracker_vpref(sca_ctx *ctx, const double *nbr0_dsq /*n, nullable*/, double *vpref_out /*n*3, nullable*/);

@@ -85,6 +85,7 @@ SIGNATURES = {
     'sca_get_history': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, fp]),
     'sca_tracker_create': (C.c_void_p, [C.c_int, dp, dp, dp, bp, C.c_double, C.c_double, C.c_double, C.c_double]),
     'sca_tracker_set_neighbor_dist': (C.c_int, [C.c_void_p, dp]),
+    'sca_tracker_set_agent_params': (C.c_int, [C.c_void_p, dp, dp, dp]),
     'sca_tracker_destroy': (None, [C.c_void_p]),
     'sca_tracker_vpref': (C.c_int, [C.c_void_p, dp, fp, dp, bp, dp, dp, C.c_int]),
     'sca_tracker_replans': (C.c_int, [C.c_void_p, ip]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     'sca_device_tracker_debug': (C.c_int, [C.c_void_p, C.c_int, dp]),
     'sca_device_tracker_enable': (C.c_int, [C.c_void_p, dp, C.c_double, C.c_double, C.c_double, C.c_int]),
     'sca_device_tracker_disable': (C.c_int, [C.c_void_p]),
+    'sca_device_tracker_set_agent_params': (C.c_int, [C.c_void_p, C.c_int, dp, dp, dp]),
     'sca_device_tracker_vpref': (C.c_int, [C.c_void_p, dp, dp]),
     'sca_device_tracker_replans': (C.c_int, [C.c_void_p, ip]),
     'sca_selftest_dubins_words': (C.c_int, [C.c_int, dp, dp, dp, C.POINTER(C.c_int64)]),

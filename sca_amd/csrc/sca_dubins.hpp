@@ -877,7 +877,16 @@ struct TrackView {
     const uint8_t *zaxis;         // [n] is_zAxis of scaPolicy.py:188-190 (condition_dist :300)
     double turning_radius, pitch_lo, pitch_hi, neighbor_dist;
     const double *nd_per_agent;   // [n] agent.neighborDist where the agents differ (scaPolicy.py:299 reads the agent's own), else null
+    // agent.turning_radius / agent.pitchlims where the tracked agents differ (scaPolicy.py:95,272,302 read the agent's own), else null.
+    // The HOST tracker plans every agent with its own values.  On the DEVICE the re-plan kernels keep Rmin and the pitch limits in scalar
+    // registers throughout the search (they sit at 256 VGPRs): tracked agents are grouped into CLASSES of equal (R, pitch_lo, pitch_hi), the
+    // re-plan kernels are launched once per class with the class's values in turning_radius / pitch_lo / pitch_hi, and an agent of another
+    // class leaves at once (cls[agent] != class_id).  The decision (track_decide: k = 3 R, the 2 R test) reads R_pa per agent.
+    const double *R_pa, *plo_pa, *phi_pa;
+    const uint8_t *cls;           // [n] the agent's class (device), null: one class
+    int class_id;
 };
+SCA_DHD static inline double trk_R(const TrackView &T, int i) { return T.R_pa ? T.R_pa[i] : T.turning_radius; }
 
 struct Pool;
 struct Tracker {
@@ -887,10 +896,13 @@ struct Tracker {
     std::vector<uint8_t> zaxis;
     double turning_radius = 1.5, pitchlims[2] = {-PI / 4, PI / 4}, neighbor_dist = 10.0;
     std::vector<double> nd_per_agent;                              // empty: neighbor_dist for everybody (sca_tracker_set_neighbor_dist)
+    std::vector<double> R_pa, plo_pa, phi_pa;                       // empty: turning_radius / pitchlims for everybody (sca_tracker_set_agent_params)
     std::vector<AgentTrack> st;
     TrackView view() const {
         return TrackView{goal.data(), goal_heading.data(), pref_speed.data(), zaxis.data(), turning_radius, pitchlims[0], pitchlims[1],
-                         neighbor_dist, nd_per_agent.empty() ? nullptr : nd_per_agent.data()};
+                         neighbor_dist, nd_per_agent.empty() ? nullptr : nd_per_agent.data(),
+                         R_pa.empty() ? nullptr : R_pa.data(), plo_pa.empty() ? nullptr : plo_pa.data(), phi_pa.empty() ? nullptr : phi_pa.data(),
+                         nullptr, 0};
     }
 };
 
@@ -909,8 +921,13 @@ SCA_DHD static void adopt_plan(AgentTrack &a, const Plan3D &P) {
 SCA_DHD static void compute_dubins(TrackView T, AgentTrack &a, int i, const double *pos, const double *heading) {  // :92-104
     double qi[5], qf[5];
     dubins_endpoints(T, i, pos, heading, qi, qf);
-    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double pl[2] = {T.pitch_lo, T.pitch_hi};                   // (device: the launch's class, see TrackView)
     adopt_plan(a, SCA_PLAN3D_LANE(qi, qf, T.turning_radius, pl));
+#else
+    const double pl[2] = {T.plo_pa ? T.plo_pa[i] : T.pitch_lo, T.phi_pa ? T.phi_pa[i] : T.pitch_hi};
+    adopt_plan(a, SCA_PLAN3D_LANE(qi, qf, trk_R(T, i), pl));
+#endif
 }
 SCA_DHD static bool path_empty(const AgentTrack &a) { return a.next >= a.plan.count; }
 SCA_DHD static bool path_pop(AgentTrack &a, double out[3]) {
@@ -952,7 +969,7 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     const double *goal = &T.goal[3 * i];
     SCA_TD_MARK(0);
     const double dis_goal = l3norm(pos, goal);
-    const double k = 3.0 * T.turning_radius;
+    const double k = 3.0 * trk_R(T, i);
     if (!a.is_use_dubins) {
         a.is_use_dubins = true;
         return true;
@@ -973,7 +990,7 @@ SCA_DHD static bool track_decide(TrackView T, AgentTrack &a, int i, const double
     SCA_TD_MARK(4);
     const double deg100 = round5_np(100.0 * (PI / 180.0));
     const double min_dist_ob = nbr0_dsq >= 0 ? round5_py(std::sqrt(nbr0_dsq)) : std::rint(T.nd_per_agent ? T.nd_per_agent[i] : T.neighbor_dist);
-    const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * T.turning_radius) : false;
+    const bool condition_dist = T.zaxis[i] ? (min_dist_ob >= 2.0 * trk_R(T, i)) : false;
     const bool par_ = is_parallel(vel, a.v_pref);
     SCA_TD_MARK(5);
     if (((par_ || dis_goal <= k) && dis < max_size) || (theta >= deg100) || condition_dist) {

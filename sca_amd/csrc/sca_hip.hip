@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -224,6 +225,9 @@ struct sca_ctx {
     AgentPar *ap_dev = nullptr;         // [n] per-agent solver attributes on the device (DeviceView::ap), null: one value per context
     double *ap_nd = nullptr;            // [n] the agents' neighborDist alone, for the tracker (TrackView::nd_per_agent)
     int32_t *h_done = nullptr;          // pinned: K4's 256 counters (stride 32) + the kd build's error word (read_active)
+    std::vector<std::array<double, 3>> trk_classes;   // (turning radius, pitch_lo, pitch_hi) of every class of tracked agents; empty: one class = the view's scalars
+    double *trk_R_pa = nullptr;         // [n] agent.turning_radius (device), for the decision
+    uint8_t *trk_cls = nullptr;         // [n] the agent's class (device)
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
     bool trk_count_pending = false;
@@ -405,6 +409,13 @@ int sca_tracker_set_neighbor_dist(void *tr, const double *neighbor_dist /*n, nul
     if (neighbor_dist) T->nd_per_agent.assign(neighbor_dist, neighbor_dist + T->n); else T->nd_per_agent.clear();
     return 0;
 }
+int sca_tracker_set_agent_params(void *tr, const double *turning_radius, const double *pitch_lo, const double *pitch_hi) {
+    if (!tr) return SCA_ERR_ARG;
+    auto *T = (sca_dubins::Tracker *)tr;
+    auto put = [&](std::vector<double> &v, const double *a) { if (a) v.assign(a, a + T->n); else v.clear(); };
+    put(T->R_pa, turning_radius); put(T->plo_pa, pitch_lo); put(T->phi_pa, pitch_hi);
+    return 0;
+}
 void sca_tracker_destroy(void *tr) {
     auto *T = (sca_dubins::Tracker *)tr;
     if (T) { delete T->pool; delete T; }
@@ -513,6 +524,9 @@ static int tracker_free(sca_ctx *c) {
     CHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->trk.st); (void)hipFree(c->trk.nbr0); (void)hipFree(c->trk.list); (void)hipFree(c->trk.count); (void)hipFree(c->trk.bcount);
     (void)hipFree(c->trk_goal_heading);
+    if (c->trk_R_pa) { (void)hipFree(c->trk_R_pa); c->trk_R_pa = nullptr; }
+    if (c->trk_cls) { (void)hipFree(c->trk_cls); c->trk_cls = nullptr; }
+    c->trk_classes.clear();
     if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
     if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
     if (c->trk_join) { (void)hipEventDestroy(c->trk_join); c->trk_join = nullptr; }
@@ -564,7 +578,8 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     CHK(c, hipStreamSynchronize(c->stream));
     c->trk.parity = 0;
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
-                                        pitch_max, c->P.neighbor_dist, c->ap_nd};
+                                        pitch_max, c->P.neighbor_dist, c->ap_nd, nullptr, nullptr, nullptr, nullptr, 0};
+    c->trk_classes.clear();
     {   // resolve the tracker's kernels now: the first launch of a kernel pays for looking it up in the code object, and the
         // forms are picked while the episode runs (k_track_replan's first launch used to fall into a timed step)
         hipFuncAttributes fa;
@@ -585,6 +600,51 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk.spec2_max = getenv("SCA_TRK_SPEC2_MAX") ? atoi(getenv("SCA_TRK_SPEC2_MAX")) : per_simd(c, TRK_SPEC2_MAX);
     c->trk.spec3_max = getenv("SCA_TRK_SPEC3_MAX") ? atoi(getenv("SCA_TRK_SPEC3_MAX")) : per_simd(c, TRK_SPEC3_MAX);
     c->trk.spec4_max = getenv("SCA_TRK_SPEC4_MAX") ? atoi(getenv("SCA_TRK_SPEC4_MAX")) : per_simd(c, TRK_SPEC4_MAX);
+    return 0;
+}
+// agent.turning_radius / agent.pitchlims per agent (scaPolicy.py:95,272,302 read the agent's own).  Arrays of n, any of them NULL = the value of
+// sca_device_tracker_enable for everybody; all NULL: back to one value.  Tracked agents are grouped into classes of equal (R, lo, hi) -- at most
+// 16 -- and the re-plan kernels run once per class (TrackView); untracked agents' entries are ignored.
+int sca_device_tracker_set_agent_params(sca_ctx *c, int n, const double *turning_radius, const double *pitch_lo, const double *pitch_hi) {
+    if (!c) return SCA_ERR_ARG;
+    if (!c->trk_on) { c->err = "sca_device_tracker_enable first"; return SCA_ERR_STATE; }
+    CHK(c, hipStreamSynchronize(c->stream));
+    if (!turning_radius && !pitch_lo && !pitch_hi) {
+        c->trk_classes.clear();
+        c->trk_view.R_pa = nullptr; c->trk_view.cls = nullptr;
+        return 0;
+    }
+    ARG(c, n == c->n);
+    std::vector<uint8_t> mode((size_t)n), cls((size_t)n, 0);
+    CHK(c, hipMemcpy(mode.data(), c->d.vpref_mode, (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<std::array<double, 3>> classes;
+    std::vector<double> R((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const std::array<double, 3> v = {turning_radius ? turning_radius[i] : c->trk_view.turning_radius, pitch_lo ? pitch_lo[i] : c->trk_view.pitch_lo,
+                                         pitch_hi ? pitch_hi[i] : c->trk_view.pitch_hi};
+        R[i] = v[0];
+        if (!mode[i]) continue;                                          // not a tracked agent
+        if (!(std::isfinite(v[0]) && v[0] > 0.0) || !std::isfinite(v[1]) || !std::isfinite(v[2])) {
+            c->err = "sca_device_tracker_set_agent_params: agent " + std::to_string(i) + " has a turning radius / pitch limit out of range"; return SCA_ERR_ARG;
+        }
+        size_t k = 0;
+        while (k < classes.size() && classes[k] != v) k++;
+        if (k == classes.size()) {
+            if (classes.size() == 16) { c->err = "more than 16 different (turning_radius, pitchlims) among the tracked agents: not supported"; return SCA_ERR_UNSUPPORTED; }
+            classes.push_back(v);
+        }
+        cls[i] = (uint8_t)k;
+    }
+    if (!c->trk_R_pa) { CHK(c, hipMalloc((void **)&c->trk_R_pa, sizeof(double) * (size_t)c->max_n)); CHK(c, hipMalloc((void **)&c->trk_cls, (size_t)c->max_n)); }
+    CHK(c, hipMemcpy(c->trk_R_pa, R.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    CHK(c, hipMemcpy(c->trk_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice));
+    c->trk_classes = classes;
+    c->trk_view.R_pa = c->trk_R_pa;
+    c->trk_view.cls = classes.size() > 1 ? c->trk_cls : nullptr;
+    if (classes.size() <= 1) {                                          // one class after all: its values in the scalars, no filter
+        if (!classes.empty()) { c->trk_view.turning_radius = classes[0][0]; c->trk_view.pitch_lo = classes[0][1]; c->trk_view.pitch_hi = classes[0][2]; }
+        c->trk_classes.clear();
+    }
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
@@ -1266,14 +1326,20 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
         }
         CHK(c, hipEventRecord(t0, rs));
     }
+    // tracked agents whose turning radius / pitch limits differ (sca_device_tracker_set_agent_params) are planned class by class: the same
+    // launches once per class of equal values, each with ITS values in the view's scalars; an agent of another class leaves at once
+    const int nclass = c->trk_classes.empty() ? 1 : (int)c->trk_classes.size();
+    for (int cl = 0; cl < nclass; cl++) {
+    sca_dubins::TrackView V = c->trk_view;
+    if (!c->trk_classes.empty()) { V.class_id = cl; V.turning_radius = c->trk_classes[cl][0]; V.pitch_lo = c->trk_classes[cl][1]; V.pitch_hi = c->trk_classes[cl][2]; }
     if (group_fused) {
         K.lo = -1; K.hi = INT_MAX;
         hipLaunchKernelGGL(k_track_group, dim3((unsigned)(((long long)cnt * 64 + TRK_GROUP_THREADS - 1) / TRK_GROUP_THREADS)), dim3(TRK_GROUP_THREADS), 0,
-                           rs, c->d, c->trk_view, K);
+                           rs, c->d, V, K);
     } else if (fused) {
         K.lo = -1; K.hi = INT_MAX;
         hipLaunchKernelGGL(k_track_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
-                           c->trk_view, K);
+                           V, K);
     } else {
         int prev_up = -1, left = nwant;
         for (int i = 0; i < 5; i++) {
@@ -1288,15 +1354,16 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
             const dim3 blk(TRK_GROUP_THREADS);
             const auto blocks = [&](int lanes) { return dim3((unsigned)(((long long)top * lanes + TRK_GROUP_THREADS - 1) / TRK_GROUP_THREADS)); };
             switch (i) {
-            case 0: hipLaunchKernelGGL(k_replan_group<64>, blocks(64), blk, 0, rs, c->d, c->trk_view, K); break;
-            case 1: hipLaunchKernelGGL(k_replan_group<32>, blocks(32), blk, 0, rs, c->d, c->trk_view, K); break;
-            case 2: hipLaunchKernelGGL(k_replan_group<16>, blocks(16), blk, 0, rs, c->d, c->trk_view, K); break;
-            case 3: hipLaunchKernelGGL(k_replan_group<4>, blocks(4), blk, 0, rs, c->d, c->trk_view, K); break;
+            case 0: hipLaunchKernelGGL(k_replan_group<64>, blocks(64), blk, 0, rs, c->d, V, K); break;
+            case 1: hipLaunchKernelGGL(k_replan_group<32>, blocks(32), blk, 0, rs, c->d, V, K); break;
+            case 2: hipLaunchKernelGGL(k_replan_group<16>, blocks(16), blk, 0, rs, c->d, V, K); break;
+            case 3: hipLaunchKernelGGL(k_replan_group<4>, blocks(4), blk, 0, rs, c->d, V, K); break;
             default:
                 hipLaunchKernelGGL(k_replan, dim3((cnt + TRK_REPLAN_LANES - 1) / TRK_REPLAN_LANES), dim3(TRK_REPLAN_LANES), 0, rs, c->d,
-                                   c->trk_view, K);
+                                   V, K);
             }
         }
+    }
     }
     if (t1) CHK(c, hipEventRecord(t1, rs));
     CHK(c, hipGetLastError());

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sc
     const int count = K.count[K.parity];
     if (idx >= count || count <= K.lo) return;                              // fewer re-plans: k_replan_few's / k_replan_mid's pass
     const int agent = trk_list_agent(K.list, K.bcount + K.parity * TRK_BUCKETS, K.n, idx);
+    if (T.cls && T.cls[agent] != T.class_id) return;                       // another class's launch plans this agent (TrackView)
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_track_replan(DeviceView
     const int agent = shard_agent(d, idx);
     const double nb0 = K.nbr0[agent];                                    // saved by the previous pass's epilogue
     if (!track_active(d, agent)) return;
+    if (T.cls && T.cls[agent] != T.class_id) return;                     // (decision AND plan by the agent's own class's launch)
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     const float vel[3] = {r.vx, r.vy, r.vz};
@@ -699,6 +701,7 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     if (idx >= count) return;                                            // whole groups leave together
     KG_ZERO();
     const int agent = trk_list_agent(K.list, K.bcount + K.parity * TRK_BUCKETS, K.n, idx);
+    if (T.cls && T.cls[agent] != T.class_id) return;                       // (whole groups: another class's launch plans this agent)
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, 1) void k_track_group(DeviceView
     if (idx >= shard_size(d)) return;                                    // whole wavefronts leave together
     const int agent = shard_agent(d, idx);
     if (!track_active(d, agent)) return;
+    if (T.cls && T.cls[agent] != T.class_id) return;                     // (decision AND search by the agent's own class's launch)
     const PubRec r = d.rec[agent];
     const double pos[3] = {r.px, r.py, r.pz};
     sca_dubins::AgentTrack &a = K.st[agent];

@@ -19,8 +19,8 @@ Differences that matter:
     MACAEnv(device_tracker=True): the same tracker as kernels inside every pass (state stays in HBM; equal to the host
     tracker bit for bit -- same statements, same restated glibc libm); without either the straight-line rule of rvo3dPolicy.py:182-196
     is used and `env.dubins_tracker` is False;
-  * the solver attributes of agent.py:24-41 are read off the agents in set_agents (per agent where they differ); turning_radius and pitchlims
-    must be the same for all tracked agents;
+  * the solver attributes of agent.py:24-41 -- turning_radius and pitchlims included -- are read off the agents in set_agents and travel per
+    agent where the agents differ;
   * history logging (agent.py:126-147, pandas) and the per-step prints are not reproduced.
 There is no CPU path: constructing the env without a GPU raises.
 """
@@ -280,10 +280,15 @@ class MACAEnv:
         self.per_agent_attributes = sorted(per_agent)             # which attributes the agents disagree on (empty: one value per context)
         self.solver.set_state(self.pos, self.vel, self.heading, self.flags)
         if self.device_tracker and self._ext.any():
+            # the planner's attributes (agent.turning_radius, agent.pitchlims: scaPolicy.py:95,272,302): the first tracked agent's become the
+            # tracker's defaults, and where the tracked agents differ every agent's own go over (classes of equal values on the device)
             tracked = [a for a in agents if a.policy.needs_external_vpref]
-            self.solver.device_tracker_enable(goal6[:, 3:6], turning_radius=self._uniform('turning_radius', float, tracked),
-                                              pitchlims=(self._uniform('pitchlims', lambda p: float(p[0]), tracked),
-                                                         self._uniform('pitchlims', lambda p: float(p[1]), tracked)))
+            trip = [(float(a.turning_radius), float(a.pitchlims[0]), float(a.pitchlims[1])) for a in agents]
+            first = (float(tracked[0].turning_radius), float(tracked[0].pitchlims[0]), float(tracked[0].pitchlims[1]))
+            self.solver.device_tracker_enable(goal6[:, 3:6], turning_radius=first[0], pitchlims=(first[1], first[2]))
+            if any((float(a.turning_radius), float(a.pitchlims[0]), float(a.pitchlims[1])) != first for a in tracked):
+                self.solver.device_tracker_set_agent_params([t[0] for t in trip], [t[1] for t in trip], [t[2] for t in trip])
+                self.per_agent_attributes = sorted(self.per_agent_attributes + ['turning_radius / pitchlims'])
         for a in agents:
             a._env = self
             a.policy._env = self
@@ -302,17 +307,6 @@ class MACAEnv:
             self.history_capacity = capped
         if self.history_capacity:
             self.solver.history_enable(self.history_capacity)
-
-    def _uniform(self, attr, conv, agents=None):
-        """The one value of a TRACKER attribute (turning_radius, pitchlims) all tracked agents carry: the device tracker takes one value of
-        each per context (sca_device_tracker_enable) and this env refuses a swarm whose tracked agents disagree rather than pick one.  (The
-        solver attributes -- maxNeighbors, neighborDist, timeStep, timeHorizon, maxSpeed, max_heading_change, dt_nominal -- may differ
-        from agent to agent: sca_set_agent_params.)"""
-        vals = {conv(getattr(a, attr)) for a in (self.agents if agents is None else agents)}
-        if len(vals) != 1:
-            raise ValueError(f'tracked agents carry {len(vals)} different values of Agent.{attr} ({sorted(vals)[:4]} ...): the device tracker '
-                             f'plans with one value per context -- not supported (SCA_ERR_UNSUPPORTED)')
-        return vals.pop()
 
     # ---- host mirrors of the device state, refreshed on first use after a step (the reference's per-agent attributes) -------
     def _state(self, name):

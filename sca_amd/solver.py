@@ -145,6 +145,19 @@ class BatchedSolver:
         self._chk(self.L.sca_device_tracker_enable(self.ctx, _lib.ptr(gh, C.c_double), float(turning_radius), float(pitchlims[0]),
                                                    float(pitchlims[1]), int(bool(in_pass))), 'sca_device_tracker_enable')
 
+    def device_tracker_set_agent_params(self, turning_radius=None, pitch_lo=None, pitch_hi=None):
+        """agent.turning_radius / agent.pitchlims per agent (arrays of n; None = device_tracker_enable's value); after device_tracker_enable"""
+        keep = []
+
+        def arr(a):
+            if a is None:
+                return None
+            b = _lib.as_d(np.broadcast_to(a, (self.n,)))
+            keep.append(b)
+            return _lib.ptr(b, C.c_double)
+        self._chk(self.L.sca_device_tracker_set_agent_params(self.ctx, self.n if True else 0, arr(turning_radius), arr(pitch_lo), arr(pitch_hi)),
+                  'sca_device_tracker_set_agent_params')
+
     def device_tracker_disable(self):
         self._chk(self.L.sca_device_tracker_disable(self.ctx), 'sca_device_tracker_disable')
 

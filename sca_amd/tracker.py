@@ -50,6 +50,20 @@ class DubinsTracker:
         if rc != 0:
             raise RuntimeError(f'sca_tracker_set_neighbor_dist rc={rc}')
 
+    def set_agent_params(self, turning_radius=None, pitch_lo=None, pitch_hi=None):
+        """agent.turning_radius / agent.pitchlims per agent (arrays of n; None = the constructor's value)"""
+        keep = []
+
+        def arr(a):
+            if a is None:
+                return None
+            b = _lib.as_d(np.broadcast_to(a, (self.n,)))
+            keep.append(b)
+            return _lib.ptr(b, C.c_double)
+        rc = self.L.sca_tracker_set_agent_params(self.h, arr(turning_radius), arr(pitch_lo), arr(pitch_hi))
+        if rc != 0:
+            raise RuntimeError(f'sca_tracker_set_agent_params rc={rc}')
+
     def note_neighbors(self, nbr_valid, nbr_n, nbr_dsq):
         """Remember agent.neighbors[0] of the policy pass that just ran (read by the next compute_v_pref, scaPolicy.py:299)."""
         v = np.asarray(nbr_valid).astype(bool)

@@ -46,11 +46,21 @@ def fixture_params(fx):
                 continue                                   # F17: this attribute differs from agent to agent -- fixture_agent_params
             params[name] = int(v[0]) if name == 'max_neighbors' else float(v[0])
     if 'attr_turning_radius' in fx:
-        for k in ('turning_radius', 'pitch_lo', 'pitch_hi'):
-            assert (fx['attr_' + k] == fx['attr_' + k][0]).all(), k
+        # (F18: the planner's attributes differ from agent to agent -- the first agent's here, everybody's own in fixture_tracker_agent_params)
         tracker = dict(turning_radius=float(fx['attr_turning_radius'][0]),
                        pitchlims=(float(fx['attr_pitch_lo'][0]), float(fx['attr_pitch_hi'][0])))
     return params, tracker
+
+
+def fixture_tracker_agent_params(fx):
+    """F18: agent.turning_radius / agent.pitchlims per agent where they differ, in sca_device_tracker_set_agent_params /
+    DubinsTracker.set_agent_params names; {} otherwise."""
+    if 'attr_turning_radius' not in fx:
+        return {}
+    keys = dict(turning_radius='attr_turning_radius', pitch_lo='attr_pitch_lo', pitch_hi='attr_pitch_hi')
+    if all((fx[v] == fx[v][0]).all() for v in keys.values()):
+        return {}
+    return {k: fx[v].astype(np.float64) for k, v in keys.items()}
 
 
 def fixture_agent_params(fx):
@@ -66,7 +76,7 @@ def fixture_agent_params(fx):
 
 
 def hetero_fixtures():
-    return [n for n in episode_fixtures() if n.startswith('F17_hetero')]
+    return [n for n in episode_fixtures() if n.startswith(('F17_hetero', 'F18_hetero'))]
 
 
 def param_fixtures():

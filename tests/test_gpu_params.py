@@ -7,7 +7,7 @@ that carry the changed attributes, closed loop, nothing from the fixture but the
 import numpy as np
 import pytest
 
-from golden_util import fixture_agent_params, fixture_params, hetero_fixtures, load, param_fixtures, static_inputs
+from golden_util import fixture_agent_params, fixture_params, fixture_tracker_agent_params, hetero_fixtures, load, param_fixtures, static_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,8 @@ def test_env_closed_loop_with_agent_attributes(name, mode):
     params, trk = fixture_params(fx)
     for k, v in params.items():
         assert getattr(env.solver.params, k) == v, k
-    assert env.per_agent_attributes == sorted(fixture_agent_params(fx))       # F17: what the agents disagree on went over as arrays
+    trk_pa = ['turning_radius / pitchlims'] if fixture_tracker_agent_params(fx) else []
+    assert env.per_agent_attributes == sorted(list(fixture_agent_params(fx)) + trk_pa)   # F17 / F18: what the agents disagree on went over as arrays
     T = len(fx['step'])
     assert np.array_equal(fx['step'], np.arange(T))
     worst = 0.0
@@ -77,10 +78,10 @@ def test_defaults_would_not_reproduce_these_scenes():
     assert differ == len(EPISODES), (differ, len(EPISODES))
 
 
-def test_heterogeneous_tracker_attributes_are_refused_solver_attributes_are_not():
-    """The reference reads every attribute per agent.  The solver attributes travel per agent (sca_set_agent_params, F17 fixtures); the device
-    tracker takes ONE turning radius and ONE pair of pitch limits per context, and the env says so instead of picking one."""
-    from sca_amd import env as E
+def test_heterogeneous_attributes_travel_per_agent():
+    """The reference reads every attribute per agent.  The solver attributes travel per agent (sca_set_agent_params, F17 fixtures), the planner's
+    two as classes of equal values (sca_device_tracker_set_agent_params, F18): at most 16 classes, more are refused."""
+    from sca_amd import env as E, solver as S
     agents = E.build_circle_agents(8, policy=E.RVO3DPolicy, rad=10.0)
     agents[3].neighborDist = 5.0
     agents[5].pitchlims = [-0.3, 0.3]                              # nobody is tracked: the planner's limits are never read
@@ -90,8 +91,18 @@ def test_heterogeneous_tracker_attributes_are_refused_solver_attributes_are_not(
     env.step({})
     sca = E.build_circle_agents(8, policy=E.SCAPolicy, rad=10.0)
     sca[5].pitchlims = [-0.3, 0.3]
-    with pytest.raises(ValueError, match='pitchlims'):
-        E.MACAEnv(device_tracker=True).set_agents(sca, obstacles=[])
+    sca[2].turning_radius = 3.0
+    env = E.MACAEnv(device_tracker=True)
+    env.set_agents(sca, obstacles=[])                              # three classes of (turning_radius, pitchlims) on the device
+    assert env.per_agent_attributes == ['turning_radius / pitchlims']
+    for _ in range(5):
+        env.step({})
+    # more than 16 different planner settings among the tracked agents: refused, with the reason
+    many = E.build_circle_agents(20, policy=E.SCAPolicy, rad=20.0)
+    for i, a in enumerate(many):
+        a.turning_radius = 1.0 + 0.1 * i
+    with pytest.raises(S.ScaError, match='16 different'):
+        E.MACAEnv(device_tracker=True).set_agents(many, obstacles=[])
 
 
 @pytest.mark.parametrize('name', EPISODES)

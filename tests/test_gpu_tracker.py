@@ -11,7 +11,7 @@ away, because the planner's radius search ends on comparisons of nearly equal pa
 import numpy as np
 import pytest
 
-from golden_util import fixture_agent_params, fixture_params, load, static_inputs, tracked_param_fixtures
+from golden_util import fixture_agent_params, fixture_params, fixture_tracker_agent_params, load, static_inputs, tracked_param_fixtures
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,8 @@ def _solver_for(fx, st, in_pass):
     if fixture_agent_params(fx):                                   # F17: attributes that differ from agent to agent
         sol.set_agent_params(**fixture_agent_params(fx))
     sol.device_tracker_enable(fx['goal6'][:, 3:6], in_pass=in_pass, **trk)
+    if fixture_tracker_agent_params(fx):                           # F18: every agent its own turning radius and pitch limits (classes on the device)
+        sol.device_tracker_set_agent_params(**fixture_tracker_agent_params(fx))
     return sol
 
 

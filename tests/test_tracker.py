@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN, fixture_agent_params, fixture_params, load, static_inputs, tracked_param_fixtures
+from golden_util import GOLDEN, fixture_agent_params, fixture_params, fixture_tracker_agent_params, load, static_inputs, tracked_param_fixtures
 
 TRACKED_PARAM_EPISODES = tracked_param_fixtures()
 
@@ -42,6 +42,8 @@ def test_tracker_reproduces_reference_v_pref(name):
                                neighbor_dist=params.get('neighbor_dist', 10.0), **trk)
     if 'neighbor_dist' in fixture_agent_params(fx):                 # F17: every agent its own neighborDist (scaPolicy.py:299)
         tr.set_neighbor_dist(fixture_agent_params(fx)['neighbor_dist'])
+    if fixture_tracker_agent_params(fx):                            # F18: every agent its own turning radius and pitch limits
+        tr.set_agent_params(**fixture_tracker_agent_params(fx))
     T = len(fx['step'])
     assert np.array_equal(fx['step'], np.arange(T))           # every step recorded: the tracker state can be replayed
     ever = np.zeros(n, bool)

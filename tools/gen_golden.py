@@ -186,8 +186,9 @@ def _apply_attrs(agents, attrs):
         attrs = attrs(n)
     for name, val in (attrs or {}).items():
         if name == 'pitchlims':
-            for a in agents:
-                a.pitchlims = [float(val[0]), float(val[1])]
+            v = np.asarray(val, dtype=np.float64)
+            for i, a in enumerate(agents):                   # one pair for everybody, or one pair per agent ([n, 2])
+                a.pitchlims = [float(v[i, 0]), float(v[i, 1])] if v.ndim == 2 else [float(v[0]), float(v[1])]
             continue
         vals = np.broadcast_to(np.asarray(val), (n,))
         for a, v in zip(agents, vals):
@@ -854,6 +855,39 @@ def main():
         nm = f'F17_hetero_fuzz_{k:02d}'
         if want(nm):
             single_step_random(agent_mod, env_mod, classes, nm, seed=1760 + k, outdir=od, attrs=_hetero(1770 + k))
+    # F18: the PLANNER's attributes per agent -- turning_radius and pitchlims differ from agent to agent (three radii, three pairs of limits),
+    # SCA and RVO3D+Dubins agents among untracked ones; the solver attributes at their defaults in the first two, drawn per agent in the third
+    def _hetero_track(seed, with_solver):
+        def draw(n):
+            rng = np.random.default_rng(seed)
+            pl = np.array([(-math.pi / 4, math.pi / 4), (-math.pi / 6, math.pi / 6), (-0.5, 0.9)])[rng.integers(0, 3, n)]
+            at = dict(turning_radius=rng.choice([0.8, 1.5, 3.0], n), pitchlims=pl)
+            if with_solver:
+                at.update(_hetero(seed + 1)(n))
+            return at
+        return draw
+    if want('F18_hetero_track_circle24'):
+        pos, goal = rs.set_circle_pos((0, 0), 12.0, 24)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        pol = [[POL_SCA, POL_SCA, POL_RVO_DUBINS, POL_SRVO][i % 4] for i in range(24)]
+        run_env_episode(agent_mod, env_mod, classes, 'F18_hetero_track_circle24', pos, goal, pol, [], 50, outdir=od, attrs=_hetero_track(1801, False))
+    if want('F18_hetero_track_takeoff16'):
+        obs = [([round(4.0 * np.cos(2 * j * np.pi / 8), 2), round(4.0 * np.sin(2 * j * np.pi / 8), 2), 5.0], 1.0) for j in range(8)]
+        pos, goal = rs.set_takeoff_landing_pos(16)
+        pol = [POL_SCA if i % 3 else POL_RVO_DUBINS for i in range(16)]
+        run_env_episode(agent_mod, env_mod, classes, 'F18_hetero_track_takeoff16', pos, goal, pol, obs, 60, outdir=od, attrs=_hetero_track(1802, False))
+    if want('F18_hetero_track_mixed36'):
+        rng = np.random.default_rng(1803)
+        n = 36
+        xyz = _cube(rng, n, 5.0, 12.0, 1.7)
+        g = -xyz + np.array([0.0, 0.0, 24.0])
+        g[: n // 6, :2] = xyz[: n // 6, :2]
+        pos = [list(map(float, xyz[i])) + [float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(-0.3, 0.3)), 0.0] for i in range(n)]
+        goal = [list(map(float, g[i])) + [float(rng.uniform(0, 2 * np.pi)), 0.0, 0.0] for i in range(n)]
+        pol = [int(x) for x in rng.choice([POL_SCA, POL_SCA, POL_RVO_DUBINS, POL_ORCA_LP, POL_RVO], n)]
+        run_env_episode(agent_mod, env_mod, classes, 'F18_hetero_track_mixed36', pos, goal, pol, [([1.0, 0.0, 12.0], 0.8)], 30, radius=rng.choice([0.3, 0.5], n),
+                        outdir=od, attrs=_hetero_track(1804, True))
     # F6: ORCA-official N=100 circle, long run, every 10th step (LP4 coverage)
     if want('F6_orcalp_circle100_long'):
         pos, goal, _ = ro.set_circle_pos(100)
