@@ -722,6 +722,71 @@ def test_random_scenes_every_step_matches_oracle(S, oracle, block):
         sol.close()
 
 
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
+@pytest.mark.parametrize('block', range(3))
+def test_random_scenes_with_per_agent_attributes_match_oracle(S, oracle, block, mode):
+    """The same fuzz with the solver attributes drawn PER AGENT (round 5: sca_set_agent_params; the reference keeps them on every Agent object):
+    maxNeighbors 1 .. 16, neighborDist 1.5 .. 30, timeStep, timeHorizon, maxSpeed, max_heading_change 0.3 .. pi / 2, dt_nominal -- or, every third
+    scene, one non-default value of each for the whole scene (sca_params).  20 scenes per block, 5 steps each, every step from the oracle's
+    state; kd-tree and SCA_NBR_AUTO (whose grid takes the LARGEST neighborDist for its cells and falls back to the kd-tree where the smallest
+    cannot hold the collision reach)."""
+    import math
+    steps = 5
+    nbr = S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE
+    try:
+        for seed in range(1000 + 20 * block, 1000 + 20 * block + 20):
+            s = _random_scene(seed)
+            n = s['n']
+            rng = np.random.default_rng(77 + seed)
+            mhc = rng.choice([0.3, math.pi / 6, math.pi / 4, 1.2, math.pi / 2], n)
+            per = dict(neighbor_dist=rng.choice([1.5, 2.5, 4.0, 10.0, 15.0, 30.0], n), max_neighbors=rng.choice([1, 2, 4, 8, 12, 16], n).astype(np.int32),
+                       time_step=rng.choice([0.05, 0.1, 0.2], n), time_horizon=rng.choice([1.0, 3.0, 10.0, 20.0], n), max_speed=rng.choice([0.7, 1.0, 1.5, 3.0], n),
+                       max_heading_change=mhc, dt_nominal=rng.choice([0.05, 0.1], n))
+            uniform = seed % 3 == 0
+            params = {k: (int(v[0]) if k == 'max_neighbors' else float(v[0])) for k, v in per.items()} if uniform else {}
+            start6 = np.concatenate([s['pos'], s['heading']], 1)
+            goal6 = np.concatenate([s['goal'], np.zeros((n, 3))], 1)
+            zaxis = S.zaxis_flags(start6, goal6)
+            sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, s['m']), params=params)
+            sol.set_obstacles(s['obs_pos'], s['obs_radius'])
+            sol.set_agents(s['radius'], s['pref_speed'], s['goal'], s['policy'], zaxis, s['max_run_dist'])
+            oracle.set_params(**params)
+            if uniform:
+                oracle.set_agent_params()
+            else:
+                sol.set_agent_params(**per)
+                oracle.set_agent_params(n, **per)
+            sol.set_vpref(s['vpref'], s['vmode'])
+            p, ve, he, fl = s['pos'].copy(), s['vel'].copy(), s['heading'].copy(), s['flags'].copy()
+            td = np.zeros(n)
+            sn = np.zeros(n, np.int32)
+            perm = np.arange(n, dtype=np.int32)
+            for t in range(steps):
+                sol.set_state(p, ve, he, fl, td, sn)
+                sol.set_kd_perm(perm)
+                sol.run_steps(1, nbr)
+                sol.synchronize()
+                g = sol.get_state()
+                nb = sol.neighbors()
+                r = oracle.policy_step(p, ve, he, s['radius'], s['pref_speed'], fl, s['goal'], s['policy'], zaxis, s['vpref'], s['vmode'],
+                                       perm, s['obs_pos'], s['obs_radius'], nthreads=8)
+                perm = r['perm']
+                valid = r['nbr_valid'].astype(bool)
+                assert np.array_equal(nb['nbr_n'][valid], r['nbr_n'][valid]), (seed, t, 'nbr_n')
+                assert np.array_equal(nb['nbr_id'][valid], r['nbr_id'][valid]), (seed, t, 'nbr_id')
+                u = oracle.env_update(p, ve, he, s['radius'], r['flags'], s['goal'], r['action'], td, s['max_run_dist'], sn,
+                                      s['obs_pos'], s['obs_radius'])
+                p, ve, he, fl, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+                assert np.array_equal(g['flags'], fl), (seed, t)
+                assert np.array_equal(sol.get_kd_perm(), perm), (seed, t)
+                assert float(np.abs(g['vel'] - ve).max()) == 0.0, (seed, t)
+                assert np.allclose(g['pos'], p, rtol=0, atol=1e-7), (seed, t)
+            sol.close()
+    finally:
+        oracle.set_params()
+        oracle.set_agent_params()
+
+
 def test_lp_lane_per_agent_form_equals_wave_form(S, oracle, monkeypatch):
     """K3 has two forms (launch_policy picks by the shard's LP agent count): the wave-per-agent chain inside k_solve and
     k_lp, one lane per agent with the planes lane-transposed in LDS.  Same statements: planeFail, the LP4 hand-over and the
