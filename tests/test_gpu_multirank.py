@@ -36,8 +36,15 @@ def make():
     sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
                    scenarios.max_run_dist(sc['start'], sc['goal']))
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    if os.environ.get('SCA_TEST_HETERO'):                      # every agent its own solver attributes (sca_set_agent_params), the same arrays on every rank
+        rng = np.random.default_rng(9)
+        sol.set_agent_params(neighbor_dist=rng.choice([4.0, 10.0, 15.0], n), max_neighbors=rng.choice([4, 9, 16], n), time_horizon=rng.choice([3.0, 10.0], n),
+                             max_speed=rng.choice([1.0, 1.5], n), max_heading_change=rng.choice([0.6, 0.7853981633974483], n), time_step=rng.choice([0.1, 0.2], n))
     if os.environ.get('SCA_TEST_TRACK'):
         sol.device_tracker_enable(sc['goal'][:, 3:6])          # the SCA third of the agents follows Dubins paths, per shard
+        if os.environ.get('SCA_TEST_HETERO'):
+            rng = np.random.default_rng(10)
+            sol.device_tracker_set_agent_params(turning_radius=rng.choice([1.0, 1.5, 2.5], n))
     return sol
 
 mode = int(os.environ.get('SCA_TEST_MODE', '0'))             # 0 kd-tree, 1 grid
@@ -76,7 +83,9 @@ sys.exit(0 if ok else 1)
                                                 (True, 0, -60000, 2), (False, 3, 3000, 2), (False, 3, -60000, 2), (True, 3, 3000, 2),
                                                 # 1 / 2 / 4 / 8 shards bit-identical to one -- kd-tree, grid, with and without the tracker
                                                 (True, 0, 4096, 4), (True, 1, 4096, 4), (False, 3, 4096, 4),
-                                                (True, 0, 4096, 8), (True, 1, 4096, 8), (False, 0, 4096, 8), (False, 3, 4096, 8)])
+                                                (True, 0, 4096, 8), (True, 1, 4096, 8), (False, 0, 4096, 8), (False, 3, 4096, 8),
+                                                # every agent its own solver / planner attributes, the same arrays on every rank (n encodes it: + 1)
+                                                (True, 0, 3001, 2), (False, 3, 3001, 2), (True, 1, 3001, 3)])
 def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n, world):
     """track=True: with the device-side v_pref tracker inside every step (tracker records are shard-local, its re-plans run
     next to the replicated kd build).  mode 1: SCA_NBR_GRID (the grid is replicated, the queries sharded).  mode 3: SCA_NBR_AUTO on two
@@ -86,7 +95,12 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path, track, mode, n, world):
     agents of all five policies in a random cube.  world = 4 / 8: as many processes sharing GPU 0, shards of 1024 / 512 agents."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
+    hetero = abs(n) % 1000 == 1
+    if hetero:
+        n -= 1
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', SCA_TEST_MODE=str(mode), SCA_TEST_N=str(abs(n)))
+    if hetero:
+        env['SCA_TEST_HETERO'] = '1'
     if n < 0:
         env['SCA_TEST_SCENE'] = 'mixed'                         # every policy in every shard, random cube
     if track:

@@ -132,3 +132,23 @@ def test_partitioned_ranks_match_single_rank(tmp_path, world, n, kind, track, ax
                         '--master-port', port, str(script), ROOT], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
     assert 'MISMATCH' not in r.stdout and 'DIFF' not in r.stdout, r.stdout[-3000:]      # (every rank exits 0 only when it agrees)
+
+
+def test_partition_refuses_per_agent_attributes():
+    """The cell-owner partition is sized with ONE neighborDist (slab cuts, halo width): with per-agent attributes it says so (either order)."""
+    from sca_amd import scenarios, solver as S
+    n = 2000
+    sc = scenarios.random_cube(n, seed=3)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+    sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], np.full(n, 3, np.uint8), S.zaxis_flags(sc['start'], sc['goal']),
+                   scenarios.max_run_dist(sc['start'], sc['goal']))
+    sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+    sol.set_agent_params(neighbor_dist=np.where(np.arange(n) % 2 == 0, 10.0, 6.0))
+    with pytest.raises(S.ScaError, match='per-agent'):
+        sol.partition_init(0, 2, axis=0)
+    sol.set_agent_params()                                         # back to one value per context
+    sol.partition_init(0, 2, axis=0)
+    with pytest.raises(S.ScaError, match='partition'):
+        sol.set_agent_params(neighbor_dist=np.full(n, 8.0))
+    sol.close()
