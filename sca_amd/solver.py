@@ -155,7 +155,7 @@ class BatchedSolver:
             b = _lib.as_d(np.broadcast_to(a, (self.n,)))
             keep.append(b)
             return _lib.ptr(b, C.c_double)
-        self._chk(self.L.sca_device_tracker_set_agent_params(self.ctx, self.n if True else 0, arr(turning_radius), arr(pitch_lo), arr(pitch_hi)),
+        self._chk(self.L.sca_device_tracker_set_agent_params(self.ctx, self.n, arr(turning_radius), arr(pitch_lo), arr(pitch_hi)),
                   'sca_device_tracker_set_agent_params')
 
     def device_tracker_disable(self):
