@@ -140,7 +140,7 @@ constexpr int TL_RING = 64;
 #ifdef SCA_TIMELINE
 // (first form: every wavefront stamped both ends and the slot pointer lived in two VGPRs across the kernel -- 8192 same-address atomics and
 // two spilled registers made k_solve 94 us instead of 12.  Now: the START is workgroup 0's first wavefront (dispatch is in order: it is the
-// first to run), the END the maximum over the workgroups' first threads -- all of a launch of up to 2048 workgroups, else every eighth, the first and the last eight -- and
+// first to run), the END the maximum over the first threads of a SAMPLE of workgroups -- all of a launch of up to 64, else every sixteenth, the first and the last eight -- and
 // the slot is recomputed from the kernel arguments, which live in SGPRs.)
 struct TlScope {
     const DeviceView &d;
@@ -150,10 +150,10 @@ struct TlScope {
         if (d.tl && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(slot(), (unsigned long long)wall_clock64());
     }
     __device__ __forceinline__ ~TlScope() {
-        if (!d.tl) return;
-        const bool every_wave = gridDim.x <= 512u && (threadIdx.x & 63u) == 0u;                  // small launches: every wavefront (a wavefront per agent / plan ends when ITS search does)
-        const bool sampled = threadIdx.x == 0 && (gridDim.x <= 2048u || (blockIdx.x & 7u) == 7u || blockIdx.x + 8u >= gridDim.x || blockIdx.x < 8u);
-        if (every_wave || sampled) atomicMax(slot() + 1, (unsigned long long)wall_clock64());
+        // (denser sampling -- every wavefront of launches of <= 512 workgroups -- was tried for the kernels whose wavefronts end at very different
+        // times (a wavefront per search): c3 AUTO then ran 0.108 instead of 0.088 ms per step; with this sample the burst runs at the product's pace)
+        if (d.tl && threadIdx.x == 0 && (gridDim.x <= 64u || (blockIdx.x & 15u) == 15u || blockIdx.x + 8u >= gridDim.x || blockIdx.x < 8u))
+            atomicMax(slot() + 1, (unsigned long long)wall_clock64());
     }
 };
 #define SCA_TL(d, kid) TlScope tl_scope_((d), (kid))
