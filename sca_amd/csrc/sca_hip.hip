@@ -1,5 +1,6 @@
 // sca_hip.hip -- host side of libsca_hip.so: context, HBM layout, launches, C-ABI (include/sca_hip.h).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>          // types and prototypes only: the library is loaded with dlopen when sca_comm_init is called
 #include <dlfcn.h>
 
@@ -270,6 +271,10 @@ struct sca_ctx {
     bool auto_ran = false, auto_fits = false;   // the last pass was an AUTO pass / the grid's candidate lists cover the collision reach
     bool kd_ahead = false;              // the kd build of the NEXT pass is already enqueued on kd_stream (sca_run_steps, behind the integrate stage)
     unsigned auto_passes = 0;
+    bool ext_stop = true;               // the fork / join / hand-over events as stop events of the kernels they follow (LAUNCH_REC); SCA_EXT_STOP=0: records
+    hipEvent_t action_stop = nullptr;   // sca_run_steps: the event to record behind this pass's k_action (the moved positions), if any
+    hipEvent_t finish_stop = nullptr;   // sca_run_steps: the event to record behind the step's last kernel (the next pass's fork), if any
+    bool fork_ready = false;            // ... it was: the pass that follows at once does not record its fork
     int kd_wave_cap = 0;                // largest subtree handed to k_kd_block (SCA_KD_WAVE_CAP: 256 .. 1536); 0: chosen per pass
     bool trk_group_fuse = true;         // k_track_group (decision + 64-lane search in one launch) for shards of <= TRK_SPEC4_MAX agents; SCA_TRACKER_NOGROUPFUSE=1: never
     bool trk_fuse = true;               // k_track_replan allowed (SCA_TRACKER_NOFUSE switches it off: A/B measurements, tests)
@@ -292,6 +297,20 @@ struct sca_ctx {
 #define ARG(ctx, cond)                                                                         \
     do {                                                                                       \
         if (!(cond)) { (ctx)->err = std::string("bad argument: ") + #cond; return SCA_ERR_ARG; } \
+    } while (0)
+
+// a kernel and "record `ev` behind it": the event as the dispatch's own completion signal (hipExtLaunchKernelGGL's stopEvent) -- one packet in
+// the queue instead of a dispatch and a barrier packet
+#define LAUNCH_REC(ctx, ev, kern, grid, block, stream, ...)                                                            \
+    do {                                                                                                               \
+        if ((ctx)->ext_stop) hipExtLaunchKernelGGL(kern, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__);         \
+        else { hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__); CHK(ctx, hipEventRecord(ev, stream)); }  \
+    } while (0)
+// ... with an event only if there is one (`ev` may be null: a plain launch)
+#define LAUNCH_OPT(ctx, ev, kern, grid, block, stream, ...)                                                            \
+    do {                                                                                                               \
+        if ((ev) != nullptr) LAUNCH_REC(ctx, ev, kern, grid, block, stream, __VA_ARGS__);                              \
+        else hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                                            \
     } while (0)
 
 template <class T>
@@ -707,6 +726,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TAIL_LEVEL")) c->kd_tail_level = std::atoi(e);
     if (const char *e = std::getenv("SCA_KD_TOP")) c->kd_top = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SCA_EXT_STOP")) c->ext_stop = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TICKET")) c->kd_force_ticket = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_WAVE_CAP")) c->kd_wave_cap = std::min(KD_WAVE_CAP, std::max(2 * KD_WAVE_FLOOR, std::atoi(e)));
     int ndev = 0;
@@ -1169,11 +1189,10 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
         CHK(c, hipEventRecord(kb0, ks));
     }
     if (top && KT_M / (wave_max + 1) >= KT_NODES) { c->err = "k_kd_top: wave_max below its table bound"; return SCA_ERR_STATE; }   // (static_assert'ed unreachable)
-    hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, ks, d, c->kd, c->P);
     if (c->kd.aux) {                                                    // SCA_NBR_AUTO: the last kernel of the build that reads the record buffer
-        CHK(c, hipEventRecord(c->ev_auto_gather[c->auto_builds & 1u], ks));
+        LAUNCH_REC(c, c->ev_auto_gather[c->auto_builds & 1u], k_kd_gather, dim3((n + 255) / 256), dim3(256), ks, d, c->kd, c->P);
         c->auto_builds++;
-    }
+    } else hipLaunchKernelGGL(k_kd_gather, dim3((n + 255) / 256), dim3(256), 0, ks, d, c->kd, c->P);
     int levels = 0;
     if (n > wave_max && top) {
         hipLaunchKernelGGL(k_kd_top, dim3(1), dim3(KT_T), 0, ks, d, c->kd);
@@ -1439,6 +1458,7 @@ static int auto_prepare(sca_ctx *c) {
     for (hipEvent_t &e : c->ev_auto_kdq) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->auto_seq = 0; c->auto_builds = 0;
     c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
+
     CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
     c->d.kdq_list = c->kdq_list; c->d.kdq_count = c->kdq_count; c->d.kdq_busy = c->auto_busy;
     c->kdq_pending = false; c->kdq_last = -1; c->auto_backoff = 0; c->kd_ahead = false;
@@ -1475,6 +1495,8 @@ static bool auto_next(const sca_ctx *c) {
 }
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
+    const bool fork_ready = c->fork_ready;
+    c->fork_ready = false;
 #ifdef SCA_TIMELINE
     c->d.tl_step++;
 #endif
@@ -1550,7 +1572,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     c->nbr_stream = overlap ? c->trk_stream : c->stream;
     const unsigned parity_now = (unsigned)c->trk.parity;
     if (overlap) {
-        CHK(c, hipEventRecord(c->trk_fork, c->stream));
+        if (!fork_ready) CHK(c, hipEventRecord(c->trk_fork, c->stream));   // (fork_ready: it rode on the previous step's last kernel, sca_run_steps)
         CHK(c, hipStreamWaitEvent(c->trk_stream, c->trk_fork, 0));
     }
     if (auto_mode && !kd_prebuilt) {
@@ -1595,37 +1617,39 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // packed K1 (4 agents per wavefront) wins once the shard fills the chip (measured: 2.3x at 16k agents, equal at 6000);
     // below that the one-agent-per-wave form with its record stack has the shorter critical path (4096 random: 30 % faster)
     const bool packed = c->k1_force < 0 ? cnt >= per_simd(c, 6144) : c->k1_force != 0;   // four agents per wavefront once that still fills the SIMDs
+    // (overlapped: the join rides on the side stream's last kernel -- the neighbour query, or the sweep behind it)
+    const hipEvent_t k1_stop = overlap && !split && c->ext_stop ? c->trk_join : nullptr;
+    const hipEvent_t sweep_stop = overlap && split && c->ext_stop ? c->trk_join : nullptr;
     if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
-                           c->P, agent_reach, obs_reach, c->max_radius);
+        LAUNCH_REC(c, c->ev_auto_k1g, k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                   c->P, agent_reach, obs_reach, c->max_radius);
     } else if (mode == SCA_NBR_GRID) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_grid<false>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->grid,
-                           c->P, agent_reach, obs_reach, c->max_radius);
+        LAUNCH_OPT(c, k1_stop, k_neighbors_grid<false>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                   c->P, agent_reach, obs_reach, c->max_radius);
     } else if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
-        hipLaunchKernelGGL(k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), 0, ns, d, c->P,
-                           agent_reach, obs_reach, c->max_radius);
+        LAUNCH_OPT(c, k1_stop, k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->P,
+                   agent_reach, obs_reach, c->max_radius);
     } else
-        hipLaunchKernelGGL(k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64), 0,
-                           ns, d, c->P, agent_reach, obs_reach, c->max_radius);
+        LAUNCH_OPT(c, k1_stop, k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64),
+                   ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if ((timed || prof) && !auto_mode) CHK(c, hipEventRecord(e1, ns));    // [e0, e1] = K1
     if (auto_mode) {
         // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
         // build on kd_stream, and nothing reads a list before that query is through
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
-        CHK(c, hipEventRecord(c->ev_auto_k1g, ns));
-        CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));
-        hipLaunchKernelGGL(k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS), dim3(K1_WAVES * 64), 0, c->kd_stream, d, c->P,
-                           agent_reach, obs_reach, c->max_radius, c->auto_ticket);
+        CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)
+        // (ev_auto_kdq: also "the last kd query": auto_join and the event form of the wait)
+        LAUNCH_REC(c, c->ev_auto_kdq[seq & 1u], k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS),
+                   dim3(K1_WAVES * 64), c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius, c->auto_ticket);
         if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
             CHK(c, hipMemcpyAsync(c->kdq_host, d.kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
             c->kdq_pending = true;
         }
-        CHK(c, hipEventRecord(c->ev_auto_kdq[seq & 1u], c->kd_stream));   // (also "the last kd query": auto_join and the event form of the wait)
         c->ev_auto_kd = c->ev_auto_kdq[seq & 1u];
         if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_neighbors_kd_auto)
@@ -1639,7 +1663,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
                                                                         // of the listed agents behind it (the lists are final here)
     }
     if (split) {
-        hipLaunchKernelGGL(k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, ns, d, c->P);
+        LAUNCH_OPT(c, sweep_stop, k_solve_sweep, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), ns, d, c->P);
     }
     if (overlap) {
         // the re-plan count of this pass for a later pass's launch decision: on the side stream, every 4th pass, never waited for
@@ -1650,7 +1674,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             CHK(c, hipEventRecord(c->trk_count_ev, ns));
             c->trk_count_pending = true;
         }
-        CHK(c, hipEventRecord(c->trk_join, ns));
+        if (!k1_stop && !sweep_stop) CHK(c, hipEventRecord(c->trk_join, ns));
         CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));                // (the prologue: track_store / the gather)
     }
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
@@ -1682,7 +1706,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     }
     if (fuse_integrate) {
         if (!solve_fb) hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-        hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
+        if (c->action_stop) LAUNCH_REC(c, c->action_stop, k_action<true>, dim3(ablocks), dim3(256), c->stream, d, c->P);
+        else hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
     } else {
         if (!solve_fb) hipLaunchKernelGGL(k_fallback<false>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         hipLaunchKernelGGL(k_action<false>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
@@ -1715,20 +1740,22 @@ static int launch_collide_finish(sca_ctx *c, bool timed) {
     }
     c->near_valid = false;
     const dim3 k4grid((cnt + K4_WAVES * K4_APW - 1) / (K4_WAVES * K4_APW));
+    // (the event that rides on the step's last kernel, if sca_run_steps asked for one: the next pass's fork)
+    const bool others = c->part_on || cnt < d.n;
+    const hipEvent_t k4_stop = others ? nullptr : c->finish_stop, others_stop = others ? c->finish_stop : nullptr;
+    const int fresh = c->state_fresh ? 1 : 0;
     if (c->nbr_mode == SCA_NBR_GRID)
-        hipLaunchKernelGGL(k_collide_finish_grid, k4grid, dim3(K4_WAVES * 64), 0, c->stream, d, c->grid, c->P, agent_reach, obs_reach,
-                           c->state_fresh ? 1 : 0);
+        LAUNCH_OPT(c, k4_stop, k_collide_finish_grid, k4grid, dim3(K4_WAVES * 64), c->stream, d, c->grid, c->P, agent_reach, obs_reach, fresh);
     else
-        hipLaunchKernelGGL(k_collide_finish, k4grid, dim3(K4_WAVES * 64), 0, c->stream, d, c->P, agent_reach, obs_reach,
-                           c->state_fresh ? 1 : 0);
+        LAUNCH_OPT(c, k4_stop, k_collide_finish, k4grid, dim3(K4_WAVES * 64), c->stream, d, c->P, agent_reach, obs_reach, fresh);
     c->state_fresh = false;
     if (c->part_on) {
         // sized with the whole present bound: d.shard_count and d.n_present are the host's UPPER bounds (part_bounds clamps the halo
         // bound to n - owned bound, i.e. to 0 for small swarms), so their difference says nothing about the halo count -- the kernel
         // reads the exact counts and returns beyond them (halo copies that arrived at their goal kept flying for their
         // neighbours on this rank for one step)
-        hipLaunchKernelGGL(k_goal_flags_others, dim3((std::max(1, d.n_present) + 255) / 256), dim3(256), 0, c->stream, d, c->P);
-    } else if (cnt < d.n) hipLaunchKernelGGL(k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), 0, c->stream, d, c->P);
+        LAUNCH_OPT(c, others_stop, k_goal_flags_others, dim3((std::max(1, d.n_present) + 255) / 256), dim3(256), c->stream, d, c->P);
+    } else if (cnt < d.n) LAUNCH_OPT(c, others_stop, k_goal_flags_others, dim3((d.n + 255) / 256), dim3(256), c->stream, d, c->P);
     if (timed) CHK(c, hipEventRecord(c->ev[5], c->stream));
     CHK(c, hipGetLastError());
     std::swap(d.rec, d.rec_new);
@@ -1823,6 +1850,7 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
     return r;
 }
 static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
+    c->fork_ready = false; c->finish_stop = nullptr; c->action_stop = nullptr;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (c->part_on && c->part_nranks > 1 && !c->shard_emulation) {
         c->err = "cell-owner partition over several ranks: drive the step with sca_step_begin / sca_partition_pack / [exchange] / "
@@ -1835,7 +1863,13 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
     }
     if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     for (int s = 0; s < steps; s++) {
-        if (int r = launch_policy(c, neighbor_mode, false, true)) return r;     // integrate fused into k_solve
+        // (SCA_NBR_AUTO, another step to follow: the moved positions' event rides on k_action -- the next pass's kd build waits on it)
+        c->action_stop = neighbor_mode == SCA_NBR_AUTO && s + 1 < steps && c->kd_stream && c->ext_stop && !c->comm && c->d.shard_count == c->n
+                             ? c->ev_auto_moved : nullptr;                      // (a shard: the records of the others arrive after k_action)
+        const int rp = launch_policy(c, neighbor_mode, false, true);           // integrate fused into k_solve
+        const bool moved_recorded = c->action_stop != nullptr;
+        c->action_stop = nullptr;
+        if (rp) return rp;
         if (c->part_on) {                                                      // one rank (or one rank alone, emulation): nobody to exchange with
             if (c->part_nranks > 1) { if (int r = sca_partition_pack(c, c->part_scratch[0], c->part_scratch[1])) return r; }
             if (int r = sca_partition_commit(c)) return r;
@@ -1854,8 +1888,8 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
             // builds as steps.
             // (the collision check goes to its stream FIRST: the host needs ~5 us per launch, and the build's eight or more launches in
             // front of it left the main stream idle for 50 us at N = 4096)
-            CHK(c, hipEventRecord(c->ev_auto_moved, c->stream));
-            if (int r = launch_collide_finish(c, false)) return r;                 // (swaps the record buffers: the moved ones are c->d.rec now)
+            if (!moved_recorded) CHK(c, hipEventRecord(c->ev_auto_moved, c->stream));
+            if (int r = launch_collide_finish(c, false)) return r;                 // ((no tracker in an AUTO pass: no fork to carry) swaps the record buffers: the moved ones are c->d.rec now)
             c->kd_ahead_enqueue = true;
             const int rb = auto_enqueue_kd_build(c, c->ev_auto_moved, c->d.rec);
             c->kd_ahead_enqueue = false;
@@ -1863,7 +1897,12 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
             c->kd_ahead = true;
             continue;
         }
-        if (int r = launch_collide_finish(c, false)) return r;
+        // the next pass's fork (tracker in the pass, its neighbour branch on the side stream) rides on this step's last kernel
+        c->finish_stop = s + 1 < steps && c->ext_stop && c->trk_on && c->trk_in_pass && !c->trk_serial && c->trk_fork ? c->trk_fork : nullptr;
+        const int rf = launch_collide_finish(c, false);
+        c->fork_ready = rf == 0 && c->finish_stop != nullptr;
+        c->finish_stop = nullptr;
+        if (rf) return rf;
     }
     return auto_join(c);
 }
