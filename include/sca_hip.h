@@ -149,7 +149,10 @@ int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/)
 int sca_run_steps(sca_ctx *ctx, int steps, int neighbor_mode);
 /* MACAEnv.step (mampenv.py:22-25) in one call: one resident step (both loops of _take_action + is_done), then the number of agents of
  * this rank still running after it (0 == is_done) -- sca_run_steps(ctx, 1, mode) + sca_active_count with one stream synchronisation and
- * one pinned 32-KB read-back.  What `while not env.step()` of the drop-in env costs per step beyond the kernels (bench.py `env_api`). */
+ * one pinned 32-KB read-back.  What `while not env.step()` of the drop-in env costs per step beyond the kernels (bench.py `env_api`).
+ * It returns when the context's stream is through; an SCA_NBR_AUTO pass may still have its kd-tree build and the kd query of the listed
+ * agents on the library's second stream -- the next sca_env_step copes with that as the steps inside sca_run_steps do, and EVERY other
+ * entry point that takes the context first puts that stream in front of the context's (so whatever is read between steps is final). */
 int sca_env_step(sca_ctx *ctx, int neighbor_mode, int *active);
 int sca_synchronize(sca_ctx *ctx);
 /* number of this rank's agents that are not done (at goal, collided or timed out) after the last env update; 0 == the

@@ -263,6 +263,7 @@ struct sca_ctx {
     hipEvent_t ev_auto_kdq[2] = {nullptr, nullptr};      // behind the kd query of the last pass of either parity (its list is reused two passes on)
     hipEvent_t ev_auto_gather[2] = {nullptr, nullptr};   // the gather kernel of the last two builds: the integrate stage must not write into
     unsigned auto_builds = 0;                            // the record buffer a build's gather still reads (the two buffers alternate)
+    bool lazy_join = false;             // sca_env_step left kd_stream unjoined: the next entry point other than sca_env_step joins (API_ENTER)
     bool auto_unjoined = false;         // kd_stream may still be working on the last AUTO pass's tree / kd query
     int *kdq_host = nullptr;            // pinned: the list length of an earlier pass (never waited for)
     bool kdq_pending = false;
@@ -319,6 +320,17 @@ static int dalloc(sca_ctx *c, T **p, size_t count) {
     CHK(c, hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), c->stream));
     return 0;
 }
+
+// sca_env_step (the drop-in loop's one call per step) returns without putting kd_stream in front of the context's stream -- an SCA_NBR_AUTO
+// pass leaves the tree build and the kd query of the listed agents there, and the next pass copes with that by itself, as inside a burst of
+// sca_run_steps.  Every OTHER entry point joins first: it may read the tree, the permutation or the lists, or enqueue work that does.
+static int auto_join(sca_ctx *c);
+static int api_enter(sca_ctx *c);
+#define API_ENTER(ctx)                                                                          \
+    do {                                                                                       \
+        if (!(ctx)) return SCA_ERR_ARG;                                                        \
+        if (int r_ = api_enter(ctx)) return r_;                                                \
+    } while (0)
 
 extern "C" {
 
@@ -562,7 +574,7 @@ static int tracker_free(sca_ctx *c) {
 }
 int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double turning_radius, double pitch_min, double pitch_max,
                               int in_pass) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     ARG(c, goal_heading && turning_radius > 0);
     if (int r = tracker_free(c)) return r;
@@ -625,7 +637,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
 // sca_device_tracker_enable for everybody; all NULL: back to one value.  Tracked agents are grouped into classes of equal (R, lo, hi) -- at most
 // 16 -- and the re-plan kernels run once per class (TrackView); untracked agents' entries are ignored.
 int sca_device_tracker_set_agent_params(sca_ctx *c, int n, const double *turning_radius, const double *pitch_lo, const double *pitch_hi) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->trk_on) { c->err = "sca_device_tracker_enable first"; return SCA_ERR_STATE; }
     CHK(c, hipStreamSynchronize(c->stream));
     if (!turning_radius && !pitch_lo && !pitch_hi) {
@@ -667,11 +679,11 @@ int sca_device_tracker_set_agent_params(sca_ctx *c, int n, const double *turning
     return 0;
 }
 int sca_device_tracker_disable(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     return tracker_free(c);
 }
 int sca_device_tracker_vpref(sca_ctx *c, const double *nbr0_dsq, double *vpref_out) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->trk_on || !c->state_set) { c->err = "sca_device_tracker_enable and sca_set_state first"; return SCA_ERR_STATE; }
     if (nbr0_dsq) CHK(c, hipMemcpyAsync(c->trk.nbr0, nbr0_dsq, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
     if (int r = launch_tracker(c, nbr0_dsq == nullptr, false)) return r;
@@ -681,6 +693,7 @@ int sca_device_tracker_vpref(sca_ctx *c, const double *nbr0_dsq, double *vpref_o
 }
 int sca_device_tracker_debug(sca_ctx *c, int agent, double *out24) {
     if (!c || !out24) return SCA_ERR_ARG;
+    if (int r_ = api_enter(c)) return r_;
     if (!c->trk_on || agent < 0 || agent >= c->n) { c->err = "no device tracker / bad agent"; return SCA_ERR_STATE; }
     sca_dubins::AgentTrack a;
     CHK(c, hipStreamSynchronize(c->stream));
@@ -689,7 +702,7 @@ int sca_device_tracker_debug(sca_ctx *c, int agent, double *out24) {
     return 0;
 }
 int sca_device_tracker_replans(sca_ctx *c, int32_t *replans) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, replans);
     if (!c->trk_on) { c->err = "sca_device_tracker_enable first"; return SCA_ERR_STATE; }
     int32_t *tmp = (int32_t *)c->trk.list;                              // free between passes
@@ -864,7 +877,7 @@ void sca_destroy(sca_ctx *c) {
 }
 
 int sca_set_obstacles(sca_ctx *c, int m, const double *pos, const double *radius) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, m >= 0 && m <= c->max_m);
     ARG(c, m == 0 || (pos && radius));
     c->m = m; c->d.m = m;
@@ -906,7 +919,7 @@ static int agent_params_clear(sca_ctx *c) {
 // returns to one value per context.  The grid's cells are sized for the largest neighborDist, the collision reach for the largest step.
 int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const int32_t *max_neighbors, const double *time_step,
                          const double *time_horizon, const double *max_speed, const double *max_heading_change, const double *dt_nominal) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     if (c->part_on) { c->err = "per-agent solver attributes with the cell-owner partition: not supported"; return SCA_ERR_UNSUPPORTED; }
     const bool any = neighbor_dist || max_neighbors || time_step || time_horizon || max_speed || max_heading_change || dt_nominal;
@@ -958,7 +971,7 @@ int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const i
 
 int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_speed, const double *goal,
                    const uint8_t *policy, const uint8_t *zaxis, const double *max_run_dist) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, n > 0 && n <= c->max_n);
     ARG(c, radius && pref_speed && goal && policy && max_run_dist);
     if (c->d.hist) {                                                  // the log's pitch is n: a new agent set starts a new log
@@ -1006,7 +1019,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
 
 int sca_set_state(sca_ctx *c, const double *pos, const float *vel, const double *heading, const uint8_t *flags,
                   const double *total_dist, const int32_t *step_num) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     ARG(c, pos && vel && heading && flags);
     const int n = c->n;
@@ -1040,7 +1053,7 @@ static int fetch_records(sca_ctx *c) {
 
 int sca_get_state(sca_ctx *c, double *pos, float *vel, double *heading, uint8_t *flags, double *total_dist,
                   int32_t *step_num) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->state_set) { c->err = "no state"; return SCA_ERR_STATE; }
     const int n = c->n;
     if (int r = fetch_records(c)) return r;
@@ -1058,14 +1071,14 @@ int sca_get_state(sca_ctx *c, double *pos, float *vel, double *heading, uint8_t 
 }
 
 int sca_set_kd_perm(sca_ctx *c, const int32_t *perm) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, perm && c->agents_set);
     c->h_perm.assign(perm, perm + c->n);
     c->perm_on_device = false;
     return 0;
 }
 int sca_get_kd_perm(sca_ctx *c, int32_t *perm) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, perm && c->agents_set);
     if (c->perm_on_device) {
         CHK(c, hipMemcpyAsync(c->h_perm.data(), c->d.aperm, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
@@ -1076,7 +1089,7 @@ int sca_get_kd_perm(sca_ctx *c, int32_t *perm) {
 }
 
 int sca_get_kd_tree(sca_ctx *c, double *tree_out) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, tree_out && c->agents_set);
     const int n = c->n;
     std::vector<KdNode> t((size_t)2 * n, KdNode{});
@@ -1115,7 +1128,7 @@ int sca_get_kd_tree(sca_ctx *c, double *tree_out) {
 }
 
 int sca_set_vpref(sca_ctx *c, const double *vpref, const uint8_t *mode) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, vpref && mode && c->agents_set);
     CHK(c, hipMemcpyAsync(c->d.vpref_ext, vpref, sizeof(double) * 3 * c->n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.vpref_mode, mode, c->n, hipMemcpyHostToDevice, c->stream));
@@ -1482,7 +1495,13 @@ static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *pos
 
 // everything kd_stream was given has to be through before a caller reads the tree, the permutation or the lists, and before a pass that
 // is not an AUTO pass builds in place: the context's stream waits for the last kd query
+static int api_enter(sca_ctx *c) {
+    if (!c->lazy_join) return 0;
+    c->lazy_join = false;
+    return auto_join(c);
+}
 static int auto_join(sca_ctx *c) {
+    c->lazy_join = false;
     if (!c->auto_unjoined) return 0;
     CHK(c, hipStreamWaitEvent(c->stream, c->ev_auto_kd, 0));
     c->auto_unjoined = false;
@@ -1768,7 +1787,7 @@ static int launch_update(sca_ctx *c, bool timed) {
 }
 
 int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (int r = launch_policy(c, neighbor_mode, true, false)) return r;
     if (int r = auto_join(c)) return r;
@@ -1781,7 +1800,7 @@ int sca_policy_pass(sca_ctx *c, int neighbor_mode) {
 
 static int read_active(sca_ctx *c, int *active, bool kd_word);
 int sca_env_update(sca_ctx *c, int *all_done) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     CHK(c, hipEventRecord(c->ev[4], c->stream));
     if (int r = launch_update(c, true)) return r;
@@ -1810,7 +1829,7 @@ static int read_active(sca_ctx *c, int *active, bool kd_word) {
     return 0;
 }
 int sca_active_count(sca_ctx *c, int *active) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, active);
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     return read_active(c, active, c->perm_on_device);
@@ -1834,22 +1853,26 @@ static int exchange_moved_records(sca_ctx *c) {
     return 0;
 }
 
-static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode);
+static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode, bool lazy);
 // A failure in the middle of the loop (an exchange, a launch, a partition commit) must not leave the AUTO bookkeeping pointing at a tree
 // built ahead from positions the caller is about to replace: forget the build-ahead, let the context's stream wait for whatever
 // kd_stream still holds, and have the next AUTO pass decide afresh.
 static void auto_abandon(sca_ctx *c) {
+    c->lazy_join = false;
     c->kd_ahead = false; c->kdq_last = -1; c->kdq_pending = false; c->auto_backoff = 0;
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipGetLastError(); }
     c->auto_unjoined = false;
 }
-int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
-    if (!c) return SCA_ERR_ARG;
-    const int r = run_steps_loop(c, steps, neighbor_mode);
+static int run_steps_guarded(sca_ctx *c, int steps, int neighbor_mode, bool lazy) {
+    const int r = run_steps_loop(c, steps, neighbor_mode, lazy);
     if (r != 0) { const std::string keep = c->err; auto_abandon(c); c->err = keep; }
     return r;
 }
-static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
+int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
+    API_ENTER(c);
+    return run_steps_guarded(c, steps, neighbor_mode, false);
+}
+static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode, bool lazy) {
     c->fork_ready = false; c->finish_stop = nullptr; c->action_stop = nullptr;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (c->part_on && c->part_nranks > 1 && !c->shard_emulation) {
@@ -1904,34 +1927,36 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode) {
         c->finish_stop = nullptr;
         if (rf) return rf;
     }
+    if (lazy && c->auto_unjoined && c->auto_ran) { c->lazy_join = true; return 0; }   // (sca_env_step: see API_ENTER)
     return auto_join(c);
 }
 int sca_env_step(sca_ctx *c, int neighbor_mode, int *active) {
-    if (!c) return SCA_ERR_ARG;
+    if (!c) return SCA_ERR_ARG;                                           // (not API_ENTER: a step after a step needs no join)
     ARG(c, active);
-    if (int r = sca_run_steps(c, 1, neighbor_mode)) return r;
+    if (int r = run_steps_guarded(c, 1, neighbor_mode, true)) return r;
+    // (the kd build's error word is read from the context's stream: a build still running on kd_stream is seen one step later)
     return read_active(c, active, c->perm_on_device);
 }
 int sca_set_shard_emulation(sca_ctx *c, int on) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (c->comm && on) { c->err = "sca_set_shard_emulation with an active communicator: the exchange is real"; return SCA_ERR_STATE; }
     c->shard_emulation = on != 0;
     return 0;
 }
 int sca_last_pass_forms(sca_ctx *c, int *forms) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, forms);
     *forms = c->forms;
     return 0;
 }
 int sca_last_kd_build_ms(sca_ctx *c, float *kd_build_ms) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, kd_build_ms);
     *kd_build_ms = c->ms_kd_build;
     return 0;
 }
 int sca_auto_stats(sca_ctx *c, int64_t *out4, int reset) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, out4);
     for (int k = 0; k < 4; k++) out4[k] = 0;
     if (!c->d.kdq_stats) return 0;                                       // no SCA_NBR_AUTO pass has run
@@ -1943,13 +1968,13 @@ int sca_auto_stats(sca_ctx *c, int64_t *out4, int reset) {
     return 0;
 }
 int sca_last_exchange_ms(sca_ctx *c, float *exchange_ms) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, exchange_ms);
     *exchange_ms = c->ms_exchange;
     return 0;
 }
 int sca_last_replan_ms(sca_ctx *c, float *replan_ms) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (replan_ms) *replan_ms = c->ms_replan;
     return 0;
 }
@@ -1967,7 +1992,7 @@ int sca_comm_unique_id(void *id_out) {
     return 0;
 }
 int sca_comm_init(sca_ctx *c, int rank, int nranks, const void *unique_id) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, unique_id && nranks >= 1 && rank >= 0 && rank < nranks);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     if (c->comm) { c->err = "communicator already initialised (sca_comm_destroy first)"; return SCA_ERR_STATE; }
@@ -1984,7 +2009,7 @@ int sca_comm_init(sca_ctx *c, int rank, int nranks, const void *unique_id) {
     return 0;
 }
 int sca_comm_destroy(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (c->comm) {
         CHK(c, hipStreamSynchronize(c->stream));
         (void)g_rccl.CommDestroy(c->comm);
@@ -2073,7 +2098,7 @@ static int part_classify(sca_ctx *c) {                                      // f
 }
 int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double *cuts, int cap_halo, int cap_mig) {
     if (c && c->ap_dev) { c->err = "the cell-owner partition with per-agent solver attributes: not supported"; return SCA_ERR_UNSUPPORTED; }
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, nranks >= 1 && rank >= 0 && rank < nranks && axis >= 0 && axis <= 2 && cap_halo >= 0 && cap_mig >= 0);
     if (!c->agents_set || !c->state_set) { c->err = "sca_set_agents and sca_set_state (the complete state, on every rank) first"; return SCA_ERR_STATE; }
     if (c->comm) { c->err = "sca_partition_init with an active communicator (the all-gather mode)"; return SCA_ERR_STATE; }
@@ -2123,7 +2148,7 @@ int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double 
     return part_classify(c);
 }
 int sca_partition_disable(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     return part_free(c);
 }
 int64_t sca_partition_message_bytes(sca_ctx *c) {
@@ -2131,7 +2156,7 @@ int64_t sca_partition_message_bytes(sca_ctx *c) {
     return (int64_t)part_message_bytes(c->part.cap_halo, c->part.cap_mig);
 }
 int sca_partition_counts(sca_ctx *c, int *owned, int *halo) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
     int h[5];
     CHK(c, hipMemcpyAsync(h, c->part.counts, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -2141,7 +2166,7 @@ int sca_partition_counts(sca_ctx *c, int *owned, int *halo) {
     return part_report(c, h[4]);
 }
 int sca_partition_owned(sca_ctx *c, int32_t *ids, int *count) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, ids && count);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
     CHK(c, hipMemcpyAsync(count, c->part.counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2151,7 +2176,7 @@ int sca_partition_owned(sca_ctx *c, int32_t *ids, int *count) {
     return 0;
 }
 int sca_partition_pack(sca_ctx *c, void *device_buf_lower, void *device_buf_upper) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
     ARG(c, (device_buf_lower || !c->part.has_peer[0]) && (device_buf_upper || !c->part.has_peer[1]));
     c->part.trk_st = c->trk_on ? c->trk.st : nullptr;
@@ -2163,7 +2188,7 @@ int sca_partition_pack(sca_ctx *c, void *device_buf_lower, void *device_buf_uppe
     return 0;
 }
 int sca_partition_unpack(sca_ctx *c, const void *device_buf_lower, const void *device_buf_upper) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
     ARG(c, (device_buf_lower || !c->part.has_peer[0]) && (device_buf_upper || !c->part.has_peer[1]));
     if (!c->part.has_peer[0] && !c->part.has_peer[1]) return 0;
@@ -2174,7 +2199,7 @@ int sca_partition_unpack(sca_ctx *c, const void *device_buf_lower, const void *d
     return 0;
 }
 int sca_partition_commit(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->part_on) { c->err = "sca_partition_init first"; return SCA_ERR_STATE; }
     const int cnt = std::max(1, c->d.shard_count);
     hipLaunchKernelGGL(k_part_keep, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->part);
@@ -2184,19 +2209,19 @@ int sca_partition_commit(sca_ctx *c) {
 }
 
 int sca_step_begin(sca_ctx *c, int neighbor_mode) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
     if (c->part_on && neighbor_mode != SCA_NBR_GRID) { c->err = "the cell-owner partition is a mode of SCA_NBR_GRID"; return SCA_ERR_UNSUPPORTED; }
     if (int r = launch_policy(c, neighbor_mode, false, true)) return r;
     return auto_join(c);                                                  // (the caller may read anything between the two halves of a step)
 }
 int sca_step_end(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     return launch_collide_finish(c, false);
 }
 
 int sca_synchronize(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     CHK(c, hipStreamSynchronize(c->stream));
     if (c->part_on) { int h[5]; CHK(c, hipMemcpy(h, c->part.counts, sizeof(h), hipMemcpyDeviceToHost)); if (int r = part_report(c, h[4])) return r; }
     if (c->perm_on_device) { if (int r = check_kd_overflow(c)) return r; }
@@ -2252,7 +2277,7 @@ int sca_synchronize(sca_ctx *c) {
 }
 
 int sca_set_profiling(sca_ctx *c, int on) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     c->profiling = on != 0;
     c->pool_used = 0;
     c->pool_trk_used = 0;
@@ -2263,7 +2288,7 @@ int sca_set_profiling(sca_ctx *c, int on) {
 }
 
 int sca_agent_steps(sca_ctx *c, int64_t *count, int reset) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     std::vector<unsigned long long> parts(256 * 16);
     CHK(c, hipMemcpyAsync(parts.data(), c->d.agent_steps, sizeof(unsigned long long) * parts.size(), hipMemcpyDeviceToHost, c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
@@ -2288,7 +2313,7 @@ int sca_debug_read_ps(sca_ctx *c, int *out, int count) {      // debug builds on
 #ifdef SCA_TIMELINE
 // debug builds only (SCA_BUILD_DEFS=-DSCA_TIMELINE): the device-side timeline of the next TL_RING steps (tools/device_timeline.py)
 int sca_debug_timeline_enable(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     const size_t cells = (size_t)TL_KERNELS * TL_RING;
     if (!c->d.tl) CHK(c, hipMalloc((void **)&c->d.tl, sizeof(unsigned long long) * 2 * cells));
     std::vector<unsigned long long> init(2 * cells);
@@ -2317,7 +2342,7 @@ int sca_debug_read_kdq(sca_ctx *c, int *out, int count) {     // debug builds on
 #endif
 
 int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, double *fast, double *exact) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, n > 0 && a && b && fast && exact);
     double *da = nullptr, *db = nullptr, *df = nullptr, *de = nullptr;
     CHK(c, hipMalloc((void **)&da, sizeof(double) * 3 * n)); CHK(c, hipMalloc((void **)&db, sizeof(double) * 3 * n));
@@ -2357,7 +2382,7 @@ int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, doub
     return 0;
 }
 int sca_selftest_libm(sca_ctx *c, int fn, int n, const double *a, const double *b, double *out) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, fn >= 0 && fn <= 10 && n > 0 && a && out && ((fn != 3 && fn != 7) || b));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     for (double **p : {&da, &db, &dout}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
@@ -2374,6 +2399,7 @@ int sca_selftest_libm(sca_ctx *c, int fn, int n, const double *a, const double *
 // ---- trajectory log (Agent.history_info, agent.py:75-77,126-148) kept in HBM --------------------------------------
 int sca_history_enable(sca_ctx *c, int capacity_rows) {
     if (!c || capacity_rows < 0) return SCA_ERR_ARG;
+    if (int r_ = api_enter(c)) return r_;
     if (c->n <= 0) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     CHK(c, hipStreamSynchronize(c->stream));
     if (c->d.hist) { CHK(c, hipFree(c->d.hist)); c->d.hist = nullptr; }
@@ -2384,14 +2410,14 @@ int sca_history_enable(sca_ctx *c, int capacity_rows) {
     return 0;
 }
 int sca_history_rows(sca_ctx *c, int *rows_logged, int *rows_dropped) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     const int r = c->d.hist ? c->d.hist_row : 0;
     if (rows_logged) *rows_logged = std::min(r, c->d.hist_cap);
     if (rows_dropped) *rows_dropped = std::max(0, r - c->d.hist_cap);
     return 0;
 }
 int sca_get_history(sca_ctx *c, int first_row, int nrows, int agent_begin, int agent_count, double *pos, double *heading, float *vel) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (!c->d.hist) { c->err = "sca_history_enable first"; return SCA_ERR_STATE; }
     const int have = std::min(c->d.hist_row, c->d.hist_cap);
     if (first_row < 0 || nrows < 0 || first_row + nrows > have || agent_begin < 0 || agent_count < 0 || agent_begin + agent_count > c->n) {
@@ -2413,7 +2439,7 @@ int sca_get_history(sca_ctx *c, int first_row, int nrows, int agent_begin, int a
 }
 
 int sca_get_actions(sca_ctx *c, float *action) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, action);
     std::vector<float> tmp((size_t)c->n * 8);
     CHK(c, hipMemcpyAsync(tmp.data(), c->d.action, sizeof(float) * 8 * c->n, hipMemcpyDeviceToHost, c->stream));
@@ -2423,7 +2449,7 @@ int sca_get_actions(sca_ctx *c, float *action) {
 }
 
 int sca_get_neighbors(sca_ctx *c, int32_t *nbr_n, int32_t *nbr_id, uint8_t *nbr_kind, double *nbr_dsq, uint8_t *nbr_valid) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     const int n = c->n;
     std::vector<int32_t> ids((size_t)n * K_MAX);
     CHK(c, hipMemcpyAsync(ids.data(), c->d.nbr_id, sizeof(int32_t) * K_MAX * n, hipMemcpyDeviceToHost, c->stream));
@@ -2441,7 +2467,7 @@ int sca_get_neighbors(sca_ctx *c, int32_t *nbr_n, int32_t *nbr_id, uint8_t *nbr_
 }
 
 int sca_get_nbr0(sca_ctx *c, double *dsq0) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, dsq0 && c->agents_set);
     double *tmp = c->kd.kx;      // build scratch, free between passes
     hipLaunchKernelGGL(k_nbr0, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d, tmp);
@@ -2451,7 +2477,7 @@ int sca_get_nbr0(sca_ctx *c, double *dsq0) {
 }
 
 int sca_get_diag(sca_ctx *c, int32_t *diag, int32_t *status, double *vpref_used) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     const int n = c->n;
     std::vector<int32_t> tmp((size_t)n * 8);
     CHK(c, hipMemcpyAsync(tmp.data(), c->d.diag, sizeof(int32_t) * 8 * n, hipMemcpyDeviceToHost, c->stream));
@@ -2463,7 +2489,7 @@ int sca_get_diag(sca_ctx *c, int32_t *diag, int32_t *status, double *vpref_used)
 }
 
 int sca_set_shard(sca_ctx *c, int begin, int count) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, begin >= 0 && count >= 0 && begin + count <= c->n);
     // with a communicator the shard IS rank * n / nranks: the in-place ncclAllGather of sca_run_steps relies on it
     if (c->part_on) { c->err = "sca_set_shard with the cell-owner partition active (sca_partition_disable first)"; return SCA_ERR_STATE; }
@@ -2473,13 +2499,13 @@ int sca_set_shard(sca_ctx *c, int begin, int count) {
     return 0;
 }
 int sca_public_records(sca_ctx *c, int which, void **device_ptr, int64_t *bytes_per_agent) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (device_ptr) *device_ptr = which ? (void *)c->d.rec_new : (void *)c->d.rec;
     if (bytes_per_agent) *bytes_per_agent = (int64_t)sizeof(PubRec);
     return 0;
 }
 int sca_bind_public_records(sca_ctx *c, void *current, void *moved, int64_t bytes_each) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     ARG(c, (current == nullptr) == (moved == nullptr));
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
     const size_t live = sizeof(PubRec) * (size_t)c->n;                    // only the n live records move, never max_agents
@@ -2497,19 +2523,19 @@ int sca_bind_public_records(sca_ctx *c, void *current, void *moved, int64_t byte
     return 0;
 }
 int sca_set_stream(sca_ctx *c, void *hip_stream) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     CHK(c, hipStreamSynchronize(c->stream));                             // work already enqueued finishes where it was
     c->stream = (hipStream_t)hip_stream;                                 // NULL is HIP's null stream (torch's default stream), taken literally
     return 0;
 }
 int sca_use_own_stream(sca_ctx *c) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     CHK(c, hipStreamSynchronize(c->stream));
     c->stream = c->stream_own;
     return 0;
 }
 int sca_last_kernel_ms(sca_ctx *c, float *neighbors_ms, float *solve_ms, float *update_ms) {
-    if (!c) return SCA_ERR_ARG;
+    API_ENTER(c);
     if (neighbors_ms) *neighbors_ms = c->ms_nbr;
     if (solve_ms) *solve_ms = c->ms_solve;
     if (update_ms) *update_ms = c->ms_update;

@@ -89,3 +89,36 @@ def test_auto_mode_hands_ties_and_overflows_to_the_kd_query():
         assert not np.array_equal(na['nbr_id'], ng['nbr_id']), kind      # (the scene does what it is for: the grid alone differs)
         for s in (a, b, g):
             s.close()
+
+
+@pytest.mark.parametrize('kind,n,look_every', [('cube', 4096, 1), ('cube', 4096, 5), ('lattice', 1000, 3), ('dense', 600, 1), ('dense', 600, 4)])
+def test_env_step_leaves_the_kd_stream_unjoined_and_every_reader_joins(kind, n, look_every):
+    """sca_env_step (the drop-in loop's one call per step) returns when the context's stream is through: an SCA_NBR_AUTO pass may still
+    have its tree build and kd query on kd_stream.  The next sca_env_step copes by itself; any other entry point joins first -- so
+    whatever is read between steps (every step, or only now and then with unjoined steps in between) equals the kd-tree mode's."""
+    from sca_amd import solver as S
+    sc, pol, n = _scene(kind, n, seed=11)
+    a, b = _solver(sc, pol, n, False), _solver(sc, pol, n, False)
+    for t in range(24):
+        ra, rb = a.env_step(S.NBR_KDTREE), b.env_step(S.NBR_AUTO)
+        assert ra == rb, (kind, t, ra, rb)                                 # the count of agents still under way
+        if (t + 1) % look_every:
+            continue
+        # a different reader first each time: each of them must join by itself
+        readers = [lambda s: s.get_kd_perm(), lambda s: s.neighbors()['nbr_id'], lambda s: s.get_state()['pos'], lambda s: s.actions()]
+        first = readers[(t // look_every) % len(readers)]
+        assert np.array_equal(first(a), first(b)), (kind, t)
+        na, nb = a.neighbors(), b.neighbors()
+        for k in ('nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq'):
+            assert np.array_equal(na[k], nb[k]), (kind, t, k)
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (kind, t, k)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (kind, t)
+    # a burst of resident steps behind unjoined single steps, and single steps behind a burst
+    b.env_step(S.NBR_AUTO); a.env_step(S.NBR_KDTREE)
+    a.run_steps(5, S.NBR_KDTREE); b.run_steps(5, S.NBR_AUTO)
+    a.env_step(S.NBR_KDTREE); b.env_step(S.NBR_AUTO)
+    assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()) and np.array_equal(a.get_state()['pos'], b.get_state()['pos'])
+    assert np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id'])
+    a.close(); b.close()
