@@ -161,7 +161,12 @@ __global__ __launch_bounds__(256) void k_track(DeviceView d, sca_dubins::TrackVi
     KT_MARK();
 }
 
-__global__ __launch_bounds__(TRK_REPLAN_LANES, 2) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
+// two wavefronts per SIMD, 256 registers each.  Measured (round 5, -DSCA_REPLAN_WAVES=3 / 4): 168 registers + 119 spilled / 128 + 291 spilled,
+// c4 0.672 -> 0.88 / 1.36 ms per step: a candidate's working set is the registers, and scratch traffic costs more than a third wavefront hides.
+#ifndef SCA_REPLAN_WAVES
+#define SCA_REPLAN_WAVES 2
+#endif
+__global__ __launch_bounds__(TRK_REPLAN_LANES, SCA_REPLAN_WAVES) void k_replan(DeviceView d, sca_dubins::TrackView T, TrackDev K) {
     SCA_TL(d, TL_REPLAN);
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
