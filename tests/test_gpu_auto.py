@@ -122,3 +122,27 @@ def test_env_step_leaves_the_kd_stream_unjoined_and_every_reader_joins(kind, n, 
     assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()) and np.array_equal(a.get_state()['pos'], b.get_state()['pos'])
     assert np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id'])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('kind,n,tracked,mode', [('circle', 1024, True, 'kd'), ('takeoff', 1024, True, 'kd'), ('cube', 4096, False, 'auto'),
+                                                  ('dense', 600, False, 'auto'), ('circle', 20000, True, 'kd')])
+def test_events_as_stop_events_change_no_bit(kind, n, tracked, mode, monkeypatch):
+    """The hand-over, fork and join events ride on the kernels they follow (hipExtLaunchKernelGGL stop events, the default) or are recorded
+    behind them (SCA_EXT_STOP=0, read at sca_create): the same dependencies either way, so the same bits -- bursts of several steps (the
+    fork rides on the previous step's last kernel, the moved positions' event on k_action) and single steps."""
+    from sca_amd import solver as S
+    sc, pol, n = _scene(kind, n, seed=5)
+    m = S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE
+    monkeypatch.setenv('SCA_EXT_STOP', '0')
+    a = _solver(sc, pol, n, tracked)
+    monkeypatch.delenv('SCA_EXT_STOP')
+    b = _solver(sc, pol, n, tracked)
+    for burst in (1, 6, 1, 5, 3):
+        a.run_steps(burst, m); b.run_steps(burst, m)
+        a.synchronize(); b.synchronize()
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (kind, burst, k)
+        assert np.array_equal(a.actions(), b.actions()) and np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (kind, burst)
+        assert np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id']), (kind, burst)
+    a.close(); b.close()
