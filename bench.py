@@ -23,7 +23,11 @@ sca_run_steps.  `--scaling weak` keeps the workload's N per GPU instead.
 At --gpus 1 the JSON line also carries: `solver_only`, `grid_mode` (the same legs with SCA_NBR_GRID), `scale_model` (what
 ONE rank of 2 / 4 / 8 executes per step -- the replicated neighbour structure over all N agents, everything else for N/G --
 timed on this GPU, and the speed-up it predicts), `extra_legs` (c2, c3, c3lp, c5: value, ms_per_step, max |dv| against the
-oracle) and `cpu_baseline`.  Prints ONE JSON line on rank 0.
+oracle) and `cpu_baseline`.
+
+Output (rank 0): the LAST stdout line is ONE compact JSON record, < 4 KB (compact_record: the contract's keys, `config`, `roofline`,
+`cpu_baseline`, one number per extra leg) -- the line the driver parses.  The full record (everything above) goes to bench_detail.json
+beside this script (SCA_BENCH_DETAIL=<path> to move it) and to stderr as one line prefixed `DETAIL `.
 """
 import argparse
 import json
@@ -218,6 +222,7 @@ def roofline_of(leg, steps, tracked, wname):
                            'k_track_replan (follow-or-re-plan decision + the re-plan, one lane per agent)' if fused else
                            'k_replan (or k_replan_group<lanes per plan>)') + ', beside the kd build, the neighbour query'
                           + (' and k_solve_sweep' if leg['forms'] & 1 else '') + ' of the same pass',
+                'kernel_short': 'k_track_group' if group else 'k_track_replan' if fused else 'k_replan',
                 'kernel_ms': leg['replan_ms'], 'bytes_per_unit': BYTES_PER_REPLAN, 'unit_name': 're-plan', 'units_per_launch': plans_per_launch,
                 'valu_issue_frac': (_pmc(wname).get('k_track_replan_valu_wave_insts_per_plan' if fused else
                                                     'k_replan_valu_wave_insts_per_plan', 0) * plans_per_launch / (leg['replan_ms'] * 1e-3)
@@ -257,6 +262,110 @@ def leg_roofline(leg, steps, tracked, wname, mode_name='kd'):
             'traffic': kd_build_traffic(wname) if name.startswith('kd build') else measured_traffic(wname, name.split(' ')[0]),
             'valu_issue_frac': valu_issue_frac(wname, per_launch, ms * 1e-3) if name.startswith('k_solve') else None,
             'candidates_ms': {c[0].split(' ')[0] if not c[0].startswith('kd build') else 'kd_build': round(c[1], 5) for c in cands}}
+
+
+COMPACT_LIMIT = 4096             # bytes: the last stdout line (the record the driver parses) stays under this, whatever the run added
+DETAIL_FILE = os.environ.get('SCA_BENCH_DETAIL') or os.path.join(ROOT, 'bench_detail.json')
+
+
+def _r(x, sig=6):
+    """a float to `sig` significant digits (the compact line carries numbers, not 17-digit reprs)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float('inf'), float('-inf')):
+        return None
+    return float(f'{x:.{sig}g}')
+
+
+def _short(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + '...'
+
+
+def compact_record(out):
+    """The ONE line the driver parses (run_sca.py:250 prints one number; this is that number with its provenance): the contract's
+    keys, `config`, `roofline` and `cpu_baseline` as flat objects of scalars and short strings, one number per extra leg.  Everything
+    else of `out` (scale_model, extra_legs, env_api, value_parity, notes ...) is detail: bench_detail.json + a stderr line."""
+    cfg = out.get('config', {})
+    c = {'metric': out['metric'], 'value': _r(out['value'], 8), 'unit': out['unit'], 'n_gpus': out['n_gpus'], 'steps': out['steps'],
+         'warmup': out['warmup'], 'ms_per_step': _r(out['ms_per_step'], 7), 'higher_is_better': out['higher_is_better'],
+         'scaling': out['scaling'], 'vs_baseline': out.get('vs_baseline'), 'dtype': out['dtype'], 'data': out['data'],
+         'config': {'workload': _short(cfg.get('workload'), 160), 'agents': cfg.get('agents'), 'agents_per_gpu': cfg.get('agents_per_gpu'),
+                    'neighbor_search': _short(cfg.get('neighbor_search_short') or cfg.get('neighbor_search'), 60),
+                    'v_pref': _short(cfg.get('v_pref_short') or cfg.get('v_pref'), 60),
+                    'parallelism': _short(cfg.get('parallelism'), 160), 'agent_steps_timed': cfg.get('agent_steps_timed'),
+                    're_plans_timed': cfg.get('re_plans_timed')}}
+    rf = out.get('roofline') or {}
+    c['roofline'] = {k: (_short(rf.get(k), 100) if isinstance(rf.get(k), str) else _r(rf.get(k)))
+                     for k in ('bound', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'bytes_per_unit', 'unit_name',
+                               'units_per_launch', 'traffic', 'valu_issue_frac', 'chip_idle_frac')
+                     if k in rf}
+    c['roofline']['kernel'] = _short(rf.get('kernel_short') or rf.get('kernel'), 100)
+    vb = rf.get('valu_busy_step')
+    if isinstance(vb, dict) and vb.get('frac') is not None:
+        c['roofline']['valu_busy_step_frac'] = _r(vb['frac'], 4)
+    cb = out.get('cpu_baseline')
+    if cb:
+        one = cb.get('one_thread') or {}
+        ref = cb.get('reference_python') or {}
+        c['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'),
+                             'sample': _short(cb.get('sample'), 150),
+                             'one_thread_value': _r(one.get('value')), 'reference_python_value': ref.get('value'),
+                             'reference_python_cores': ref.get('cores'),
+                             'one_thread': {'value': _r(one.get('value'))},
+                             'reference_python': {'value': ref.get('value'), 'cores': ref.get('cores')},
+                             'max_abs_dv': cb.get('max_abs_dv_vs_hip_solver_given_vpref')}
+    c['rccl_ranks_seen'] = out.get('rccl_ranks_seen')
+    pg = out.get('process_group') or {}
+    if pg.get('exchange') not in (None, 'none'):
+        c['exchange'] = pg.get('exchange')
+        c['exchange_ms_measured'] = _r(pg.get('exchange_ms_measured'))
+    dvs = []
+    if cb and cb.get('max_abs_dv_vs_hip_solver_given_vpref') is not None:
+        dvs.append(cb['max_abs_dv_vs_hip_solver_given_vpref'])
+    vp = out.get('value_parity') or {}
+    if vp.get('max_abs_dv') is not None:
+        dvs.append(vp['max_abs_dv'])
+    legs = out.get('extra_legs') or {}
+    for name, leg in legs.items():
+        if isinstance(leg, dict) and leg.get('max_abs_dv_solver_given_vpref') is not None:
+            dvs.append(leg['max_abs_dv_solver_given_vpref'])
+    c['max_abs_dv'] = max(dvs) if dvs else None
+    so = out.get('solver_only') or {}
+    if so.get('ms_per_step') is not None:
+        c['solver_only_ms'] = _r(so['ms_per_step'], 5)
+    for name, key in (('c2', 'c2_ms'), ('c3', 'c3_auto_ms'), ('c3lp', 'c3lp_auto_ms'), ('c5', 'c5_ms'), ('heldout', 'heldout_ms')):
+        leg = legs.get(name)
+        if isinstance(leg, dict) and leg.get('ms_per_step') is not None:
+            c[key] = _r(leg['ms_per_step'], 5)
+    if isinstance(legs.get('c3'), dict):
+        r3 = legs['c3'].get('roofline') or {}
+        if r3.get('chip_idle_frac') is not None:
+            c['c3_auto_chip_idle_frac'] = _r(r3['chip_idle_frac'], 3)
+    if out.get('emulated'):
+        c['emulated_rank_of'] = out['emulated'].get('rank_of')
+    c['detail'] = 'bench_detail.json beside bench.py; the stderr line prefixed DETAIL'
+    def cap(o, n):
+        if isinstance(o, dict):
+            return {k: cap(v, n) for k, v in o.items()}
+        return _short(o, n)
+    for n in (160, 60, 24):                              # every string leaf is capped; tighter only if some run managed to fill 4 KB anyway
+        line = json.dumps(cap(c, n), separators=(',', ':'))
+        if len(line) < COMPACT_LIMIT:
+            break
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out):
+    """rank 0: the full record to bench_detail.json and to stderr (`DETAIL {...}`), then the compact record as the LAST stdout line"""
+    full = json.dumps(out)
+    try:
+        with open(DETAIL_FILE, 'w') as f:
+            f.write(full + '\n')
+    except OSError as e:                                  # a read-only checkout: the stderr copy still goes out
+        print(f'[bench] cannot write {DETAIL_FILE}: {e}', file=sys.stderr)
+    print('DETAIL ' + full, file=sys.stderr, flush=True)
+    print(compact_record(out), flush=True)
 
 
 def self_launch(n):
@@ -513,7 +622,8 @@ def main():
             'config': {'workload': w['desc'] + (f' [--agents {args.agents}]' if args.agents else '')
                        + (f' -- weak scaling: {w["n"] if not args.agents else args.agents} agents per GPU'
                           if world > 1 and args.scaling == 'weak' else ''),
-                       'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': NBR_DESC[args.nbr],
+                       'agents': n, 'agents_per_gpu': n // world, 'neighbor_search': NBR_DESC[args.nbr], 'neighbor_search_short': args.nbr,
+                       'v_pref_short': vpref,
                        'v_pref': {'straight': 'straight-line rule on the device' + (' (SCA\'s Dubins tracker left out: --vpref)' if has_tracker else ''),
                                   'dubins': 'native Dubins tracker on the host every step (end-to-end SCA, bit-exact, host-bound)',
                                   'dubins-device': 'SCA as shipped: Dubins tracker + 3-D Dubins planner on the device inside every step '
@@ -546,7 +656,7 @@ def main():
         out.update(extras)
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        print(json.dumps(out), flush=True)
+        emit(out)
     sol.close()
     if dist is not None:
         dist.barrier()

@@ -12,12 +12,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env=None, timeout=900):
-    r = subprocess.run([sys.executable] + args, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+COMPACT_KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                'data', 'config', 'roofline', 'rccl_ranks_seen', 'max_abs_dv', 'detail'}
+
+
+def _run(args, env=None, timeout=900, tmp=None):
+    """-> the full record.  stdout holds ONE line, the compact record (< 4 KB: the driver's parser lost round 5's 24-KB line); the full
+    record is the file SCA_BENCH_DETAIL names and the stderr line prefixed DETAIL -- both are read and must agree with the compact one."""
+    import tempfile
+    detail = os.path.join(tmp or tempfile.mkdtemp(prefix='sca_bench_'), 'bench_detail.json')
+    r = subprocess.run([sys.executable] + args, env=dict(os.environ, SCA_BENCH_DETAIL=detail, **(env or {})), capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    compact = json.loads(lines[0])
+    assert COMPACT_KEYS <= set(compact), sorted(COMPACT_KEYS - set(compact))
+    with open(detail) as f:
+        full = json.load(f)
+    err = [l for l in r.stderr.splitlines() if l.startswith('DETAIL ')]
+    assert len(err) == 1 and json.loads(err[0][7:]) == full
+    for k in ('metric', 'unit', 'n_gpus', 'steps', 'warmup', 'scaling', 'dtype', 'data', 'higher_is_better'):
+        assert compact[k] == full[k], k
+    assert abs(compact['value'] - full['value']) <= 1e-6 * full['value'] and abs(compact['ms_per_step'] - full['ms_per_step']) <= 1e-5 * full['ms_per_step']
+    full['_compact'] = compact
+    return full
 
 
 def test_single_gpu_json_line_small_swarm():
@@ -32,6 +52,16 @@ def test_single_gpu_json_line_small_swarm():
     assert cpu['kind'] == 'port' and cpu['max_abs_dv_vs_hip_solver_given_vpref'] == 0.0
     assert cpu['with_tracker']['value'] < cpu['policy_only']['value'] and cpu['value'] == cpu['with_tracker']['value']
     assert 'solver_only' in out and 'grid_mode' in out and 'scale_model' in out
+    # the compact line: the record the driver parses carries the roofline and the CPU baseline as flat objects
+    c = out['_compact']
+    assert c['config']['agents'] == 6000 and c['config']['workload'].startswith('c4')
+    cr = c['roofline']
+    assert {'bound', 'kernel', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'bytes_per_unit', 'units_per_launch', 'traffic'} <= set(cr)
+    assert cr['bound'] == 'hbm' and abs(cr['frac'] - cr['achieved'] / cr['peak']) < 1e-5 * cr['frac'] + 1e-12
+    cc = c['cpu_baseline']
+    assert cc['kind'] == 'port' and cc['cores'] >= 1 and cc['value'] > 0 and cc['one_thread']['value'] > 0 and cc['reference_python']['value'] > 0
+    assert c['max_abs_dv'] == 0.0 and c['rccl_ranks_seen'] == 1
+    assert all(not isinstance(v, (dict, list)) for k in ('config', 'roofline') for v in c[k].values())
 
 
 def test_host_tracker_leg_prints_its_line():
@@ -68,8 +98,9 @@ def test_bench_self_launches_two_ranks():
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout[-2000:]
+    assert json.loads(lines[0])['rccl_ranks_seen'] == 2 and json.loads(lines[0])['exchange'] == 'torch'
+    out = json.loads([l for l in r.stderr.splitlines() if l.startswith('DETAIL ')][0][7:])
     assert out['n_gpus'] == 2 and out['rccl_ranks_seen'] == 2 and out['process_group']['backend'] == 'gloo'
     assert out['config']['agent_steps_timed'] == 6000 * 4 and out['value'] > 0
 
@@ -80,7 +111,9 @@ def test_bench_self_launch_partition_variant():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3', '--agents', '6000',
                         '--nbr', 'grid', '--partition'], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    c = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert c['rccl_ranks_seen'] == 2 and c['exchange'] == 'partition'
+    out = json.loads([l for l in r.stderr.splitlines() if l.startswith('DETAIL ')][0][7:])
     assert out['rccl_ranks_seen'] == 2 and out['process_group']['exchange'] == 'partition'
 
 

@@ -183,3 +183,41 @@ def test_bench_self_launch_starts_torch_distributed_run_as_a_child_and_returns_i
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and ('needs a GPU' in both or 'No HIP GPUs' in both or 'ProcessGroupNCCL' in both or 'NCCL' in both or 'CUDA' in both), both[-3000:]
+
+
+def test_bench_compact_line_stays_under_4k_and_keeps_the_contract_keys():
+    """the driver could not parse round 5's 24-KB stdout line.  bench.py's last stdout line is compact_record(out): run on the
+    full record round 5 printed (profiles/r05_a_bench_c4_driver_cmd.json, 23.8 KB) it must stay under 4 KB and carry the contract's
+    keys, `roofline` and `cpu_baseline` as flat objects, one number per extra leg -- also when every string in the record is huge."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'r05_a_bench_c4_driver_cmd.json')) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_record(full)
+    assert len(line) < 4096 and '\n' not in line
+    c = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline', 'rccl_ranks_seen', 'max_abs_dv', 'c2_ms', 'c3_auto_ms', 'c5_ms'):
+        assert k in c, k
+    assert c['metric'] == full['metric'] and c['steps'] == 20 and c['warmup'] == 5 and c['n_gpus'] == 1 and c['dtype'] == 'f64'
+    assert abs(c['value'] - full['value']) < 1e-6 * full['value'] and abs(c['ms_per_step'] - full['ms_per_step']) < 1e-6
+    assert {'workload', 'agents', 'agents_per_gpu', 'neighbor_search', 'v_pref', 'parallelism'} <= set(c['config'])
+    r = c['roofline']
+    assert {'bound', 'kernel', 'kernel_ms', 'achieved', 'peak', 'unit', 'frac', 'bytes_per_unit', 'units_per_launch', 'traffic', 'valu_issue_frac'} <= set(r)
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-6 and r['bound'] == 'hbm'
+    b = c['cpu_baseline']
+    assert b['kind'] == 'port' and b['cores'] == 16 and b['one_thread']['value'] > 0 and b['reference_python'] == {'value': 35.9, 'cores': 1}
+    # nested objects only where asked for; everything else scalar (the driver's parser keeps scalars of sub-objects)
+    assert all(not isinstance(v, (dict, list)) for k in ('config', 'roofline') for v in c[k].values())
+    # a hostile record: every string 5 KB long
+    def blow(o):
+        if isinstance(o, dict):
+            return {k: blow(v) for k, v in o.items()}
+        if isinstance(o, str) and o not in ('hbm', 'port', 'GB/s'):
+            return o + ' x' * 2500
+        return o
+    fat = blow(full)
+    fat['metric'], fat['unit'], fat['scaling'], fat['dtype'], fat['data'] = full['metric'], full['unit'], full['scaling'], full['dtype'], full['data']
+    assert len(bench.compact_record(fat)) < 4096
