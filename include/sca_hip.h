@@ -89,9 +89,10 @@ enum sca_status_bit {             /* per-agent status word of the last policy pa
     SCA_ST_BAD_PREF_SPEED = 4,    /* np.arange(0.5, ps+0.03, ps-0.5) does not have 2 elements (scaPolicy.py:195) */
     SCA_ST_KD_STACK = 16,         /* kd traversal stack overflow (tree deeper than 48) */
     SCA_ST_NBR_OVERFLOW = 32,     /* grid mode: > max_neighbors in range, reference list is visit-order dependent */
-    SCA_ST_VPREF_EDGE = 128,      /* straight-line v_pref (rvo3dPolicy.py:182-196): one of its 5-decimal roundings sat within 1e-9 of
-                                     flipping.  On identical inputs the pass is the reference's bit for bit; in a free-running episode
-                                     positions carry ~1e-14 m of sin / cos rounding noise, which matters exactly here */
+    SCA_ST_VPREF_EDGE = 128,      /* reserved, never set.  Round 5 marked agent-steps whose straight-line v_pref (rvo3dPolicy.py:182-196)
+                                     had a 5-decimal rounding within 1e-9 of flipping, because positions of a free-running episode
+                                     carried ~1e-14 m of device sin / cos noise; since round 6 update_velocitie (mampenv.py:83-105) and
+                                     cartesian2spherical (util.py:44-55) run on the restated glibc and the episode is the reference's */
     SCA_ST_TRACKER_EDGE = 64      /* reserved, never set.  Rounds 1-2 marked agent-steps whose device-tracker v_pref might differ from the
                                      reference's by a 5-decimal step (the device ran on another libm); since round 3 the device tracker
                                      computes glibc's bits (sca_amd/csrc/sca_glibc_math.h) and equals the host tracker bit for bit */
@@ -263,7 +264,8 @@ int sca_selftest_l3norm(sca_ctx *ctx, int n, const double *a /*n*3*/, const doub
 /* The tracker's libm (sca_amd/csrc/sca_glibc_math.h: glibc 2.35's sin / cos / atan2 / acos / pow(x, 2) restated operation for
  * operation, so that the device computes the reference's -- i.e. Python's math module's -- bits).  fn: 0 sin(a), 1 cos(a),
  * 2 acos(a), 3 atan2(a, b), 4 pow(a, 2) -- the branch-free forms the kernels call; 5 sin, 6 cos, 7 atan2, 8 pow as the literal
- * restatements of glibc's control flow; 9 / 10 the sine / cosine of the fused sincos.  b may be NULL unless fn is 3 or 7.  sca_selftest_libm evaluates on the device,
+ * restatements of glibc's control flow; 9 / 10 the sine / cosine of the fused sincos; 11 atan2, 12 sin, 13 cos, 14 pow(a, 2) as cartesian2spherical (util.py:44-55),
+ * get_phi (util.py:145) and update_velocitie (mampenv.py:83-105) call them on the device (constant tables).  b may be NULL unless fn is 3, 7 or 11.  sca_selftest_libm evaluates on the device,
  * sca_selftest_libm_host on the host (no GPU needed); tests demand both equal the running glibc bit for bit. */
 int sca_selftest_libm(sca_ctx *ctx, int fn, int n, const double *a, const double *b, double *out /*n*/);
 int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out /*n*/);

@@ -11,6 +11,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include "sca_glibc_math.h"
 
 #if defined(__HIPCC__)
 #define SCA_HD __host__ __device__ __forceinline__
@@ -19,6 +20,13 @@
 #endif
 
 namespace sca {
+
+// math.atan2 / math.sin / math.cos of the reference (util.py:48-49,150-152, mampenv.py:93-95) are the host libm's; the device
+// library's are within an ulp of them, not equal.  Both builds of this header go through the restated glibc (sca_glibc_math.h,
+// constant tables): equal bits on gfx950 and on the host, hence free-running episodes whose positions and headings ARE the reference's.
+SCA_HD double m_atan2(double y, double x) { return sca_gm::g_atan2_glob(y, x); }
+SCA_HD double m_pow2(double x) { return sca_gm::g_pow2_glob(x); }                    // np.float64 ** 2 = pow(x, 2.0) (mampenv.py:94)
+SCA_HD void m_sincos(double x, double &s, double &c) { const sca_gm::SinCos r = sca_gm::g_sincos_glob(x); s = r.s; c = r.c; }
 
 constexpr int K_MAX = 16;              // agent.py:32 maxNeighbors
 constexpr int MAX_LEAF = 10;           // kdTree.py:53
@@ -35,7 +43,7 @@ enum Status : int32_t {
     ST_KD_STACK = 16,          // kd traversal stack overflow
     ST_NBR_OVERFLOW = 32,      // grid mode: more than K objects in range (reference list is order dependent)
     ST_TRACKER_EDGE = 64,      // never set since round 3 (the device tracker computes the reference's bits: sca_glibc_math.h)
-    ST_VPREF_EDGE = 128,       // straight-line v_pref: a 5-decimal rounding of it sat within 1e-9 of flipping (straight_v_pref)
+    ST_VPREF_EDGE = 128,       // never set since round 6 (update_velocitie and cartesian2spherical compute the reference's bits)
 };
 constexpr int NBR_OBSTACLE_BIT = 1 << 30;
 
@@ -154,8 +162,8 @@ SCA_HD double l3norm_f32zero(F3 v, bool plus_eps) {
 // util.py:145 get_phi -> integer numerator P (phi = P / 1e5)
 SCA_HD double get_phi_num(double vx, double vy) {
     double phi;
-    if (vy >= 0) phi = atan2(vy, vx);
-    else phi = TWO_PI + atan2(vy, vx);
+    if (vy >= 0) phi = m_atan2(vy, vx);
+    else phi = TWO_PI + m_atan2(vy, vx);
     double t = trunc(phi * EPS5);
     if (t == 0.0) t = 0.0;
     return t;
@@ -175,32 +183,21 @@ SCA_HD void cartesian2spherical(double yaw, double pitch, V3 v, bool official, d
     double speed = official ? distance5(v, zero) : l3norm(v, zero);
     double alpha = 0.0, beta = 0.0;
     if (!(speed < 0.001)) {
-        alpha = atan2(v.y, v.x) - yaw;
-        beta = atan2(v.z, sqrt(v.x * v.x + v.y * v.y)) - pitch;
+        alpha = m_atan2(v.y, v.x) - yaw;
+        beta = m_atan2(v.z, sqrt(v.x * v.x + v.y * v.y)) - pitch;
     }
     act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = speed; act[4] = alpha; act[5] = beta; act[6] = 0.0;
 }
 
-// straight-line compute_v_pref: rvo3dPolicy.py:182-196 (l3norm) / orca3dPolicy.py:348-362 (distance)
-// *edge (optional): set when one of the 5-decimal roundings on the way -- the rounded norm (util.py:104 / :140), the truncation of
-// the three components (:195) -- sits within 1e-9 of flipping.  On identical inputs this function is the reference's bit for
-// bit; in a free-running episode the positions differ from the reference's by the rounding noise of sin / cos in
-// update_velocitie (~1e-14 m), which can only matter at such an edge: SCA_ST_VPREF_EDGE tells the caller where.
-SCA_HD V3 straight_v_pref(V3 goal, V3 pos, double pref_speed, bool use_distance, bool *edge = nullptr) {
+// straight-line compute_v_pref: rvo3dPolicy.py:182-196 (l3norm) / orca3dPolicy.py:348-362 (distance).  The reference's bit for bit on
+// identical inputs -- and since round 6 the inputs of a free-running episode ARE identical (update_velocitie integrates on the restated
+// glibc, m_sincos above), so the round-5 "a 5-decimal rounding sits near a flip" mark (SCA_ST_VPREF_EDGE) is gone: reserved, never set.
+SCA_HD V3 straight_v_pref(V3 goal, V3 pos, double pref_speed, bool use_distance) {
     V3 zero = v3(0, 0, 0);
     V3 dif = goal - pos;
     double nrm = use_distance ? distance5(dif, zero) : l3norm(dif, zero);
     nrm = trunc5(nrm);
     V3 v = v3(dif.x * pref_speed / nrm, dif.y * pref_speed / nrm, dif.z * pref_speed / nrm);
-    if (edge) {
-        const double r = sqrt(dot(dif, dif)) + (use_distance ? 1e-5 : 0.0), y = r * EPS5;
-        bool e = fabs(fabs(y - floor(y) - 0.5)) < 1e-4;                                  // round(., 5) near a tie
-        const double c[3] = {v.x, v.y, v.z};
-        for (int k = 0; k < 3; k++) { const double q = c[k] * EPS5; if (fabs(q - rint(q)) < 1e-4 && q != 0.0) e = true; }   // int(. * 1e5) near a step
-        const double g = sqrt(dot(dif, dif)) * EPS5;                                     // util.reached: l3norm(goal, pos) < 0.2
-        if (fabs(g - 19999.5) < 1e-4) e = true;
-        *edge = e;
-    }
     if (l3norm(goal, pos) < 0.2) v = zero;                 // util.reached :23
     return trunc5(v);
 }

@@ -2359,7 +2359,7 @@ int sca_selftest_l3norm(sca_ctx *c, int n, const double *a, const double *b, dou
 
 // the restated glibc functions (sca_glibc_math.h): fn 0 sin(a), 1 cos(a), 2 acos(a), 3 atan2(a, b), 4 pow(a, 2) in the branch-free
 // forms the kernels call; 5 sin, 6 cos, 7 atan2, 8 pow as the literal restatements (glibc's control flow); 9 / 10 the sine / cosine
-// of the fused sincos
+// of the fused sincos; 11 atan2, 12 sin, 13 cos, 14 pow(a, 2) as the policy epilogue and the env update call them (sca_core.h m_*)
 static double libm_eval_host(int fn, double a, double b) {
     double s2, c2;
     switch (fn) {
@@ -2373,17 +2373,21 @@ static double libm_eval_host(int fn, double a, double b) {
     case 7: return sca_gm::g_atan2_ref(a, b);
     case 8: return sca_gm::g_pow2_ref(a);
     case 9: sca_gm::g_sincos(a, s2, c2); return s2;
-    default: sca_gm::g_sincos(a, s2, c2); return c2;
+    case 10: sca_gm::g_sincos(a, s2, c2); return c2;
+    case 11: return sca::m_atan2(a, b);
+    case 12: sca::m_sincos(a, s2, c2); return s2;
+    case 13: sca::m_sincos(a, s2, c2); return c2;
+    default: return sca::m_pow2(a);
     }
 }
 int sca_selftest_libm_host(int fn, int n, const double *a, const double *b, double *out) {
-    if (fn < 0 || fn > 10 || n < 0 || !a || !out || ((fn == 3 || fn == 7) && !b)) return SCA_ERR_ARG;
+    if (fn < 0 || fn > 14 || n < 0 || !a || !out || ((fn == 3 || fn == 7 || fn == 11) && !b)) return SCA_ERR_ARG;
     for (int i = 0; i < n; i++) out[i] = libm_eval_host(fn, a[i], b ? b[i] : 0.0);
     return 0;
 }
 int sca_selftest_libm(sca_ctx *c, int fn, int n, const double *a, const double *b, double *out) {
     API_ENTER(c);
-    ARG(c, fn >= 0 && fn <= 10 && n > 0 && a && out && ((fn != 3 && fn != 7) || b));
+    ARG(c, fn >= 0 && fn <= 14 && n > 0 && a && out && ((fn != 3 && fn != 7 && fn != 11) || b));
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     for (double **p : {&da, &db, &dout}) CHK(c, hipMalloc((void **)p, sizeof(double) * n));
     CHK(c, hipMemcpyAsync(da, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));

@@ -803,9 +803,8 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pc
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const double ps = d.pref_speed[agent];
     V3 vpref;
-    bool vedge = false;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
-    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca, &vedge);
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
     Prep r;
     r.vpref[0] = vpref.x; r.vpref[1] = vpref.y; r.vpref[2] = vpref.z;
     r.nvA = (double)normf(vA);
@@ -815,7 +814,6 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pc
     if (!candidate_speeds(ps, rad1)) { bits |= 2u; rad1 = ps; }
     r.rad1 = rad1;
     if (posture_ok(P, vA, r.nvA, pA.z, vpref)) bits |= 4u;
-    if (vedge) bits |= 16u;
     double kn;
     l3norm(vpref, vpref, &kn);
     r.vp_key = pack_key(kn, 0);
@@ -857,10 +855,13 @@ __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Param
     const double b = pi_2_pi(d.heading[agent * 3 + 1] + (double)act[5]);
     const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
     const double dt = d.ap ? d.ap[agent].dt_nominal : P.dt_nominal;               // agent.dt_nominal (mampenv.py:90-92)
-    const double dx = speed * cos(b) * cos(a) * dt;
-    const double dy = speed * cos(b) * sin(a) * dt;
-    const double dz = speed * sin(b) * dt;
-    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    double sa, ca, sb, cb;                                                        // math.sin / math.cos: the restated glibc (sca_core.h)
+    m_sincos(a, sa, ca);
+    m_sincos(b, sb, cb);
+    const double dx = speed * cb * ca * dt;
+    const double dy = speed * cb * sa * dt;
+    const double dz = speed * sb * dt;
+    const double len = sqrt(m_pow2(dx) + m_pow2(dy) + m_pow2(dz));               // sqrt(dx ** 2 + dy ** 2 + dz ** 2), mampenv.py:94
     d.total_dist[agent] += len;
     r.px += dx; r.py += dy; r.pz += dz;
     r.vx = act[0]; r.vy = act[1]; r.vz = act[2];
@@ -997,10 +998,8 @@ __device__ __forceinline__ void solve_one(const DeviceView &d, const Params &Pct
     const double ps = d.pref_speed[agent];
     int st = 0;
     V3 vpref;
-    bool vedge = false;
     if (d.vpref_mode[agent]) vpref = v3(d.vpref_ext[agent * 3], d.vpref_ext[agent * 3 + 1], d.vpref_ext[agent * 3 + 2]);
-    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca, &vedge);
-    if (vedge) st |= ST_VPREF_EDGE;
+    else vpref = straight_v_pref(v3(d.goal[agent * 3], d.goal[agent * 3 + 1], d.goal[agent * 3 + 2]), pA, ps, orca);
     const bool first_step = l3norm_f32zero(vA, orca) <= 1e-5;                        // scaPolicy.py:34 / orca3dPolicy.py:53
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
     V3 vpost;
@@ -1262,7 +1261,7 @@ __device__ __forceinline__ void solve_fast(const DeviceView &d, const Params &Pc
         pr.vp_key = 0;
         if (pol == POL_ORCA_LP || (pr.bits & 1u)) return;                            // no candidate sweep for these
     } else pr = ((const Prep *)d.prep)[agent];
-    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1, dg_pfail = -1, dg_lp4 = -1;
@@ -1595,7 +1594,7 @@ __device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     const V3 vA64 = to_v3(vA);
     const Prep pr = pr_;
-    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0);
     const V3 vpref = v3(pr.vpref[0], pr.vpref[1], pr.vpref[2]);
     const bool first_step = (pr.bits & 1u) != 0;
     int dg_nsuit = -1, dg_fallback = -1, dg_chosen = -1;
@@ -1772,7 +1771,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params Pctx, const int3
     d.vpost[agent * 3 + 0] = nv.x; d.vpost[agent * 3 + 1] = nv.y; d.vpost[agent * 3 + 2] = nv.z;      // :113: not truncated
     diag[0] = -1; diag[1] = -1; diag[2] = -1; diag[3] = pf; diag[4] = 0;
     d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
-    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0) | ((pr.bits & 16u) ? ST_VPREF_EDGE : 0);
+    const int st = ((pr.bits & 2u) ? ST_BAD_PREF_SPEED : 0);
     if (st) atomicOr(&d.status[agent], st);
 }
 

@@ -794,7 +794,8 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, 1) void k_track_group(DeviceView
 }
 
 // self-test: the device build of sca_glibc_math.h, one function per launch (fn as sca_selftest_libm numbers them: 0-4 the
-// branch-free forms the kernels use, 5-8 the literal restatements, 9 / 10 the two results of the fused sincos)
+// branch-free forms the kernels use, 5-8 the literal restatements, 9 / 10 the two results of the fused sincos, 11-14 the
+// constant-table entry points of the policy epilogue and the env update: atan2, sin, cos, pow(x, 2))
 __global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, const double *b, int n, double *out) {
     sca_gm::lds_tables_load();                                           // atan2's and sin / cos's tables into LDS (all threads, first)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -812,7 +813,11 @@ __global__ __launch_bounds__(256) void k_selftest_libm(int fn, const double *a, 
     case 7: r = sca_gm::g_atan2_ref(a[i], b[i]); break;
     case 8: r = sca_gm::g_pow2_ref(a[i]); break;
     case 9: sca_gm::g_sincos(a[i], s2, c2); r = s2; break;
-    default: sca_gm::g_sincos(a[i], s2, c2); r = c2; break;
+    case 10: sca_gm::g_sincos(a[i], s2, c2); r = c2; break;
+    case 11: r = m_atan2(a[i], b[i]); break;                             // what cartesian2spherical / get_phi / update_velocitie call:
+    case 12: m_sincos(a[i], s2, c2); r = s2; break;                      // the same forms on the constant tables (sca_core.h)
+    case 13: m_sincos(a[i], s2, c2); r = c2; break;
+    default: r = m_pow2(a[i]); break;
     }
     out[i] = r;
 }

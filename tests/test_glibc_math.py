@@ -68,6 +68,11 @@ def test_library_build_equals_python_math():
     assert same(_host(3, y, x), [math.atan2(p, q) for p, q in zip(y, x)])
     assert same(_host(4, x), [float(v) ** 2 for v in x])
     assert same(_host(4, x), [math.pow(v, 2) for v in x])
+    # 11-14: the entry points of the policy epilogue and the env update (sca_core.h m_atan2 / m_sincos / m_pow2): util.py:48-49,150-152
+    # call math.atan2, mampenv.py:91-94 numpy's sin / cos and np.float64 ** 2
+    assert same(_host(11, y, x), [math.atan2(p, q) for p, q in zip(y, x)])
+    assert same(_host(12, x), np.sin(x)) and same(_host(13, x), np.cos(x))
+    assert same(_host(14, x), [np.float64(v) ** 2 for v in x])          # the SCALAR power (libm's pow; an array ** 2 is x * x)
 
 
 def test_libm_check_says_what_the_parity_claim_is_conditional_on(tmp_path):

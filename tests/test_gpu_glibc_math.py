@@ -38,7 +38,7 @@ def test_device_libm_equals_host_libm_bit_for_bit():
                          mag(-60, 26), rng.choice(edges, n // 4) * (1 + rng.uniform(-1e-12, 1e-12, n // 4)) * rng.choice([-1.0, 1.0], n // 4),
                          rng.integers(0, 4000, n // 4) * 1.5707963267948966 + rng.uniform(-1e-9, 1e-9, n // 4),
                          [0.0, -0.0, 5e-324, 1e-300, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-10, 2.2250738585072014e-308]])
-    for fn in (0, 1, 5, 6, 9, 10):
+    for fn in (0, 1, 5, 6, 9, 10, 12, 13):                       # (12 / 13: update_velocitie's sin / cos, constant tables)
         d, h = _both(sol, fn, xs)
         bad = ~_same(d, h)
         assert not bad.any(), (fn, int(bad.sum()), xs[bad][:4], d[bad][:4], h[bad][:4])
@@ -52,7 +52,7 @@ def test_device_libm_equals_host_libm_bit_for_bit():
     # pow(x, 2)
     ps = np.concatenate([rng.uniform(-100, 100, 2 * n), rng.uniform(-2, 2, n), mag(-60, 60), mag(-359, 359), 1 + rng.uniform(-1e-6, 1e-6, n) * np.exp2(rng.uniform(-40, 0, n)),
                          [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 3.0]])
-    for fn in (4, 8):
+    for fn in (4, 8, 14):
         d, h = _both(sol, fn, ps)
         bad = ~_same(d, h)
         assert not bad.any(), (fn, int(bad.sum()), ps[bad][:4], d[bad][:4], h[bad][:4])
@@ -69,7 +69,7 @@ def test_device_libm_equals_host_libm_bit_for_bit():
     ys.append(x6 * np.exp2(rng.uniform(-70, 70, n)) * rng.choice([-1.0, 1.0], n))
     xq.append(x6)
     ya, xa = np.concatenate(ys), np.concatenate(xq)
-    for fn in (3, 7):
+    for fn in (3, 7, 11):                                        # (11: cartesian2spherical's / get_phi's atan2)
         d, h = _both(sol, fn, ya, xa)
         bad = ~_same(d, h)
         assert not bad.any(), (fn, int(bad.sum()), ya[bad][:4], xa[bad][:4], d[bad][:4], h[bad][:4])
@@ -98,4 +98,7 @@ def test_device_libm_equals_python_math_on_a_sample():
     assert _same(_both(sol, 2, u)[0], [math.acos(v) for v in u]).all()
     assert _same(_both(sol, 3, y, x)[0], [math.atan2(p, q) for p, q in zip(y, x)]).all()
     assert _same(_both(sol, 4, x)[0], [float(v) ** 2 for v in x]).all()
+    assert _same(_both(sol, 11, y, x)[0], [math.atan2(p, q) for p, q in zip(y, x)]).all()
+    assert _same(_both(sol, 12, x)[0], np.sin(x)).all() and _same(_both(sol, 13, x)[0], np.cos(x)).all()      # mampenv.py:91-93 calls numpy's
+    assert _same(_both(sol, 14, x)[0], [np.float64(v) ** 2 for v in x]).all()      # the scalar power: libm's pow (an array ** 2 is x * x)
     sol.close()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from golden_util import episode_fixtures, fixture_agent_params, fixture_params, load, static_inputs
-from test_gpu_parity import ANG_TOL, _scenario_state, make_solver
+from test_gpu_parity import _scenario_state, make_solver
 
 pytestmark = pytest.mark.gpu
 OVERFLOW = 32
@@ -99,7 +99,7 @@ def test_grid_pass_vs_golden(S, name):
         ok = called & ~over & (~lp | same_order(nb, fx['nbr_n'][t], fx['nbr_id'][t], fx['nbr_kind'][t]) | ~valid)
         a = sol.actions()
         assert np.array_equal(a[ok, :4], fx['action'][t][ok, :4]), ctx + ('velocity',)
-        assert np.allclose(a[ok, 4:], fx['action'][t][ok, 4:], rtol=0, atol=ANG_TOL), ctx
+        assert np.array_equal(a[ok, 4:], fx['action'][t][ok, 4:]), ctx
         flags = sol.get_state()['flags']
         assert np.array_equal((flags >> 1) & 1, fx['coll_after_policy'][t]), ctx + ('collision',)
         n_over += int((over & valid).sum()); n_checked += int(ok.sum())
@@ -189,7 +189,7 @@ def test_grid_pass_vs_oracle_baseline_sizes(S, oracle, label, kind, n, pol):
     ok = rows & ((s['policy'] != 4) | same_order(nb, ref['nbr_n'], ref['nbr_id'], ref['nbr_kind']))
     a = sol.actions()
     assert np.array_equal(a[ok, :4], ref['action'][ok, :4])
-    assert np.allclose(a[ok, 4:], ref['action'][ok, 4:], rtol=0, atol=ANG_TOL)
+    assert np.array_equal(a[ok, 4:], ref['action'][ok, 4:])
     assert np.array_equal(dg['diag'][ok, :2], ref['diag'][ok, :2])
     sol.close()
 
@@ -267,6 +267,6 @@ def test_grid_dense_collisions_match_oracle(S, oracle):
         a = sol.actions()
         u = oracle.env_update(pos, vel, head, radius, ref['flags'], goal, a, td, mrd, sn, obs_pos, obs_r)
         assert np.array_equal(got['flags'], u['flags']), t
-        assert np.allclose(got['pos'], u['pos'], rtol=0, atol=1e-6)
+        assert np.array_equal(got['pos'], u['pos'])
         pos, vel, head, flags, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
     sol.close()

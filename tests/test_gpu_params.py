@@ -36,8 +36,8 @@ def _agents_from_fixture(E, fx, with_attrs=True):
 @pytest.mark.parametrize('name', EPISODES)
 def test_env_closed_loop_with_agent_attributes(name, mode):
     """`while not env.step()` on Agent objects with non-default attributes, the Dubins tracker on the device with the agents' turning
-    radius and pitch limits: every step's velocities within 1e-5 of the reference's (they are discrete picks: equal or a candidate apart),
-    the same agents arrive / collide / time out at the same steps, positions to 1e-6."""
+    radius and pitch limits: every step's velocities and positions EQUAL to the reference's (round 6: the whole
+    loop runs on the restated glibc), the same agents arrive / collide / time out at the same steps."""
     from sca_amd import env as E, solver as S
     fx = load(name)
     agents, obstacles = _agents_from_fixture(E, fx)
@@ -54,9 +54,9 @@ def test_env_closed_loop_with_agent_attributes(name, mode):
     for t in range(T):
         env.step({})
         worst = max(worst, float(np.abs(env.vel - fx['vel_after'][t]).max()))
-        assert worst <= VEL_TOL, (name, mode, t, worst)
+        assert worst == 0.0, (name, mode, t, worst)
         assert np.array_equal(env.flags, fx['flags_after'][t]), (name, mode, t)
-        assert np.allclose(env.pos, fx['pos_after'][t], rtol=0, atol=1e-6), (name, mode, t)
+        assert np.array_equal(env.pos, fx['pos_after'][t]), (name, mode, t)
     assert np.array_equal(np.array(env.kdTree.agentIDs), fx['perm_after'][-1])
 
 
