@@ -47,9 +47,11 @@ typedef struct sca_params {
     double max_heading_change;   /* agent.py:29  pi/4 */
     double near_goal_threshold;  /* config.py:3  0.5 */
     int32_t max_neighbors;       /* agent.py:32  16 (1 .. SCA_MAX_NEIGHBORS) */
-    int32_t reserved;
+    int32_t struct_bytes;        /* sizeof(sca_params) as the CALLER compiled it (sca_default_params_v2 / SCA_DEFAULT_PARAMS store it).
+                                    0 = a version-100 caller: its struct ends here (56 bytes, this field was `reserved`, always 0), nothing
+                                    beyond is read and dt_nominal = time_step, which is what version 100 integrated with */
     double dt_nominal;           /* agent.py:41  DT = 0.1: the integrator's step (mampenv.py:90-92); time_step is the one the constraints
-                                    read (util.py:8, orca3dPolicyOfficial.py:98).  Version 101 on. */
+                                    read (util.py:8, orca3dPolicyOfficial.py:98).  Version 101 on; read only when struct_bytes >= 64. */
 } sca_params;
 
 enum sca_policy {                 /* which find_next_action the agent runs */
@@ -102,7 +104,9 @@ enum sca_error {
     SCA_OK = 0, SCA_ERR_ARG = -1, SCA_ERR_HIP = -2, SCA_ERR_STATE = -3, SCA_ERR_NOMEM = -4, SCA_ERR_UNSUPPORTED = -5
 };
 
-void sca_default_params(sca_params *p);
+void sca_default_params(sca_params *p);                 /* the version-100 entry point: writes the first 56 bytes only (struct_bytes = 0) */
+void sca_default_params_v2(sca_params *p, int32_t struct_bytes);   /* every field that fits into struct_bytes, and struct_bytes itself */
+#define SCA_DEFAULT_PARAMS(p) sca_default_params_v2((p), (int32_t)sizeof(sca_params))
 int sca_version(void);
 
 int sca_create(const sca_params *p, int device, int max_agents, int max_obstacles, sca_ctx **out);
@@ -118,8 +122,8 @@ int sca_set_agents(sca_ctx *ctx, int n, const double *radius /*n*/, const double
 /* The solver attributes PER AGENT, as the reference keeps them (agent.py:24-41: maxNeighbors, neighborDist, timeStep, timeHorizon, maxSpeed,
  * max_heading_change, dt_nominal are attributes of every Agent object, read by its own policy calls).  Arrays of n (= sca_set_agents' n); a NULL
  * array keeps the context's sca_params value for every agent; n = 0 or all NULL: back to one value per context.  Call after sca_set_agents
- * (which clears them) and before sca_device_tracker_enable.  turning_radius and the pitch limits stay one value per context
- * (sca_device_tracker_enable).  Not with the cell-owner partition.  Parity: tests/golden/F17_hetero_*. */
+ * (which clears them) and before sca_device_tracker_enable.  The planner's two attributes, turning_radius and pitchlims, go per agent
+ * through sca_device_tracker_set_agent_params (below).  Parity: tests/golden/F17_hetero_*. */
 int sca_set_agent_params(sca_ctx *ctx, int n, const double *neighbor_dist, const int32_t *max_neighbors, const double *time_step,
                          const double *time_horizon, const double *max_speed, const double *max_heading_change, const double *dt_nominal);
 
@@ -328,9 +332,12 @@ int sca_device_tracker_enable(sca_ctx *ctx, const double *goal_heading /*n*3, ag
 /* the tracked agents take v_pref from their policy's own straight-line rule again (sca_set_vpref afterwards to feed it from the host) */
 int sca_device_tracker_disable(sca_ctx *ctx);
 /* agent.turning_radius / agent.pitchlims PER AGENT (the reference keeps them on every Agent object; scaPolicy.py:95,272,302 read the agent's own).
- * Arrays of n, a NULL array = sca_device_tracker_enable's value for everybody, all NULL = back to one value.  The tracked agents are grouped
- * into classes of equal (turning_radius, pitch_lo, pitch_hi), at most 16, and the re-plan kernels run once per class (the search keeps these
- * three in scalar registers).  After sca_device_tracker_enable.  Parity: tests/golden/F18_hetero_track_*. */
+ * Arrays of n, a NULL array = sca_device_tracker_enable's value for everybody, all NULL = back to that one value.  Entries of untracked agents
+ * (policy not SCA / RVO3D_DUBINS) are ignored; a tracked agent needs turning_radius > 0 and pitch_lo < pitch_hi (SCA_ERR_ARG otherwise).
+ * Up to 16 distinct (turning_radius, pitch_lo, pitch_hi) among the tracked agents: classes -- the re-plan kernels run once per class with the
+ * class's values as kernel arguments (the search keeps the three in scalar registers).  More (the reference has no limit): the per-agent
+ * form -- every re-plan gets a wavefront of its own, which loads its agent's values; slower for large re-plan counts, never refused.
+ * After sca_device_tracker_enable.  Parity: tests/golden/F18_hetero_track_* (3 x 3 classes; F18_hetero_track_circle30_each: 30 settings). */
 int sca_device_tracker_set_agent_params(sca_ctx *ctx, int n, const double *turning_radius, const double *pitch_lo, const double *pitch_hi);
 /* one compute_v_pref per active tracked agent on the current state; nbr0_dsq as in sca_tracker_vpref, NULL = from the
  * device's neighbour lists; vpref_out nullable */

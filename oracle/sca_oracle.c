@@ -860,6 +860,7 @@ int orc_policy_step(int n, int m, const double *pos, const float *vel, const dou
         status[i] = st;
     }
     free(atree); free(aids); free(otree); free(oids); free(flags_in);
+    g_par = g_ctx;                  /* (the calling thread ran some agents too: the scalar KAT helpers must see the scene's values again) */
     return 0;
 }
 
@@ -903,6 +904,7 @@ int orc_env_update(int n, int m, double *pos, float *vel, double *heading, const
         if (orc_l3norm(&pos[3 * i], &goal[3 * i]) <= g_ctx.near_goal_threshold) flags[i] |= FLAG_AT_GOAL;
         if (!(flags[i] & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT))) all_done = 0;
     }
+    g_par = g_ctx;                  /* (the last agent's attributes must not outlive the call on this thread) */
     return all_done;
 }
 

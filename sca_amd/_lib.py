@@ -20,12 +20,13 @@ bp = C.POINTER(C.c_uint8)
 class Params(C.Structure):
     _fields_ = [('neighbor_dist', C.c_double), ('time_step', C.c_double), ('time_horizon', C.c_double),
                 ('max_speed', C.c_double), ('max_heading_change', C.c_double), ('near_goal_threshold', C.c_double),
-                ('max_neighbors', C.c_int32), ('reserved', C.c_int32), ('dt_nominal', C.c_double)]
+                ('max_neighbors', C.c_int32), ('struct_bytes', C.c_int32), ('dt_nominal', C.c_double)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/sca_hip.h
 SIGNATURES = {
-    'sca_default_params': (None, [C.POINTER(Params)]),
+    'sca_default_params': (None, [C.c_void_p]),                   # (version-100 form: 56 bytes)
+    'sca_default_params_v2': (None, [C.POINTER(Params), C.c_int32]),
     'sca_version': (C.c_int, []),
     'sca_create': (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     'sca_destroy': (None, [C.c_void_p]),

@@ -4,11 +4,14 @@
 // Dubins path (mamp/policies/sca/scaPolicy.py:92-104,243-338), planned by dubinsmaneuver3d.py:34-162 on top of the 2-D
 // planner dubinsmaneuver2d.py:33-218,260-297.  This file is a C++ restatement that follows the Python statement by
 // statement and is compiled twice from the same text:
-//   * for the host (sca_tracker_*): thread-parallel over agents, libm through function pointers so that the compiler cannot
-//     fold pow(x, 2) or fuse sin/cos -- bit-exact against the reference on the fixtures (tests/test_tracker.py);
-//   * for gfx950 (sca_device_tracker_*, kernels in sca_tracker.hip.h): one lane per agent, state resident in HBM.  The
-//     device's sin / cos / atan2 / acos are not glibc's (they differ in the last bit in a few percent of the calls), so
-//     the device tracker is the reference's algorithm to within rounding noise, not bit for bit: see DESIGN.md.
+//   * for the host (sca_tracker_*): thread-parallel over agents -- bit-exact against the reference on the fixtures
+//     (tests/test_tracker.py);
+//   * for gfx950 (sca_device_tracker_*, kernels in sca_tracker.hip.h): one lane up to one wavefront per plan, state resident in
+//     HBM.
+// Both builds call the SAME libm: sca_glibc_math.h, glibc 2.35's sin / cos / atan2 / acos / pow(x, 2) restated operation for
+// operation (the ROCm device library's differ from glibc's in the last bit in a few per cent of the calls, which a discrete radius
+// search does not forgive).  Since round 3 the device tracker therefore equals the host tracker -- and the reference -- bit for
+// bit: every v_pref, every follow-or-re-plan decision, every plan (tests/test_gpu_tracker.py, tests/test_gpu_value_parity.py).
 // generate_course (dubinsmaneuver2d.py:221-257) is not reproduced: the 3-D planner never reads its output.
 #pragma once
 #include <cmath>
@@ -881,7 +884,9 @@ struct TrackView {
     // The HOST tracker plans every agent with its own values.  On the DEVICE the re-plan kernels keep Rmin and the pitch limits in scalar
     // registers throughout the search (they sit at 256 VGPRs): tracked agents are grouped into CLASSES of equal (R, pitch_lo, pitch_hi), the
     // re-plan kernels are launched once per class with the class's values in turning_radius / pitch_lo / pitch_hi, and an agent of another
-    // class leaves at once (cls[agent] != class_id).  The decision (track_decide: k = 3 R, the 2 R test) reads R_pa per agent.
+    // class leaves at once (cls[agent] != class_id).  The decision (track_decide: k = 3 R, the 2 R test) reads R_pa per agent.  With more
+    // classes than launches are worth (sca_device_tracker_set_agent_params), plo_pa / phi_pa are DEVICE arrays too and cls is null: every
+    // re-plan then has a wavefront of its own, which loads its agent's three values into scalar registers (own_plan_params).
     const double *R_pa, *plo_pa, *phi_pa;
     const uint8_t *cls;           // [n] the agent's class (device), null: one class
     int class_id;

@@ -229,6 +229,9 @@ struct sca_ctx {
     std::vector<std::array<double, 3>> trk_classes;   // (turning radius, pitch_lo, pitch_hi) of every class of tracked agents; empty: one class = the view's scalars
     double *trk_R_pa = nullptr;         // [n] agent.turning_radius (device), for the decision
     uint8_t *trk_cls = nullptr;         // [n] the agent's class (device)
+    double *trk_plo_pa = nullptr, *trk_phi_pa = nullptr;   // [n] agent.pitchlims (device): the per-agent form (more than TRK_MAX_CLASSES classes)
+    bool trk_many = false;              // the per-agent form: every re-plan by a wavefront of its own, which reads ITS agent's three values
+    double trk_enable_vals[3] = {1.5, 0, 0};   // (turning radius, pitch_lo, pitch_hi) of sca_device_tracker_enable: what "back to one value" restores
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
     hipEvent_t trk_count_ev = nullptr;
     bool trk_count_pending = false;
@@ -334,10 +337,16 @@ static int api_enter(sca_ctx *c);
 
 extern "C" {
 
-void sca_default_params(sca_params *p) {
+// A version-100 caller's sca_params is 56 bytes (no dt_nominal) with `reserved` = 0 where struct_bytes now sits: sca_default_params keeps
+// writing exactly those 56 bytes, sca_create reads dt_nominal only from a struct that says it has one.
+void sca_default_params_v2(sca_params *p, int32_t struct_bytes) {
     p->neighbor_dist = 10.0; p->time_step = 0.1; p->time_horizon = 10.0; p->max_speed = 1.0;
-    p->max_heading_change = M_PI / 4; p->near_goal_threshold = 0.5; p->max_neighbors = 16; p->reserved = 0; p->dt_nominal = 0.1;
+    p->max_heading_change = M_PI / 4; p->near_goal_threshold = 0.5; p->max_neighbors = 16;
+    const bool has_dt = struct_bytes >= (int32_t)(offsetof(sca_params, dt_nominal) + sizeof(double));
+    p->struct_bytes = has_dt ? struct_bytes : 0;
+    if (has_dt) p->dt_nominal = 0.1;
 }
+void sca_default_params(sca_params *p) { sca_default_params_v2(p, 0); }
 int sca_version(void) { return 101; }
 
 const char *sca_last_error(const sca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -557,6 +566,9 @@ static int tracker_free(sca_ctx *c) {
     (void)hipFree(c->trk_goal_heading);
     if (c->trk_R_pa) { (void)hipFree(c->trk_R_pa); c->trk_R_pa = nullptr; }
     if (c->trk_cls) { (void)hipFree(c->trk_cls); c->trk_cls = nullptr; }
+    if (c->trk_plo_pa) { (void)hipFree(c->trk_plo_pa); c->trk_plo_pa = nullptr; }
+    if (c->trk_phi_pa) { (void)hipFree(c->trk_phi_pa); c->trk_phi_pa = nullptr; }
+    c->trk_many = false;
     c->trk_classes.clear();
     if (c->trk_stream) { (void)hipStreamSynchronize(c->trk_stream); (void)hipStreamDestroy(c->trk_stream); c->trk_stream = nullptr; }
     if (c->trk_fork) { (void)hipEventDestroy(c->trk_fork); c->trk_fork = nullptr; }
@@ -611,6 +623,8 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     c->trk_view = sca_dubins::TrackView{c->d.goal, c->trk_goal_heading, c->d.pref_speed, c->d.zaxis, turning_radius, pitch_min,
                                         pitch_max, c->P.neighbor_dist, c->ap_nd, nullptr, nullptr, nullptr, nullptr, 0};
     c->trk_classes.clear();
+    c->trk_many = false;
+    c->trk_enable_vals[0] = turning_radius; c->trk_enable_vals[1] = pitch_min; c->trk_enable_vals[2] = pitch_max;
     {   // resolve the tracker's kernels now: the first launch of a kernel pays for looking it up in the code object, and the
         // forms are picked while the episode runs (k_track_replan's first launch used to fall into a timed step)
         hipFuncAttributes fa;
@@ -634,47 +648,66 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
     return 0;
 }
 // agent.turning_radius / agent.pitchlims per agent (scaPolicy.py:95,272,302 read the agent's own).  Arrays of n, any of them NULL = the value of
-// sca_device_tracker_enable for everybody; all NULL: back to one value.  Tracked agents are grouped into classes of equal (R, lo, hi) -- at most
-// 16 -- and the re-plan kernels run once per class (TrackView); untracked agents' entries are ignored.
+// sca_device_tracker_enable for everybody; all NULL: back to that one value.  Untracked agents' entries (policy not SCA / RVO3D+Dubins) are ignored.
+// Up to TRK_MAX_CLASSES distinct (R, lo, hi) among the tracked agents: CLASSES -- the re-plan kernels run once per class with the class's
+// values as kernel arguments (scalar registers throughout the search).  More than that (the reference has no limit, agent.py:24-29): the
+// PER-AGENT form -- every re-plan gets a wavefront of its own (k_replan_group<64> / k_track_group at any count), which loads ITS agent's
+// three values into scalar registers; slower than the lane-per-plan forms for large counts, never refused.
+constexpr size_t TRK_MAX_CLASSES = 16;
 int sca_device_tracker_set_agent_params(sca_ctx *c, int n, const double *turning_radius, const double *pitch_lo, const double *pitch_hi) {
     API_ENTER(c);
     if (!c->trk_on) { c->err = "sca_device_tracker_enable first"; return SCA_ERR_STATE; }
     CHK(c, hipStreamSynchronize(c->stream));
-    if (!turning_radius && !pitch_lo && !pitch_hi) {
-        c->trk_classes.clear();
-        c->trk_view.R_pa = nullptr; c->trk_view.cls = nullptr;
-        return 0;
-    }
+    // (every call starts from the enable-time values: a one-class call overwrites the view's scalars, and "any of them NULL" / "all NULL"
+    // promise sca_device_tracker_enable's values, not the previous call's -- ADVICE r5)
+    c->trk_view.turning_radius = c->trk_enable_vals[0]; c->trk_view.pitch_lo = c->trk_enable_vals[1]; c->trk_view.pitch_hi = c->trk_enable_vals[2];
+    c->trk_classes.clear();
+    c->trk_many = false;
+    c->trk_view.R_pa = nullptr; c->trk_view.plo_pa = nullptr; c->trk_view.phi_pa = nullptr; c->trk_view.cls = nullptr; c->trk_view.class_id = 0;
+    if (!turning_radius && !pitch_lo && !pitch_hi) return 0;
     ARG(c, n == c->n);
-    std::vector<uint8_t> mode((size_t)n), cls((size_t)n, 0);
-    CHK(c, hipMemcpy(mode.data(), c->d.vpref_mode, (size_t)n, hipMemcpyDeviceToHost));
+    // tracked = by POLICY, as the kernels decide it (tracker_owns), not by the v_pref mode of the moment (sca_set_vpref may change that later)
+    std::vector<uint8_t> pol((size_t)n), cls((size_t)n, 0);
+    CHK(c, hipMemcpy(pol.data(), c->d.policy, (size_t)n, hipMemcpyDeviceToHost));
     std::vector<std::array<double, 3>> classes;
-    std::vector<double> R((size_t)n);
+    std::vector<double> R((size_t)n), LO((size_t)n), HI((size_t)n);
+    bool many = false;
     for (int i = 0; i < n; i++) {
-        const std::array<double, 3> v = {turning_radius ? turning_radius[i] : c->trk_view.turning_radius, pitch_lo ? pitch_lo[i] : c->trk_view.pitch_lo,
-                                         pitch_hi ? pitch_hi[i] : c->trk_view.pitch_hi};
-        R[i] = v[0];
-        if (!mode[i]) continue;                                          // not a tracked agent
-        if (!(std::isfinite(v[0]) && v[0] > 0.0) || !std::isfinite(v[1]) || !std::isfinite(v[2])) {
-            c->err = "sca_device_tracker_set_agent_params: agent " + std::to_string(i) + " has a turning radius / pitch limit out of range"; return SCA_ERR_ARG;
+        const std::array<double, 3> v = {turning_radius ? turning_radius[i] : c->trk_enable_vals[0], pitch_lo ? pitch_lo[i] : c->trk_enable_vals[1],
+                                         pitch_hi ? pitch_hi[i] : c->trk_enable_vals[2]};
+        R[i] = v[0]; LO[i] = v[1]; HI[i] = v[2];
+        if (pol[i] != SCA_POLICY_SCA && pol[i] != SCA_POLICY_RVO3D_DUBINS) continue;     // not a tracked agent
+        if (!(std::isfinite(v[0]) && v[0] > 0.0) || !std::isfinite(v[1]) || !std::isfinite(v[2]) || !(v[1] < v[2])) {
+            c->err = "sca_device_tracker_set_agent_params: agent " + std::to_string(i) + " has a turning radius / pitch limits out of range (R > 0, pitch_lo < pitch_hi)";
+            return SCA_ERR_ARG;
         }
+        if (many) continue;
         size_t k = 0;
         while (k < classes.size() && classes[k] != v) k++;
         if (k == classes.size()) {
-            if (classes.size() == 16) { c->err = "more than 16 different (turning_radius, pitchlims) among the tracked agents: not supported"; return SCA_ERR_UNSUPPORTED; }
+            if (classes.size() == TRK_MAX_CLASSES) { many = true; continue; }
             classes.push_back(v);
         }
         cls[i] = (uint8_t)k;
     }
     if (!c->trk_R_pa) { CHK(c, hipMalloc((void **)&c->trk_R_pa, sizeof(double) * (size_t)c->max_n)); CHK(c, hipMalloc((void **)&c->trk_cls, (size_t)c->max_n)); }
     CHK(c, hipMemcpy(c->trk_R_pa, R.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    CHK(c, hipMemcpy(c->trk_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice));
-    c->trk_classes = classes;
     c->trk_view.R_pa = c->trk_R_pa;
-    c->trk_view.cls = classes.size() > 1 ? c->trk_cls : nullptr;
-    if (classes.size() <= 1) {                                          // one class after all: its values in the scalars, no filter
-        if (!classes.empty()) { c->trk_view.turning_radius = classes[0][0]; c->trk_view.pitch_lo = classes[0][1]; c->trk_view.pitch_hi = classes[0][2]; }
-        c->trk_classes.clear();
+    if (many) {
+        if (!c->trk_plo_pa) {
+            CHK(c, hipMalloc((void **)&c->trk_plo_pa, sizeof(double) * (size_t)c->max_n));
+            CHK(c, hipMalloc((void **)&c->trk_phi_pa, sizeof(double) * (size_t)c->max_n));
+        }
+        CHK(c, hipMemcpy(c->trk_plo_pa, LO.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        CHK(c, hipMemcpy(c->trk_phi_pa, HI.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        c->trk_view.plo_pa = c->trk_plo_pa; c->trk_view.phi_pa = c->trk_phi_pa;
+        c->trk_many = true;
+        return 0;
+    }
+    CHK(c, hipMemcpy(c->trk_cls, cls.data(), (size_t)n, hipMemcpyHostToDevice));
+    if (classes.size() > 1) { c->trk_classes = classes; c->trk_view.cls = c->trk_cls; }
+    else if (!classes.empty()) {                                        // one class after all: its values in the scalars, no filter
+        c->trk_view.turning_radius = classes[0][0]; c->trk_view.pitch_lo = classes[0][1]; c->trk_view.pitch_hi = classes[0][2];
     }
     return 0;
 }
@@ -716,9 +749,15 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (!out || max_agents <= 0 || max_obstacles < 0) return SCA_ERR_ARG;
     sca_ctx *c = new sca_ctx();
     *out = c;
-    sca_params def;
-    sca_default_params(&def);
+    sca_params def, own;
+    sca_default_params_v2(&def, (int32_t)sizeof(sca_params));
     if (!p) p = &def;
+    if (p->struct_bytes < (int32_t)(offsetof(sca_params, dt_nominal) + sizeof(double))) {     // a version-100 struct: 56 bytes, no dt_nominal
+        memcpy(&own, p, offsetof(sca_params, dt_nominal));
+        own.struct_bytes = (int32_t)sizeof(sca_params);
+        own.dt_nominal = own.time_step;
+        p = &own;
+    }
     if (p->max_neighbors < 1 || p->max_neighbors > SCA_MAX_NEIGHBORS) { c->err = "max_neighbors out of range (1 .. 16)"; return SCA_ERR_ARG; }
     {   // the kernels divide by these, size grid cells with them and bisect acos on max_heading_change: refuse what they were not built for
         auto pos = [](double x) { return std::isfinite(x) && x > 0.0; };
@@ -1342,10 +1381,12 @@ static int launch_tracker(sca_ctx *c, bool from_lists, bool in_pass) {
     }
     if (!c->trk_quad) { for (int i = 0; i < 4; i++) want[i] = false; want[4] = true; nwant = 1; }
     if (nwant == 0) { want[4] = true; nwant = 1; }
+    // the per-agent form (more classes of (turning radius, pitch limits) than launches are worth): a wavefront per plan at ANY count
+    if (c->trk_many) { want[0] = true; for (int i = 1; i < 5; i++) want[i] = false; nwant = 1; }
     const bool lane = want[4];
     const bool fused = in_pass && lane && nwant == 1 && c->trk_fuse && !c->part_on && (long long)lc * 4 >= (long long)cnt * 3;
     // a shard of so few agents that each can have a wavefront (and a SIMD): decision and search in one launch (k_track_group)
-    const bool group_fused = in_pass && c->trk_quad && c->trk_group_fuse && !c->part_on && cnt <= K.spec4_max;
+    const bool group_fused = in_pass && (c->trk_quad || c->trk_many) && c->trk_group_fuse && !c->part_on && cnt <= K.spec4_max;
     if (group_fused) c->forms |= SCA_FORM_TRACK_FUSED | SCA_FORM_REPLAN_FEW;
     else c->forms |= (fused ? SCA_FORM_TRACK_FUSED : 0) | (nwant > (lane ? 1 : 0) ? SCA_FORM_REPLAN_FEW : 0) | (lane ? SCA_FORM_REPLAN_LANE : 0);
     if (!fused && !group_fused) hipLaunchKernelGGL(k_track, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->d, c->trk_view, K);
@@ -1444,8 +1485,12 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
 // launches at ~2.3 us and ten event operations at ~5 us), so a cross-stream wait is only enqueued when the event it would wait for has
 // not fired yet (in the steady state the kd stream is a whole pass ahead of what these guards protect; the query costs < 1 us).
 static int wait_if_pending(sca_ctx *c, hipStream_t s, hipEvent_t e) {
+    // (launch errors of the kernels enqueued before this call are sticky in hipGetLastError: look at them BEFORE the query below, whose
+    // hipErrorNotReady has to be cleared -- ADVICE r5: a failed launch in front of a pending event used to be dropped with it)
+    CHK(c, hipGetLastError());
     const hipError_t q = hipEventQuery(e);
     if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) CHK(c, q);                                // a real error of the query is an error
     (void)hipGetLastError();                                             // (hipErrorNotReady is an answer, not a failure)
     CHK(c, hipStreamWaitEvent(s, e, 0));
     return 0;

@@ -698,6 +698,15 @@ __device__ __forceinline__ sca_dubins::Plan3D plan3d_spec(const double qi[5], co
     return P;
 }
 
+// The per-agent form of agent.turning_radius / agent.pitchlims (sca_device_tracker_set_agent_params with more classes than launches are
+// worth): a wavefront that plans ONE agent loads that agent's three values through a wave-uniform index, i.e. into scalar registers like
+// the kernel arguments they replace -- the search keeps its register allocation.  T.plo_pa is null in every other form.
+__device__ __forceinline__ void own_plan_params(const sca_dubins::TrackView &T, int agent, double &Rmin, double pl[2]) {
+    if (!T.plo_pa) return;
+    const int a = __builtin_amdgcn_readfirstlane(agent);
+    Rmin = T.R_pa[a]; pl[0] = T.plo_pa[a]; pl[1] = T.phi_pa[a];
+}
+
 // one group of LANES lanes per plan: 4 = the quad planner, 16 / 32 / 64 = speculative search of depth 2 / 3 / 4
 template <int LANES, typename TREES>
 __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubins::TrackView T, const TrackDev K, int count, const TREES &TR) {
@@ -712,12 +721,16 @@ __device__ __forceinline__ void replan_group(const DeviceView d, const sca_dubin
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
     double qi[5], qf[5];
     sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
-    const double pl[2] = {T.pitch_lo, T.pitch_hi};
+    double pl[2] = {T.pitch_lo, T.pitch_hi};
     sca_dubins::Plan3D P;
     if constexpr (LANES == 4) P = plan3d_quad(qi, qf, T.turning_radius, pl, sub, lane);
     else if constexpr (LANES == 16) P = plan3d_spec<2>(qi, qf, T.turning_radius, pl, sub, lane, TR);
     else if constexpr (LANES == 32) P = plan3d_spec<3>(qi, qf, T.turning_radius, pl, sub, lane, TR);
-    else P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane, TR);
+    else {
+        double Rmin = T.turning_radius;
+        own_plan_params(T, agent, Rmin, pl);                              // (the per-agent form: this wavefront's agent's own three values)
+        P = plan3d_spec<4>(qi, qf, Rmin, pl, sub, lane, TR);
+    }
     if ((gid & (LANES - 1)) != 0) return;
     sca_dubins::AgentTrack &a = K.st[agent];
     double dif[3], V[3];
@@ -785,8 +798,10 @@ __global__ __launch_bounds__(TRK_GROUP_THREADS, 1) void k_track_group(DeviceView
     const double heading[3] = {d.heading[agent * 3], d.heading[agent * 3 + 1], d.heading[agent * 3 + 2]};
     double qi[5], qf[5];
     sca_dubins::dubins_endpoints(T, agent, pos, heading, qi, qf);
-    const double pl[2] = {T.pitch_lo, T.pitch_hi};
-    const sca_dubins::Plan3D P = plan3d_spec<4>(qi, qf, T.turning_radius, pl, sub, lane, TR);
+    double pl[2] = {T.pitch_lo, T.pitch_hi};
+    double Rmin = T.turning_radius;
+    own_plan_params(T, agent, Rmin, pl);                                 // (the per-agent form: this wavefront's agent's own three values)
+    const sca_dubins::Plan3D P = plan3d_spec<4>(qi, qf, Rmin, pl, sub, lane, TR);
     if (lane != 0) return;
     sca_dubins::track_adopt(a, P, pos, dif);
     sca_dubins::track_finish(T, a, agent, pos, dif, V);

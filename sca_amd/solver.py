@@ -25,7 +25,7 @@ class BatchedSolver:
     def __init__(self, max_agents, max_obstacles=0, device=0, params=None):
         self.L = _lib.lib()
         p = _lib.Params()
-        self.L.sca_default_params(C.byref(p))
+        self.L.sca_default_params_v2(C.byref(p), C.sizeof(p))
         for k, v in (params or {}).items():
             setattr(p, k, v)
         self.params = p

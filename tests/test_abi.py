@@ -30,12 +30,31 @@ def test_default_params_are_the_reference_constants():
     import math
     from sca_amd import _lib
     p = _lib.Params()
-    _lib.lib().sca_default_params(C.byref(p))
+    _lib.lib().sca_default_params_v2(C.byref(p), C.sizeof(p))
     # agent.py:27-36, config.py:2-3
     assert (p.neighbor_dist, p.max_neighbors, p.time_step, p.time_horizon, p.max_speed) == (10.0, 16, 0.1, 10.0, 1.0)
     assert p.max_heading_change == math.pi / 4 and p.near_goal_threshold == 0.5
     assert p.dt_nominal == 0.1                                    # agent.py:41
-    assert C.sizeof(_lib.Params) == 64 and _lib.lib().sca_version() >= 101
+    assert C.sizeof(_lib.Params) == 64 and _lib.lib().sca_version() >= 101 and p.struct_bytes == 64
+
+
+def test_version_100_callers_keep_their_56_byte_struct():
+    """sca_params grew a trailing dt_nominal in version 101.  The version-100 entry point must not write beyond the 56 bytes
+    such a caller allocated, and marks the struct (struct_bytes = 0, where `reserved` sat) so that sca_create does not read beyond them
+    either (it integrates with time_step then, as version 100 did)."""
+    import ctypes as C
+    from sca_amd import _lib
+    buf = (C.c_ubyte * 72)(*([0xA5] * 72))
+    _lib.lib().sca_default_params(C.cast(buf, C.c_void_p))
+    assert bytes(buf[56:]) == bytes([0xA5] * 16)                   # nothing written behind the old struct
+    p = _lib.Params.from_buffer_copy(bytes(buf[:64]))
+    assert (p.neighbor_dist, p.max_neighbors, p.time_step, p.struct_bytes) == (10.0, 16, 0.1, 0)
+    # a version-100 struct with garbage where dt_nominal would be: the range check must not see it
+    ctx = C.c_void_p()
+    p.time_step = 0.2
+    rc = _lib.lib().sca_create(C.byref(p), 0, 8, 1, C.byref(ctx))
+    assert 'dt_nominal' not in _lib.lib().sca_last_error(ctx).decode(), rc
+    _lib.lib().sca_destroy(ctx)
 
 
 @pytest.mark.parametrize('field,value', [('neighbor_dist', 0.0), ('neighbor_dist', float('nan')), ('time_step', -0.1), ('time_horizon', 0.0),
@@ -47,7 +66,7 @@ def test_create_refuses_parameters_the_kernels_were_not_built_for(field, value):
     from sca_amd import _lib
     L = _lib.lib()
     p = _lib.Params()
-    L.sca_default_params(C.byref(p))
+    L.sca_default_params_v2(C.byref(p), C.sizeof(p))
     setattr(p, field, value)
     ctx = C.c_void_p()
     assert L.sca_create(C.byref(p), 0, 8, 1, C.byref(ctx)) == -1          # SCA_ERR_ARG

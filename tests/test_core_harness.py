@@ -22,9 +22,9 @@ def harness():
     ubsan = bool(os.environ.get('SCA_HARNESS_UBSAN'))          # tests/test_sanitizers.py re-runs this module with it set
     out = os.path.join(ROOT, 'tests', '_build', 'libcore_harness_ubsan.so' if ubsan else 'libcore_harness.so')
     src = os.path.join(ROOT, 'tests', 'core_harness.cpp')
-    hdr = os.path.join(ROOT, 'sca_amd', 'csrc', 'sca_core.h')
+    hdrs = [os.path.join(ROOT, 'sca_amd', 'csrc', h) for h in ('sca_core.h', 'sca_glibc_math.h', 'sca_glibc_tables.h')]    # (sca_core.h includes them)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
         san = ['-O1', '-g', '-fsanitize=undefined', '-fno-sanitize-recover=all'] if ubsan else ['-O2']
         subprocess.check_call(['g++', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-mfma',
                                '-fno-builtin-pow', '-I' + os.path.join(ROOT, 'sca_amd', 'csrc'), '-o', out, src] + san)

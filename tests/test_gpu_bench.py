@@ -24,8 +24,9 @@ def _run(args, env=None, timeout=900, tmp=None):
     r = subprocess.run([sys.executable] + args, env=dict(os.environ, SCA_BENCH_DETAIL=detail, **(env or {})), capture_output=True, text=True,
                        timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[-2000:]
+    nonempty = [l for l in r.stdout.splitlines() if l.strip()]
+    lines = [l for l in nonempty if l.startswith('{')]                # (gloo prints its own "[Gloo] Rank ..." lines to stdout)
+    assert len(lines) == 1 and nonempty[-1] == lines[0], r.stdout[-2000:]     # ONE JSON line, and it is the LAST line
     assert len(lines[0]) < 4096, len(lines[0])
     compact = json.loads(lines[0])
     assert COMPACT_KEYS <= set(compact), sorted(COMPACT_KEYS - set(compact))

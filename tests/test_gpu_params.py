@@ -80,7 +80,7 @@ def test_defaults_would_not_reproduce_these_scenes():
 
 def test_heterogeneous_attributes_travel_per_agent():
     """The reference reads every attribute per agent.  The solver attributes travel per agent (sca_set_agent_params, F17 fixtures), the planner's
-    two as classes of equal values (sca_device_tracker_set_agent_params, F18): at most 16 classes, more are refused."""
+    two as classes of equal values (sca_device_tracker_set_agent_params, F18) -- up to 16 classes; beyond, per agent (next test)."""
     from sca_amd import env as E, solver as S
     agents = E.build_circle_agents(8, policy=E.RVO3DPolicy, rad=10.0)
     agents[3].neighborDist = 5.0
@@ -97,12 +97,51 @@ def test_heterogeneous_attributes_travel_per_agent():
     assert env.per_agent_attributes == ['turning_radius / pitchlims']
     for _ in range(5):
         env.step({})
-    # more than 16 different planner settings among the tracked agents: refused, with the reason
-    many = E.build_circle_agents(20, policy=E.SCAPolicy, rad=20.0)
-    for i, a in enumerate(many):
-        a.turning_radius = 1.0 + 0.1 * i
-    with pytest.raises(S.ScaError, match='16 different'):
-        E.MACAEnv(device_tracker=True).set_agents(many, obstacles=[])
+    # more than 16 different planner settings among the tracked agents (the reference has no limit, agent.py:24-29): round 5 refused them;
+    # now the per-agent form takes over (a wavefront per plan reading its agent's own three values) -- see the test below
+
+
+@pytest.mark.parametrize('n,steps', [(20, 60), (300, 12)])
+def test_more_than_16_planner_settings_equal_the_host_tracker(n, steps):
+    """every tracked agent its own (turning_radius, pitchlims) -- 20 / 300 distinct settings.  The device tracker's
+    per-agent form against the native host tracker, which plans every agent with its own values and which the F18 fixtures pin to the
+    reference: positions, velocities, flags and re-plan counts equal after every step.  (n = 300: beyond k_track_group's range, so the
+    list + k_replan_group<64> launches run.)"""
+    from sca_amd import env as E, scenarios, solver as S, tracker
+    rng = np.random.default_rng(n)
+    R = 0.8 + 2.2 * rng.random(n)
+    lo = -(0.35 + 0.4 * rng.random(n))
+    hi = 0.35 + 0.5 * rng.random(n)
+
+    def run(device):
+        sc = scenarios.circle(n, rad=max(10.0, 0.4 * n))
+        pol = [E.SCAPolicy if i % 5 else E.RVO3dDubinsPolicy for i in range(n)]
+        agents = [E.Agent(start_pos=list(sc['start'][i]), goal_pos=list(sc['goal'][i]), vel=[0.0, 0.0, 0.0], radius=0.5,
+                          pref_speed=1.0, policy=pol[i], id=i) for i in range(n)]
+        for i, a in enumerate(agents):
+            a.turning_radius = float(R[i])
+            a.pitchlims = [float(lo[i]), float(hi[i])]
+        fn = None
+        if not device:
+            fn = tracker.DubinsTracker(sc['goal'][:, :3], sc['goal'][:, 3:6], np.ones(n), S.zaxis_flags(sc['start'], sc['goal']))
+            fn.set_agent_params(R, lo, hi)
+        env = E.MACAEnv(v_pref_fn=fn, device_tracker=device)
+        env.set_agents(agents, obstacles=[])
+        if device:
+            assert env.per_agent_attributes == ['turning_radius / pitchlims']
+        trail = []
+        for _ in range(steps):
+            env.step({})
+            trail.append((env.pos.copy(), env.vel.copy(), env.flags.copy()))
+        plans = env.solver.device_tracker_replans() if device else fn.replans()
+        return trail, plans
+
+    host, plans_h = run(False)
+    dev, plans_d = run(True)
+    for t, (h, d) in enumerate(zip(host, dev)):
+        for k in range(3):
+            assert np.array_equal(h[k], d[k]), (n, t, ('pos', 'vel', 'flags')[k])
+    assert np.array_equal(plans_h, plans_d) and plans_h.sum() >= n
 
 
 @pytest.mark.parametrize('name', EPISODES)

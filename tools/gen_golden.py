@@ -872,6 +872,19 @@ def main():
         goal = [[float(v) for v in g_] for g_ in goal]
         pol = [[POL_SCA, POL_SCA, POL_RVO_DUBINS, POL_SRVO][i % 4] for i in range(24)]
         run_env_episode(agent_mod, env_mod, classes, 'F18_hetero_track_circle24', pos, goal, pol, [], 50, outdir=od, attrs=_hetero_track(1801, False))
+    # every tracked agent its OWN (turning_radius, pitchlims): 30 distinct settings -- more than the 16 classes the device tracker's
+    # class form holds, so its per-agent form runs
+    if want('F18_hetero_track_circle30_each'):
+        def _each(n):
+            rng = np.random.default_rng(1805)
+            lo = -(0.35 + 0.4 * rng.random(n))
+            hi = 0.35 + 0.5 * rng.random(n)
+            return dict(turning_radius=np.round(0.8 + 2.2 * rng.random(n), 3), pitchlims=np.stack([lo, hi], 1))
+        pos, goal = rs.set_circle_pos((0, 0), 14.0, 30)
+        pos = [[float(v) for v in p_] for p_ in pos]
+        goal = [[float(v) for v in g_] for g_ in goal]
+        pol = [POL_SCA if i % 4 else POL_RVO_DUBINS for i in range(30)]
+        run_env_episode(agent_mod, env_mod, classes, 'F18_hetero_track_circle30_each', pos, goal, pol, [], 45, outdir=od, attrs=_each)
     if want('F18_hetero_track_takeoff16'):
         obs = [([round(4.0 * np.cos(2 * j * np.pi / 8), 2), round(4.0 * np.sin(2 * j * np.pi / 8), 2), 5.0], 1.0) for j in range(8)]
         pos, goal = rs.set_takeoff_landing_pos(16)
