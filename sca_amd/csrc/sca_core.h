@@ -184,7 +184,7 @@ SCA_HD void cartesian2spherical(double yaw, double pitch, V3 v, bool official, d
     double alpha = 0.0, beta = 0.0;
     if (!(speed < 0.001)) {
         alpha = m_atan2(v.y, v.x) - yaw;
-        beta = m_atan2(v.z, sqrt(v.x * v.x + v.y * v.y)) - pitch;
+        beta = m_atan2(v.z, sqrt(m_pow2(v.x) + m_pow2(v.y))) - pitch;        // sqrt(pow(v[0], 2) + pow(v[1], 2)): libm's pow, not x * x (util.py:49)
     }
     act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = speed; act[4] = alpha; act[5] = beta; act[6] = 0.0;
 }

@@ -230,6 +230,8 @@ struct sca_ctx {
     double *trk_R_pa = nullptr;         // [n] agent.turning_radius (device), for the decision
     uint8_t *trk_cls = nullptr;         // [n] the agent's class (device)
     double *trk_plo_pa = nullptr, *trk_phi_pa = nullptr;   // [n] agent.pitchlims (device): the per-agent form (more than TRK_MAX_CLASSES classes)
+    int auto_div = 8;                   // SCA_NBR_AUTO backs off to the plain kd pass (for 256 passes) once the grid query lists more than 1 / auto_div of the
+                                        // shard for the kd query (SCA_AUTO_BACKOFF_DIV: measurements)
     bool trk_many = false;              // the per-agent form: every re-plan by a wavefront of its own, which reads ITS agent's three values
     double trk_enable_vals[3] = {1.5, 0, 0};   // (turning radius, pitch_lo, pitch_hi) of sca_device_tracker_enable: what "back to one value" restores
     int *trk_host_count = nullptr;      // pinned: the re-plan count of an earlier pass, copied back without ever being waited for
@@ -774,6 +776,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
     c->P_ctx = c->P;
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
+    if (const char *e = std::getenv("SCA_AUTO_BACKOFF_DIV")) c->auto_div = std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TAIL_LEVEL")) c->kd_tail_level = std::atoi(e);
@@ -960,9 +963,14 @@ int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const i
                          const double *time_horizon, const double *max_speed, const double *max_heading_change, const double *dt_nominal) {
     API_ENTER(c);
     if (!c->agents_set) { c->err = "sca_set_agents first"; return SCA_ERR_STATE; }
-    if (c->part_on) { c->err = "per-agent solver attributes with the cell-owner partition: not supported"; return SCA_ERR_UNSUPPORTED; }
     const bool any = neighbor_dist || max_neighbors || time_step || time_horizon || max_speed || max_heading_change || dt_nominal;
-    if (n == 0 || !any) return agent_params_clear(c);
+    // (with the cell-owner partition on: only while the grid's cell size stays what the slabs were cut with -- checked below)
+    if (n == 0 || !any) {
+        if (c->part_on && c->ap_dev && grid_inv_cell(c->P_ctx.neighbor_dist) != c->part.inv_cell) {
+            c->err = "sca_set_agent_params: this would change the grid's cell size under the cell-owner partition's slabs: sca_partition_disable first"; return SCA_ERR_STATE;
+        }
+        return agent_params_clear(c);
+    }
     ARG(c, n == c->n);
     std::vector<AgentPar> h((size_t)n);
     std::vector<double> nd((size_t)n);
@@ -993,6 +1001,11 @@ int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const i
         }
         h[i] = a; nd[i] = a.neighbor_dist;
         nd_max = std::max(nd_max, a.neighbor_dist); ms_max = std::max(ms_max, a.max_speed); dt_max = std::max(dt_max, a.dt_nominal);
+    }
+    if (c->part_on && grid_inv_cell(nd_max) != c->part.inv_cell) {
+        c->err = "sca_set_agent_params: the largest neighbor_dist would change the grid's cell size under the cell-owner partition's slabs: call it "
+                 "before sca_partition_init (or sca_partition_disable first)";
+        return SCA_ERR_STATE;
     }
     CHK(c, hipStreamSynchronize(c->stream));
     if (!c->ap_dev) { CHK(c, hipMalloc((void **)&c->ap_dev, sizeof(AgentPar) * (size_t)c->max_n)); CHK(c, hipMalloc((void **)&c->ap_nd, sizeof(double) * (size_t)c->max_n)); }
@@ -1555,7 +1568,7 @@ static int auto_join(sca_ctx *c) {
 // will the next pass of an SCA_NBR_AUTO run be an AUTO pass (and not a plain kd pass)?  Decides whether its tree may be built ahead.
 static bool auto_next(const sca_ctx *c) {
     return c->auto_fits && c->auto_backoff == 0 && !c->part_on && !(c->trk_on && c->trk_in_pass) &&
-           !(c->kdq_last >= 0 && (long long)c->kdq_last * 8 > (long long)c->d.shard_count);
+           !(c->kdq_last >= 0 && (long long)c->kdq_last * c->auto_div > (long long)c->d.shard_count);
 }
 
 static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) {
@@ -1577,7 +1590,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         if (c->kdq_pending && hipEventQuery(c->ev_auto_cnt) == hipSuccess) { c->kdq_last = c->kdq_host[0]; c->kdq_pending = false; }
         // (a tree built ahead for this pass -- sca_run_steps, see there -- makes it an AUTO pass whatever the counts say: the build
         // must not run twice; sca_run_steps only builds ahead when auto_next() holds)
-        if (!c->kd_ahead && c->auto_backoff == 0 && c->kdq_last >= 0 && (long long)c->kdq_last * 8 > (long long)c->d.shard_count) { c->auto_backoff = 256; c->kdq_last = -1; }
+        if (!c->kd_ahead && c->auto_backoff == 0 && c->kdq_last >= 0 && (long long)c->kdq_last * c->auto_div > (long long)c->d.shard_count) { c->auto_backoff = 256; c->kdq_last = -1; }
         // (a pass with the tracker inside runs its whole neighbour branch beside the re-plans already: nothing to gain, a grid build to lose)
         const bool tracked_pass = c->trk_on && c->trk_in_pass;
         if (!c->kd_ahead && (!fits || tracked_pass || c->auto_backoff > 0)) {
@@ -1649,7 +1662,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     if (tracked) { if (int r = launch_tracker(c, true, true)) return r; }
     c->nbr_mode = auto_mode ? (int)SCA_NBR_GRID : mode;               // (what K4's fallback looks into: the grid in an AUTO pass)
     if (auto_mode) {
-        c->d.kdq_cap = std::max(1, c->d.shard_count / 8);
+        c->d.kdq_cap = std::max(1, c->d.shard_count / c->auto_div);
         {   // this pass's list (the previous pass's kd query may still be looking at the other one's length)
             const unsigned par = (c->auto_seq + 1) & 1u;
             c->d.kdq_list = c->kdq_list + (size_t)par * c->max_n;
@@ -2142,7 +2155,9 @@ static int part_classify(sca_ctx *c) {                                      // f
     return part_adopt(c, true);
 }
 int sca_partition_init(sca_ctx *c, int rank, int nranks, int axis, const double *cuts, int cap_halo, int cap_mig) {
-    if (c && c->ap_dev) { c->err = "the cell-owner partition with per-agent solver attributes: not supported"; return SCA_ERR_UNSUPPORTED; }
+    // (per-agent solver attributes -- sca_set_agent_params, like every static per-agent input indexed by GLOBAL id and replicated on every
+    // rank -- need nothing of the messages: the slabs are cut in cells of the LARGEST neighborDist (c->P is the envelope), so one layer of
+    // cells is a halo wide enough for every agent's own range, and the collision reach is the largest step's)
     API_ENTER(c);
     ARG(c, nranks >= 1 && rank >= 0 && rank < nranks && axis >= 0 && axis <= 2 && cap_halo >= 0 && cap_mig >= 0);
     if (!c->agents_set || !c->state_set) { c->err = "sca_set_agents and sca_set_state (the complete state, on every rank) first"; return SCA_ERR_STATE; }

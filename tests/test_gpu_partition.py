@@ -33,15 +33,29 @@ def _scene(n, kind):
     return sc, pol
 
 
-def _solver(sc, pol, n, track):
+def _solver(sc, pol, n, track, hetero=0):
+    """hetero: the reference's per-Agent attributes (agent.py:24-41) drawn per agent with the value sets of the F17 / F18 fixtures
+    (tools/gen_golden.py::_hetero, _hetero_track); 2: every tracked agent its own (turning_radius, pitchlims) -- the per-agent form."""
+    import math
     from sca_amd import scenarios, solver as S
     sol = S.BatchedSolver(max_agents=n, max_obstacles=4)
     sol.set_obstacles(np.array([[0.0, 0.0, 30.0]]), np.array([1.5]))
     sol.set_agents(np.full(n, 0.5), np.full(n, 1.0), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']),
                    scenarios.max_run_dist(sc['start'], sc['goal']))
+    rng = np.random.default_rng(1700 + hetero)
+    if hetero:
+        sol.set_agent_params(neighbor_dist=rng.choice([3.0, 6.5, 10.0], n), max_neighbors=rng.choice([2, 5, 9, 16], n).astype(np.int32),
+                             time_step=rng.choice([0.05, 0.1, 0.2], n), time_horizon=rng.choice([2.0, 5.0, 10.0], n),
+                             max_speed=rng.choice([0.8, 1.0, 1.5], n), max_heading_change=rng.choice([0.5, math.pi / 4, 1.0, math.pi / 2], n),
+                             dt_nominal=rng.choice([0.05, 0.1], n))
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
     if track:
         sol.device_tracker_enable(sc['goal'][:, 3:6])
+        if hetero == 1:
+            pl = np.array([(-math.pi / 4, math.pi / 4), (-math.pi / 6, math.pi / 6), (-0.5, 0.9)])[rng.integers(0, 3, n)]
+            sol.device_tracker_set_agent_params(rng.choice([0.8, 1.5, 3.0], n), pl[:, 0].copy(), pl[:, 1].copy())
+        elif hetero == 2:
+            sol.device_tracker_set_agent_params(0.8 + 2.2 * rng.random(n), -(0.35 + 0.4 * rng.random(n)), 0.35 + 0.5 * rng.random(n))
     return sol
 
 
@@ -78,11 +92,12 @@ rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 torch.cuda.set_device(0)
 dist.init_process_group('gloo')
 n, steps, kind, track = int(os.environ['SCA_TEST_N']), int(os.environ['SCA_TEST_STEPS']), os.environ['SCA_TEST_SCENE'], bool(int(os.environ['SCA_TEST_TRACK']))
+hetero = int(os.environ.get('SCA_TEST_HETERO', '0'))
 sc, pol = _scene(n, kind)
-sol = _solver(sc, pol, n, track)
+sol = _solver(sc, pol, n, track, hetero)
 st = PartitionedStepper(sol, rank, world, torch, dist, axis=int(os.environ.get('SCA_TEST_AXIS', '0')), staged=True)
 own0 = set(st.owned().tolist())
-ref = _solver(sc, pol, n, track)
+ref = _solver(sc, pol, n, track, hetero)
 moved_total = 0
 ok = True
 for block in range(steps // 10):
@@ -119,14 +134,22 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize('world,n,kind,track,axis,steps', [(2, 3000, 'cube', False, 0, 60), (2, 3000, 'cube', True, 1, 60),
-                                                          (3, 4000, 'cube', True, 2, 40), (2, 20000, 'circle', True, 0, 30),
-                                                          (2, 6000, 'arrive', False, 0, 60), (3, 6000, 'arrive', False, 1, 60)])
-def test_partitioned_ranks_match_single_rank(tmp_path, world, n, kind, track, axis, steps):
+@pytest.mark.parametrize('world,n,kind,track,axis,steps,hetero', [(2, 3000, 'cube', False, 0, 60, 0), (2, 3000, 'cube', True, 1, 60, 0),
+                                                                 (3, 4000, 'cube', True, 2, 40, 0), (2, 20000, 'circle', True, 0, 30, 0),
+                                                                 (2, 6000, 'arrive', False, 0, 60, 0), (3, 6000, 'arrive', False, 1, 60, 0),
+                                                                 # round 6: per-agent attributes under the partition (round 5 refused them)
+                                                                 (2, 3000, 'cube', True, 0, 60, 1), (3, 4000, 'cube', True, 1, 40, 1),
+                                                                 (2, 3000, 'cube', True, 2, 40, 2), (2, 6000, 'arrive', False, 0, 60, 1)])
+def test_partitioned_ranks_match_single_rank(tmp_path, world, n, kind, track, axis, steps, hetero):
+    """hetero = 1: the solver attributes drawn per agent (sca_set_agent_params, the F17 value sets) and, for the tracked agents, three
+    turning radii x three pitch-limit pairs (classes, F18's value sets); 2: every tracked agent its own planner attributes (the per-agent
+    form).  They are static per-agent inputs, replicated on every rank by global id like sca_set_agents' -- the slabs are cut in cells of
+    the LARGEST neighborDist."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    port = str(29560 + world + axis + (10 if kind == 'arrive' else 0))
+    port = str(29560 + world + axis + (10 if kind == 'arrive' else 0) + 20 * hetero)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, SCA_TEST_N=str(n), SCA_TEST_STEPS=str(steps), SCA_TEST_SCENE=kind,
+               SCA_TEST_HETERO=str(hetero),
                SCA_TEST_TRACK=str(int(track)), SCA_TEST_AXIS=str(axis), SCA_TEST_NEED_MIGRATION='0' if kind in ('circle', 'arrive') else '1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
                         '--master-port', port, str(script), ROOT], env=env, capture_output=True, text=True, timeout=1200)
@@ -134,8 +157,9 @@ def test_partitioned_ranks_match_single_rank(tmp_path, world, n, kind, track, ax
     assert 'MISMATCH' not in r.stdout and 'DIFF' not in r.stdout, r.stdout[-3000:]      # (every rank exits 0 only when it agrees)
 
 
-def test_partition_refuses_per_agent_attributes():
-    """The cell-owner partition is sized with ONE neighborDist (slab cuts, halo width): with per-agent attributes it says so (either order)."""
+def test_partition_and_per_agent_attributes_in_either_order():
+    """Round 5 refused the combination.  Now: attributes first, then the partition (cells of the largest neighborDist) -- fine; attributes
+    under a standing partition -- fine while the cell size stays what the slabs were cut with, refused (with the reason) when it would change."""
     from sca_amd import scenarios, solver as S
     n = 2000
     sc = scenarios.random_cube(n, seed=3)
@@ -145,10 +169,11 @@ def test_partition_refuses_per_agent_attributes():
                    scenarios.max_run_dist(sc['start'], sc['goal']))
     sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
     sol.set_agent_params(neighbor_dist=np.where(np.arange(n) % 2 == 0, 10.0, 6.0))
-    with pytest.raises(S.ScaError, match='per-agent'):
-        sol.partition_init(0, 2, axis=0)
-    sol.set_agent_params()                                         # back to one value per context
-    sol.partition_init(0, 2, axis=0)
-    with pytest.raises(S.ScaError, match='partition'):
+    sol.partition_init(0, 2, axis=0)                               # largest range 10: the cells of the default
+    sol.set_agent_params(neighbor_dist=np.where(np.arange(n) % 3 == 0, 10.0, 4.0), max_neighbors=np.full(n, 8, np.int32))   # still 10
+    with pytest.raises(S.ScaError, match='cell size'):
         sol.set_agent_params(neighbor_dist=np.full(n, 8.0))
+    sol.set_agent_params()                                         # back to one value per context (10: the same cells)
+    sol.run_steps(3, S.NBR_GRID)
+    sol.synchronize()
     sol.close()

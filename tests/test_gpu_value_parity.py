@@ -42,8 +42,9 @@ def _solver(scene):
 # far block, its table pieces, the literal way for near problems, and the hand-over between them)
 # ... and so do BASELINE config 5 itself (round 4: 40 steps of ~285 before): take-off / landing N = 16 384 until the last agent is
 # done -- arrivals, the NEAR_GOAL hand-over, agents standing at their goals as obstacles-to-be, with the tracker on the device -- and
-# BASELINE config 2 (N = 1024 circle) for 12 000 steps: the crossing in the middle, arrivals, collisions (97.9 % of the agents are done by
-# then; the last 22 circle each other until the 3 x distance time-out of agent.py:74 at step ~12 400)
+# BASELINE config 2 (N = 1024 circle) for 12 000 steps: the crossing in the middle, arrivals, collisions (~97 % of the agents are done by
+# then; the last two or three dozen circle each other until the 3 x distance time-out of agent.py:74 at step ~12 400 -- how many exactly
+# moved with round 6's bit-exact integration: 22 before, 31 with the device's sin / cos replaced by the restated glibc's)
 @pytest.mark.parametrize('kind,n,steps', [('circle', 1024, 60), ('takeoff', 16384, 40), ('circle', 100000, 12), ('circle', 160, 800),
                                           ('takeoff', 16384, -400), ('circle', 1024, -12000)])
 def test_value_leg_equals_host_tracker_run(kind, n, steps):
@@ -78,7 +79,7 @@ def test_value_leg_equals_host_tracker_run(kind, n, steps):
             break
     if to_the_end:
         fl = b.get_state()['flags']
-        assert ((fl & 7) != 0).mean() > 0.97, f'episode not (nearly) over after {steps} steps: {int(((fl & 7) == 0).sum())} agents still flying'
+        assert ((fl & 7) != 0).mean() > 0.95, f'episode not (nearly) over after {steps} steps: {int(((fl & 7) == 0).sum())} agents still flying'
         assert (fl & 1).mean() > 0.9, 'fewer than 90 % of the agents arrived'
     ra, rb = a.device_tracker_replans()[ext], host.replans()[ext]
     assert np.array_equal(ra, rb)
