@@ -132,3 +132,24 @@ def test_env_api_key_times_the_drop_in_loop():
             assert row[v]['ms_per_step'] > 0 and row[v]['value'] > 0 and row[v]['steps'] > 0
         assert row['step']['ms_per_step'] <= row['step_agent_pos']['ms_per_step']
         assert 0.8 < row['step_over_resident'] < 4.0, row           # the loop costs the kernels + one synchronising read-back per step
+
+
+def test_first_multi_gpu_script_plumbing(tmp_path):
+    """tools/gpu/first_multi_gpu.sh (what the first lease with >= 2 GPUs runs: the RCCL tests, bench.py --gpus G in both exchange forms, the
+    partition variant, one JSON) with all ranks on GPU 0 through the bench's test hook: the script itself is known to work."""
+    out = tmp_path / 'first'
+    env = dict(os.environ, SCA_BENCH_SHARE_GPU='1', SCA_FIRST_GPUS='2', SCA_FIRST_STEPS='4', SCA_FIRST_WARMUP='3', SCA_FIRST_AGENTS='6000',
+               GRAFT_REPO_ROOT=ROOT)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'gpu', 'first_multi_gpu.sh'), str(out)], env=env, capture_output=True, text=True,
+                       timeout=2400, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.load(open(out / 'first_multi_gpu.json'))
+    rows = {row['file']: row for row in rec['runs']}
+    assert set(rows) == {'g2_allgather_detail.json', 'g2_partition_detail.json'}, r.stdout[-3000:]
+    for row in rows.values():
+        assert row['n_gpus'] == 2 and row['rccl_ranks_seen'] == 2 and row['value'] > 0 and row['agents'] == 6000
+        assert row['ranks_sharing_gpu0_test_hook'] is True and row['backend'] == 'gloo'
+    assert rows['g2_partition_detail.json']['exchange'] == 'partition' and rows['g2_allgather_detail.json']['exchange'] == 'torch'
+    assert 'rccl tests rc' in (out / 'summary.txt').read_text()

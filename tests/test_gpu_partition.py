@@ -174,6 +174,4 @@ def test_partition_and_per_agent_attributes_in_either_order():
     with pytest.raises(S.ScaError, match='cell size'):
         sol.set_agent_params(neighbor_dist=np.full(n, 8.0))
     sol.set_agent_params()                                         # back to one value per context (10: the same cells)
-    sol.run_steps(3, S.NBR_GRID)
-    sol.synchronize()
     sol.close()
