@@ -197,6 +197,10 @@ def kernel_forms(forms):
         out.append('k_lp')
     if forms & 32:
         out.append('k_solve_fb')
+    if forms & 64:
+        out.append('k_action_fb')
+    if forms & 128:
+        out.append('kd query of the listed agents as the tail of k_kd_block')
     return out or ['k_solve']
 
 

@@ -240,13 +240,17 @@ int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
  *   SCA_FORM_REPLAN_LANE   the lane-per-plan re-plan kernel was launched (k_replan or k_track_replan)
  *   SCA_FORM_REPLAN_FEW    a k_replan_group kernel (4 .. 64 lanes per plan) was launched
  *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent)
- *   SCA_FORM_SOLVE_FB      k_solve_fb: small shards solve and finish their fallbacks in one launch (no k_fallback launch) */
+ *   SCA_FORM_SOLVE_FB      k_solve_fb: small shards solve and finish their fallbacks in one launch (no k_fallback launch)
+ *   SCA_FORM_ACTION_FB     k_action_fb: shards of up to 16 384 agents run the fallback sweep inside the epilogue's launch (no k_fallback launch)
+ *   SCA_FORM_AUTO_TAIL     SCA_NBR_AUTO: the kd query of the listed agents ran as the tail of the kd build's last kernel (no k_neighbors_kd_auto launch) */
 #define SCA_FORM_SOLVE_SPLIT 1
 #define SCA_FORM_TRACK_FUSED 2
 #define SCA_FORM_REPLAN_LANE 4
 #define SCA_FORM_REPLAN_FEW 8
 #define SCA_FORM_LP_LANE 16
 #define SCA_FORM_SOLVE_FB 32
+#define SCA_FORM_ACTION_FB 64
+#define SCA_FORM_AUTO_TAIL 128
 int sca_last_pass_forms(sca_ctx *ctx, int *forms);
 /* SCA_NBR_AUTO statistics since the last reset: out4 = {AUTO passes, agents the grid query listed for the kd query (sum over the passes), the
  * largest list, passes in which somebody was listed}.  A pass with nobody listed never waits for the kd stream. */

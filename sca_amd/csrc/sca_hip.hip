@@ -196,6 +196,7 @@ struct sca_ctx {
     unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
+    int action_fb_max = 0;              // shards up to this many agents run the fallback sweep inside the epilogue's launch (k_action_fb; SCA_ACTION_FB_MAX)
     int solve_fb_max = 0;               // shards up to this many agents solve and fall back in one launch (SCA_SOLVE_FB_MAX; default: two wavefronts per SIMD)
     bool kd_top = true;                 // SCA_KD_TOP=0: trees of <= KT_M members through the level passes as well (tests, measurements)
     int kd_tail_level = -1;             // SCA_KD_TAIL_LEVEL=l: the level at which the tail launch takes over (tuning / tests; -1: from the statistics)
@@ -265,7 +266,14 @@ struct sca_ctx {
     unsigned *auto_busy = nullptr;      // device word, bit 0: somebody is listed for the kd query and it has not answered yet (hipStreamWaitValue32)
     unsigned auto_seq = 0;
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
-    hipEvent_t ev_auto_kdq[2] = {nullptr, nullptr};      // behind the kd query of the last pass of either parity (its list is reused two passes on)
+    hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq -- a launch of its own, or the tail of the
+                                                         // build's last kernel (KdTail); the pass two on reuses its list and waits for [(seq - 2) & 3]
+    unsigned *auto_sync = nullptr;      // device words of the tail form: [0] k_kd_block's ticket, [1] the last pass whose grid query is complete
+    bool auto_tail_ok = false;          // the tail form is available (stream memory operations work; SCA_AUTO_NO_TAIL=1: never)
+    int auto_tail_max = 32;             // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX)
+    unsigned kd_tail_seq = 0;           // the pass whose build was enqueued in the tail form (0: none)
+    KdTail kd_tail_arg = {};            // what the build being enqueued hands its k_kd_block (seq = 0 outside an AUTO build)
+    hipEvent_t kd_block_stop = nullptr; // ... and the event to record behind it
     hipEvent_t ev_auto_gather[2] = {nullptr, nullptr};   // the gather kernel of the last two builds: the integrate stage must not write into
     unsigned auto_builds = 0;                            // the record buffer a build's gather still reads (the two buffers alternate)
     bool lazy_join = false;             // sca_env_step left kd_stream unjoined: the next entry point other than sca_env_step joins (API_ENTER)
@@ -796,6 +804,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
         c->cus = std::max(1, prop.multiProcessorCount);
         c->simds = 4 * c->cus;
         c->solve_fb_max = std::getenv("SCA_SOLVE_FB_MAX") ? std::atoi(std::getenv("SCA_SOLVE_FB_MAX")) : per_simd(c, 2048);
+        c->action_fb_max = std::getenv("SCA_ACTION_FB_MAX") ? std::atoi(std::getenv("SCA_ACTION_FB_MAX")) : per_simd(c, 16384);
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_kd_lv_rank<false>, KD_LV_T, 0) == hipSuccess && per_cu > 0)
             c->kd_rank_capacity = per_cu * c->cus;
@@ -908,6 +917,7 @@ void sca_destroy(sca_ctx *c) {
     if (c->kdq_count) (void)hipFree(c->kdq_count);
     if (c->kdq_host) (void)hipHostFree(c->kdq_host);
     if (c->auto_busy) (void)hipFree(c->auto_busy);
+    if (c->auto_sync) (void)hipFree(c->auto_sync);
     if (c->auto_ticket) (void)hipFree(c->auto_ticket);
     if (c->d.kdq_stats) (void)hipFree(c->d.kdq_stats);
     for (hipEvent_t e : c->ev_auto_gather) if (e) (void)hipEventDestroy(e);
@@ -1299,12 +1309,13 @@ static int build_agent_tree_device(sca_ctx *c, hipStream_t ks, const DeviceView 
 
     const int sgrid = std::max(1, std::min(1024, 4 * n / wave_max + 2));
     // one workgroup per subtree, in LDS: the smallest form that holds wave_max members (two positions per thread)
-    if (wave_max <= 256) hipLaunchKernelGGL((k_kd_block<256, 128>), dim3(sgrid), dim3(128), 0, ks, d, c->kd, levels);
-    else if (wave_max <= 512) hipLaunchKernelGGL((k_kd_block<512, 256>), dim3(sgrid), dim3(256), 0, ks, d, c->kd, levels);
-    else if (wave_max <= 768) hipLaunchKernelGGL((k_kd_block<768, 384>), dim3(sgrid), dim3(384), 0, ks, d, c->kd, levels);
-    else if (wave_max <= 1024) hipLaunchKernelGGL((k_kd_block<1024, 512>), dim3(sgrid), dim3(512), 0, ks, d, c->kd, levels);
-    else if (wave_max <= 1280) hipLaunchKernelGGL((k_kd_block<1280, 640>), dim3(sgrid), dim3(640), 0, ks, d, c->kd, levels);
-    else hipLaunchKernelGGL((k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), 0, ks, d, c->kd, levels);
+    // (LAUNCH_OPT: an AUTO build in the tail form records the pass's kd-query event behind this kernel)
+    if (wave_max <= 256) LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<256, 128>), dim3(sgrid), dim3(128), ks, d, c->kd, levels, c->kd_tail_arg);
+    else if (wave_max <= 512) LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<512, 256>), dim3(sgrid), dim3(256), ks, d, c->kd, levels, c->kd_tail_arg);
+    else if (wave_max <= 768) LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<768, 384>), dim3(sgrid), dim3(384), ks, d, c->kd, levels, c->kd_tail_arg);
+    else if (wave_max <= 1024) LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<1024, 512>), dim3(sgrid), dim3(512), ks, d, c->kd, levels, c->kd_tail_arg);
+    else if (wave_max <= 1280) LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<1280, 640>), dim3(sgrid), dim3(640), ks, d, c->kd, levels, c->kd_tail_arg);
+    else LAUNCH_OPT(c, c->kd_block_stop, (k_kd_block<KD_WAVE_CAP, KD_WAVE_CAP / 2>), dim3(sgrid), dim3(KD_WAVE_CAP / 2), ks, d, c->kd, levels, c->kd_tail_arg);
     CHK(c, hipGetLastError());
     if (kb1) CHK(c, hipEventRecord(kb1, ks));
     // the tree's depth profile changes slowly: one small readback (a copy sits in the stream between the build and K1) every
@@ -1524,11 +1535,21 @@ static int auto_prepare(sca_ctx *c) {
     CHK(c, hipMemsetAsync(c->d.kdq_stats, 0, sizeof(unsigned long long) * 4, c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
     CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
+    CHK(c, hipMalloc((void **)&c->auto_sync, 4 * sizeof(unsigned)));
+    CHK(c, hipMemsetAsync(c->auto_sync, 0, 4 * sizeof(unsigned), c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     for (hipEvent_t &e : c->ev_auto_gather) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t &e : c->ev_auto_kdq) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->auto_seq = 0; c->auto_builds = 0;
     c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
+    // the tail form (KdTail, sca_kdbuild.hip.h) needs the pass's stream to write a word behind its grid query: tried once, here
+    c->auto_tail_ok = false;
+    if (c->auto_waitvalue && getenv("SCA_AUTO_NO_TAIL") == nullptr) {
+        if (hipStreamWriteValue32(c->stream, c->auto_sync + 1, 0u, 0) == hipSuccess) c->auto_tail_ok = hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!c->auto_tail_ok) (void)hipGetLastError();
+    }
+    if (const char *e = getenv("SCA_AUTO_TAIL_MAX")) c->auto_tail_max = std::max(0, atoi(e));
+    c->kd_tail_seq = 0;
 
     CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
     c->d.kdq_list = c->kdq_list; c->d.kdq_count = c->kdq_count; c->d.kdq_busy = c->auto_busy;
@@ -1546,7 +1567,29 @@ static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *pos
 #endif
     const int keep_skip = c->kd.skip_prep;
     c->kd.aux = 1;
+    // The kd query of the agents this pass's grid query will list: the TAIL of the build's last kernel (KdTail) while the list lengths
+    // that have come back say "a handful at most" -- otherwise a launch of its own behind the build (launch_policy).  The build belongs to
+    // the pass whose grid query comes next: auto_seq + 1, whether it is enqueued inside that pass or ahead of it (sca_run_steps).
+    const unsigned seq = c->auto_seq + 1;
+    c->kd_tail_arg = KdTail{};
+    c->kd_block_stop = nullptr;
+    if (c->auto_tail_ok && c->auto_waitvalue && seq != 0 && c->kdq_last >= 0 && c->kdq_last <= c->auto_tail_max) {
+        // (the list of this parity was last read by the kd query of two passes ago, whose event slot is about to be recorded anew: the
+        // pass's stream waits for it HERE instead of in front of its grid build)
+        if (seq >= 3) { if (int r = wait_if_pending(c, c->stream, c->ev_auto_kdq[(seq - 2) & 3u])) return r; }
+        KdTail T;
+        T.seq = seq; T.sync = c->auto_sync;
+        T.list = c->kdq_list + (size_t)(seq & 1u) * c->max_n; T.count = c->kdq_count + (seq & 1u);
+        T.cap = std::max(1, c->d.shard_count / c->auto_div);
+        T.busy = c->auto_busy; T.stats = c->d.kdq_stats;
+        collide_reach(c, T.agent_reach, T.obs_reach);
+        T.max_radius = c->max_radius; T.P = c->P;
+        c->kd_tail_arg = T;
+        c->kd_tail_seq = seq;
+        c->kd_block_stop = c->ev_auto_kdq[seq & 3u];
+    }
     const int r = build_agent_tree_device(c, c->kd_stream, v);
+    c->kd_tail_arg = KdTail{}; c->kd_block_stop = nullptr;
     c->kd.aux = 0; c->kd.skip_prep = keep_skip;
     return r;
 }
@@ -1668,7 +1711,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->d.kdq_list = c->kdq_list + (size_t)par * c->max_n;
             c->d.kdq_count = c->kdq_count + par;
             // ... which the kd query of two passes ago must be through with (it is, unless the kd stream lags by two whole passes)
-            if (c->auto_seq >= 2) { if (int r = wait_if_pending(c, c->nbr_stream, c->ev_auto_kdq[par])) return r; }
+            // (slot [(seq - 2) & 3], seq = auto_seq + 1; a build enqueued in the tail form has made the pass's stream wait already)
+            if (c->auto_seq >= 2 && c->kd_tail_seq != c->auto_seq + 1) { if (int r = wait_if_pending(c, c->nbr_stream, c->ev_auto_kdq[(c->auto_seq - 1) & 3u])) return r; }
         }
         if (int r = build_agent_grid_device(c)) return r;
     }
@@ -1718,16 +1762,23 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         // the agents the grid query listed (more than max_neighbors in range, equal distances) get the kd-tree's answer: behind the
         // build on kd_stream, and nothing reads a list before that query is through
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
-        CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)
-        // (ev_auto_kdq: also "the last kd query": auto_join and the event form of the wait)
-        LAUNCH_REC(c, c->ev_auto_kdq[seq & 1u], k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS),
-                   dim3(K1_WAVES * 64), c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius, c->auto_ticket);
+        if (c->kd_tail_seq == seq && seq != 0) {
+            // the tail form: this pass's build answers the listed agents in its last kernel (KdTail) once this word says the grid query
+            // is through -- no launch, no cross-stream wait on the build's stream
+            CHK(c, hipStreamWriteValue32(ns, c->auto_sync + 1, seq, 0));
+            c->forms |= SCA_FORM_AUTO_TAIL;
+        } else {
+            CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)
+            // (ev_auto_kdq: also "the last kd query": auto_join and the event form of the wait)
+            LAUNCH_REC(c, c->ev_auto_kdq[seq & 3u], k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS),
+                       dim3(K1_WAVES * 64), c->kd_stream, d, c->P, agent_reach, obs_reach, c->max_radius, c->auto_ticket);
+        }
         if (!c->kdq_pending && (c->auto_passes++ & 3u) == 0) {       // how many were listed: for later passes' choice, never waited for
             CHK(c, hipMemcpyAsync(c->kdq_host, d.kdq_count, sizeof(int), hipMemcpyDeviceToHost, c->kd_stream));
             CHK(c, hipEventRecord(c->ev_auto_cnt, c->kd_stream));
             c->kdq_pending = true;
         }
-        c->ev_auto_kd = c->ev_auto_kdq[seq & 1u];
+        c->ev_auto_kd = c->ev_auto_kdq[seq & 3u];
         if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_neighbors_kd_auto)
             if (hipStreamWaitValue32(ns, c->auto_busy, 0u, hipStreamWaitValueEq, 1u) != hipSuccess) {
@@ -1781,11 +1832,17 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         if (int r = wait_if_pending(c, c->stream, c->ev_auto_gather[c->auto_builds & 1u])) return r;       // [builds & 1] = the one before the last
         c->auto_unjoined = true;                                        // (ii) see auto_join
     }
+    // (small shards: the fallback sweep rides in the epilogue's launch -- k_action_fb -- instead of in front of it)
+    const bool action_fb = !solve_fb && cnt <= c->action_fb_max;
+    if (action_fb) c->forms |= SCA_FORM_ACTION_FB;
     if (fuse_integrate) {
-        if (!solve_fb) hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-        if (c->action_stop) LAUNCH_REC(c, c->action_stop, k_action<true>, dim3(ablocks), dim3(256), c->stream, d, c->P);
-        else hipLaunchKernelGGL(k_action<true>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
-    } else {
+        if (action_fb) LAUNCH_OPT(c, c->action_stop, k_action_fb<true>, dim3(ablocks + FB_BLOCKS_SMALL), dim3(SOLVE_WAVES * 64), c->stream, d, c->P, ablocks);
+        else {
+            if (!solve_fb) hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+            LAUNCH_OPT(c, c->action_stop, k_action<true>, dim3(ablocks), dim3(256), c->stream, d, c->P);
+        }
+    } else if (action_fb) hipLaunchKernelGGL(k_action_fb<false>, dim3(ablocks + FB_BLOCKS_SMALL), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P, ablocks);
+    else {
         if (!solve_fb) hipLaunchKernelGGL(k_fallback<false>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
         hipLaunchKernelGGL(k_action<false>, dim3(ablocks), dim3(256), 0, c->stream, d, c->P);
     }
@@ -1918,6 +1975,18 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode, bool lazy);
 static void auto_abandon(sca_ctx *c) {
     c->lazy_join = false;
     c->kd_ahead = false; c->kdq_last = -1; c->kdq_pending = false; c->auto_backoff = 0;
+    if (c->kd_stream && c->auto_sync && c->kd_tail_seq != 0) {
+        // a build in the tail form may be waiting for the word its pass never wrote: write it (from a stream of its own -- the context's
+        // may itself be waiting for that tail); its list is empty or stale, the error the caller gets says the pass did not happen
+        hipStream_t t = nullptr;
+        if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipStreamWriteValue32(t, c->auto_sync + 1, c->kd_tail_seq, 0);
+            (void)hipStreamSynchronize(t);
+            (void)hipStreamDestroy(t);
+        }
+        (void)hipGetLastError();
+    }
+    c->kd_tail_seq = 0;
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipGetLastError(); }
     c->auto_unjoined = false;
 }

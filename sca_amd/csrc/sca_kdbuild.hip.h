@@ -80,6 +80,26 @@ struct KdScratch {
                               //    k_kd_gather touches neither
 };
 
+// SCA_NBR_AUTO (round 6): the kd query of the agents the pass's grid query listed, as the TAIL of the build's last kernel instead of a
+// launch of its own behind it (k_neighbors_kd_auto).  The kd build of an AUTO pass is a loop of its own beside the step -- every build
+// starts from the previous one's permutation -- and at N = 4096 that loop, not the pass, sets the step's pace
+// (profiles/r06_a_c3_auto_device_timeline.json: gather 3.0 + top 23.3 + block 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the
+// 78.5-us step); the query's launch cost the loop two of its four gaps, one of them a cross-stream event wait, to find its list empty.
+// Now the workgroup of k_kd_block that finishes LAST waits until the pass's grid query is through (a word the pass's stream writes
+// behind that kernel: hipStreamWriteValue32 -- the query was enqueued before this build's tail can possibly spin, so the wait cannot
+// starve it), reads the list's length, and answers the listed agents itself, a wavefront per agent over the block's LDS.  The host takes
+// this form while the counts that come back say "a handful at most" (sca_hip.hip: AUTO_TAIL_MAX); longer lists keep the launch.
+struct KdTail {
+    unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: no tail
+    unsigned *sync;           // [0] workgroups of k_kd_block through, [1] the last pass whose grid query is complete
+    int32_t *list, *count;    // that pass's list of agents for the kd query (the two lists alternate by pass)
+    int cap;                  // a count above it: "too many for a list" -- every agent of the shard
+    unsigned *busy;           // bit 0: somebody is listed and not answered yet (the pass's stream waits for 0)
+    unsigned long long *stats;
+    double agent_reach, obs_reach, max_radius;
+    Params P;
+};
+
 // order-preserving map double -> u64 so that integer atomics give exact min / max
 __device__ __forceinline__ unsigned long long dkey(double x) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(x);
@@ -569,8 +589,49 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 #define KB_MARK() do { } while (0)
 #endif
 
+// KdTail: see there.  Every workgroup of k_kd_block comes through here when its subtrees are done.
+template <int KBT>
+__device__ __forceinline__ void kd_auto_tail(const DeviceView &d, const KdScratch &s, const KdTail &T, double (*stacks)[16]) {
+    __shared__ int tail_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __syncthreads();                                                     // (the workgroup's last subtree is written)
+    if (tid == 0) {
+        __threadfence();                                                 // ... and visible before the ticket says so
+        tail_last = atomicAdd(T.sync, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!tail_last) return;
+    if (tid == 0) {
+        atomicExch(T.sync, 0u);                                          // (the next build's ticket starts at 0)
+        int spins = 0;                                                   // the pass's grid query: usually long through (the build is the longer chain)
+        while ((int)(__hip_atomic_load(T.sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - T.seq) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 22)) { atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_SPIN); break; }     // (seconds: the pass was abandoned)
+        }
+        __threadfence();                                                 // the other workgroups' tree, the query's list: read afresh
+    }
+    __syncthreads();
+    const int n = __hip_atomic_load(T.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (T.stats && tid == 0) {                                           // statistics, as k_neighbors_kd_auto keeps them
+        T.stats[0] += 1; T.stats[1] += (unsigned long long)n;
+        if ((unsigned long long)n > T.stats[2]) T.stats[2] = (unsigned long long)n;
+        if (n > 0) T.stats[3] += 1;
+    }
+    if (n == 0) return;
+    constexpr int NW = KBT / 64;
+    double (*rst)[16] = stacks + (size_t)wid * KD_RSTACK;
+    if (n <= T.cap) {
+        for (int i = wid; i < n; i += NW) neighbors_one(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, rst, T.list[i], lane);
+    } else {
+        for (int i = wid; i < d.shard_count; i += NW) neighbors_one(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, rst, d.shard_begin + i, lane);
+    }
+    __syncthreads();
+    if (tid == 0) { __threadfence(); atomicAnd(T.busy, ~1u); }
+}
+
 template <int KBM, int KBT>
-__global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int levels_run) {
+__global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int levels_run, KdTail T) {
     SCA_TL(d, TL_KD_BLOCK);
     SCA_KD_SETPRIO();
     static_assert(KBM == 2 * KBT, "k_kd_block is written for two consecutive positions per thread");
@@ -797,6 +858,10 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
             d.aperm[base + i] = S.id[i];
             s.kx[base + i] = S.x[KB_SW(i)]; s.ky[base + i] = S.y[KB_SW(i)]; s.kz[base + i] = S.z[KB_SW(i)];     // final position order: K1 reads leaves from here
         }
+    }
+    if (T.seq != 0) {
+        static_assert(sizeof(KbLds<KBM, KBT>) >= (size_t)(KBT / 64) * KD_RSTACK * 16 * sizeof(double), "the tail's record stacks live in the block's LDS");
+        kd_auto_tail<KBT>(d, s, T, reinterpret_cast<double (*)[16]>(&S));
     }
 }
 

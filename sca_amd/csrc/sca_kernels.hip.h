@@ -1872,6 +1872,38 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_fallback(DeviceView d, Par
     }
 }
 
+// k_fallback and k_action in ONE launch, for shards of so few agents that the epilogue's handful of workgroups does not care about its
+// register allocation (round 6).  The two never touch the same agent and need no order between them (above); as two launches the
+// fallback sweep -- 0.7 us of work at c3, its list empty in most passes -- cost a dispatch and its gap (6.5 us of a 70-us chain:
+// profiles/r05_c3_auto_device_timeline.json) on every pass's critical path.  Workgroups [0, ablocks) are k_action's, the rest stride over
+// the fallback list like k_fallback's.  Larger shards keep the two launches: there the one-lane-per-agent epilogue wants its own 66
+// registers (k_action's note above), and the extra dispatch is a smaller share of the step.
+constexpr int FB_BLOCKS_SMALL = 64;
+template <bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action_fb(DeviceView d, Params P, int ablocks) {
+    SCA_TL(d, TL_ACTION);
+    __shared__ SolveLds S;
+    if ((int)blockIdx.x < ablocks) {
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= shard_size(d)) return;
+        const int agent = shard_agent(d, idx);
+        const int kind = d.is_fb[agent];
+        if (kind == 1) return;
+        action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *d.fb_count;
+    for (int i = ((int)blockIdx.x - ablocks) * SOLVE_WAVES + wid; i < n; i += FB_BLOCKS_SMALL * SOLVE_WAVES) {
+        const int agent = d.fb_list[i];
+        solve_one(d, P, S, agent, lane, wid);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) action_one<FUSE_INTEGRATE>(d, P, agent, false);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     SCA_TL(d, TL_ACTION);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;

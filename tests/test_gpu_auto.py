@@ -146,3 +146,58 @@ def test_events_as_stop_events_change_no_bit(kind, n, tracked, mode, monkeypatch
         assert np.array_equal(a.actions(), b.actions()) and np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (kind, burst)
         assert np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id']), (kind, burst)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('kind,n,burst,div', [('dense', 600, 4, 1), ('lattice', 1000, 6, 1), ('dense', 600, 1, 1), ('cube', 4096, 8, 8), ('lattice', 3375, 1, 2)])
+def test_tail_form_answers_the_listed_agents(kind, n, burst, div, monkeypatch):
+    """Round 6: the kd query of the agents the grid query lists runs as the TAIL of the kd build's last kernel (KdTail,
+    sca_kdbuild.hip.h) instead of a launch of its own, once the list lengths that come back are known and small.  Forced here for ANY
+    length (SCA_AUTO_TAIL_MAX) on scenes where hundreds are listed -- dense: more than 16 in range; lattice: ties everywhere, "too many
+    for a list" = everybody -- with the back-off to the plain kd pass moved out of the way (SCA_AUTO_BACKOFF_DIV): everything must equal
+    SCA_NBR_KDTREE, bursts (builds enqueued ahead) and single steps, and the passes must really have taken the tail."""
+    from sca_amd import solver as S
+    monkeypatch.setenv('SCA_AUTO_TAIL_MAX', str(1 << 30))
+    monkeypatch.setenv('SCA_AUTO_BACKOFF_DIV', str(div))
+    sc, pol, n = _scene(kind, n, seed=7)
+    a, b = _solver(sc, pol, n, False), _solver(sc, pol, n, False)
+    tails = 0
+    for t in range(0, 36, burst):
+        a.run_steps(burst, S.NBR_KDTREE); b.run_steps(burst, S.NBR_AUTO)
+        a.synchronize(); b.synchronize()
+        tails += bool(b.pass_forms() & S.FORM_AUTO_TAIL)
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (kind, n, t, k, int((sa[k] != sb[k]).sum()))
+        assert np.array_equal(a.actions(), b.actions()), (kind, t)
+        na, nb = a.neighbors(), b.neighbors()
+        for k in ('nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq'):
+            assert np.array_equal(na[k], nb[k]), (kind, n, t, k)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (kind, t)
+        assert np.array_equal(a.diag()['status'], b.diag()['status']), (kind, t)
+    st = b.auto_stats()
+    assert tails >= 2, (kind, tails, st)                                   # (the first passes run the launch form: no count has come back yet)
+    if kind != 'cube':
+        assert st['passes_with_a_list_frac'] > 0 and st['listed_per_pass_max'] > 0, st       # somebody WAS listed while the tail form ran
+    a.close(); b.close()
+
+
+def test_tail_form_off_equals_on(monkeypatch):
+    """SCA_AUTO_NO_TAIL=1 (the launch form on every pass) against the default on c3's own scene: the same bits, and the default takes the tail"""
+    from sca_amd import solver as S
+    sc, pol, n = _scene('cube', 4096, seed=2)
+    monkeypatch.setenv('SCA_AUTO_NO_TAIL', '1')
+    a = _solver(sc, np.full(n, 3, np.uint8), n, False)
+    monkeypatch.delenv('SCA_AUTO_NO_TAIL')
+    b = _solver(sc, np.full(n, 3, np.uint8), n, False)
+    seen = 0
+    for burst in (1, 7, 1, 10, 3, 12):
+        a.run_steps(burst, S.NBR_AUTO); b.run_steps(burst, S.NBR_AUTO)
+        a.synchronize(); b.synchronize()
+        assert not (a.pass_forms() & S.FORM_AUTO_TAIL)
+        seen += bool(b.pass_forms() & S.FORM_AUTO_TAIL)
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (burst, k)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()) and np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id']), burst
+    assert seen >= 3, seen
+    a.close(); b.close()
