@@ -148,11 +148,10 @@ __device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long 
 // AUTO (SCA_NBR_AUTO): a list the grid cannot give exactly -- it overflowed, or two neighbours of one kind have the same rounded distance
 // (the reference orders those by the kd-tree's visit order, agent.py:87-90: append, stable sort) -- is not flagged but handed to the kd
 // query (d.kdq_list); every other list IS the reference's, entry for entry: a sorted list without ties has one order.
+// (the kernel's body; `listed` comes back true for the lanes of a group whose agent went onto the kd query's list)
 template <bool AUTO>
-__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
-                                                                  double obs_reach, double max_radius) {
-    SCA_TL(d, TL_NBR_GRID);
-    SCA_K1_SETPRIO();
+__device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const GridDev &g, const Params &P, double agent_reach,
+                                                    double obs_reach, double max_radius, bool &listed) {
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
     __shared__ int pfx[K1P_WAVES][K1P_APW][32], fpos[K1P_WAVES][K1P_APW][32];
     __shared__ unsigned long long pkey[K1P_WAVES][K1P_APW][32];
@@ -378,6 +377,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
                 const int at = base + __popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull));
                 if (at < d.n) d.kdq_list[at] = agent;
             }
+            listed = true;                                               // (the whole wavefront: its workgroup fences before it reports)
         }
     }
     d.nbr_id[agent * K_MAX + gl] = (gl < cnt) ? Li : -1;
@@ -388,6 +388,31 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
         d.coll_new[agent] = coll ? 1u : 0u;
         d.status[agent] = st;
         d.near_n[agent] = complete ? near_cnt : -1;
+    }
+}
+
+template <bool AUTO>
+__global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
+                                                                  double obs_reach, double max_radius) {
+    SCA_TL(d, TL_NBR_GRID);
+    SCA_K1_SETPRIO();
+    bool listed = false;
+    neighbors_grid_body<AUTO>(d, g, P, agent_reach, obs_reach, max_radius, listed);
+    if (AUTO && d.auto_sync) {
+        // The tail form of the kd query (KdTail, sca_kdbuild.hip.h): the build's last kernel, on ANOTHER stream, answers the listed agents
+        // once this launch is through -- which its last workgroup says here, by ticket, instead of a packet on the pass's stream behind
+        // the launch (hipStreamWriteValue32: 82.5 -> 86.5 us per step at c3, measured: a dispatch of its own on the pass's chain).
+        // A workgroup that listed nobody publishes nothing but its count atomics, whose results it holds: no fence.  One that did list
+        // somebody first writes back what it stored -- the list entries, and the lists the kd query is about to overwrite from another
+        // XCD -- before its ticket says "through".
+        if (__syncthreads_or(listed ? 1 : 0)) __threadfence();
+        else __syncthreads();
+        if (threadIdx.x == 0) {
+            if (__hip_atomic_fetch_add(d.auto_sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                __hip_atomic_store(d.auto_sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.auto_sync + 1, d.auto_pass_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

@@ -269,7 +269,8 @@ struct sca_ctx {
     hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq -- a launch of its own, or the tail of the
                                                          // build's last kernel (KdTail); the pass two on reuses its list and waits for [(seq - 2) & 3]
     unsigned *auto_sync = nullptr;      // device words of the tail form: [0] k_kd_block's ticket, [1] the last pass whose grid query is complete
-    bool auto_tail_ok = false;          // the tail form is available (stream memory operations work; SCA_AUTO_NO_TAIL=1: never)
+    bool auto_tail_ok = false;          // the tail form is available (with the wait-value form of the pass's wait; SCA_AUTO_NO_TAIL=1, read at sca_create: never)
+    bool auto_no_tail = false;
     int auto_tail_max = 32;             // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX)
     unsigned kd_tail_seq = 0;           // the pass whose build was enqueued in the tail form (0: none)
     KdTail kd_tail_arg = {};            // what the build being enqueued hands its k_kd_block (seq = 0 outside an AUTO build)
@@ -785,6 +786,8 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P_ctx = c->P;
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_AUTO_BACKOFF_DIV")) c->auto_div = std::min(64, std::max(1, std::atoi(e)));
+    c->auto_no_tail = std::getenv("SCA_AUTO_NO_TAIL") != nullptr;
+    if (const char *e = std::getenv("SCA_AUTO_TAIL_MAX")) c->auto_tail_max = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_TAIL_LEVEL")) c->kd_tail_level = std::atoi(e);
@@ -1542,13 +1545,8 @@ static int auto_prepare(sca_ctx *c) {
     for (hipEvent_t &e : c->ev_auto_kdq) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->auto_seq = 0; c->auto_builds = 0;
     c->auto_waitvalue = getenv("SCA_AUTO_EVENT_WAIT") == nullptr;
-    // the tail form (KdTail, sca_kdbuild.hip.h) needs the pass's stream to write a word behind its grid query: tried once, here
     c->auto_tail_ok = false;
-    if (c->auto_waitvalue && getenv("SCA_AUTO_NO_TAIL") == nullptr) {
-        if (hipStreamWriteValue32(c->stream, c->auto_sync + 1, 0u, 0) == hipSuccess) c->auto_tail_ok = hipStreamSynchronize(c->stream) == hipSuccess;
-        if (!c->auto_tail_ok) (void)hipGetLastError();
-    }
-    if (const char *e = getenv("SCA_AUTO_TAIL_MAX")) c->auto_tail_max = std::max(0, atoi(e));
+    c->auto_tail_ok = c->auto_waitvalue && !c->auto_no_tail;
     c->kd_tail_seq = 0;
 
     CHK(c, hipHostMalloc((void **)&c->kdq_host, sizeof(int)));
@@ -1743,6 +1741,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const hipEvent_t sweep_stop = overlap && split && c->ext_stop ? c->trk_join : nullptr;
     if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
+        // (the tail form: the grid query reports by ticket that it is through; d is c->d)
+        c->d.auto_sync = c->kd_tail_seq == c->auto_seq + 1 && c->kd_tail_seq != 0 ? c->auto_sync : nullptr;
+        c->d.auto_pass_seq = c->auto_seq + 1;
         LAUNCH_REC(c, c->ev_auto_k1g, k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
                    c->P, agent_reach, obs_reach, c->max_radius);
     } else if (mode == SCA_NBR_GRID) {
@@ -1763,9 +1764,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         // build on kd_stream, and nothing reads a list before that query is through
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
         if (c->kd_tail_seq == seq && seq != 0) {
-            // the tail form: this pass's build answers the listed agents in its last kernel (KdTail) once this word says the grid query
-            // is through -- no launch, no cross-stream wait on the build's stream
-            CHK(c, hipStreamWriteValue32(ns, c->auto_sync + 1, seq, 0));
+            // the tail form: this pass's build answers the listed agents in its last kernel (KdTail) once the grid query's last workgroup
+            // has said it is through (k_neighbors_grid<true>) -- no launch, no cross-stream wait on the build's stream
             c->forms |= SCA_FORM_AUTO_TAIL;
         } else {
             CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)

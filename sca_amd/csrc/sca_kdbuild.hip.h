@@ -85,13 +85,13 @@ struct KdScratch {
 // starts from the previous one's permutation -- and at N = 4096 that loop, not the pass, sets the step's pace
 // (profiles/r06_a_c3_auto_device_timeline.json: gather 3.0 + top 23.3 + block 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the
 // 78.5-us step); the query's launch cost the loop two of its four gaps, one of them a cross-stream event wait, to find its list empty.
-// Now the workgroup of k_kd_block that finishes LAST waits until the pass's grid query is through (a word the pass's stream writes
-// behind that kernel: hipStreamWriteValue32 -- the query was enqueued before this build's tail can possibly spin, so the wait cannot
-// starve it), reads the list's length, and answers the listed agents itself, a wavefront per agent over the block's LDS.  The host takes
+// Now the workgroup of k_kd_block that finishes LAST waits until the pass's grid query is through (a word that launch's last workgroup
+// writes, k_neighbors_grid<true>; the launch is ahead of this kernel in the host's order, so the wait cannot starve it), reads the list's
+// length, and answers the listed agents itself, a wavefront per agent over the block's LDS.  The host takes
 // this form while the counts that come back say "a handful at most" (sca_hip.hip: AUTO_TAIL_MAX); longer lists keep the launch.
 struct KdTail {
     unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: no tail
-    unsigned *sync;           // [0] workgroups of k_kd_block through, [1] the last pass whose grid query is complete
+    unsigned *sync;           // [0] workgroups of k_kd_block through, [1] the last pass whose grid query is complete, [2] that query's ticket
     int32_t *list, *count;    // that pass's list of agents for the kd query (the two lists alternate by pass)
     int cap;                  // a count above it: "too many for a list" -- every agent of the shard
     unsigned *busy;           // bit 0: somebody is listed and not answered yet (the pass's stream waits for 0)
