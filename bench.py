@@ -259,6 +259,26 @@ def leg_roofline(leg, steps, tracked, wname, mode_name='kd'):
                       + (' (on its own stream beside the pass)' if auto else ''), leg['kd_build_ms'], 216, leg.get('n_all', per_launch), 'agent in the tree'))
     if tracked and leg['replan_ms'] > 0:
         cands.append(('re-plan kernel (k_replan / k_replan_group)', leg['replan_ms'], BYTES_PER_REPLAN, leg['my_plans'] / max(steps, 1), 're-plan'))
+    if auto:
+        # An AUTO step at this size is two dependent CHAINS, not one kernel: the pass on the context's stream (grid count / alloc / fill,
+        # grid query, [wait], solve, epilogue, collision check: 7-8 dispatches) and beside it the kd-build loop on a stream of its own
+        # (gather -> top -> block [+ the kd query of the listed agents]), each build starting from the previous one's permutation.  The
+        # LONGER chain paces the step and most of either is the gap between dependent dispatches.  So the leg's entry is
+        # the whole step -- SURVEY 8(d)'s 880 B per agent-step over the step's wall time, measured live -- with the chains' lengths and the
+        # chip's idle share from the device-side timeline of the same command (profiles/, a debug build's stamps); the kernels the library
+        # times stay under candidates_ms.
+        tl = _timeline(wname, 'auto')
+        ms = leg['ms_per_step']
+        gbs = BYTES_PER_AGENT_STEP * per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out = {'bound': 'hbm', 'kernel': 'the AUTO step\'s two dependent chains -- the pass (k_grid_count .. k_collide_finish) and the kd-build loop beside it '
+                                         '(k_kd_gather -> k_kd_top -> k_kd_block + the kd query of the listed agents as its tail): the longer one paces the step',
+               'kernel_short': 'AUTO step: pass chain | kd-build loop (latency of dependent dispatches)',
+               'kernel_ms': ms, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+               'bytes_per_unit': BYTES_PER_AGENT_STEP, 'unit_name': 'agent-step (whole step)', 'units_per_launch': per_launch,
+               'traffic': None, 'valu_issue_frac': None,
+               'candidates_ms': {c[0].split(' ')[0] if not c[0].startswith('kd build') else 'kd_build': round(c[1], 5) for c in cands}}
+        out.update(tl)
+        return out
     name, ms, bpu, units, uname = max(cands, key=lambda t: t[1])
     gbs = bpu * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {'bound': 'hbm', 'kernel': name, 'kernel_ms': ms, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
@@ -1036,6 +1056,30 @@ def step_valu_busy(wname, ms_per_step):
         busy_us += us
     return {'frac': busy_us / (ms_per_step * 1e3), 'valu_busy_us_per_simd_per_step': round(busy_us, 1), 'by_kernel_us': parts,
             'source': 'VALU wave-instructions per launch from the PMC capture of this workload (profiles/r0x_pmc_traffic.json) / calibrated mix rates'}
+
+
+def _timeline(wname, mode):
+    """chains of an AUTO step from the committed device-side timeline of `tools/device_timeline.py <wname> --nbr <mode>` (stamps of a
+    -DSCA_TIMELINE build, medians over 38 steps): length of the pass's chain and of the kd-build loop, kernel time inside them, the step
+    window and the chip's idle share.  {} when no capture is committed."""
+    for rnd in ('r06', 'r05'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{rnd}_{wname}_{mode}_device_timeline.json')) as f:
+                d = json.load(f)['summary']
+        except (OSError, ValueError, KeyError):
+            continue
+        ks = d.get('kernels_median', [])
+        kd = [k for k in ks if k['k'].startswith(('k_kd_', 'k_neighbors_kd_auto'))]
+        main = [k for k in ks if not k['k'].startswith(('k_kd_', 'k_neighbors_kd_auto'))]
+        if not kd or not main or not d.get('wall_us_median'):
+            continue
+        return {'chip_idle_frac': d['chip_idle_us_median'] / d['wall_us_median'], 'step_window_us': d['wall_us_median'],
+                'pass_chain_us': round(max(k['end_us'] for k in main) - min(k['start_us'] for k in main), 2),
+                'pass_chain_kernel_us': round(sum(k['dur_us'] for k in main), 2), 'pass_chain_dispatches': len(main),
+                'kd_loop_us': round(max(k['end_us'] for k in kd) - min(k['start_us'] for k in kd), 2),
+                'kd_loop_kernel_us': round(sum(k['dur_us'] for k in kd), 2), 'kd_loop_dispatches': len(kd),
+                'timeline_source': f'profiles/{rnd}_{wname}_{mode}_device_timeline.json'}
+    return {}
 
 
 def _pmc(wname):

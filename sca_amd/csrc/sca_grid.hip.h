@@ -24,6 +24,7 @@
 //                  sorted list one entry per lane
 #pragma once
 #include "sca_kernels.hip.h"
+#include "sca_kdbuild.hip.h"      // kd_answer_listed / auto_arrive_second (the launch-free form of SCA_NBR_AUTO's kd query)
 
 namespace sca {
 
@@ -399,20 +400,26 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
     bool listed = false;
     neighbors_grid_body<AUTO>(d, g, P, agent_reach, obs_reach, max_radius, listed);
     if (AUTO && d.auto_sync) {
-        // The tail form of the kd query (KdTail, sca_kdbuild.hip.h): the build's last kernel, on ANOTHER stream, answers the listed agents
-        // once this launch is through -- which its last workgroup says here, by ticket, instead of a packet on the pass's stream behind
-        // the launch (hipStreamWriteValue32: 82.5 -> 86.5 us per step at c3, measured: a dispatch of its own on the pass's chain).
-        // A workgroup that listed nobody publishes nothing but its count atomics, whose results it holds: no fence.  One that did list
-        // somebody first writes back what it stored -- the list entries, and the lists the kd query is about to overwrite from another
-        // XCD -- before its ticket says "through".
+        // The launch-free form of the kd query (KdTail, sca_kdbuild.hip.h): this launch's last workgroup -- by ticket -- arrives at the
+        // pass's word; if the pass's kd build has arrived already, it answers the listed agents here and now, otherwise the build's last
+        // workgroup will.  A workgroup that listed nobody publishes nothing but its count atomics, whose results it holds: no fence.  One
+        // that did list somebody first writes back what it stored -- the list entries, and the lists the kd query is about to overwrite
+        // from another XCD -- before its ticket says "through".
+        __shared__ int grid_second;
+        __shared__ double rst[K1P_WAVES * KD_RSTACK][16];
         if (__syncthreads_or(listed ? 1 : 0)) __threadfence();
         else __syncthreads();
         if (threadIdx.x == 0) {
+            int second = 0;
             if (__hip_atomic_fetch_add(d.auto_sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(d.auto_sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(d.auto_sync + 1, d.auto_pass_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                second = auto_arrive_second(d.auto_sync, d.auto_pass_seq) ? 1 : 0;
             }
+            grid_second = second;
         }
+        __syncthreads();
+        if (grid_second)
+            kd_answer_listed<K1P_WAVES>(d, P, agent_reach, obs_reach, max_radius, d.kdq_list, d.kdq_count, d.kdq_cap, d.kdq_busy, d.kdq_stats, rst);
     }
 }
 

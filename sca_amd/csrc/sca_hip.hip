@@ -268,7 +268,7 @@ struct sca_ctx {
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
     hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq -- a launch of its own, or the tail of the
                                                          // build's last kernel (KdTail); the pass two on reuses its list and waits for [(seq - 2) & 3]
-    unsigned *auto_sync = nullptr;      // device words of the tail form: [0] k_kd_block's ticket, [1] the last pass whose grid query is complete
+    unsigned *auto_sync = nullptr;      // device words of the launch-free form (KdTail): [0] k_kd_block's ticket, [2] the grid query's, [4 + (seq & 3)] the pass's arrival word
     bool auto_tail_ok = false;          // the tail form is available (with the wait-value form of the pass's wait; SCA_AUTO_NO_TAIL=1, read at sca_create: never)
     bool auto_no_tail = false;
     int auto_tail_max = 32;             // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX)
@@ -1538,8 +1538,8 @@ static int auto_prepare(sca_ctx *c) {
     CHK(c, hipMemsetAsync(c->d.kdq_stats, 0, sizeof(unsigned long long) * 4, c->stream));
     CHK(c, hipMalloc((void **)&c->auto_ticket, sizeof(int)));
     CHK(c, hipMemsetAsync(c->auto_ticket, 0, sizeof(int), c->stream));
-    CHK(c, hipMalloc((void **)&c->auto_sync, 4 * sizeof(unsigned)));
-    CHK(c, hipMemsetAsync(c->auto_sync, 0, 4 * sizeof(unsigned), c->stream));
+    CHK(c, hipMalloc((void **)&c->auto_sync, 8 * sizeof(unsigned)));
+    CHK(c, hipMemsetAsync(c->auto_sync, 0, 8 * sizeof(unsigned), c->stream));
     CHK(c, hipStreamSynchronize(c->stream));
     for (hipEvent_t &e : c->ev_auto_gather) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t &e : c->ev_auto_kdq) CHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1741,7 +1741,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const hipEvent_t sweep_stop = overlap && split && c->ext_stop ? c->trk_join : nullptr;
     if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
-        // (the tail form: the grid query reports by ticket that it is through; d is c->d)
+        // (the launch-free form: the grid query's last workgroup arrives at the pass's word; d is c->d)
         c->d.auto_sync = c->kd_tail_seq == c->auto_seq + 1 && c->kd_tail_seq != 0 ? c->auto_sync : nullptr;
         c->d.auto_pass_seq = c->auto_seq + 1;
         LAUNCH_REC(c, c->ev_auto_k1g, k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
@@ -1764,8 +1764,8 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         // build on kd_stream, and nothing reads a list before that query is through
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
         if (c->kd_tail_seq == seq && seq != 0) {
-            // the tail form: this pass's build answers the listed agents in its last kernel (KdTail) once the grid query's last workgroup
-            // has said it is through (k_neighbors_grid<true>) -- no launch, no cross-stream wait on the build's stream
+            // the launch-free form: of this pass's grid query and its kd build, the one whose last workgroup is through SECOND answers the
+            // listed agents (KdTail) -- no launch, no cross-stream wait on the build's stream
             c->forms |= SCA_FORM_AUTO_TAIL;
         } else {
             CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)
@@ -1975,19 +1975,14 @@ static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode, bool lazy);
 static void auto_abandon(sca_ctx *c) {
     c->lazy_join = false;
     c->kd_ahead = false; c->kdq_last = -1; c->kdq_pending = false; c->auto_backoff = 0;
-    if (c->kd_stream && c->auto_sync && c->kd_tail_seq != 0) {
-        // a build in the tail form may be waiting for the word its pass never wrote: write it (from a stream of its own -- the context's
-        // may itself be waiting for that tail); its list is empty or stale, the error the caller gets says the pass did not happen
-        hipStream_t t = nullptr;
-        if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) == hipSuccess) {
-            (void)hipStreamWriteValue32(t, c->auto_sync + 1, c->kd_tail_seq, 0);
-            (void)hipStreamSynchronize(t);
-            (void)hipStreamDestroy(t);
-        }
-        (void)hipGetLastError();
-    }
     c->kd_tail_seq = 0;
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipGetLastError(); }
+    if (c->auto_sync) {
+        // (a build in the launch-free form whose pass never came has arrived alone at its pass's word: the words start from zero again)
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemset(c->auto_sync, 0, 8 * sizeof(unsigned));
+        (void)hipGetLastError();
+    }
     c->auto_unjoined = false;
 }
 static int run_steps_guarded(sca_ctx *c, int steps, int neighbor_mode, bool lazy) {

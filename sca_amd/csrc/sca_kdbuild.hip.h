@@ -80,18 +80,22 @@ struct KdScratch {
                               //    k_kd_gather touches neither
 };
 
-// SCA_NBR_AUTO (round 6): the kd query of the agents the pass's grid query listed, as the TAIL of the build's last kernel instead of a
-// launch of its own behind it (k_neighbors_kd_auto).  The kd build of an AUTO pass is a loop of its own beside the step -- every build
-// starts from the previous one's permutation -- and at N = 4096 that loop, not the pass, sets the step's pace
-// (profiles/r06_a_c3_auto_device_timeline.json: gather 3.0 + top 23.3 + block 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the
-// 78.5-us step); the query's launch cost the loop two of its four gaps, one of them a cross-stream event wait, to find its list empty.
-// Now the workgroup of k_kd_block that finishes LAST waits until the pass's grid query is through (a word that launch's last workgroup
-// writes, k_neighbors_grid<true>; the launch is ahead of this kernel in the host's order, so the wait cannot starve it), reads the list's
-// length, and answers the listed agents itself, a wavefront per agent over the block's LDS.  The host takes
-// this form while the counts that come back say "a handful at most" (sca_hip.hip: AUTO_TAIL_MAX); longer lists keep the launch.
+// SCA_NBR_AUTO (round 6): the kd query of the agents the pass's grid query listed WITHOUT a launch of its own (k_neighbors_kd_auto).
+// The kd build of an AUTO pass is a loop of its own beside the step -- every build starts from the previous one's permutation -- and at
+// N = 4096 that loop, not the pass, sets the step's pace (profiles/r06_a_c3_auto_device_timeline.json: gather 3.0 + top 23.3 + block
+// 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the 78.5-us step); the query's launch cost the loop two of its four gaps, one of
+// them a cross-stream event wait, to find its list empty.
+// The query needs two things: the pass's list (complete when the grid query's last workgroup is through) and the pass's tree (complete
+// when k_kd_block's last workgroup is).  Each of the two ARRIVES at a word of the pass (an atomic add); the one that arrives SECOND has
+// both and answers the listed agents on the spot, a wavefront per agent over its kernel's LDS (kd_answer_listed).  Nobody waits for
+// anybody: the build may be enqueued a whole step ahead of the pass (sca_run_steps), i.e. BEFORE its grid query in the host's order, and a
+// kernel that spun for a later launch would deadlock whenever the two streams share a hardware queue.  (A first version did spin -- and
+// the suite that passed in four minutes took fifteen.)  In the steady state of a small swarm the build is the longer chain and its last
+// workgroup answers; the host takes this form while the list lengths that come back say "a handful at most" (sca_hip.hip:
+// auto_tail_max), longer lists keep the launch.
 struct KdTail {
     unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: no tail
-    unsigned *sync;           // [0] workgroups of k_kd_block through, [1] the last pass whose grid query is complete, [2] that query's ticket
+    unsigned *sync;           // [0] k_kd_block's ticket, [2] the grid query's ticket, [4 + (seq & 3)] the pass's arrival word
     int32_t *list, *count;    // that pass's list of agents for the kd query (the two lists alternate by pass)
     int cap;                  // a count above it: "too many for a list" -- every agent of the shard
     unsigned *busy;           // bit 0: somebody is listed and not answered yet (the pass's stream waits for 0)
@@ -99,6 +103,39 @@ struct KdTail {
     double agent_reach, obs_reach, max_radius;
     Params P;
 };
+
+// the second arriver's work (see KdTail): every thread of the workgroup calls it; `stacks`: NW x KD_RSTACK x 16 doubles of LDS
+template <int NW>
+__device__ __forceinline__ void kd_answer_listed(const DeviceView &d, const Params &P, double agent_reach, double obs_reach, double max_radius,
+                                                 const int32_t *list, const int32_t *count, int cap, unsigned *busy, unsigned long long *stats,
+                                                 double (*stacks)[16]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stats && tid == 0) {                                             // statistics, as k_neighbors_kd_auto keeps them
+        stats[0] += 1; stats[1] += (unsigned long long)n;
+        if ((unsigned long long)n > stats[2]) stats[2] = (unsigned long long)n;
+        if (n > 0) stats[3] += 1;
+    }
+    if (n == 0) return;
+    double (*rst)[16] = stacks + (size_t)wid * KD_RSTACK;
+    if (n <= cap) {
+        for (int i = wid; i < n; i += NW) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rst, list[i], lane);
+    } else {
+        for (int i = wid; i < d.shard_count; i += NW) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rst, d.shard_begin + i, lane);
+    }
+    __syncthreads();
+    if (tid == 0) { __threadfence(); atomicAnd(busy, ~1u); }
+}
+// one side's arrival at the pass's word: true for the side that comes second (thread 0 of the side's LAST workgroup calls it, after
+// that side's data is written back; the word is free again for the pass four on)
+__device__ __forceinline__ bool auto_arrive_second(unsigned *sync, unsigned seq) {
+    unsigned *w = sync + 4 + (seq & 3u);
+    __threadfence();
+    const bool second = __hip_atomic_fetch_add(w, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+    if (second) { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __threadfence(); }   // the other side's data: read afresh
+    return second;
+}
 
 // order-preserving map double -> u64 so that integer atomics give exact min / max
 __device__ __forceinline__ unsigned long long dkey(double x) {
@@ -592,42 +629,21 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 // KdTail: see there.  Every workgroup of k_kd_block comes through here when its subtrees are done.
 template <int KBT>
 __device__ __forceinline__ void kd_auto_tail(const DeviceView &d, const KdScratch &s, const KdTail &T, double (*stacks)[16]) {
-    __shared__ int tail_last;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int tail_second;
+    const int tid = threadIdx.x;
     __syncthreads();                                                     // (the workgroup's last subtree is written)
     if (tid == 0) {
         __threadfence();                                                 // ... and visible before the ticket says so
-        tail_last = atomicAdd(T.sync, 1u) == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!tail_last) return;
-    if (tid == 0) {
-        atomicExch(T.sync, 0u);                                          // (the next build's ticket starts at 0)
-        int spins = 0;                                                   // the pass's grid query: usually long through (the build is the longer chain)
-        while ((int)(__hip_atomic_load(T.sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - T.seq) < 0) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 22)) { atomicOr(&s.counts[KD_MAX_LEVELS + 1], KD_ERR_SPIN); break; }     // (seconds: the pass was abandoned)
+        int second = 0;
+        if (atomicAdd(T.sync, 1u) == gridDim.x - 1) {                    // the build's last workgroup: the tree is complete
+            atomicExch(T.sync, 0u);                                      // (the next build's ticket starts at 0)
+            second = auto_arrive_second(T.sync, T.seq) ? 1 : 0;
         }
-        __threadfence();                                                 // the other workgroups' tree, the query's list: read afresh
+        tail_second = second;
     }
     __syncthreads();
-    const int n = __hip_atomic_load(T.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (T.stats && tid == 0) {                                           // statistics, as k_neighbors_kd_auto keeps them
-        T.stats[0] += 1; T.stats[1] += (unsigned long long)n;
-        if ((unsigned long long)n > T.stats[2]) T.stats[2] = (unsigned long long)n;
-        if (n > 0) T.stats[3] += 1;
-    }
-    if (n == 0) return;
-    constexpr int NW = KBT / 64;
-    double (*rst)[16] = stacks + (size_t)wid * KD_RSTACK;
-    if (n <= T.cap) {
-        for (int i = wid; i < n; i += NW) neighbors_one(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, rst, T.list[i], lane);
-    } else {
-        for (int i = wid; i < d.shard_count; i += NW) neighbors_one(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, rst, d.shard_begin + i, lane);
-    }
-    __syncthreads();
-    if (tid == 0) { __threadfence(); atomicAnd(T.busy, ~1u); }
+    if (!tail_second) return;
+    kd_answer_listed<KBT / 64>(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, T.list, T.count, T.cap, T.busy, T.stats, stacks);
 }
 
 template <int KBM, int KBT>

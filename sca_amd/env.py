@@ -140,17 +140,46 @@ class Agent:
     def _get(self, name, local):
         return local if self._env is None else getattr(self._env, name)[self.id]
 
+    # The three attributes the reference's callers read per agent per step (run_sca.py:181-196).  The env's host mirrors are refreshed IN
+    # PLACE (one bulk read-back on first use after a step), so an agent's row view is made once and stays valid: a read is an attribute
+    # test, a staleness test and a return (100 000 reads per step went through three property hops and a fresh view).
+    _row_pos = _row_vel = _row_heading = None
+
     @property
     def pos_global_frame(self):
-        return self._get('pos', self._pos)
+        env = self._env
+        if env is None:
+            return self._pos
+        if env._stale:
+            env._state('pos')
+        r = self._row_pos
+        if r is None:
+            r = self._row_pos = env._mirror['pos'][self.id]
+        return r
 
     @property
     def vel_global_frame(self):
-        return self._get('vel', self._vel)
+        env = self._env
+        if env is None:
+            return self._vel
+        if env._stale:
+            env._state('vel')
+        r = self._row_vel
+        if r is None:
+            r = self._row_vel = env._mirror['vel'][self.id]
+        return r
 
     @property
     def heading_global_frame(self):
-        return self._get('heading', self._heading)
+        env = self._env
+        if env is None:
+            return self._heading
+        if env._stale:
+            env._state('heading')
+        r = self._row_heading
+        if r is None:
+            r = self._row_heading = env._mirror['heading'][self.id]
+        return r
 
     @property
     def total_time(self):
@@ -291,6 +320,7 @@ class MACAEnv:
                 self.per_agent_attributes = sorted(self.per_agent_attributes + ['turning_radius / pitchlims'])
         for a in agents:
             a._env = self
+            a._row_pos = a._row_vel = a._row_heading = None        # (row views belong to the mirrors of the env they were made for)
             a.policy._env = self
         self.kdTree = _KdTreeView(self)
         self._row_cache = None
