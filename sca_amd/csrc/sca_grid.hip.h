@@ -264,7 +264,7 @@ __device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const G
                     const V3 pO = v3(orec.px, orec.py, orec.pz);
                     const double distSq1 = l3normsq(pA, pO);
                     const double tt = l3norm(pA, pO) - orec.radius;
-                    dsq = tt * tt;
+                    dsq = m_pow2(tt);                        // (... ) ** 2 = libm's pow (agent.py:106)
                     const double rs = me.radius + orec.radius;
                     r = dsq < rangeSq;
                     c = r && distSq1 < rs * rs;

@@ -475,7 +475,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
                 const V3 pO = v3(ob.px, ob.py, ob.pz);
                 const double distSq1 = l3normsq(pA, pO);
                 const double t = l3norm(pA, pO) - ob.radius;
-                distSq = t * t;
+                distSq = m_pow2(t);                                  // (l3norm(pA, pO) - r) ** 2 = libm's pow (agent.py:106): the list's distSq is the reference's bits
                 const double rs = me.radius + ob.radius;
                 r = distSq < rangeSq;
                 c = r && distSq1 < rs * rs;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                         const V3 pO = v3(orec.px, orec.py, orec.pz);
                         const double distSq1 = l3normsq(pA, pO);
                         const double tt = l3norm(pA, pO) - orec.radius;
-                        dsq = tt * tt;
+                        dsq = m_pow2(tt);                        // (... ) ** 2 = libm's pow (agent.py:106)
                         const double rs = me.radius + orec.radius;
                         r = dsq < rangeSq;
                         c = r && distSq1 < rs * rs;
