@@ -26,6 +26,15 @@ namespace sca {
 // constant tables): equal bits on gfx950 and on the host, hence free-running episodes whose positions and headings ARE the reference's.
 SCA_HD double m_atan2(double y, double x) { return sca_gm::g_atan2_glob(y, x); }
 SCA_HD double m_pow2(double x) { return sca_gm::g_pow2_glob(x); }                    // np.float64 ** 2 = pow(x, 2.0) (mampenv.py:94)
+// the same value INLINE, for call sites inside the neighbour queries: a call would cost those kernels the callee's register window
+// (k_neighbors_kd4 62 -> 80 VGPRs, measured) for a branch only scenes with obstacles take.  Its argument there is l3norm(pA, pO) - r_O:
+// zero or between 1e-17 and 1e4 in magnitude, always inside the branch-free form's domain (2^-360 <= |x| < 2^361); x * x stands in
+// formally for the rest of the double range.
+SCA_HD double m_pow2_inline(double x) {
+    bool dom = true;
+    const double r = sca_gm::pow2_core<sca_gm::TabGlobal>(x, dom);
+    return dom ? r : x * x;
+}
 SCA_HD void m_sincos(double x, double &s, double &c) { const sca_gm::SinCos r = sca_gm::g_sincos_glob(x); s = r.s; c = r.c; }
 
 constexpr int K_MAX = 16;              // agent.py:32 maxNeighbors

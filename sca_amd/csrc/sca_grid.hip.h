@@ -150,7 +150,7 @@ __device__ __forceinline__ unsigned long long grid_probe_key(long long cx, long 
 // (the reference orders those by the kd-tree's visit order, agent.py:87-90: append, stable sort) -- is not flagged but handed to the kd
 // query (d.kdq_list); every other list IS the reference's, entry for entry: a sorted list without ties has one order.
 // (the kernel's body; `listed` comes back true for the lanes of a group whose agent went onto the kd query's list)
-template <bool AUTO>
+template <bool AUTO, bool HAS_OBS>
 __device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const GridDev &g, const Params &P, double agent_reach,
                                                     double obs_reach, double max_radius, bool &listed) {
     __shared__ int stacks[K1P_WAVES][K1P_APW][KD_STACK];
@@ -222,7 +222,7 @@ __device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const G
     };
 
     // ---- obstacles: kd-tree of kdTree.py:232-262, as in k_neighbors_kd4
-    if (d.m > 0) {
+    if (HAS_OBS && d.m > 0) {
         const double *wd = (const double *)d.owide;
         int node = 0, sp = 0;
         bool have = scan;
@@ -392,13 +392,13 @@ __device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const G
     }
 }
 
-template <bool AUTO>
+template <bool AUTO, bool HAS_OBS>
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d, GridDev g, Params P, double agent_reach,
                                                                   double obs_reach, double max_radius) {
     SCA_TL(d, TL_NBR_GRID);
     SCA_K1_SETPRIO();
     bool listed = false;
-    neighbors_grid_body<AUTO>(d, g, P, agent_reach, obs_reach, max_radius, listed);
+    neighbors_grid_body<AUTO, HAS_OBS>(d, g, P, agent_reach, obs_reach, max_radius, listed);
     if (AUTO && d.auto_sync) {
         // The launch-free form of the kd query (KdTail, sca_kdbuild.hip.h): this launch's last workgroup -- by ticket -- arrives at the
         // pass's word; if the pass's kd build has arrived already, it answers the listed agents here and now, otherwise the build's last
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
         }
         __syncthreads();
         if (grid_second)
-            kd_answer_listed<K1P_WAVES>(d, P, agent_reach, obs_reach, max_radius, d.kdq_list, d.kdq_count, d.kdq_cap, d.kdq_busy, d.kdq_stats, rst);
+            kd_answer_listed<K1P_WAVES, HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, d.kdq_list, d.kdq_count, d.kdq_cap, d.kdq_busy, d.kdq_stats, rst);
     }
 }
 

@@ -1739,24 +1739,33 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // (overlapped: the join rides on the side stream's last kernel -- the neighbour query, or the sweep behind it)
     const hipEvent_t k1_stop = overlap && !split && c->ext_stop ? c->trk_join : nullptr;
     const hipEvent_t sweep_stop = overlap && split && c->ext_stop ? c->trk_join : nullptr;
+    const bool obs = d.m > 0;                                           // (scenes without obstacles: the K1 forms without the obstacle phase, see neighbors_one)
     if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
         // (the launch-free form: the grid query's last workgroup arrives at the pass's word; d is c->d)
         c->d.auto_sync = c->kd_tail_seq == c->auto_seq + 1 && c->kd_tail_seq != 0 ? c->auto_sync : nullptr;
         c->d.auto_pass_seq = c->auto_seq + 1;
-        LAUNCH_REC(c, c->ev_auto_k1g, k_neighbors_grid<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
-                   c->P, agent_reach, obs_reach, c->max_radius);
+        if (obs) LAUNCH_REC(c, c->ev_auto_k1g, (k_neighbors_grid<true, true>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                            c->P, agent_reach, obs_reach, c->max_radius);
+        else LAUNCH_REC(c, c->ev_auto_k1g, (k_neighbors_grid<true, false>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                        c->P, agent_reach, obs_reach, c->max_radius);
     } else if (mode == SCA_NBR_GRID) {
         const int per_block = K1P_WAVES * K1P_APW;
-        LAUNCH_OPT(c, k1_stop, k_neighbors_grid<false>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
-                   c->P, agent_reach, obs_reach, c->max_radius);
+        if (obs) LAUNCH_OPT(c, k1_stop, (k_neighbors_grid<false, true>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                            c->P, agent_reach, obs_reach, c->max_radius);
+        else LAUNCH_OPT(c, k1_stop, (k_neighbors_grid<false, false>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
+                        c->P, agent_reach, obs_reach, c->max_radius);
     } else if (packed) {
         const int per_block = K1P_WAVES * K1P_APW;
-        LAUNCH_OPT(c, k1_stop, k_neighbors_kd4, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->P,
-                   agent_reach, obs_reach, c->max_radius);
+        if (obs) LAUNCH_OPT(c, k1_stop, k_neighbors_kd4<true>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->P,
+                            agent_reach, obs_reach, c->max_radius);
+        else LAUNCH_OPT(c, k1_stop, k_neighbors_kd4<false>, dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->P,
+                        agent_reach, obs_reach, c->max_radius);
     } else
-        LAUNCH_OPT(c, k1_stop, k_neighbors_kd, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64),
-                   ns, d, c->P, agent_reach, obs_reach, c->max_radius);
+        if (obs) LAUNCH_OPT(c, k1_stop, k_neighbors_kd<true>, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64),
+                            ns, d, c->P, agent_reach, obs_reach, c->max_radius);
+        else LAUNCH_OPT(c, k1_stop, k_neighbors_kd<false>, dim3(std::min((cnt + K1_WAVES - 1) / K1_WAVES, MAX_GRID)), dim3(K1_WAVES * 64),
+                        ns, d, c->P, agent_reach, obs_reach, c->max_radius);
     c->near_valid = true;
     if ((timed || prof) && !auto_mode) CHK(c, hipEventRecord(e1, ns));    // [e0, e1] = K1
     if (auto_mode) {

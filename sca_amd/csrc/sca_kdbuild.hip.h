@@ -105,7 +105,7 @@ struct KdTail {
 };
 
 // the second arriver's work (see KdTail): every thread of the workgroup calls it; `stacks`: NW x KD_RSTACK x 16 doubles of LDS
-template <int NW>
+template <int NW, bool HAS_OBS = true>
 __device__ __forceinline__ void kd_answer_listed(const DeviceView &d, const Params &P, double agent_reach, double obs_reach, double max_radius,
                                                  const int32_t *list, const int32_t *count, int cap, unsigned *busy, unsigned long long *stats,
                                                  double (*stacks)[16]) {
@@ -120,9 +120,9 @@ __device__ __forceinline__ void kd_answer_listed(const DeviceView &d, const Para
     if (n == 0) return;
     double (*rst)[16] = stacks + (size_t)wid * KD_RSTACK;
     if (n <= cap) {
-        for (int i = wid; i < n; i += NW) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rst, list[i], lane);
+        for (int i = wid; i < n; i += NW) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rst, list[i], lane);
     } else {
-        for (int i = wid; i < d.shard_count; i += NW) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rst, d.shard_begin + i, lane);
+        for (int i = wid; i < d.shard_count; i += NW) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rst, d.shard_begin + i, lane);
     }
     __syncthreads();
     if (tid == 0) { __threadfence(); atomicAnd(busy, ~1u); }

@@ -440,6 +440,9 @@ __device__ __forceinline__ int kd_traverse_rec(const KdWide *tree, V3 p, double 
 
 // agent_reach / obs_reach: see k_collide_finish.  Every object that can touch this agent after the move is visited
 // here anyway (it is within neighborDist), so the few that are close enough are written down for K4.
+// HAS_OBS (round 6): the obstacle phase squares a surface distance with libm's pow (agent.py:106) -- a call whose register window (62 ->
+// 80 VGPRs in k_neighbors_kd4) a scene WITHOUT obstacles should not pay for: the host launches the <false> form there (no obstacle code).
+template <bool HAS_OBS = true>
 __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params &P, double agent_reach, double obs_reach,
                                               double max_radius, double (*rstack)[16], int agent, int lane) {
     const PubRec me = d.rec[agent];
@@ -465,7 +468,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     WaveList L; L.dsq = 0.0; L.id = -1; L.cnt = 0;
     bool coll = false;
     // obstacles first (scaPolicy.py:114-116), agent.py:101-124
-    if (d.m > 0) {
+    if (HAS_OBS && d.m > 0) {
         st |= kd_traverse_rec(d.owide, pA, rangeSq, rstack, lane, [&](int begin, int end) {
             const bool valid = lane < end - begin;
             int o = 0; double distSq = 0.0; bool c = false, r = false, nr = false;
@@ -546,6 +549,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     }
 }
 
+template <bool HAS_OBS>
 __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                 double max_radius) {
     SCA_TL(d, TL_NBR_KD);
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k_neighbors_kd(DeviceView d, Pa
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int agent = d.shard_begin + blockIdx.x * K1_WAVES + wid;
-    if (agent < d.shard_begin + d.shard_count) neighbors_one(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], agent, lane);
+    if (agent < d.shard_begin + d.shard_count) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rstacks[wid], agent, lane);
 }
 
 // SCA_NBR_AUTO: the kd query behind the build, ONE launch on the build's stream: nobody listed by the grid query (the usual case) --
@@ -616,6 +620,7 @@ constexpr int K1P_APW = 4;
 #else
 #define SCA_K1_SETPRIO() ((void)0)
 #endif
+template <bool HAS_OBS>
 __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, Params P, double agent_reach, double obs_reach,
                                                                  double max_radius) {
     SCA_TL(d, TL_NBR_KD);
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
     int *stack = stacks[wid][g];
 
-    for (int phase = 0; phase < 2; phase++) {                       // obstacles first (scaPolicy.py:114-116)
-        const bool ob = phase == 0;
+    for (int phase = HAS_OBS ? 0 : 1; phase < 2; phase++) {         // obstacles first (scaPolicy.py:114-116)
+        const bool ob = HAS_OBS && phase == 0;
         if (ob && d.m <= 0) continue;
         const double *wd = (const double *)(ob ? d.owide : d.awide);
         int node = 0, sp = 0;
