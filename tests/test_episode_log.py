@@ -72,11 +72,9 @@ def test_metrics_with_failures():
 def test_device_trajectory_log_follows_reference_history(name, tmp_path):
     """Whole SCA episode on the device with the HBM trajectory log on; the log must be the reference's history_info, the
     written env_cfg.json the reference's, and the files must read back the way visualization/draw_episode.py:17-32 consumes
-    them.  Tolerances over the free-running episode: positions 1e-5, headings 2e-5, float32 velocities 5e-5
-    (1e-5 at the first step that deviates; per-step parity on identical inputs is tests/test_gpu_parity.py's job).  (take-off/landing
-    agrees to 4e-15 over all 285 steps.  In the circle run the device's sin/cos/atan2 leave positions 1e-14 away from the
-    host libm's, and at step 151 one v_pref component sits within that distance of a 5-decimal truncation edge
-    (0.08048 vs 0.08047): one velocity component differs by one unit of the reference's own 1e-5 grid for a few steps.)"""
+    them.  Round 6: EQUALITY over the whole free-running episode -- positions, headings, float32 velocities, flags of every step (until
+    round 5 the device's sin / cos / atan2 left positions 1e-14 away from the host libm's, and at step 151 of the circle run one v_pref
+    component sat within that distance of a 5-decimal truncation edge: tolerances of 1e-5 … 5e-5 covered it)."""
     from sca_amd import env as E, metrics, tracker, solver as S
     fx = _load(name)
     agents, obstacles = _agents_and_obstacles(fx, E)
@@ -94,14 +92,8 @@ def test_device_trajectory_log_follows_reference_history(name, tmp_path):
     traj = metrics.trajectories(env)
     want = fx['hist']
     assert traj.shape == want.shape
-    assert np.allclose(traj[:, :, 0:3], want[:, :, 0:3], rtol=0, atol=1e-5)
-    assert np.allclose(traj[:, :, 3:6], want[:, :, 3:6], rtol=0, atol=2e-5)
-    if 'takeoff' in name:
-        assert np.allclose(traj[:, :, 0:9], want[:, :, 0:9], rtol=0, atol=1e-13)
-    # once the two runs are 1e-6 apart, later truncations land on neighbouring 1e-5 grid points now and then
-    assert np.abs(traj[:, :, 6:9] - want[:, :, 6:9]).max() <= 5e-5
-    first = int(np.argmax(np.abs(traj[:, :, 6:9] - want[:, :, 6:9]).max(axis=(0, 2)) > 0))
-    assert np.abs(traj[:, first, 6:9] - want[:, first, 6:9]).max() <= 1.0000000000010001e-05      # the first deviation is one grid unit
+    for lo, hi, what in ((0, 3, 'pos'), (3, 6, 'heading'), (6, 9, 'vel')):
+        assert np.array_equal(traj[:, :, lo:hi], want[:, :, lo:hi]), (name, what, float(np.abs(traj[:, :, lo:hi] - want[:, :, lo:hi]).max()))
     assert np.array_equal(traj[:, :, 9:13], want[:, :, 9:13])
     assert np.array_equal(env.step_num, fx['step_num'])
     # log == the state the env reports after each step (last row = final state)
