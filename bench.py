@@ -1083,7 +1083,7 @@ def _timeline(wname, mode):
 
 
 def _pmc(wname):
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f).get(wname)

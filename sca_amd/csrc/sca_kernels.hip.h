@@ -656,8 +656,10 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
     int *stack = stacks[wid][g];
 
-    for (int phase = HAS_OBS ? 0 : 1; phase < 2; phase++) {         // obstacles first (scaPolicy.py:114-116)
-        const bool ob = HAS_OBS && phase == 0;
+    // (HAS_OBS = false, launched for scenes without obstacles, keeps the loop's shape -- the obstacle phase stays in the code, with x * x,
+    // and is never taken: without it the compiler turned 1.2 M scalar instructions per launch into 6.7 M vector ones at c4, PMC-measured)
+    for (int phase = 0; phase < 2; phase++) {                       // obstacles first (scaPolicy.py:114-116)
+        const bool ob = phase == 0;
         if (ob && d.m <= 0) continue;
         const double *wd = (const double *)(ob ? d.owide : d.awide);
         int node = 0, sp = 0;
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
                         const V3 pO = v3(orec.px, orec.py, orec.pz);
                         const double distSq1 = l3normsq(pA, pO);
                         const double tt = l3norm(pA, pO) - orec.radius;
-                        dsq = m_pow2(tt);                        // (... ) ** 2 = libm's pow (agent.py:106)
+                        dsq = HAS_OBS ? m_pow2(tt) : tt * tt;    // (... ) ** 2 = libm's pow (agent.py:106); <false>: never reached
                         const double rs = me.radius + orec.radius;
                         r = dsq < rangeSq;
                         c = r && distSq1 < rs * rs;
@@ -856,6 +858,7 @@ __device__ __forceinline__ double phi_from_idx(const CandTab &T, int idx, V3 vpr
 
 // update_velocitie (mampenv.py:83-105) for one agent: the moved record goes to rec_new (positions of the
 // current step stay readable for everybody else until the host swaps the buffers).
+template <bool INLINE_LIBM = false>
 __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Params &P, int agent, PubRec r, const float *act) {
     const double speed = (double)act[3];
     const double a = pi_2_pi(d.heading[agent * 3 + 0] + (double)act[4]);
@@ -863,12 +866,12 @@ __device__ __forceinline__ void integrate_agent(const DeviceView &d, const Param
     const double g = pi_2_pi(d.heading[agent * 3 + 2] + (double)act[6]);
     const double dt = d.ap ? d.ap[agent].dt_nominal : P.dt_nominal;               // agent.dt_nominal (mampenv.py:90-92)
     double sa, ca, sb, cb;                                                        // math.sin / math.cos: the restated glibc (sca_core.h)
-    m_sincos(a, sa, ca);
-    m_sincos(b, sb, cb);
+    if (INLINE_LIBM) { m_sincos_i(a, sa, ca); m_sincos_i(b, sb, cb); }       // (k_action: the two overlap; the 250-register fallback sweep calls)
+    else { m_sincos(a, sa, ca); m_sincos(b, sb, cb); }
     const double dx = speed * cb * ca * dt;
     const double dy = speed * cb * sa * dt;
     const double dz = speed * sb * dt;
-    const double len = sqrt(m_pow2(dx) + m_pow2(dy) + m_pow2(dz));               // sqrt(dx ** 2 + dy ** 2 + dz ** 2), mampenv.py:94
+    const double len = INLINE_LIBM ? sqrt(m_pow2_i(dx) + m_pow2_i(dy) + m_pow2_i(dz)) : sqrt(m_pow2(dx) + m_pow2(dy) + m_pow2(dz));               // sqrt(dx ** 2 + dy ** 2 + dz ** 2), mampenv.py:94
     d.total_dist[agent] += len;
     r.px += dx; r.py += dy; r.pz += dz;
     r.vx = act[0]; r.vy = act[1]; r.vz = act[2];
@@ -1790,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
-template <bool FUSE_INTEGRATE>
+template <bool FUSE_INTEGRATE, bool INLINE_LIBM = false>
 __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent, bool derive) {
     PubRec me = d.rec[agent];
     float actf[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1809,7 +1812,7 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
             v = trunc5(cand_from_idx(T, d.diag[(size_t)agent * 8 + 2], v3(pr.vpref[0], pr.vpref[1], pr.vpref[2])));
             d.vpost[agent * 3] = v.x; d.vpost[agent * 3 + 1] = v.y; d.vpost[agent * 3 + 2] = v.z;
         } else v = v3(d.vpost[agent * 3], d.vpost[agent * 3 + 1], d.vpost[agent * 3 + 2]);
-        cartesian2spherical(d.heading[agent * 3 + 0], d.heading[agent * 3 + 1], v, d.policy[agent] == POL_ORCA_LP, act);
+        cartesian2spherical<INLINE_LIBM>(d.heading[agent * 3 + 0], d.heading[agent * 3 + 1], v, d.policy[agent] == POL_ORCA_LP, act);
 #pragma unroll
         for (int k = 0; k < 7; k++) actf[k] = (float)act[k];
         if (d.coll_new[agent]) { me.flags |= FLAG_COLLISION; d.rec[agent].flags = me.flags; }
@@ -1820,7 +1823,7 @@ __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P,
     for (int k = 0; k < 7; k++) out[k] = actf[k];
     out[7] = 0.0f;
     if (d.trk_nbr0 && d.nbr_valid[agent]) d.trk_nbr0[agent] = d.nbr_n[agent] > 0 ? d.nbr_dsq[(size_t)agent * K_MAX] : -1.0;   // agent.py:79-99
-    if (FUSE_INTEGRATE) integrate_agent(d, P, agent, me, actf);
+    if (FUSE_INTEGRATE) integrate_agent<INLINE_LIBM>(d, P, agent, me, actf);
 }
 
 // K2 epilogue: one LANE per agent (see above), skipping the agents k_solve could not finish -- those are k_fallback's.
@@ -1834,7 +1837,7 @@ __global__ __launch_bounds__(256) void k_action(DeviceView d, Params P) {
     const int agent = shard_agent(d, idx);
     const int kind = d.is_fb[agent];
     if (kind == 1) return;
-    action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
+    action_one<FUSE_INTEGRATE, true>(d, P, agent, kind == 2);
 }
 // The agents without any suitable candidate (rare): one wavefront per entry of the fallback list runs the complete sweep (all
 // 513 candidates in registers, incl. compute_without_suitV, scaPolicy.py:224-238) and then the same epilogue for that agent.
@@ -1896,7 +1899,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_action_fb(DeviceView d, Pa
         const int agent = shard_agent(d, idx);
         const int kind = d.is_fb[agent];
         if (kind == 1) return;
-        action_one<FUSE_INTEGRATE>(d, P, agent, kind == 2);
+        action_one<FUSE_INTEGRATE, true>(d, P, agent, kind == 2);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -1918,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_integrate(DeviceView d, Params P) {
     const int agent = shard_agent(d, idx);
     float act[7];
     for (int k = 0; k < 7; k++) act[k] = d.action[(size_t)agent * 8 + k];
-    integrate_agent(d, P, agent, d.rec[agent], act);
+    integrate_agent<true>(d, P, agent, d.rec[agent], act);
 }
 
 // check_agent_state (mampenv.py:61-80) + is_done (mampenv.py:51-59).  Candidates come from the kd-tree of the step's OLD
