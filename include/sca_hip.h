@@ -107,7 +107,7 @@ enum sca_error {
 void sca_default_params(sca_params *p);                 /* the version-100 entry point: writes the first 56 bytes only (struct_bytes = 0) */
 void sca_default_params_v2(sca_params *p, int32_t struct_bytes);   /* every field that fits into struct_bytes, and struct_bytes itself */
 #define SCA_DEFAULT_PARAMS(p) sca_default_params_v2((p), (int32_t)sizeof(sca_params))
-int sca_version(void);
+int sca_version(void);                     /* 102 (100: round 4; 101: dt_nominal appended to sca_params; 102: struct_bytes, sca_default_params_v2) */
 
 int sca_create(const sca_params *p, int device, int max_agents, int max_obstacles, sca_ctx **out);
 void sca_destroy(sca_ctx *ctx);

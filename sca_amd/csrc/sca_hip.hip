@@ -358,7 +358,7 @@ void sca_default_params_v2(sca_params *p, int32_t struct_bytes) {
     if (has_dt) p->dt_nominal = 0.1;
 }
 void sca_default_params(sca_params *p) { sca_default_params_v2(p, 0); }
-int sca_version(void) { return 101; }
+int sca_version(void) { return 102; }   // 102: sca_params.struct_bytes + sca_default_params_v2, selftest codes 11-14, SCA_FORM_ACTION_FB / _AUTO_TAIL
 
 const char *sca_last_error(const sca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

@@ -826,7 +826,9 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pc
     double kn;
     l3norm(vpref, vpref, &kn);
     r.vp_key = pack_key(kn, 0);
-    bits |= (unsigned)get_phi_num(vpref.x, vpref.y) << 8;                            // util.py:145 of the v_pref candidate, <= 628318
+    // util.py:145 of the v_pref candidate (<= 628318): read by shunted_strategy only (SCA, S-RVO3D) -- the other policies' prologue skips
+    // the atan2 (a call into the restated libm since round 6)
+    if (pol == POL_SCA || pol == POL_SRVO) bits |= (unsigned)get_phi_num(vpref.x, vpref.y) << 8;
     r.bits = bits;
     out[agent] = r;
 }
