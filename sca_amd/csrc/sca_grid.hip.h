@@ -400,26 +400,42 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_grid(DeviceView d,
     bool listed = false;
     neighbors_grid_body<AUTO, HAS_OBS>(d, g, P, agent_reach, obs_reach, max_radius, listed);
     if (AUTO && d.auto_sync) {
-        // The launch-free form of the kd query (KdTail, sca_kdbuild.hip.h): this launch's last workgroup -- by ticket -- arrives at the
-        // pass's word; if the pass's kd build has arrived already, it answers the listed agents here and now, otherwise the build's last
-        // workgroup will.  A workgroup that listed nobody publishes nothing but its count atomics, whose results it holds: no fence.  One
-        // that did list somebody first writes back what it stored -- the list entries, and the lists the kd query is about to overwrite
-        // from another XCD -- before its ticket says "through".
-        __shared__ int grid_second;
+        // The launch-free form of the kd query (KdTail, sca_kdbuild.hip.h): this launch's last workgroup -- by ticket -- knows the list's
+        // final length.  Zero: nothing to do, nobody fenced, nobody waits.  Otherwise it waits for the pass's tree (whose build is ahead
+        // of this launch in the host's order) and answers the listed agents here, before the launch ends: the solve behind it needs no
+        // stream wait.  A workgroup that listed somebody first writes back what it stored -- the list entries, and the lists the kd query
+        // is about to overwrite, possibly from another XCD -- before its ticket says "through".
+        __shared__ int grid_listed;
         __shared__ double rst[K1P_WAVES * KD_RSTACK][16];
         if (__syncthreads_or(listed ? 1 : 0)) __threadfence();
         else __syncthreads();
         if (threadIdx.x == 0) {
-            int second = 0;
+            int n = 0;
             if (__hip_atomic_fetch_add(d.auto_sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(d.auto_sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                second = auto_arrive_second(d.auto_sync, d.auto_pass_seq) ? 1 : 0;
+                n = __hip_atomic_load(d.kdq_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d.kdq_stats) {                                       // statistics, as k_neighbors_kd_auto keeps them
+                    d.kdq_stats[0] += 1; d.kdq_stats[1] += (unsigned long long)n;
+                    if ((unsigned long long)n > d.kdq_stats[2]) d.kdq_stats[2] = (unsigned long long)n;
+                    if (n > 0) d.kdq_stats[3] += 1;
+                }
+                if (n > 0) {
+                    int spins = 0;                                       // the pass's tree: usually long complete
+                    while ((int)(__hip_atomic_load(d.auto_sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - d.auto_pass_seq) < 0) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (++spins > (1 << 24)) { if (d.auto_err) atomicOr(d.auto_err, KD_ERR_SPIN); break; }   // (tens of seconds: the build died)
+                    }
+                    __threadfence();                                     // the tree, the other workgroups' list entries: read afresh
+                }
             }
-            grid_second = second;
+            grid_listed = n;
         }
         __syncthreads();
-        if (grid_second)
-            kd_answer_listed<K1P_WAVES, HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, d.kdq_list, d.kdq_count, d.kdq_cap, d.kdq_busy, d.kdq_stats, rst);
+        if (grid_listed > 0) {
+            kd_answer_listed<K1P_WAVES, HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, grid_listed, rst);
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAnd(d.kdq_busy, ~1u);            // (nobody waits for the bit in this form; kept consistent)
+        }
     }
 }
 

@@ -268,11 +268,12 @@ struct sca_ctx {
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
     hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq -- a launch of its own, or the tail of the
                                                          // build's last kernel (KdTail); the pass two on reuses its list and waits for [(seq - 2) & 3]
-    unsigned *auto_sync = nullptr;      // device words of the launch-free form (KdTail): [0] k_kd_block's ticket, [2] the grid query's, [4 + (seq & 3)] the pass's arrival word
+    unsigned *auto_sync = nullptr;      // device words of the launch-free form (KdTail): [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the grid query's ticket
     bool auto_tail_ok = false;          // the tail form is available (with the wait-value form of the pass's wait; SCA_AUTO_NO_TAIL=1, read at sca_create: never)
     bool auto_no_tail = false;
     int auto_tail_max = 32;             // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX)
     unsigned kd_tail_seq = 0;           // the pass whose build was enqueued in the tail form (0: none)
+    bool kdq_on_kd_stream[4] = {false, false, false, false};   // [seq & 3]: pass seq's kd query was a launch on kd_stream (its list's next user must wait for it)
     KdTail kd_tail_arg = {};            // what the build being enqueued hands its k_kd_block (seq = 0 outside an AUTO build)
     hipEvent_t kd_block_stop = nullptr; // ... and the event to record behind it
     hipEvent_t ev_auto_gather[2] = {nullptr, nullptr};   // the gather kernel of the last two builds: the integrate stage must not write into
@@ -1565,23 +1566,20 @@ static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *pos
 #endif
     const int keep_skip = c->kd.skip_prep;
     c->kd.aux = 1;
-    // The kd query of the agents this pass's grid query will list: the TAIL of the build's last kernel (KdTail) while the list lengths
-    // that have come back say "a handful at most" -- otherwise a launch of its own behind the build (launch_policy).  The build belongs to
-    // the pass whose grid query comes next: auto_seq + 1, whether it is enqueued inside that pass or ahead of it (sca_run_steps).
+    // The kd query of the agents this pass's grid query will list: answered by that query's own last workgroup, once this build's last
+    // kernel has published its tree (KdTail), while the list lengths that have come back say "a handful at most" -- otherwise a launch of
+    // its own behind the build (launch_policy).  The build belongs to the pass whose grid query comes next: auto_seq + 1, whether it is
+    // enqueued inside that pass or ahead of it (sca_run_steps) -- in front of that grid query in the host's order either way.
     const unsigned seq = c->auto_seq + 1;
     c->kd_tail_arg = KdTail{};
     c->kd_block_stop = nullptr;
     if (c->auto_tail_ok && c->auto_waitvalue && seq != 0 && c->kdq_last >= 0 && c->kdq_last <= c->auto_tail_max) {
         // (the list of this parity was last read by the kd query of two passes ago, whose event slot is about to be recorded anew: the
         // pass's stream waits for it HERE instead of in front of its grid build)
-        if (seq >= 3) { if (int r = wait_if_pending(c, c->stream, c->ev_auto_kdq[(seq - 2) & 3u])) return r; }
+        // (... if that query was a launch on kd_stream; in the launch-free form it ran inside the pass's own grid query, on this stream)
+        if (seq >= 3 && c->kdq_on_kd_stream[(seq - 2) & 3u]) { if (int r = wait_if_pending(c, c->stream, c->ev_auto_kdq[(seq - 2) & 3u])) return r; }
         KdTail T;
         T.seq = seq; T.sync = c->auto_sync;
-        T.list = c->kdq_list + (size_t)(seq & 1u) * c->max_n; T.count = c->kdq_count + (seq & 1u);
-        T.cap = std::max(1, c->d.shard_count / c->auto_div);
-        T.busy = c->auto_busy; T.stats = c->d.kdq_stats;
-        collide_reach(c, T.agent_reach, T.obs_reach);
-        T.max_radius = c->max_radius; T.P = c->P;
         c->kd_tail_arg = T;
         c->kd_tail_seq = seq;
         c->kd_block_stop = c->ev_auto_kdq[seq & 3u];
@@ -1710,7 +1708,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->d.kdq_count = c->kdq_count + par;
             // ... which the kd query of two passes ago must be through with (it is, unless the kd stream lags by two whole passes)
             // (slot [(seq - 2) & 3], seq = auto_seq + 1; a build enqueued in the tail form has made the pass's stream wait already)
-            if (c->auto_seq >= 2 && c->kd_tail_seq != c->auto_seq + 1) { if (int r = wait_if_pending(c, c->nbr_stream, c->ev_auto_kdq[(c->auto_seq - 1) & 3u])) return r; }
+            if (c->auto_seq >= 2 && c->kd_tail_seq != c->auto_seq + 1 && c->kdq_on_kd_stream[(c->auto_seq - 1) & 3u]) { if (int r = wait_if_pending(c, c->nbr_stream, c->ev_auto_kdq[(c->auto_seq - 1) & 3u])) return r; }
         }
         if (int r = build_agent_grid_device(c)) return r;
     }
@@ -1742,9 +1740,10 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     const bool obs = d.m > 0;                                           // (scenes without obstacles: the K1 forms without the obstacle phase, see neighbors_one)
     if (auto_mode) {
         const int per_block = K1P_WAVES * K1P_APW;
-        // (the launch-free form: the grid query's last workgroup arrives at the pass's word; d is c->d)
+        // (the launch-free form: the grid query's last workgroup answers whoever is listed, from the tree its pass's build publishes; d is c->d)
         c->d.auto_sync = c->kd_tail_seq == c->auto_seq + 1 && c->kd_tail_seq != 0 ? c->auto_sync : nullptr;
         c->d.auto_pass_seq = c->auto_seq + 1;
+        c->d.auto_err = c->kd.counts + KD_MAX_LEVELS + 1;
         if (obs) LAUNCH_REC(c, c->ev_auto_k1g, (k_neighbors_grid<true, true>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
                             c->P, agent_reach, obs_reach, c->max_radius);
         else LAUNCH_REC(c, c->ev_auto_k1g, (k_neighbors_grid<true, false>), dim3((cnt + per_block - 1) / per_block), dim3(K1P_WAVES * 64), ns, d, c->grid,
@@ -1773,10 +1772,12 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         // build on kd_stream, and nothing reads a list before that query is through
         const unsigned seq = ++c->auto_seq;                            // (its parity picks the list; it may wrap)
         if (c->kd_tail_seq == seq && seq != 0) {
-            // the launch-free form: of this pass's grid query and its kd build, the one whose last workgroup is through SECOND answers the
-            // listed agents (KdTail) -- no launch, no cross-stream wait on the build's stream
+            // the launch-free form: the grid query's own last workgroup has answered the listed agents from this pass's tree (KdTail) -- no
+            // launch, no cross-stream wait on the build's stream, no stream wait operation on this one
             c->forms |= SCA_FORM_AUTO_TAIL;
+            c->kdq_on_kd_stream[seq & 3u] = false;
         } else {
+            c->kdq_on_kd_stream[seq & 3u] = true;
             CHK(c, hipStreamWaitEvent(c->kd_stream, c->ev_auto_k1g, 0));     // (recorded behind the grid query above)
             // (ev_auto_kdq: also "the last kd query": auto_join and the event form of the wait)
             LAUNCH_REC(c, c->ev_auto_kdq[seq & 3u], k_neighbors_kd_auto, dim3(c->kdq_last >= 0 && c->kdq_last <= KDQ_BLOCKS_FEW * K1_WAVES ? KDQ_BLOCKS_FEW : KDQ_BLOCKS),
@@ -1788,7 +1789,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
             c->kdq_pending = true;
         }
         c->ev_auto_kd = c->ev_auto_kdq[seq & 3u];
-        if (c->auto_waitvalue) {
+        if (c->forms & SCA_FORM_AUTO_TAIL) {
+            // (the launch-free form: the lists are final when the grid query's launch ends -- its last workgroup answered whoever was listed)
+        } else if (c->auto_waitvalue) {
             // lists final: at once when the grid query listed nobody, else behind the kd query (see k_neighbors_kd_auto)
             if (hipStreamWaitValue32(ns, c->auto_busy, 0u, hipStreamWaitValueEq, 1u) != hipSuccess) {
                 (void)hipGetLastError();                              // a platform without stream memory operations: the event wait from now on
@@ -1985,9 +1988,10 @@ static void auto_abandon(sca_ctx *c) {
     c->lazy_join = false;
     c->kd_ahead = false; c->kdq_last = -1; c->kdq_pending = false; c->auto_backoff = 0;
     c->kd_tail_seq = 0;
+    for (bool &b : c->kdq_on_kd_stream) b = false;
     if (c->kd_stream) { (void)hipStreamSynchronize(c->kd_stream); (void)hipGetLastError(); }
     if (c->auto_sync) {
-        // (a build in the launch-free form whose pass never came has arrived alone at its pass's word: the words start from zero again)
+        // (tickets of a pass that was cut short: the words start from zero again)
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemset(c->auto_sync, 0, 8 * sizeof(unsigned));
         (void)hipGetLastError();

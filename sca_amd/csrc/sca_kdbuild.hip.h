@@ -80,61 +80,40 @@ struct KdScratch {
                               //    k_kd_gather touches neither
 };
 
-// SCA_NBR_AUTO (round 6): the kd query of the agents the pass's grid query listed WITHOUT a launch of its own (k_neighbors_kd_auto).
+// SCA_NBR_AUTO (round 6): the kd query of the agents the pass's grid query listed WITHOUT a launch of its own (k_neighbors_kd_auto)
+// and without a stream wait operation on the pass's chain.
 // The kd build of an AUTO pass is a loop of its own beside the step -- every build starts from the previous one's permutation -- and at
-// N = 4096 that loop, not the pass, sets the step's pace (profiles/r06_a_c3_auto_device_timeline.json: gather 3.0 + top 23.3 + block
-// 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the 78.5-us step); the query's launch cost the loop two of its four gaps, one of
-// them a cross-stream event wait, to find its list empty.
-// The query needs two things: the pass's list (complete when the grid query's last workgroup is through) and the pass's tree (complete
-// when k_kd_block's last workgroup is).  Each of the two ARRIVES at a word of the pass (an atomic add); the one that arrives SECOND has
-// both and answers the listed agents on the spot, a wavefront per agent over its kernel's LDS (kd_answer_listed).  Nobody waits for
-// anybody: the build may be enqueued a whole step ahead of the pass (sca_run_steps), i.e. BEFORE its grid query in the host's order, and a
-// kernel that spun for a later launch would deadlock whenever the two streams share a hardware queue.  (A first version did spin -- and
-// the suite that passed in four minutes took fifteen.)  In the steady state of a small swarm the build is the longer chain and its last
-// workgroup answers; the host takes this form while the list lengths that come back say "a handful at most" (sca_hip.hip:
-// auto_tail_max), longer lists keep the launch.
+// N = 4096 that loop and the pass are equally long chains of dependent dispatches (profiles/r06_a_c3_auto_device_timeline.json: the loop
+// gather 3.0 + top 23.3 + block 32.0 + kd query 0.9 us of kernels, 19.7 us of gaps = the 78.5-us step; the pass 40.6 us of kernels in
+// 73.0).  The query's launch cost the loop two of its four gaps, one of them a cross-stream event wait, to find its list empty; and the
+// pass paid a hipStreamWaitValue32 -- a 2-us kernel of the runtime's and its gaps, 8.6 us -- in front of the solve for the same news.
+// Now: k_kd_block's workgroups count out by ticket and the last one publishes "the tree of pass `seq` is complete" (one word); the grid
+// query's workgroups count out by ticket and the last one reads the list's length.  Nobody listed (the usual case): done, the launch
+// ends, the solve follows -- no wait, no launch, no fence.  Somebody listed: that workgroup waits for the tree's word and answers the
+// listed agents on the spot, a wavefront per agent (kd_answer_listed), before the launch ends.  The wait is safe: a pass's build is
+// ALWAYS enqueued before its grid query in the host's order (ahead, behind the previous step's integrate stage, or inside the pass in
+// front of the grid build), so whether the two streams share a hardware queue (the build then ran first) or not (it runs beside, on
+// other CUs: one spinning workgroup starves nobody) the word comes.  (The first version had it the other way round -- the BUILD's last
+// workgroup waited for the grid query, a LATER launch -- and the suite that takes four minutes took fifteen: a kernel that waits for a
+// launch behind it in a shared hardware queue waits for ever.)  The host takes this form while the list lengths that come back say "a
+// handful at most" (sca_hip.hip: auto_tail_max); longer lists keep the launch, which answers them with 64 .. 1024 workgroups.
 struct KdTail {
-    unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: no tail
-    unsigned *sync;           // [0] k_kd_block's ticket, [2] the grid query's ticket, [4 + (seq & 3)] the pass's arrival word
-    int32_t *list, *count;    // that pass's list of agents for the kd query (the two lists alternate by pass)
-    int cap;                  // a count above it: "too many for a list" -- every agent of the shard
-    unsigned *busy;           // bit 0: somebody is listed and not answered yet (the pass's stream waits for 0)
-    unsigned long long *stats;
-    double agent_reach, obs_reach, max_radius;
-    Params P;
+    unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: publish nothing
+    unsigned *sync;           // [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the grid query's ticket
 };
 
-// the second arriver's work (see KdTail): every thread of the workgroup calls it; `stacks`: NW x KD_RSTACK x 16 doubles of LDS
+// the kd query of the listed agents by ONE workgroup (every thread calls it); `stacks`: NW x KD_RSTACK x 16 doubles of LDS
 template <int NW, bool HAS_OBS = true>
 __device__ __forceinline__ void kd_answer_listed(const DeviceView &d, const Params &P, double agent_reach, double obs_reach, double max_radius,
-                                                 const int32_t *list, const int32_t *count, int cap, unsigned *busy, unsigned long long *stats,
-                                                 double (*stacks)[16]) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (stats && tid == 0) {                                             // statistics, as k_neighbors_kd_auto keeps them
-        stats[0] += 1; stats[1] += (unsigned long long)n;
-        if ((unsigned long long)n > stats[2]) stats[2] = (unsigned long long)n;
-        if (n > 0) stats[3] += 1;
-    }
-    if (n == 0) return;
+                                                 int n, double (*stacks)[16]) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double (*rst)[16] = stacks + (size_t)wid * KD_RSTACK;
-    if (n <= cap) {
-        for (int i = wid; i < n; i += NW) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rst, list[i], lane);
-    } else {
+    if (n <= d.kdq_cap) {
+        for (int i = wid; i < n; i += NW) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rst, d.kdq_list[i], lane);
+    } else {                                                             // "too many for a list": every agent of the shard
         for (int i = wid; i < d.shard_count; i += NW) neighbors_one<HAS_OBS>(d, P, agent_reach, obs_reach, max_radius, rst, d.shard_begin + i, lane);
     }
-    __syncthreads();
-    if (tid == 0) { __threadfence(); atomicAnd(busy, ~1u); }
-}
-// one side's arrival at the pass's word: true for the side that comes second (thread 0 of the side's LAST workgroup calls it, after
-// that side's data is written back; the word is free again for the pass four on)
-__device__ __forceinline__ bool auto_arrive_second(unsigned *sync, unsigned seq) {
-    unsigned *w = sync + 4 + (seq & 3u);
-    __threadfence();
-    const bool second = __hip_atomic_fetch_add(w, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 1u;
-    if (second) { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __threadfence(); }   // the other side's data: read afresh
-    return second;
 }
 
 // order-preserving map double -> u64 so that integer atomics give exact min / max
@@ -626,24 +605,16 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 #define KB_MARK() do { } while (0)
 #endif
 
-// KdTail: see there.  Every workgroup of k_kd_block comes through here when its subtrees are done.
-template <int KBT>
-__device__ __forceinline__ void kd_auto_tail(const DeviceView &d, const KdScratch &s, const KdTail &T, double (*stacks)[16]) {
-    __shared__ int tail_second;
-    const int tid = threadIdx.x;
+// KdTail: see there.  Every workgroup of k_kd_block comes through here when its subtrees are done; the last one says so.
+__device__ __forceinline__ void kd_publish_tree(const KdTail &T) {
     __syncthreads();                                                     // (the workgroup's last subtree is written)
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         __threadfence();                                                 // ... and visible before the ticket says so
-        int second = 0;
         if (atomicAdd(T.sync, 1u) == gridDim.x - 1) {                    // the build's last workgroup: the tree is complete
             atomicExch(T.sync, 0u);                                      // (the next build's ticket starts at 0)
-            second = auto_arrive_second(T.sync, T.seq) ? 1 : 0;
+            __hip_atomic_store(T.sync + 1, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        tail_second = second;
     }
-    __syncthreads();
-    if (!tail_second) return;
-    kd_answer_listed<KBT / 64>(d, T.P, T.agent_reach, T.obs_reach, T.max_radius, T.list, T.count, T.cap, T.busy, T.stats, stacks);
 }
 
 template <int KBM, int KBT>
@@ -875,10 +846,7 @@ __global__ __launch_bounds__(KBT) void k_kd_block(DeviceView d, KdScratch s, int
             s.kx[base + i] = S.x[KB_SW(i)]; s.ky[base + i] = S.y[KB_SW(i)]; s.kz[base + i] = S.z[KB_SW(i)];     // final position order: K1 reads leaves from here
         }
     }
-    if (T.seq != 0) {
-        static_assert(sizeof(KbLds<KBM, KBT>) >= (size_t)(KBT / 64) * KD_RSTACK * 16 * sizeof(double), "the tail's record stacks live in the block's LDS");
-        kd_auto_tail<KBT>(d, s, T, reinterpret_cast<double (*)[16]>(&S));
-    }
+    if (T.seq != 0) kd_publish_tree(T);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,8 +122,9 @@ struct DeviceView {
     const AgentPar *ap;      // [n] per-agent solver attributes (null: the context's Params for everybody) -- agent_params()
     unsigned long long *kdq_stats;   // [4] AUTO passes, agents listed over them (sum, max), passes in which somebody was listed (sca_auto_stats)
     unsigned *kdq_busy;      // [1] bit 0: the grid query of this pass listed somebody and the kd query has not answered yet (the pass's stream waits for 0)
-    unsigned *auto_sync;     // the launch-free form of the kd query (KdTail): [0] k_kd_block's ticket, [2] the grid query's ticket, [4 + (seq & 3)] the
-    unsigned auto_pass_seq;  // pass's arrival word; null: this pass's kd query is a launch of its own
+    unsigned *auto_sync;     // the launch-free form of the kd query (KdTail): [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the
+    unsigned auto_pass_seq;  // grid query's ticket; null: this pass's kd query is a launch of its own
+    int *auto_err;           // the kd build's error word (KD_ERR_SPIN: the wait for the tree gave up)
     double *trk_nbr0;        // [n] tracker in the pass: distSq of agent.neighbors[0] of THIS pass for the tracker of the next one (the
                              // epilogue saves it, so that the next pass's neighbour query may overwrite the lists while the tracker runs)
 #ifdef SCA_TIMELINE

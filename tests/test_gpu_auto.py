@@ -150,8 +150,9 @@ def test_events_as_stop_events_change_no_bit(kind, n, tracked, mode, monkeypatch
 
 @pytest.mark.parametrize('kind,n,burst,div', [('dense', 600, 4, 1), ('lattice', 1000, 6, 1), ('dense', 600, 1, 1), ('cube', 4096, 8, 8), ('lattice', 3375, 1, 2)])
 def test_tail_form_answers_the_listed_agents(kind, n, burst, div, monkeypatch):
-    """Round 6: the kd query of the agents the grid query lists runs as the TAIL of the kd build's last kernel (KdTail,
-    sca_kdbuild.hip.h) instead of a launch of its own, once the list lengths that come back are known and small.  Forced here for ANY
+    """Round 6: the kd query of the agents the grid query lists is answered by that query's own last workgroup, from the tree its
+    pass's build publishes (KdTail, sca_kdbuild.hip.h), instead of by a launch of its own behind a stream wait -- once the list lengths
+    that come back are known and small.  Forced here for ANY
     length (SCA_AUTO_TAIL_MAX) on scenes where hundreds are listed -- dense: more than 16 in range; lattice: ties everywhere, "too many
     for a list" = everybody -- with the back-off to the plain kd pass moved out of the way (SCA_AUTO_BACKOFF_DIV): everything must equal
     SCA_NBR_KDTREE, bursts (builds enqueued ahead) and single steps, and the passes must really have taken the tail."""
