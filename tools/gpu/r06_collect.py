@@ -15,7 +15,7 @@ DST = os.path.join(ROOT, 'profiles')
 
 def one(pattern):
     g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None          # (gpurun merges into gpurun_out/: an earlier call's files stay beside the new ones)
 
 
 def main():
