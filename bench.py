@@ -200,7 +200,7 @@ def kernel_forms(forms):
     if forms & 64:
         out.append('k_action_fb')
     if forms & 128:
-        out.append('kd query of the listed agents as the tail of k_kd_block')
+        out.append('kd query of the listed agents inside k_neighbors_grid (no launch, no stream wait)')
     return out or ['k_solve']
 
 

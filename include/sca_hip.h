@@ -242,7 +242,8 @@ int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
  *   SCA_FORM_LP_LANE       the ORCA3D-Official agents went to k_lp (one lane per agent)
  *   SCA_FORM_SOLVE_FB      k_solve_fb: small shards solve and finish their fallbacks in one launch (no k_fallback launch)
  *   SCA_FORM_ACTION_FB     k_action_fb: shards of up to 16 384 agents run the fallback sweep inside the epilogue's launch (no k_fallback launch)
- *   SCA_FORM_AUTO_TAIL     SCA_NBR_AUTO: the kd query of the listed agents ran as the tail of the kd build's last kernel (no k_neighbors_kd_auto launch) */
+ *   SCA_FORM_AUTO_TAIL     SCA_NBR_AUTO: the kd query of the listed agents ran inside the pass's grid query (its last workgroup, from the tree the pass's
+ *                          build publishes): no k_neighbors_kd_auto launch, no stream wait in front of the solve */
 #define SCA_FORM_SOLVE_SPLIT 1
 #define SCA_FORM_TRACK_FUSED 2
 #define SCA_FORM_REPLAN_LANE 4

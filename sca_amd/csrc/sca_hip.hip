@@ -266,8 +266,8 @@ struct sca_ctx {
     unsigned *auto_busy = nullptr;      // device word, bit 0: somebody is listed for the kd query and it has not answered yet (hipStreamWaitValue32)
     unsigned auto_seq = 0;
     bool auto_waitvalue = true;         // SCA_AUTO_EVENT_WAIT=1: an event wait behind the kd query instead (the build is then on every pass's path)
-    hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq -- a launch of its own, or the tail of the
-                                                         // build's last kernel (KdTail); the pass two on reuses its list and waits for [(seq - 2) & 3]
+    hipEvent_t ev_auto_kdq[4] = {nullptr, nullptr, nullptr, nullptr};   // [seq & 3] behind the kd query of pass seq (a launch on kd_stream) or, in the
+                                                         // launch-free form, behind its build's last kernel; the pass two on reuses the list: [(seq - 2) & 3]
     unsigned *auto_sync = nullptr;      // device words of the launch-free form (KdTail): [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the grid query's ticket
     bool auto_tail_ok = false;          // the tail form is available (with the wait-value form of the pass's wait; SCA_AUTO_NO_TAIL=1, read at sca_create: never)
     bool auto_no_tail = false;
