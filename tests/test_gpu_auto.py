@@ -202,3 +202,31 @@ def test_tail_form_off_equals_on(monkeypatch):
         assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()) and np.array_equal(a.neighbors()['nbr_id'], b.neighbors()['nbr_id']), burst
     assert seen >= 3, seen
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('tail_max,burst', [(60, 5), (150, 1), (25, 9)])
+def test_form_switches_mid_episode(tail_max, burst, monkeypatch):
+    """The host picks the launch-free form from list lengths that come back every fourth pass: in a dense blob that thins out the count
+    falls through the threshold (and the forms alternate while it hovers around it).  Mixed sequences of launch-form and launch-free
+    passes -- their lists alternate by parity, the launch form's query runs on kd_stream, the other inside the pass's grid query --
+    must stay equal to the kd-tree mode step for step."""
+    from sca_amd import solver as S
+    monkeypatch.setenv('SCA_AUTO_TAIL_MAX', str(tail_max))
+    monkeypatch.setenv('SCA_AUTO_BACKOFF_DIV', '1')
+    sc, pol, n = _scene('dense', 700, seed=23)
+    a, b = _solver(sc, pol, n, False), _solver(sc, pol, n, False)
+    seen = {True: 0, False: 0}
+    for t in range(0, 180, burst):
+        a.run_steps(burst, S.NBR_KDTREE); b.run_steps(burst, S.NBR_AUTO)
+        a.synchronize(); b.synchronize()
+        seen[bool(b.pass_forms() & S.FORM_AUTO_TAIL)] += 1
+        sa, sb = a.get_state(), b.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(sa[k], sb[k]), (tail_max, t, k, int((sa[k] != sb[k]).sum()))
+        na, nb = a.neighbors(), b.neighbors()
+        for k in ('nbr_valid', 'nbr_n', 'nbr_id', 'nbr_kind', 'nbr_dsq'):
+            assert np.array_equal(na[k], nb[k]), (tail_max, t, k)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (tail_max, t)
+    print('passes seen in the launch-free / launch form:', seen, b.auto_stats())
+    assert seen[True] > 0 and seen[False] > 0, seen           # both forms ran in this episode
+    a.close(); b.close()
