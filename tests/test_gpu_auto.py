@@ -204,10 +204,10 @@ def test_tail_form_off_equals_on(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize('tail_max,burst', [(60, 5), (150, 1), (25, 9)])
+@pytest.mark.parametrize('tail_max,burst', [(330, 5), (310, 1), (345, 9)])
 def test_form_switches_mid_episode(tail_max, burst, monkeypatch):
-    """The host picks the launch-free form from list lengths that come back every fourth pass: in a dense blob that thins out the count
-    falls through the threshold (and the forms alternate while it hovers around it).  Mixed sequences of launch-form and launch-free
+    """The host picks the launch-free form from list lengths that come back every fourth pass: in this dense blob 250 .. 445 agents
+    are listed per pass, and a threshold in the middle of that range makes the forms alternate all episode long.  Mixed sequences of launch-form and launch-free
     passes -- their lists alternate by parity, the launch form's query runs on kd_stream, the other inside the pass's grid query --
     must stay equal to the kd-tree mode step for step."""
     from sca_amd import solver as S
