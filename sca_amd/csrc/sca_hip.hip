@@ -271,7 +271,9 @@ struct sca_ctx {
     unsigned *auto_sync = nullptr;      // device words of the launch-free form (KdTail): [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the grid query's ticket
     bool auto_tail_ok = false;          // the tail form is available (with the wait-value form of the pass's wait; SCA_AUTO_NO_TAIL=1, read at sca_create: never)
     bool auto_no_tail = false;
-    int auto_tail_max = 32;             // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX)
+    int auto_tail_max = 0;              // ... and taken while the list lengths that come back stay at or below this (SCA_AUTO_TAIL_MAX).  0: while NOBODY is
+                                        // listed -- one workgroup answering even a handful of agents per pass lost against the launch form over a
+                                        // whole c3 episode (3000 steps: 0.172 ms per step at 32, 0.121-0.125 at 8, 0.099-0.101 at 0, 0.104 launch form)
     unsigned kd_tail_seq = 0;           // the pass whose build was enqueued in the tail form (0: none)
     bool kdq_on_kd_stream[4] = {false, false, false, false};   // [seq & 3]: pass seq's kd query was a launch on kd_stream (its list's next user must wait for it)
     KdTail kd_tail_arg = {};            // what the build being enqueued hands its k_kd_block (seq = 0 outside an AUTO build)
@@ -1567,7 +1569,7 @@ static int auto_enqueue_kd_build(sca_ctx *c, hipEvent_t after, const PubRec *pos
     const int keep_skip = c->kd.skip_prep;
     c->kd.aux = 1;
     // The kd query of the agents this pass's grid query will list: answered by that query's own last workgroup, once this build's last
-    // kernel has published its tree (KdTail), while the list lengths that have come back say "a handful at most" -- otherwise a launch of
+    // kernel has published its tree (KdTail), while the list lengths that have come back say "nobody" -- otherwise a launch of
     // its own behind the build (launch_policy).  The build belongs to the pass whose grid query comes next: auto_seq + 1, whether it is
     // enqueued inside that pass or ahead of it (sca_run_steps) -- in front of that grid query in the host's order either way.
     const unsigned seq = c->auto_seq + 1;

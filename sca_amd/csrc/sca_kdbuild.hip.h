@@ -95,8 +95,9 @@ struct KdScratch {
 // front of the grid build), so whether the two streams share a hardware queue (the build then ran first) or not (it runs beside, on
 // other CUs: one spinning workgroup starves nobody) the word comes.  (The first version had it the other way round -- the BUILD's last
 // workgroup waited for the grid query, a LATER launch -- and the suite that takes four minutes took fifteen: a kernel that waits for a
-// launch behind it in a shared hardware queue waits for ever.)  The host takes this form while the list lengths that come back say "a
-// handful at most" (sca_hip.hip: auto_tail_max); longer lists keep the launch, which answers them with 64 .. 1024 workgroups.
+// launch behind it in a shared hardware queue waits for ever.)  The host takes this form while the list lengths that come back say
+// "nobody" (sca_hip.hip: auto_tail_max = 0); a list that appears is answered here by this one workgroup for the few passes until the
+// host has seen its length, then by the launch form with its 64 .. 1024 workgroups.
 struct KdTail {
     unsigned seq;             // the pass this build belongs to (sca_ctx::auto_seq of its grid query); 0: publish nothing
     unsigned *sync;           // [0] k_kd_block's ticket, [1] the last pass whose tree is complete, [2] the grid query's ticket
