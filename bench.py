@@ -199,8 +199,6 @@ def kernel_forms(forms):
         out.append('k_solve_fb')
     if forms & 64:
         out.append('k_action_fb')
-    if forms & 256:
-        out.append('epilogue inside k_solve_pick4 (no k_action launch)')
     if forms & 128:
         out.append('kd query of the listed agents inside k_neighbors_grid (no launch, no stream wait)')
     return out or ['k_solve']

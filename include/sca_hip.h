@@ -243,8 +243,7 @@ int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
  *   SCA_FORM_SOLVE_FB      k_solve_fb: small shards solve and finish their fallbacks in one launch (no k_fallback launch)
  *   SCA_FORM_ACTION_FB     k_action_fb: shards of up to 16 384 agents run the fallback sweep inside the epilogue's launch (no k_fallback launch)
  *   SCA_FORM_AUTO_TAIL     SCA_NBR_AUTO: the kd query of the listed agents ran inside the pass's grid query (its last workgroup, from the tree the pass's
- *                          build publishes): no k_neighbors_kd_auto launch, no stream wait in front of the solve
- *   SCA_FORM_PICK_ACTION   the split pass of a resident step ran the epilogue (cartesian2spherical, update_velocitie) inside k_solve_pick4 (no k_action launch) */
+ *                          build publishes): no k_neighbors_kd_auto launch, no stream wait in front of the solve */
 #define SCA_FORM_SOLVE_SPLIT 1
 #define SCA_FORM_TRACK_FUSED 2
 #define SCA_FORM_REPLAN_LANE 4
@@ -253,7 +252,6 @@ int sca_last_exchange_ms(sca_ctx *ctx, float *exchange_ms);
 #define SCA_FORM_SOLVE_FB 32
 #define SCA_FORM_ACTION_FB 64
 #define SCA_FORM_AUTO_TAIL 128
-#define SCA_FORM_PICK_ACTION 256
 int sca_last_pass_forms(sca_ctx *ctx, int *forms);
 /* SCA_NBR_AUTO statistics since the last reset: out4 = {AUTO passes, agents the grid query listed for the kd query (sum over the passes), the
  * largest list, passes in which somebody was listed}.  A pass with nobody listed never waits for the kd stream. */

@@ -196,7 +196,6 @@ struct sca_ctx {
     unsigned kd_builds = 0;             // device builds so far: the level statistics are read back every 8th
     unsigned kd_gen = 0, kd_ev_gen = 0; // positions replaced from outside (sca_set_state ...): statistics of older trees do not apply
     bool kd_nohint = false;             // SCA_KD_NOHINT=1: ignore the statistics of earlier builds (diagnostics)
-    bool pick_action = true;            // SCA_PICK_ACTION=0: the split pass keeps k_action as a launch of its own (A/B)
     int action_fb_max = 0;              // shards up to this many agents run the fallback sweep inside the epilogue's launch (k_action_fb; SCA_ACTION_FB_MAX)
     int solve_fb_max = 0;               // shards up to this many agents solve and fall back in one launch (SCA_SOLVE_FB_MAX; default: two wavefronts per SIMD)
     bool kd_top = true;                 // SCA_KD_TOP=0: trees of <= KT_M members through the level passes as well (tests, measurements)
@@ -645,7 +644,7 @@ int sca_device_tracker_enable(sca_ctx *c, const double *goal_heading, double tur
         hipFuncAttributes fa;
         for (const void *f : {(const void *)k_track, (const void *)k_replan, (const void *)k_replan_group<64>, (const void *)k_replan_group<32>,
                               (const void *)k_replan_group<16>, (const void *)k_replan_group<4>,
-                              (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4<true>, (const void *)k_solve_pick4<false>})
+                              (const void *)k_track_replan, (const void *)k_solve_sweep, (const void *)k_solve_pick4})
             (void)hipFuncGetAttributes(&fa, f);
     }
     (void)libm_check_run();              // informational: one note on stderr, the verdict through sca_libm_check(); sca_last_error stays for failures
@@ -791,7 +790,6 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
     if (const char *e = std::getenv("SCA_AUTO_BACKOFF_DIV")) c->auto_div = std::min(64, std::max(1, std::atoi(e)));
     c->auto_no_tail = std::getenv("SCA_AUTO_NO_TAIL") != nullptr;
-    if (const char *e = std::getenv("SCA_PICK_ACTION")) c->pick_action = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_AUTO_TAIL_MAX")) c->auto_tail_max = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("SCA_SOLVE_SPLIT")) c->solve_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("SCA_KD_NOHINT")) c->kd_nohint = std::atoi(e) != 0;
@@ -1822,14 +1820,9 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
         CHK(c, hipStreamWaitEvent(c->stream, c->trk_join, 0));                // (the prologue: track_store / the gather)
     }
     if (timed || prof) CHK(c, hipEventRecord(e2, c->stream));
-    // (the split pass of a resident step without ORCA3D-Official agents: the epilogue rides in the pick's launch, see k_solve_pick4)
-    const bool pick_action = split && fuse_integrate && lp_hi == lp_lo && !c->action_stop && c->pick_action;
     if (split) {
         const int per_block = SOLVE_WAVES * PICK_APW;
-        if (pick_action) {
-            hipLaunchKernelGGL(k_solve_pick4<true>, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
-            c->forms |= SCA_FORM_PICK_ACTION;
-        } else hipLaunchKernelGGL(k_solve_pick4<false>, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
+        hipLaunchKernelGGL(k_solve_pick4, dim3((cnt + per_block - 1) / per_block), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
     }
     else if (solve_fb) {
         hipLaunchKernelGGL(k_solve_fb, dim3((cnt + SOLVE_WAVES - 1) / SOLVE_WAVES), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);
@@ -1856,9 +1849,7 @@ static int launch_policy(sca_ctx *c, int mode, bool timed, bool fuse_integrate) 
     // (small shards: the fallback sweep rides in the epilogue's launch -- k_action_fb -- instead of in front of it)
     const bool action_fb = !solve_fb && cnt <= c->action_fb_max;
     if (action_fb) c->forms |= SCA_FORM_ACTION_FB;
-    if (pick_action) {
-        hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);   // (k_solve_pick4<true> has run everybody else's epilogue)
-    } else if (fuse_integrate) {
+    if (fuse_integrate) {
         if (action_fb) LAUNCH_OPT(c, c->action_stop, k_action_fb<true>, dim3(ablocks + FB_BLOCKS_SMALL), dim3(SOLVE_WAVES * 64), c->stream, d, c->P, ablocks);
         else {
             if (!solve_fb) hipLaunchKernelGGL(k_fallback<true>, dim3(FB_BLOCKS), dim3(SOLVE_WAVES * 64), 0, c->stream, d, c->P);

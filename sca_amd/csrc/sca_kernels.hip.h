@@ -1580,9 +1580,7 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned x) {             // eve
     return (unsigned)v;
 }
 
-// returns what is left to do for the agent: 0 the epilogue on d.vpost (or the zero row of a finished agent), 2 the epilogue derives the
-// velocity from the chosen candidate's index, 1 k_fallback finishes it, 3 k_lp computes its velocity first
-__device__ __forceinline__ int solve_pick4(const DeviceView &d, const Params &P, unsigned int *pk, int agent, int j, int row) {
+__device__ __forceinline__ void solve_pick4(const DeviceView &d, const Params &P, unsigned int *pk, int agent, int j, int row) {
     // Everything the row reads that is addressed by the agent id alone is loaded up front, before the first branch: the kernel is
     // a chain of dependent memory round trips (record -> prologue -> cones / survivors), not arithmetic, and the loads below the
     // early exits would each wait for the previous one's data (45 -> 41 us at c4).  All addresses are valid for any agent.
@@ -1601,7 +1599,7 @@ __device__ __forceinline__ int solve_pick4(const DeviceView &d, const Params &P,
     if (me.flags & (FLAG_AT_GOAL | FLAG_COLLISION | FLAG_TIMEOUT)) {                // mampenv.py:35
         if (j < 8) diag[j] = -1;
         if (j < 3) d.vpref_used[agent * 3 + j] = __builtin_nan("");
-        return 0;
+        return;
     }
     const int pol = pol_;
     const bool orca = (pol == POL_ORCA || pol == POL_ORCA_LP);
@@ -1616,7 +1614,7 @@ __device__ __forceinline__ int solve_pick4(const DeviceView &d, const Params &P,
     V3 vpost = v3(0, 0, 0);
     bool defer = false;
     const int K = nbrv_ ? nbrn_ : 0;
-    if (pol == POL_ORCA_LP && !first_step) return 3;                                 // K3: k_lp
+    if (pol == POL_ORCA_LP && !first_step) return;                                   // K3: k_lp
     if (first_step) {
         vpost = v3(0.3 * vpref.x, 0.3 * vpref.y, 0.3 * vpref.z);                     // scaPolicy.py:38
     } else {
@@ -1659,7 +1657,7 @@ __device__ __forceinline__ int solve_pick4(const DeviceView &d, const Params &P,
         if (nS == 0) {
             // no suitable candidate: compute_without_suitV needs all 513 candidates -> the epilogue's second half finishes this agent
             if (j == 0) { const int at = atomicAdd(d.fb_count, 1); d.fb_list[at] = agent; d.is_fb[agent] = 1; }
-            return 1;
+            return;
         }
         dg_fallback = 0;
         best = vpk < best ? vpk : best;
@@ -1711,17 +1709,8 @@ __device__ __forceinline__ int solve_pick4(const DeviceView &d, const Params &P,
         d.vpref_used[agent * 3 + 0] = vpref.x; d.vpref_used[agent * 3 + 1] = vpref.y; d.vpref_used[agent * 3 + 2] = vpref.z;
         if (st) atomicOr(&d.status[agent], st);
     }
-    return defer ? 2 : 0;
 }
 
-template <bool FUSE_INTEGRATE, bool INLINE_LIBM = false>
-__device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent, bool derive);      // (below, with k_action)
-// FUSE_ACTION (round 6): the row's first lane runs the policy epilogue and update_velocitie for its agent on the spot (action_one, what
-// k_action<true> does one lane per agent in a launch of its own behind k_fallback): in a tracked pass this kernel sits behind the join, on
-// the step's critical path, with the chip nearly empty -- the epilogue's launch (20 us at c4: a memory-latency-bound read of what this
-// kernel has just had in registers) and its gap go.  Only for passes without ORCA3D-Official agents (k_lp computes their velocity after
-// this kernel) and with the state resident (the caller of sca_policy_pass wants the action rows BEFORE the update).
-template <bool FUSE_ACTION>
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, Params P) {
     SCA_TL(d, TL_SOLVE_PICK);
     __shared__ PickLds S;
@@ -1729,10 +1718,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve_pick4(DeviceView d, 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = lane >> 4;
     const int idx = (blockIdx.x * SOLVE_WAVES + wid) * PICK_APW + row;
-    if (idx >= shard_size(d)) return;                                                // whole rows leave together
-    const int agent = shard_agent(d, idx);
-    const int kind = solve_pick4(d, P, S.pk[wid][row], agent, lane & 15, row);
-    if (FUSE_ACTION && (lane & 15) == 0 && kind != 1) action_one<true, true>(d, P, agent, kind == 2);
+    if (idx < shard_size(d)) solve_pick4(d, P, S.pk[wid][row], shard_agent(d, idx), lane & 15, row);   // whole rows leave together
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1810,7 +1796,7 @@ __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the
 // is_collision flag of agent.py:84, and -- when the state stays resident -- update_velocitie (mampenv.py:83-105).
-template <bool FUSE_INTEGRATE, bool INLINE_LIBM>
+template <bool FUSE_INTEGRATE, bool INLINE_LIBM = false>
 __device__ __forceinline__ void action_one(const DeviceView &d, const Params &P, int agent, bool derive) {
     PubRec me = d.rec[agent];
     float actf[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -13,7 +13,7 @@ from . import _lib
 POL_SCA, POL_RVO3D, POL_SRVO3D, POL_ORCA3D, POL_ORCA3D_LP, POL_RVO3D_DUBINS = range(6)
 FLAG_AT_GOAL, FLAG_COLLISION, FLAG_TIMEOUT = 1, 2, 4
 NBR_KDTREE, NBR_GRID, NBR_KDTREE_HOSTBUILD, NBR_AUTO = 0, 1, 2, 3
-FORM_SOLVE_SPLIT, FORM_TRACK_FUSED, FORM_REPLAN_LANE, FORM_REPLAN_FEW, FORM_LP_LANE, FORM_SOLVE_FB, FORM_ACTION_FB, FORM_AUTO_TAIL, FORM_PICK_ACTION = 1, 2, 4, 8, 16, 32, 64, 128, 256   # sca_last_pass_forms
+FORM_SOLVE_SPLIT, FORM_TRACK_FUSED, FORM_REPLAN_LANE, FORM_REPLAN_FEW, FORM_LP_LANE, FORM_SOLVE_FB, FORM_ACTION_FB, FORM_AUTO_TAIL = 1, 2, 4, 8, 16, 32, 64, 128   # sca_last_pass_forms
 K = _lib.K
 
 

@@ -106,7 +106,7 @@ def test_python_constants_mirror_the_header():
              'SCA_POLICY_SCA': S.POL_SCA, 'SCA_POLICY_RVO3D': S.POL_RVO3D, 'SCA_POLICY_SRVO3D': S.POL_SRVO3D,
              'SCA_POLICY_ORCA3D': S.POL_ORCA3D, 'SCA_POLICY_ORCA3D_LP': S.POL_ORCA3D_LP, 'SCA_POLICY_RVO3D_DUBINS': S.POL_RVO3D_DUBINS,
              'SCA_FORM_SOLVE_SPLIT': S.FORM_SOLVE_SPLIT, 'SCA_FORM_TRACK_FUSED': S.FORM_TRACK_FUSED,
-             'SCA_FORM_REPLAN_LANE': S.FORM_REPLAN_LANE, 'SCA_FORM_REPLAN_FEW': S.FORM_REPLAN_FEW, 'SCA_FORM_LP_LANE': S.FORM_LP_LANE, 'SCA_FORM_SOLVE_FB': S.FORM_SOLVE_FB, 'SCA_FORM_ACTION_FB': S.FORM_ACTION_FB, 'SCA_FORM_AUTO_TAIL': S.FORM_AUTO_TAIL, 'SCA_FORM_PICK_ACTION': S.FORM_PICK_ACTION,
+             'SCA_FORM_REPLAN_LANE': S.FORM_REPLAN_LANE, 'SCA_FORM_REPLAN_FEW': S.FORM_REPLAN_FEW, 'SCA_FORM_LP_LANE': S.FORM_LP_LANE, 'SCA_FORM_SOLVE_FB': S.FORM_SOLVE_FB, 'SCA_FORM_ACTION_FB': S.FORM_ACTION_FB, 'SCA_FORM_AUTO_TAIL': S.FORM_AUTO_TAIL,
              'SCA_MAX_NEIGHBORS': S.K}
     for name, val in pairs.items():
         assert hdr.get(name) == val, (name, hdr.get(name), val)
