@@ -1517,7 +1517,10 @@ static bool choose_solve_split(const sca_ctx *c, bool overlap, int cnt) {
 static int wait_if_pending(sca_ctx *c, hipStream_t s, hipEvent_t e) {
     // (launch errors of the kernels enqueued before this call are sticky in hipGetLastError: look at them BEFORE the query below, whose
     // hipErrorNotReady has to be cleared -- ADVICE r5: a failed launch in front of a pending event used to be dropped with it)
-    CHK(c, hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();                         // (an earlier query's hipErrorNotReady is an answer, not a failure)
+        if (le != hipSuccess && le != hipErrorNotReady) CHK(c, le);
+    }
     const hipError_t q = hipEventQuery(e);
     if (q == hipSuccess) return 0;
     if (q != hipErrorNotReady) CHK(c, q);                                // a real error of the query is an error
