@@ -73,14 +73,16 @@ struct Params {                 // agent.py:27-36, config.py
     int max_neighbors;          // 16
     int pad;
     double dt_nominal;          // 0.1: the integrator's step (agent.py:41, mampenv.py:90-92)
+    double range_sq;            // neighborDist ** 2 as the reference computes it (scaPolicy.py:112: libm's pow, on the host: sca_gm::g_pow2)
 };
 
 // The reference keeps the solver attributes on every Agent object (agent.py:24-41) and every policy reads ITS agent's.  A context holds one value
 // of each (Params); a swarm whose agents differ hands over one AgentPar per agent (sca_set_agent_params) and every per-agent code path then
-// works on agent_params(d, P, agent) instead of P.  56 bytes, read once per agent and pass.
+// works on agent_params(d, P, agent) instead of P.  64 bytes, read once per agent and pass.
 struct AgentPar {
     double neighbor_dist, time_step, time_horizon, max_speed, cos_heading_thr, dt_nominal;
     int max_neighbors, pad;
+    double range_sq;            // neighbor_dist ** 2 (libm's pow, computed on the host)
 };
 
 // 48-byte public record: everything another agent (or another GPU) needs to know about an agent.

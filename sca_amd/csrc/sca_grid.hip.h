@@ -174,8 +174,7 @@ __device__ __forceinline__ void neighbors_grid_body(const DeviceView &d, const G
     const bool scan = exists && !done;
     const bool want_list = scan && !bootstrap;
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;   // (the agent's own where the swarm is heterogeneous; a cell is the LARGEST)
-    const double rangeSq = nd_ * nd_;                               // scaPolicy.py:112
+    const double rangeSq = d.ap ? d.ap[agent].range_sq : P.range_sq;         // scaPolicy.py:112: neighborDist ** 2, the agent's own where the swarm is heterogeneous (a cell is the LARGEST)
     const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);

@@ -785,6 +785,7 @@ int sca_create(const sca_params *p, int device, int max_agents, int max_obstacle
     c->P.neighbor_dist = p->neighbor_dist; c->P.time_step = p->time_step; c->P.time_horizon = p->time_horizon;
     c->P.max_speed = p->max_speed; c->P.max_heading_change = p->max_heading_change;
     c->P.near_goal_threshold = p->near_goal_threshold; c->P.max_neighbors = p->max_neighbors; c->P.pad = 0; c->P.dt_nominal = p->dt_nominal;
+    c->P.range_sq = sca_gm::g_pow2(c->P.neighbor_dist);                 // neighborDist ** 2 (scaPolicy.py:112): glibc's pow, restated
     c->P.cos_heading_thr = cos_threshold(p->max_heading_change);
     c->P_ctx = c->P;
     if (const char *e = std::getenv("SCA_K1_PACKED")) c->k1_force = std::atoi(e) != 0;    // A/B switch for measurements
@@ -1003,6 +1004,7 @@ int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const i
         a.dt_nominal = dt_nominal ? dt_nominal[i] : c->P_ctx.dt_nominal;
         a.max_neighbors = max_neighbors ? max_neighbors[i] : c->P_ctx.max_neighbors;
         a.pad = 0;
+        a.range_sq = sca_gm::g_pow2(a.neighbor_dist);
         const double mhc = max_heading_change ? max_heading_change[i] : c->P_ctx.max_heading_change;
         if (!pos(a.neighbor_dist) || !pos(a.time_step) || !pos(a.time_horizon) || !pos(a.max_speed) || !pos(a.dt_nominal) ||
             a.max_neighbors < 1 || a.max_neighbors > SCA_MAX_NEIGHBORS || !(mhc >= 0.0 && mhc <= M_PI)) {
@@ -1029,7 +1031,7 @@ int sca_set_agent_params(sca_ctx *c, int n, const double *neighbor_dist, const i
     CHK(c, hipMemcpy(c->ap_nd, nd.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     c->d.ap = c->ap_dev;
     // the context's own Params become the envelope: what sizes the grid's cells (largest range) and the collision reach (largest step)
-    env.neighbor_dist = nd_max; env.max_speed = ms_max; env.dt_nominal = dt_max;
+    env.neighbor_dist = nd_max; env.max_speed = ms_max; env.dt_nominal = dt_max; env.range_sq = sca_gm::g_pow2(nd_max);
     c->P = env;
     c->grid.inv_cell = grid_inv_cell(c->P.neighbor_dist);
     if (c->trk_on) c->trk_view.nd_per_agent = c->ap_nd;

@@ -170,7 +170,7 @@ __device__ __forceinline__ Params agent_params(const DeviceView &d, const Params
     if (d.ap) {
         const AgentPar a = d.ap[agent];
         Q.neighbor_dist = a.neighbor_dist; Q.time_step = a.time_step; Q.time_horizon = a.time_horizon; Q.max_speed = a.max_speed;
-        Q.cos_heading_thr = a.cos_heading_thr; Q.dt_nominal = a.dt_nominal; Q.max_neighbors = a.max_neighbors;
+        Q.cos_heading_thr = a.cos_heading_thr; Q.dt_nominal = a.dt_nominal; Q.max_neighbors = a.max_neighbors; Q.range_sq = a.range_sq;
     }
     return Q;
 }
@@ -463,8 +463,7 @@ __device__ __forceinline__ void neighbors_one(const DeviceView &d, const Params 
     int *near_out = d.near_id + (size_t)agent * NEAR_MAX;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;         // (the agent's own where the swarm is heterogeneous)
-    const double rangeSq = nd_ * nd_;                                              // scaPolicy.py:112
+    const double rangeSq = d.ap ? d.ap[agent].range_sq : P.range_sq;              // scaPolicy.py:112 (the agent's own where the swarm is heterogeneous)
     const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     WaveList L; L.dsq = 0.0; L.id = -1; L.cnt = 0;
     bool coll = false;
@@ -642,8 +641,7 @@ __global__ __launch_bounds__(K1P_WAVES * 64) void k_neighbors_kd4(DeviceView d, 
     F3 vA; vA.x = me.vx; vA.y = me.vy; vA.z = me.vz;
     if (!orca && l3norm_f32zero(vA, false) <= 1e-5) skip = true;    // scaPolicy.py:34: no computeNeighbors on the bootstrap step
     const V3 pA = v3(me.px, me.py, me.pz);
-    const double nd_ = d.ap ? d.ap[agent].neighbor_dist : P.neighbor_dist;   // (the agent's own where the swarm is heterogeneous)
-    const double rangeSq = nd_ * nd_;                               // scaPolicy.py:112
+    const double rangeSq = d.ap ? d.ap[agent].range_sq : P.range_sq;         // scaPolicy.py:112: neighborDist ** 2, the agent's own where the swarm is heterogeneous
     const int maxn = d.ap ? d.ap[agent].max_neighbors : P.max_neighbors;
     const double reach_a = me.radius + agent_reach, reach_o = me.radius + obs_reach;
     const double rmax2 = (me.radius + max_radius) * (me.radius + max_radius);
