@@ -802,6 +802,7 @@ __device__ __forceinline__ bool tracker_owns(const DeviceView &d, int agent) {
     const int pol = d.policy[agent];
     return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;
 }
+template <bool LDS_TABLES = false>
 __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pctx, Prep *out, int agent) {
     const Params P = agent_params(d, Pctx, agent);
     const PubRec me = d.rec[agent];
@@ -827,7 +828,7 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pc
     r.vp_key = pack_key(kn, 0);
     // util.py:145 of the v_pref candidate (<= 628318): read by shunted_strategy only (SCA, S-RVO3D) -- the other policies' prologue skips
     // the atan2 (a call into the restated libm since round 6)
-    if (pol == POL_SCA || pol == POL_SRVO) bits |= (unsigned)get_phi_num(vpref.x, vpref.y) << 8;
+    if (pol == POL_SCA || pol == POL_SRVO) bits |= (unsigned)get_phi_num<LDS_TABLES>(vpref.x, vpref.y) << 8;
     r.bits = bits;
     out[agent] = r;
 }

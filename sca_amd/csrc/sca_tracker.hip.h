@@ -89,7 +89,11 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
     }
     // inside a policy pass: the agent's prologue for the solve (it reads the v_pref just stored), by the lane that has it --
     // a launch of its own behind the join (k_prep_shard, 6.5 us + its gap on the critical path) until the end of round 2
-    if (K.prep) prep_agent(d, K.P, (Prep *)d.prep, agent);
+#ifdef SCA_TRK_PREP_CALL                                                    // (A/B: the arctangent as a call into the constant-table copy)
+    if (K.prep) prep_agent<false>(d, K.P, (Prep *)d.prep, agent);
+#else
+    if (K.prep) prep_agent<true>(d, K.P, (Prep *)d.prep, agent);              // (every kernel that stores a v_pref has the libm tables in LDS)
+#endif
 }
 
 #ifdef SCA_KT_TIMING    // per-phase wall-clock ticks of workgroup 0's thread 0 into d.kdq_list (debug builds only)
