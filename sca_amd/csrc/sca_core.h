@@ -177,12 +177,13 @@ SCA_HD double l3norm_f32zero(F3 v, bool plus_eps) {
     return round5_py(plus_eps ? r + 1e-5 : r);
 }
 // util.py:145 get_phi -> integer numerator P (phi = P / 1e5)
-// LDS_TABLES: for device code inside a kernel that has the libm tables in LDS (the tracker's kernels: sca_gm::lds_tables_load) -- the
+// LIBM 1: for device code inside a kernel that has the libm tables in LDS (the tracker's kernels: sca_gm::lds_tables_load) -- the
 // arctangent inline on those tables instead of a call into the constant-table copy (same operations, same bits)
-template <bool LDS_TABLES = false>
+// (LIBM 2: inline on the constant tables -- the lane-per-agent prologue kernels, where the call's latency is the kernel's)
+template <int LIBM = 0>
 SCA_HD double get_phi_num(double vx, double vy) {
     double phi;
-    const double at = LDS_TABLES ? sca_gm::g_atan2<sca_gm::TabDefault>(vy, vx) : m_atan2(vy, vx);
+    const double at = LIBM == 1 ? sca_gm::g_atan2<sca_gm::TabDefault>(vy, vx) : LIBM == 2 ? m_atan2_i(vy, vx) : m_atan2(vy, vx);
     if (vy >= 0) phi = at;
     else phi = TWO_PI + at;
     double t = trunc(phi * EPS5);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DeviceView d, GridDev g, Par
     g.bucket[i] = h;
     g.slot[i] = atomicAdd(&g.count[h], 1);
     const bool mine = d.present ? i < shard_size(d) : shard_owns(d, a);
-    if (mine && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, a))) prep_agent(d, P, (Prep *)d.prep, a);
+    if (mine && g.skip_prep != 2 && !(g.skip_prep && tracker_owns(d, a))) prep_agent<PREP_LIBM>(d, P, (Prep *)d.prep, a);
 }
 
 // GRID_ALLOC_PER buckets per lane: one atomic on the cursor per 2048 buckets (an atomic per 256 buckets, 1024 of them on one

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_kd_gather(DeviceView d, KdScratch s, Pa
         s.kx[p] = rx; s.ky[p] = ry; s.kz[p] = rz;
         mn[0] = mx[0] = rx; mn[1] = mx[1] = ry; mn[2] = mx[2] = rz;
         // every agent appears once in the permutation; the prologue is only needed for the rank's own shard
-        if (!s.aux && shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent(d, P, (Prep *)d.prep, id);
+        if (!s.aux && shard_owns(d, id) && !(s.skip_prep && tracker_owns(d, id))) prep_agent<PREP_LIBM>(d, P, (Prep *)d.prep, id);
     }
     if (d.n > s.wave_max) {
 #pragma unroll

@@ -802,7 +802,11 @@ __device__ __forceinline__ bool tracker_owns(const DeviceView &d, int agent) {
     const int pol = d.policy[agent];
     return (pol == POL_SCA || pol == POL_RVO_DUBINS) && (d.rec[agent].flags & 7u) == 0u;
 }
-template <bool LDS_TABLES = false>
+#ifndef SCA_PREP_LIBM
+#define SCA_PREP_LIBM 2             // the prologue kernels' arctangent: 2 inline on the constant tables, 0 a call (A/B)
+#endif
+constexpr int PREP_LIBM = SCA_PREP_LIBM;
+template <int LIBM = 0>
 __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pctx, Prep *out, int agent) {
     const Params P = agent_params(d, Pctx, agent);
     const PubRec me = d.rec[agent];
@@ -828,7 +832,7 @@ __device__ __forceinline__ void prep_agent(const DeviceView &d, const Params &Pc
     r.vp_key = pack_key(kn, 0);
     // util.py:145 of the v_pref candidate (<= 628318): read by shunted_strategy only (SCA, S-RVO3D) -- the other policies' prologue skips
     // the atan2 (a call into the restated libm since round 6)
-    if (pol == POL_SCA || pol == POL_SRVO) bits |= (unsigned)get_phi_num<LDS_TABLES>(vpref.x, vpref.y) << 8;
+    if (pol == POL_SCA || pol == POL_SRVO) bits |= (unsigned)get_phi_num<LIBM>(vpref.x, vpref.y) << 8;
     r.bits = bits;
     out[agent] = r;
 }
@@ -1790,7 +1794,7 @@ __global__ __launch_bounds__(64) void k_lp(DeviceView d, Params Pctx, const int3
 __global__ __launch_bounds__(256) void k_prep(DeviceView d, Params P) {
     const int agent = blockIdx.x * blockDim.x + threadIdx.x;
     if (agent == 0) *d.fb_count = 0;                                       // start of a pass: empty fallback list
-    if (agent < d.n) prep_agent(d, P, (Prep *)d.prep, agent);
+    if (agent < d.n) prep_agent<PREP_LIBM>(d, P, (Prep *)d.prep, agent);
 }
 
 // K2 epilogue, one LANE per agent: cartesian2spherical (util.py:44-55) -> float32 action row (mampenv.py:31,40), the

@@ -90,9 +90,9 @@ __device__ __forceinline__ void track_store(const DeviceView &d, const TrackDev 
     // inside a policy pass: the agent's prologue for the solve (it reads the v_pref just stored), by the lane that has it --
     // a launch of its own behind the join (k_prep_shard, 6.5 us + its gap on the critical path) until the end of round 2
 #ifdef SCA_TRK_PREP_CALL                                                    // (A/B: the arctangent as a call into the constant-table copy)
-    if (K.prep) prep_agent<false>(d, K.P, (Prep *)d.prep, agent);
+    if (K.prep) prep_agent<0>(d, K.P, (Prep *)d.prep, agent);
 #else
-    if (K.prep) prep_agent<true>(d, K.P, (Prep *)d.prep, agent);              // (every kernel that stores a v_pref has the libm tables in LDS)
+    if (K.prep) prep_agent<1>(d, K.P, (Prep *)d.prep, agent);                 // (every kernel that stores a v_pref has the libm tables in LDS)
 #endif
 }
 
