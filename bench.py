@@ -365,6 +365,9 @@ def compact_record(out):
         r3 = legs['c3'].get('roofline') or {}
         if r3.get('chip_idle_frac') is not None:
             c['c3_auto_chip_idle_frac'] = _r(r3['chip_idle_frac'], 3)
+    hh = ((out.get('env_api') or {}).get('c4') or {}).get('host_handover') or {}
+    if hh.get('ms_per_step') is not None:                # the PCIe-inclusive rate of the same workload (host buffers every step); never `value`
+        c['host_handover_ms'] = _r(hh['ms_per_step'], 5)
     if out.get('emulated'):
         c['emulated_rank_of'] = out['emulated'].get('rank_of')
     c['detail'] = 'bench_detail.json beside bench.py; the stderr line prefixed DETAIL'
@@ -986,9 +989,48 @@ def env_api_legs(S, device, steps, warmup, names=('c2', 'c3', 'c4')):
         leg = timed_leg(sol, scene, ShardedStepper(sol, 0, 1, mode=mode), Timer(__import__('torch'), None, 'cuda'), steps, warmup, tracked)
         row['resident_ms_per_step'] = leg['ms_per_step']
         row['step_over_resident'] = row['step']['ms_per_step'] / leg['ms_per_step']
+        row['host_handover'] = host_handover_leg(sol, scene, steps, warmup, tracked, mode)
+        row['host_handover']['over_resident'] = row['host_handover']['ms_per_step'] / leg['ms_per_step']
         sol.close()
         out[name] = row
     return out
+
+
+def host_handover_leg(sol, scene, steps, warmup, tracked, mode):
+    """The boundary with HOST buffers on both sides of every step -- INTEGRATION.md stub B, the six calls a maintainer puts into
+    mampenv.py:_take_action when the reference's Python env stays the owner of the state: sca_set_state (pageable numpy arrays up) ->
+    sca_policy_pass -> sca_get_actions (float32 [n,7] down) -> sca_env_update (+ done) -> sca_get_state (everything down again).
+    The PCIe-inclusive rate of the path: reported beside the resident one, never as `value`."""
+    n = scene['n']
+    reset_state(sol, scene)
+    if tracked:
+        sol.device_tracker_enable(scene['sc']['goal'][:, 3:6])
+    else:
+        sol.device_tracker_disable()
+    st = sol.get_state()
+
+    def one(st):
+        sol.set_state(st['pos'], st['vel'], st['heading'], st['flags'], st['total_dist'], st['step_num'])
+        sol.policy_pass(mode)
+        a = sol.actions()
+        sol.env_update(True)
+        return sol.get_state(), a
+
+    for _ in range(warmup):
+        st, _a = one(st)
+    sol.synchronize()
+    served = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        served += int(np.count_nonzero((st['flags'] & 7) == 0))
+        st, _a = one(st)
+    sol.synchronize()
+    dt = time.perf_counter() - t0
+    up = n * (24 + 12 + 24 + 1 + 8 + 4)
+    down = n * 28 + up
+    return {'ms_per_step': dt / steps * 1e3, 'value': served / dt, 'unit': 'agent-steps/s', 'steps': steps,
+            'host_to_device_bytes_per_step': up, 'device_to_host_bytes_per_step': down,
+            'calls_per_step': 'sca_set_state, sca_policy_pass, sca_get_actions, sca_env_update, sca_get_state (INTEGRATION.md stub B; pageable numpy buffers)'}
 
 
 def parity_sample(scene, sol, S, tracked, warmup, mode=0):

@@ -132,6 +132,10 @@ def test_env_api_key_times_the_drop_in_loop():
             assert row[v]['ms_per_step'] > 0 and row[v]['value'] > 0 and row[v]['steps'] > 0
         assert row['step']['ms_per_step'] <= row['step_agent_pos']['ms_per_step']
         assert 0.8 < row['step_over_resident'] < 4.0, row           # the loop costs the kernels + one synchronising read-back per step
+        # the boundary with host buffers on both sides of every step (INTEGRATION.md stub B): the PCIe-inclusive rate, beside the resident one
+        hh = row['host_handover']
+        assert hh['ms_per_step'] > row['resident_ms_per_step'] and hh['value'] > 0 and hh['steps'] == 20
+        assert hh['host_to_device_bytes_per_step'] == n * 73 and hh['device_to_host_bytes_per_step'] == n * 101
 
 
 def test_first_multi_gpu_script_plumbing(tmp_path):
