@@ -4,12 +4,12 @@
 # the driver's form and at 100 steps, c2 / c3 AUTO / c5 at 300 steps.  Scheduling does not change a single result bit (no reassociation).
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06_sched
+O=$R/gpurun_out/${OUTDIR:-r06_sched}
 mkdir -p $O
 cd $R
 cp sca_amd/lib/libsca_hip.so /tmp/base.so
 for rep in 1 2; do
-for v in base ilp bias0 memcl iterilp; do
+for v in ${VARIANTS:-base ilp bias0 memcl iterilp}; do
   if [ $v = base ]; then cp /tmp/base.so sca_amd/lib/libsca_hip.so; else cp tools/_build/variants/$v.so sca_amd/lib/libsca_hip.so; fi
   SCA_BENCH_DETAIL=$O/c4drv_${v}_$rep.json timeout 300 python3 bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > /dev/null 2> $O/err.txt
   SCA_BENCH_DETAIL=$O/c4std_${v}_$rep.json timeout 300 python3 bench.py --steps 100 --warmup 20 --no-extra --no-cpu-baseline > /dev/null 2> $O/err.txt
