@@ -912,3 +912,56 @@ def test_free_running_episode_equals_the_oracle_run(S, oracle):
         assert np.array_equal(sol.get_kd_perm(), perm), t
     assert served > 0.5 * n * steps, served
     sol.close()
+
+
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
+@pytest.mark.parametrize('scene', ['sca_circle_tracker', 'mixed_takeoff_obstacles', 'orca_random'])
+def test_host_buffer_loop_of_integration_stub_b_equals_the_resident_loop(S, scene, mode):
+    """INTEGRATION.md stub B -- what a maintainer puts into mampenv.py:_take_action when the reference's Python env stays the owner of the
+    state: every step sca_set_state (host arrays up) -> sca_policy_pass -> sca_get_actions -> sca_env_update -> sca_get_state (everything
+    down again).  That loop must walk through the SAME states as the resident one (sca_run_steps), bit for bit, with the Dubins tracker on
+    the device for SCA (its plans live across the sca_set_state calls), with obstacles, in kd and AUTO mode; and the action rows it hands
+    back are the ones the resident step integrates."""
+    from sca_amd import scenarios
+    nbr = S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE
+    if scene == 'sca_circle_tracker':
+        sc, n, policy, tracked = scenarios.circle(300), 300, np.zeros(300, np.uint8), True
+    elif scene == 'mixed_takeoff_obstacles':
+        sc = scenarios.takeoff_landing(160)
+        n = len(sc['start'])
+        policy, tracked = np.where(np.arange(n) % 2 == 0, 0, 2).astype(np.uint8), True
+    else:
+        sc, n, policy, tracked = scenarios.random_cube(700, seed=5), 700, np.full(700, 3, np.uint8), False
+    steps = 25
+    zaxis = S.zaxis_flags(sc['start'], sc['goal'])
+    mrd = scenarios.max_run_dist(sc['start'], sc['goal'])
+
+    def mk():
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=max(1, len(sc['obs_radius'])))
+        sol.set_obstacles(sc['obs_pos'], sc['obs_radius'])
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], policy, zaxis, mrd)
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        if tracked:
+            sol.device_tracker_enable(sc['goal'][:, 3:6])
+        return sol
+
+    a, b = mk(), mk()
+    st = b.get_state()
+    for t in range(steps):
+        a.run_steps(1, nbr)
+        a.synchronize()
+        b.set_state(st['pos'], st['vel'], st['heading'], st['flags'], st['total_dist'], st['step_num'])
+        b.policy_pass(nbr)
+        act = b.actions()
+        b.env_update(True)
+        st = b.get_state()
+        ra = a.get_state()
+        for k in ('pos', 'vel', 'heading', 'flags', 'total_dist', 'step_num'):
+            assert np.array_equal(ra[k], st[k]), (scene, mode, t, k)
+        assert np.array_equal(a.actions(), act), (scene, mode, t)
+        assert np.array_equal(a.get_kd_perm(), b.get_kd_perm()), (scene, mode, t)
+    if tracked:
+        assert np.array_equal(a.device_tracker_replans(), b.device_tracker_replans())
+    assert ((st['flags'] & 7) == 0).any()                       # (the loop was still doing something at the end)
+    a.close()
+    b.close()
