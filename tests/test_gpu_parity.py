@@ -965,3 +965,63 @@ def test_host_buffer_loop_of_integration_stub_b_equals_the_resident_loop(S, scen
     assert ((st['flags'] & 7) == 0).any()                       # (the loop was still doing something at the end)
     a.close()
     b.close()
+
+
+def _reuse_scene(rng, n, m, with_tracker):
+    side = 6.0 * n ** (1.0 / 3.0)
+    start = np.zeros((n, 6)); goal = np.zeros((n, 6))
+    start[:, :3] = rng.uniform(-side, side, (n, 3)); start[:, 2] = np.abs(start[:, 2]) + 2.0
+    goal[:, :3] = rng.uniform(-side, side, (n, 3)); goal[:, 2] = np.abs(goal[:, 2]) + 2.0
+    start[:, 3] = rng.uniform(0, 2 * np.pi, n); goal[:, 3] = rng.uniform(0, 2 * np.pi, n)
+    policy = (rng.integers(0, 5, n) if not with_tracker else rng.choice([0, 2, 3], n)).astype(np.uint8)
+    obs_pos = rng.uniform(-side, side, (m, 3)); obs_pos[:, 2] = np.abs(obs_pos[:, 2])
+    return dict(n=n, start=start, goal=goal, policy=policy, radius=rng.choice([0.3, 0.5], n), pref_speed=rng.choice([1.0, 0.8], n),
+                obs_pos=obs_pos, obs_radius=rng.choice([0.5, 1.5], m), tracker=with_tracker)
+
+
+@pytest.mark.parametrize('mode', ['kd', 'auto', 'grid'])
+def test_one_context_through_agent_sets_of_different_sizes_equals_fresh_contexts(S, mode):
+    """A context outlives its agent set: sca_set_agents / sca_set_obstacles again with another count (the reference builds a new MACAEnv per
+    run; a long-lived service re-uses the library handle).  Whatever the previous set left behind -- kd statistics and build hints, grid
+    tables, near lists, AUTO's counters and look-ahead tree, tracker records, per-agent attributes, the LP list -- must not leak into the
+    next: five sets of different sizes (across the form thresholds at 2048 / 4096 / 6144), with and without obstacles and the device
+    tracker, on ONE context, each equal bit for bit to the same set on a fresh context."""
+    from sca_amd import scenarios
+    nbr = {'kd': S.NBR_KDTREE, 'auto': S.NBR_AUTO, 'grid': S.NBR_GRID}[mode]
+    rng = np.random.default_rng(2024)
+    sets = [_reuse_scene(rng, 5000, 30, False), _reuse_scene(rng, 300, 0, True), _reuse_scene(rng, 7000, 0, False),
+            _reuse_scene(rng, 2500, 12, True), _reuse_scene(rng, 64, 3, False)]
+    steps = 7
+
+    def load(sol, s):
+        n = s['n']
+        sol.set_obstacles(s['obs_pos'], s['obs_radius'])
+        sol.set_agents(s['radius'], s['pref_speed'], s['goal'][:, :3], s['policy'], S.zaxis_flags(s['start'], s['goal']),
+                       scenarios.max_run_dist(s['start'], s['goal']))
+        if s['n'] == 7000:
+            sol.set_agent_params(neighbor_dist=np.where(np.arange(n) % 3 == 0, 6.0, 10.0), max_neighbors=np.where(np.arange(n) % 2 == 0, 8, 16).astype(np.int32))
+        sol.set_state(s['start'][:, :3], np.zeros((n, 3), np.float32), s['start'][:, 3:6], np.zeros(n, np.uint8))
+        if s['tracker']:
+            sol.device_tracker_enable(s['goal'][:, 3:6])
+
+    def run(sol, s):
+        out = []
+        for t in range(steps):
+            sol.run_steps(1, nbr)
+            sol.synchronize()
+            g = sol.get_state()
+            out.append((g['pos'], g['vel'], g['heading'], g['flags'], g['total_dist'], sol.actions(), sol.get_kd_perm()))
+        return out
+
+    shared = S.BatchedSolver(max_agents=7000, max_obstacles=30)
+    for i, s in enumerate(sets):
+        load(shared, s)
+        got = run(shared, s)
+        fresh = S.BatchedSolver(max_agents=s['n'], max_obstacles=max(1, len(s['obs_radius'])))
+        load(fresh, s)
+        ref = run(fresh, s)
+        fresh.close()
+        for t, (a, b) in enumerate(zip(got, ref)):
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert np.array_equal(x, y), (mode, 'set', i, 'step', t, 'field', k)
+    shared.close()
