@@ -1025,3 +1025,50 @@ def test_one_context_through_agent_sets_of_different_sizes_equals_fresh_contexts
             for k, (x, y) in enumerate(zip(a, b)):
                 assert np.array_equal(x, y), (mode, 'set', i, 'step', t, 'field', k)
     shared.close()
+
+
+@pytest.mark.parametrize('mode', ['kd', 'auto', 'grid'])
+@pytest.mark.parametrize('n', [1, 37, 5000])
+def test_nobody_left_to_step_is_a_no_op(S, oracle, n, mode):
+    """The end of every episode (mampenv.py:35, :51-59): every agent at its goal, collided or timed out.  A pass over such a swarm writes
+    zero action rows and moves nobody -- as the oracle says; update_velocitie still zeroes the velocity and wraps the heading of everybody -- `sca_run_steps(ctx, 0, ...)` does nothing at all, and the library keeps
+    answering (active count 0) however often it is stepped; the kd permutation is still rebuilt from the positions (kdTree.py:56-59 runs
+    before anybody looks at a flag)."""
+    nbr = {'kd': S.NBR_KDTREE, 'auto': S.NBR_AUTO, 'grid': S.NBR_GRID}[mode]
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(-20, 20, (n, 3)) + np.array([0, 0, 30.0])
+    goal = rng.uniform(-20, 20, (n, 3)) + np.array([0, 0, 30.0])
+    vel = rng.normal(0, 0.5, (n, 3)).astype(np.float32)
+    head = np.zeros((n, 3)); head[:, 0] = rng.uniform(0, 6, n)
+    flags = rng.choice([1, 2, 4, 3, 5], n).astype(np.uint8)
+    policy = rng.integers(0, 6, n).astype(np.uint8)
+    rad = np.full(n, 0.5); ps = np.ones(n); z = np.zeros(n, np.uint8); mrd = np.full(n, 1e9)
+    e3, e0 = np.zeros((0, 3)), np.zeros(0)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(e3, e0)
+    sol.set_agents(rad, ps, goal, policy, z, mrd)
+    td = rng.uniform(0, 50, n)
+    sn = rng.integers(0, 900, n).astype(np.int32)
+    sol.set_state(pos, vel, head, flags, td, sn)
+    sol.run_steps(0, nbr)
+    sol.synchronize()
+    g = sol.get_state()
+    assert np.array_equal(g['pos'], pos) and np.array_equal(g['flags'], flags) and np.array_equal(g['step_num'], sn)
+    perm = np.arange(n, dtype=np.int32)
+    for t in range(3):
+        ref = oracle.policy_step(pos, vel, head, rad, ps, flags, goal, policy, z, np.zeros((n, 3)), np.zeros(n, np.uint8), perm, e3, e0)
+        u = oracle.env_update(pos, vel, head, rad, ref['flags'], goal, ref['action'], td, mrd, sn, e3, e0)
+        assert not ref['action'].any() and np.array_equal(u['pos'], pos)            # (the oracle agrees: zero rows, nobody moves)
+        perm = ref['perm']
+        sol.run_steps(1, nbr)
+        sol.synchronize()
+        g = sol.get_state()
+        assert not sol.actions().any()
+        # update_velocitie runs for EVERY agent (mampenv.py:42-43) on its zero row: the velocity becomes zero and the heading goes through pi_2_pi
+        for k, want in (('pos', pos), ('vel', u['vel']), ('heading', u['heading']), ('flags', u['flags']), ('total_dist', u['total_dist']), ('step_num', u['step_num'])):
+            assert np.array_equal(g[k], want), (n, mode, t, k)
+        vel, head, flags, td, sn = u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+        if mode != 'grid':
+            assert np.array_equal(sol.get_kd_perm(), perm), (n, mode, t)
+        assert sol.active_count() == 0
+    sol.close()
