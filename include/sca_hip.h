@@ -150,7 +150,8 @@ int sca_get_neighbors(sca_ctx *ctx, int32_t *nbr_n /*n*/, int32_t *nbr_id /*n*16
 int sca_get_nbr0(sca_ctx *ctx, double *dsq0 /*n*/);
 int sca_get_diag(sca_ctx *ctx, int32_t *diag /*n*5*/, int32_t *status /*n*/, double *vpref_used /*n*3*/);
 int sca_env_update(sca_ctx *ctx, int *all_done /*nullable: skips the readback*/);
-/* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising */
+/* `steps` x (policy pass + env update) with the state resident in HBM; returns without synchronising.  steps == 0 does nothing;
+ * steps < 0 is SCA_ERR_ARG, a neighbor_mode outside sca_neighbor_mode SCA_ERR_UNSUPPORTED, no state yet SCA_ERR_STATE (tests/test_gpu_abi_errors.py) */
 int sca_run_steps(sca_ctx *ctx, int steps, int neighbor_mode);
 /* MACAEnv.step (mampenv.py:22-25) in one call: one resident step (both loops of _take_action + is_done), then the number of agents of
  * this rank still running after it (0 == is_done) -- sca_run_steps(ctx, 1, mode) + sca_active_count with one stream synchronisation and

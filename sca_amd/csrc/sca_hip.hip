@@ -1044,6 +1044,7 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     API_ENTER(c);
     ARG(c, n > 0 && n <= c->max_n);
     ARG(c, radius && pref_speed && goal && policy && max_run_dist);
+    for (int i = 0; i < n; i++) ARG(c, policy[i] <= SCA_POLICY_RVO3D_DUBINS);        // (before anything of the previous set is torn down)
     if (c->d.hist) {                                                  // the log's pitch is n: a new agent set starts a new log
         CHK(c, hipStreamSynchronize(c->stream));
         CHK(c, hipFree(c->d.hist));
@@ -1072,7 +1073,6 @@ int sca_set_agents(sca_ctx *c, int n, const double *radius, const double *pref_s
     c->perm_on_device = false;
     std::vector<uint8_t> z(n, 0), mode(n, 0);
     if (zaxis) z.assign(zaxis, zaxis + n);
-    for (int i = 0; i < n; i++) ARG(c, policy[i] <= SCA_POLICY_RVO3D_DUBINS);
     CHK(c, hipMemcpyAsync(c->d.pref_speed, pref_speed, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.goal, goal, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d.policy, policy, n, hipMemcpyHostToDevice, c->stream));
@@ -2017,6 +2017,10 @@ int sca_run_steps(sca_ctx *c, int steps, int neighbor_mode) {
 static int run_steps_loop(sca_ctx *c, int steps, int neighbor_mode, bool lazy) {
     c->fork_ready = false; c->finish_stop = nullptr; c->action_stop = nullptr;
     if (!c->state_set) { c->err = "sca_set_state first"; return SCA_ERR_STATE; }
+    if (steps < 0) { c->err = "steps must not be negative"; return SCA_ERR_ARG; }
+    if (neighbor_mode < SCA_NBR_KDTREE || neighbor_mode > SCA_NBR_AUTO) {     // (also for steps == 0: a wrong mode is a wrong call)
+        c->err = "neighbor mode not available in this build"; return SCA_ERR_UNSUPPORTED;
+    }
     if (c->part_on && c->part_nranks > 1 && !c->shard_emulation) {
         c->err = "cell-owner partition over several ranks: drive the step with sca_step_begin / sca_partition_pack / [exchange] / "
                  "sca_partition_unpack / sca_partition_commit / sca_step_end (sca_amd.distributed.PartitionedStepper)";

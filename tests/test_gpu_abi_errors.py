@@ -1,0 +1,89 @@
+"""The C-ABI's error behaviour on a live context (-m gpu; tests/test_abi.py checks what can be checked without a GPU): wrong arguments and
+calls out of order come back as SCA_ERR_ARG / SCA_ERR_STATE with a message in sca_last_error, never as a crash or a silent wrong answer, and
+the context keeps working afterwards.  (The reference raises Python exceptions at the same places: an empty agent list has no kd-tree,
+kdTree.py:56-59; a policy is asked for an action only after set_agents, mampenv.py:16-20.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OK, ERR_ARG, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -3, -5
+
+
+@pytest.fixture(scope='module')
+def L():
+    from sca_amd import _lib
+    return _lib.lib()
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_create_refuses_bad_sizes_and_null_out(L):
+    ctx = C.c_void_p()
+    assert L.sca_create(None, 0, 0, 0, C.byref(ctx)) == ERR_ARG
+    assert L.sca_create(None, 0, -5, 0, C.byref(ctx)) == ERR_ARG
+    assert L.sca_create(None, 0, 10, -1, C.byref(ctx)) == ERR_ARG
+    assert L.sca_create(None, 0, 10, 0, None) == ERR_ARG
+    assert L.sca_create(None, 0, 10, 0, C.byref(ctx)) == OK and ctx.value
+    L.sca_destroy(ctx)
+
+
+def test_calls_out_of_order_and_bad_arguments_are_refused_and_the_context_survives(L):
+    from sca_amd import _lib
+    n = 40
+    ctx = C.c_void_p()
+    assert L.sca_create(None, 0, n, 2, C.byref(ctx)) == OK
+    rng = np.random.default_rng(3)
+    pos, ppos = _d(rng.uniform(-10, 10, (n, 3)) + [0, 0, 20])
+    goal, pgoal = _d(-pos + [0, 0, 40])
+    head, phead = _d(np.zeros((n, 3)))
+    rad, prad = _d(np.full(n, 0.5))
+    ps, pps = _d(np.ones(n))
+    mrd, pmrd = _d(np.full(n, 1e9))
+    vel = np.zeros((n, 3), np.float32); pvel = vel.ctypes.data_as(C.POINTER(C.c_float))
+    flags = np.zeros(n, np.uint8); pflags = flags.ctypes.data_as(C.POINTER(C.c_uint8))
+    pol = np.zeros(n, np.uint8); ppol = pol.ctypes.data_as(C.POINTER(C.c_uint8))
+    act = np.zeros((n, 7), np.float32); pact = act.ctypes.data_as(C.POINTER(C.c_float))
+    err = lambda: L.sca_last_error(ctx).decode()
+    # nothing is set yet
+    assert L.sca_set_state(ctx, ppos, pvel, phead, pflags, None, None) == ERR_STATE and 'sca_set_agents' in err()
+    assert L.sca_policy_pass(ctx, 0) == ERR_STATE
+    assert L.sca_run_steps(ctx, 1, 0) == ERR_STATE
+    assert L.sca_get_state(ctx, ppos, pvel, phead, pflags, None, None) == ERR_STATE
+    # agent sets that cannot be
+    assert L.sca_set_agents(ctx, 0, prad, pps, pgoal, ppol, None, pmrd) == ERR_ARG
+    assert L.sca_set_agents(ctx, n + 1, prad, pps, pgoal, ppol, None, pmrd) == ERR_ARG
+    assert L.sca_set_agents(ctx, n, None, pps, pgoal, ppol, None, pmrd) == ERR_ARG
+    bad_pol = pol.copy(); bad_pol[7] = 6
+    assert L.sca_set_agents(ctx, n, prad, pps, pgoal, bad_pol.ctypes.data_as(C.POINTER(C.c_uint8)), None, pmrd) == ERR_ARG
+    assert L.sca_set_obstacles(ctx, 3, None, None) == ERR_ARG              # more obstacles than the context was created for / no arrays
+    # a good set, then a pass without a state
+    assert L.sca_set_agents(ctx, n, prad, pps, pgoal, ppol, None, pmrd) == OK
+    assert L.sca_policy_pass(ctx, 0) == ERR_STATE
+    assert L.sca_set_state(ctx, None, pvel, phead, pflags, None, None) == ERR_ARG
+    assert L.sca_set_state(ctx, ppos, pvel, phead, pflags, None, None) == OK
+    # neighbour modes that do not exist, negative step counts
+    assert L.sca_policy_pass(ctx, 7) == ERR_UNSUPPORTED and 'mode' in err().lower()
+    assert L.sca_run_steps(ctx, -1, 0) == ERR_ARG
+    assert L.sca_run_steps(ctx, 1, 9) == ERR_UNSUPPORTED
+    assert L.sca_get_actions(ctx, None) == ERR_ARG
+    # per-agent attributes out of range name the agent
+    nd = np.full(n, 10.0); nd[3] = -1.0
+    assert L.sca_set_agent_params(ctx, n, nd.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, None, None, None) == ERR_ARG
+    assert 'agent 3' in err()
+    # ... and after all that the context still answers, with the answer of a context that never saw an error
+    assert L.sca_policy_pass(ctx, 0) == OK and L.sca_get_actions(ctx, pact) == OK
+    ctx2 = C.c_void_p()
+    assert L.sca_create(None, 0, n, 2, C.byref(ctx2)) == OK
+    assert L.sca_set_agents(ctx2, n, prad, pps, pgoal, ppol, None, pmrd) == OK
+    assert L.sca_set_state(ctx2, ppos, pvel, phead, pflags, None, None) == OK
+    act2 = np.zeros((n, 7), np.float32)
+    assert L.sca_policy_pass(ctx2, 0) == OK and L.sca_get_actions(ctx2, act2.ctypes.data_as(C.POINTER(C.c_float))) == OK
+    assert np.array_equal(act, act2) and act.any()
+    L.sca_destroy(ctx)
+    L.sca_destroy(ctx2)
