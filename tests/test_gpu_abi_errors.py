@@ -87,3 +87,79 @@ def test_calls_out_of_order_and_bad_arguments_are_refused_and_the_context_surviv
     assert np.array_equal(act, act2) and act.any()
     L.sca_destroy(ctx)
     L.sca_destroy(ctx2)
+
+
+def test_contexts_give_their_memory_back():
+    """A long-lived service creates and destroys contexts: after 150 contexts that each ran kd, grid and AUTO passes with the device tracker,
+    per-agent attributes and the episode log, the device has (within allocator granularity) the free memory it started with."""
+    import torch
+    from sca_amd import scenarios, solver as S
+    sc = scenarios.circle(3000)
+    n = 3000
+    zaxis = S.zaxis_flags(sc['start'], sc['goal'])
+    mrd = scenarios.max_run_dist(sc['start'], sc['goal'])
+
+    def once():
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=4)
+        sol.set_obstacles(np.array([[0.0, 0.0, 3.0]]), np.array([1.0]))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], np.where(np.arange(n) % 3 == 0, 3, 0).astype(np.uint8), zaxis, mrd)
+        sol.set_agent_params(neighbor_dist=np.where(np.arange(n) % 2 == 0, 8.0, 10.0))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        sol.device_tracker_enable(sc['goal'][:, 3:6])
+        sol.history_enable(16)
+        for mode in (S.NBR_KDTREE, S.NBR_AUTO, S.NBR_GRID):
+            sol.run_steps(2, mode)
+        sol.synchronize()
+        sol.close()
+
+    for _ in range(3):
+        once()                                               # (first uses: code objects, streams, the allocator's pools)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(150):
+        once()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)          # 150 leaked contexts of this size would be gigabytes
+
+
+def test_two_contexts_stepped_from_two_host_threads_at_once_equal_the_serial_runs():
+    """Contexts share nothing but the code object and its constant tables: two episodes stepped concurrently from two host threads (ctypes
+    releases the GIL inside every library call), one with the device tracker in kd mode and one without in SCA_NBR_AUTO, walk through the
+    states of the same episodes run one after the other."""
+    import threading
+    from sca_amd import scenarios, solver as S
+
+    def episode(kind, out):
+        if kind == 'sca':
+            sc, n, pol, mode = scenarios.circle(1500), 1500, np.zeros(1500, np.uint8), S.NBR_KDTREE
+        else:
+            sc, n, pol, mode = scenarios.random_cube(4096, seed=3), 4096, np.full(4096, 3, np.uint8), S.NBR_AUTO
+        sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+        sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+        sol.set_agents(np.full(n, 0.5), np.ones(n), sc['goal'][:, :3], pol, S.zaxis_flags(sc['start'], sc['goal']), scenarios.max_run_dist(sc['start'], sc['goal']))
+        sol.set_state(sc['start'][:, :3], np.zeros((n, 3), np.float32), sc['start'][:, 3:6], np.zeros(n, np.uint8))
+        if kind == 'sca':
+            sol.device_tracker_enable(sc['goal'][:, 3:6])
+        snaps = []
+        for t in range(30):
+            sol.run_steps(3, mode)
+            sol.synchronize()
+            g = sol.get_state()
+            snaps.append((g['pos'], g['vel'], g['flags'], sol.get_kd_perm()))
+        sol.close()
+        out[kind] = snaps
+
+    serial, both = {}, {}
+    episode('sca', serial)
+    episode('orca', serial)
+    th = [threading.Thread(target=episode, args=(k, both)) for k in ('sca', 'orca')]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in ('sca', 'orca'):
+        assert len(both[k]) == 30
+        for i, (a, b) in enumerate(zip(serial[k], both[k])):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (k, i)
