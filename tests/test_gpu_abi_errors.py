@@ -92,8 +92,14 @@ def test_calls_out_of_order_and_bad_arguments_are_refused_and_the_context_surviv
 def test_contexts_give_their_memory_back():
     """A long-lived service creates and destroys contexts: after 150 contexts that each ran kd, grid and AUTO passes with the device tracker,
     per-agent attributes and the episode log, the device has (within allocator granularity) the free memory it started with."""
-    import torch
     from sca_amd import scenarios, solver as S
+    hip = C.CDLL('libamdhip64.so')                       # (the runtime the library itself links: no second framework in the process)
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
     sc = scenarios.circle(3000)
     n = 3000
     zaxis = S.zaxis_flags(sc['start'], sc['goal'])
@@ -114,12 +120,10 @@ def test_contexts_give_their_memory_back():
 
     for _ in range(3):
         once()                                               # (first uses: code objects, streams, the allocator's pools)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info(0)[0]
+    free0 = free_bytes()
     for _ in range(150):
         once()
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info(0)[0]
+    free1 = free_bytes()
     assert free0 - free1 < 64 << 20, (free0, free1)          # 150 leaked contexts of this size would be gigabytes
 
 
