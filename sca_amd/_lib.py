@@ -108,6 +108,31 @@ SIGNATURES = {
 _LIB = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's): whichever of the two a
+    process loads first is the one everybody gets.  With torch first that is torch's, and libsca_hip.so runs on it (bench.py, the
+    multi-GPU steppers); with libsca_hip.so first it would be /opt/rocm's, and a later `import torch` finds no GPU
+    (torch.cuda.is_available() == False, measured).  So when a torch installation is present but not imported yet, its runtime is loaded
+    here, before the library: either import order then works.  SCA_OWN_HIP_RUNTIME=1 skips this (the system's runtime, no torch later)."""
+    import importlib.util
+    import sys
+    if os.environ.get('SCA_OWN_HIP_RUNTIME') or 'torch' in sys.modules:
+        return None
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def lib():
     """Loads sca_amd/lib/libsca_hip.so.  Raises if it has not been built (python -m sca_amd.build)."""
     global _LIB
@@ -115,6 +140,7 @@ def lib():
         if not os.path.exists(_build.LIB):
             raise RuntimeError(f'{_build.LIB} is missing: build it with `python -m sca_amd.build` '
                                '(there is no CPU fallback)')
+        _share_torch_hip_runtime()
         L = C.CDLL(_build.LIB)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

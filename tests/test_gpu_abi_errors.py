@@ -93,7 +93,7 @@ def test_contexts_give_their_memory_back():
     """A long-lived service creates and destroys contexts: after 150 contexts that each ran kd, grid and AUTO passes with the device tracker,
     per-agent attributes and the episode log, the device has (within allocator granularity) the free memory it started with."""
     from sca_amd import scenarios, solver as S
-    hip = C.CDLL('libamdhip64.so')                       # (the runtime the library itself links: no second framework in the process)
+    hip = C.CDLL('libamdhip64.so.7')                     # by SONAME: the runtime this process already has (the library's; never a second one)
 
     def free_bytes():
         free, total = C.c_size_t(0), C.c_size_t(0)
@@ -167,3 +167,38 @@ def test_two_contexts_stepped_from_two_host_threads_at_once_equal_the_serial_run
         for i, (a, b) in enumerate(zip(serial[k], both[k])):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), (k, i)
+
+
+def test_torch_imported_after_the_library_still_sees_the_gpu():
+    """One HIP runtime per process (sca_amd/_lib.py::_share_torch_hip_runtime): PyTorch-ROCm ships its own libamdhip64 under the system's
+    SONAME, and with libsca_hip.so loaded first on the system's runtime a later `import torch` found no GPU.  A fresh process that steps a
+    swarm FIRST and imports torch AFTERWARDS must see the device, share a buffer with the library, and get the same velocities as a
+    process that never imports torch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from sca_amd import scenarios, solver as S
+sc = scenarios.circle(500)
+sol = S.BatchedSolver(max_agents=500)
+sol.set_obstacles(np.zeros((0, 3)), np.zeros(0))
+sol.set_agents(np.full(500, 0.5), np.ones(500), sc['goal'][:, :3], np.full(500, 3, np.uint8), S.zaxis_flags(sc['start'], sc['goal']), scenarios.max_run_dist(sc['start'], sc['goal']))
+sol.set_state(sc['start'][:, :3], np.zeros((500, 3), np.float32), sc['start'][:, 3:6], np.zeros(500, np.uint8))
+sol.run_steps(5, 0); sol.synchronize()
+if WITH_TORCH:
+    import torch
+    assert torch.cuda.is_available(), 'torch sees no GPU after libsca_hip.so'
+    t = torch.arange(8, device='cuda', dtype=torch.float64)
+    assert float((t * 2).sum().item()) == 56.0
+sol.run_steps(5, 0); sol.synchronize()
+print('VEL', sol.get_state()['vel'].tobytes().hex()[:4000])
+''' % root
+    outs = []
+    for with_torch in (True, False):
+        r = subprocess.run([sys.executable, '-c', code.replace('WITH_TORCH', str(with_torch))], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('VEL')][0])
+    assert outs[0] == outs[1]
