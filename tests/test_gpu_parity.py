@@ -1072,3 +1072,45 @@ def test_nobody_left_to_step_is_a_no_op(S, oracle, n, mode):
             assert np.array_equal(sol.get_kd_perm(), perm), (n, mode, t)
         assert sol.active_count() == 0
     sol.close()
+
+
+@pytest.mark.parametrize('mode', ['kd', 'auto'])
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_arrivals_collisions_and_timeouts_in_the_middle_of_an_episode_match_the_oracle(S, oracle, seed, mode):
+    """The three ways an agent leaves the loop (mampenv.py:51-59, :61-80), all inside one short free-running episode: goals 0.6 .. 4 m away
+    (most agents ARRIVE within 40 steps and become static neighbours, scaPolicy.py:53), a dense start (some COLLIDE on the way), and a
+    max_run_dist of 0.3 .. 3 m for a third of the agents (they TIME OUT mid-flight, mampenv.py:77-79).  After every resident step: flags,
+    step counts (an arrived agent stops counting, :44-45), float32 velocities, positions, headings, travelled distance and the kd
+    permutation EQUAL the oracle's; and each exit is actually taken by a few dozen agents."""
+    nbr = S.NBR_AUTO if mode == 'auto' else S.NBR_KDTREE
+    rng = np.random.default_rng(500 + seed)
+    n, steps = 600, 40
+    pos = rng.uniform(-9, 9, (n, 3)); pos[:, 2] = np.abs(pos[:, 2]) + 3.0
+    d = rng.normal(0, 1, (n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    goal = pos + d * rng.uniform(0.6, 4.0, (n, 1)); goal[:, 2] = np.abs(goal[:, 2]) + 0.5
+    head = np.zeros((n, 3)); head[:, 0] = np.arctan2(d[:, 1], d[:, 0])
+    policy = rng.choice([1, 2, 3, 4], n).astype(np.uint8)
+    rad = rng.choice([0.2, 0.3], n); ps = np.ones(n); z = np.zeros(n, np.uint8)
+    mrd = np.where(rng.random(n) < 0.33, rng.uniform(0.3, 3.0, n), 1e9)
+    e3, e0 = np.zeros((0, 3)), np.zeros(0)
+    sol = S.BatchedSolver(max_agents=n, max_obstacles=1)
+    sol.set_obstacles(e3, e0)
+    sol.set_agents(rad, ps, goal, policy, z, mrd)
+    p, ve, he, fl = pos.copy(), np.zeros((n, 3), np.float32), head.copy(), np.zeros(n, np.uint8)
+    td, sn, perm = np.zeros(n), np.zeros(n, np.int32), np.arange(n, dtype=np.int32)
+    sol.set_state(p, ve, he, fl, td, sn)
+    for t in range(steps):
+        sol.run_steps(1, nbr)
+        sol.synchronize()
+        g = sol.get_state()
+        r = oracle.policy_step(p, ve, he, rad, ps, fl, goal, policy, z, np.zeros((n, 3)), np.zeros(n, np.uint8), perm, e3, e0, nthreads=8)
+        perm = r['perm']
+        u = oracle.env_update(p, ve, he, rad, r['flags'], goal, r['action'], td, mrd, sn, e3, e0)
+        p, ve, he, fl, td, sn = u['pos'], u['vel'], u['heading'], u['flags'], u['total_dist'], u['step_num']
+        for k, want in (('flags', fl), ('step_num', sn), ('vel', ve), ('pos', p), ('heading', he), ('total_dist', td)):
+            assert np.array_equal(g[k], want), (seed, mode, t, k)
+        assert np.array_equal(sol.get_kd_perm(), perm), (seed, mode, t)
+    arrived, collided, timed_out = int((fl & 1).astype(bool).sum()), int((fl & 2).astype(bool).sum()), int((fl & 4).astype(bool).sum())
+    assert arrived > 100 and collided > 10 and timed_out > 30, (arrived, collided, timed_out)
+    assert sol.active_count() == int(((fl & 7) == 0).sum())
+    sol.close()
