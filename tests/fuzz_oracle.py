@@ -5,7 +5,7 @@ sparse boxes, SCA_NBR_KDTREE and SCA_NBR_AUTO, FREE-RUNNING from the scene's sta
 permutation, float32 velocities, positions, headings and travelled distance must EQUAL the oracle's (tests/test_gpu_parity.py's fuzz family,
 whose scenes stop at 1600 agents and 6 steps).
 
-    python tests/fuzz_oracle.py <seed> <scenes>
+    python tests/fuzz_oracle.py <seed> <scenes> [max agents per cubic metre: 0.2 (default; the oracle needs minutes for the largest dense scenes), 0.02]
 """
 import os
 import sys
@@ -21,6 +21,7 @@ from sca_amd import solver as S                       # noqa: E402
 orc.build()
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 nscenes = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+max_density = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
 rng = np.random.default_rng(seed0)
 threads = min(16, os.cpu_count() or 1)
 bad = 0
@@ -29,7 +30,7 @@ t0 = time.time()
 for sc_i in range(nscenes):
     n = int(rng.choice([1, 7, 100, 1000, 2047, 2049, 4096, 4097, 6143, 6145, 10000, 16383, 16385, 25000, 40000]))
     m = int(rng.choice([0, 0, 3, 40, 400]))
-    density = float(rng.choice([0.002, 0.02, 0.2]))                        # agents per cubic metre: <1, ~8, ~80 in range of one another
+    density = float(rng.choice([dd for dd in (0.002, 0.02, 0.2) if dd <= max_density]))                        # agents per cubic metre: <1, ~8, ~80 in range of one another
     side = max(2.0, 0.5 * (n / density) ** (1.0 / 3.0))
     steps = int(rng.integers(4, 13)) if n <= 10000 else int(rng.integers(3, 7))
     mode = S.NBR_AUTO if rng.random() < 0.5 else S.NBR_KDTREE
@@ -92,4 +93,5 @@ for sc_i in range(nscenes):
         print('STATUS BITS scene', sc_i, np.unique(st))
     bad += not ok
     sol.close()
+    print('scene', sc_i, 'n', n, 'm', m, 'density', density, 'policy', one, 'mode', mode, 'steps', steps, 'ok' if ok else 'BAD', '%.0f s' % (time.time() - t0), flush=True)
 print('scenes', nscenes, 'bad', bad, 'agent-steps', agent_steps, 'seconds %.0f' % (time.time() - t0))
